@@ -1,0 +1,91 @@
+"""Host-side helpers shared by the two classes: dtype handling, tensor checks, per-device plans."""
+
+from __future__ import annotations
+
+import ctypes
+import threading
+import weakref
+
+import torch
+
+from . import _lib
+
+_DTYPE_NAMES = {
+    "float32": torch.float32, "fp32": torch.float32, "float": torch.float32,
+    "float64": torch.float64, "fp64": torch.float64, "double": torch.float64,
+    "bfloat16": torch.bfloat16, "bf16": torch.bfloat16,
+    "float16": torch.float16, "fp16": torch.float16, "half": torch.float16,
+}
+
+
+def as_torch_dtype(dtype):
+    """Accept torch dtypes, numpy dtypes / type objects and strings where the reference takes a tf.DType."""
+    if isinstance(dtype, torch.dtype):
+        return dtype
+    name = getattr(dtype, "name", None) or getattr(dtype, "__name__", None) or str(dtype)
+    name = name.replace("torch.", "").replace("tf.", "").lower()
+    if name in _DTYPE_NAMES:
+        return _DTYPE_NAMES[name]
+    raise TypeError("unsupported dtype %r" % (dtype,))
+
+
+def require_hip_compute_dtype(compute_dtype, who):
+    if compute_dtype != torch.float32:
+        raise NotImplementedError(
+            "%s: the HIP kernels compute in float32 only (got compute_dtype=%s); "
+            "there is no CPU or other-precision fallback" % (who, compute_dtype))
+
+
+def check_device_tensor(t, name, dtype, ndim):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor, got %s" % (name, type(t).__name__))
+    if t.dtype != dtype:
+        raise ValueError("%s has dtype %s but compute_dtype is %s (no implicit cast, as in the reference)"
+                         % (name, t.dtype, dtype))
+    if t.dim() != ndim:
+        raise ValueError("%s must have %d dimensions, got shape %s" % (name, ndim, tuple(t.shape)))
+    if not t.is_cuda:
+        raise RuntimeError("%s lives on %s: this package only runs on a ROCm device tensor (device='cuda'); "
+                           "there is no CPU fallback" % (name, t.device))
+    return t.contiguous()
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class PlanCache:
+    """One native plan per device index, created on first use and destroyed with the owner."""
+
+    def __init__(self, owner, create, destroy):
+        self._create = create
+        self._plans = {}
+        self._lock = threading.Lock()
+        plans = self._plans
+        weakref.finalize(owner, PlanCache._cleanup, plans, destroy)
+
+    @staticmethod
+    def _cleanup(plans, destroy):
+        for handle in plans.values():
+            try:
+                destroy(handle)
+            except Exception:
+                pass
+        plans.clear()
+
+    def get(self, device):
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        handle = self._plans.get(idx)
+        if handle is None:
+            with self._lock:
+                handle = self._plans.get(idx)
+                if handle is None:
+                    out = ctypes.c_void_p()
+                    _lib.check(self._create(idx, ctypes.byref(out)))
+                    handle = out
+                    self._plans[idx] = handle
+        return handle

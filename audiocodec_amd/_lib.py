@@ -1,0 +1,104 @@
+"""ctypes binding of ``libaudiocodec_amd.so`` (the C ABI declared in ``include/audiocodec_amd.h``).
+
+There is no fallback: if the shared library is missing or a call fails the product raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libaudiocodec_amd.so")
+
+AC_OK = 0
+AC_EINVAL, AC_EHIP, AC_ENOMEM, AC_ENODEV, AC_EUNSUPPORTED = -1, -2, -3, -4, -5
+WINDOW_IDS = {"vorbis": 0, "sine": 1}   # anything else -> 2 (rectangular), mdctransformer.py:199-211
+WINDOW_RECT = 2
+
+# name -> (restype, argtypes); mirrors include/audiocodec_amd.h one to one
+PROTOTYPES = {
+    "ac_version": (c_int, []),
+    "ac_last_error": (c_char_p, []),
+    "ac_set_force_generic": (c_int, [c_int]),
+    "ac_mdct_fold_coefficients_host": (c_int, [c_int, c_int, POINTER(c_double)]),
+    "ac_mdct_dense_matrices_host": (c_int, [c_int, c_int, POINTER(c_float), POINTER(c_float)]),
+    "ac_psy_tables_host": (c_int, [c_int, c_int, c_double, c_double, POINTER(c_float), POINTER(c_float),
+                                   POINTER(c_float), POINTER(c_float), POINTER(c_double)]),
+    "ac_mdct_plan_create": (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
+    "ac_mdct_plan_destroy": (c_int, [c_void_p]),
+    "ac_psy_plan_create": (c_int, [c_int, c_int, c_double, c_double, c_int, POINTER(c_void_p)]),
+    "ac_psy_plan_destroy": (c_int, [c_void_p]),
+    "ac_mdct_plan_is_fast": (c_int, [c_void_p]),
+    "ac_psy_plan_is_fast": (c_int, [c_void_p]),
+    "ac_mdct_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ac_mdct_inverse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ac_tonality": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ac_mask_threshold": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ac_encode_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int,
+                                c_int, c_void_p]),
+    "ac_stream_create": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    "ac_stream_reset": (c_int, [c_void_p, c_void_p]),
+    "ac_stream_destroy": (c_int, [c_void_p]),
+    "ac_stream_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ac_stream_inverse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ac_amplitude_to_db": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "ac_add_noise": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_uint64, c_void_p]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class AudioCodecError(RuntimeError):
+    """A libaudiocodec_amd call returned a non-zero status."""
+
+    def __init__(self, status, message):
+        super().__init__("libaudiocodec_amd status %d: %s" % (status, message))
+        self.status = status
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C audiocodec_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in PROTOTYPES.items():
+            fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if lib.ac_version() < 100:
+            raise ImportError("libaudiocodec_amd too old: %d" % lib.ac_version())
+        _lib = lib
+    return _lib
+
+
+def check(status):
+    """Turn a non-zero status into an exception (ValueError for AC_EINVAL, like a shape error)."""
+    if status == AC_OK:
+        return
+    msg = load().ac_last_error()
+    msg = msg.decode("utf-8", "replace") if msg else ""
+    if status == AC_EINVAL:
+        raise ValueError(msg)
+    raise AudioCodecError(status, msg)
+
+
+def window_id(window_type):
+    """Reference semantics (mdctransformer.py:199-211): case-insensitive 'sine' / 'vorbis', else rectangular.
+    ``None`` selects the rectangular window (the reference raises AttributeError; documented fix)."""
+    if isinstance(window_type, str):
+        return WINDOW_IDS.get(window_type.lower(), WINDOW_RECT)
+    if window_type is None:
+        return WINDOW_RECT
+    raise TypeError("window_type must be a string or None")

@@ -1,0 +1,126 @@
+"""``encode()`` / ``decode()`` and the streaming overlap-add wrappers.
+
+The reference has no ``encode``/``decode``; BASELINE.json's north star names them as the API surface,
+and SURVEY.md section 0 item 3 defines them as thin compositions of the reference's methods:
+
+    encode(x)  = transform -> tonality -> global_masking_threshold   (one fused HIP pass over the PCM)
+    decode(X)  = inverse_transform
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _host, _lib
+from .mdctransformer import MDCTransformer
+from .psychoacoustic import PsychoacousticModel
+
+
+class AudioCodec:
+    """MDCT analysis + psychoacoustic masking (encode) and MDCT synthesis (decode)."""
+
+    def __init__(self, sample_rate=48000, filters_n=1024, bark_bands_n=64, alpha=0.6, window_type="vorbis",
+                 compute_dtype=torch.float32):
+        self.mdct = MDCTransformer(filters_n, window_type=window_type, compute_dtype=compute_dtype)
+        self.psy = PsychoacousticModel(sample_rate, filter_bands_n=filters_n, bark_bands_n=bark_bands_n,
+                                       alpha=alpha, compute_dtype=compute_dtype)
+        self.filters_n = int(filters_n)
+        self.compute_dtype = self.mdct.compute_dtype
+        self._lib = _lib.load()
+
+    def encode(self, x, drown=0.0):
+        """x [B, K*N, C] -> (X [B,K+1,N,C], tonality [B,K+1,1,C], threshold [B,K+1,N,C])."""
+        x = _host.check_device_tensor(x, "x", self.compute_dtype, 3)
+        B, S, C = x.shape
+        N = self.filters_n
+        if S % N != 0:
+            raise ValueError("samples_n (%d) is not a multiple of filters_n (%d)" % (S, N))
+        K = S // N
+        X = torch.empty((B, K + 1, N, C), dtype=x.dtype, device=x.device)
+        t = torch.empty((B, K + 1, 1, C), dtype=x.dtype, device=x.device)
+        thr = torch.empty((B, K + 1, N, C), dtype=x.dtype, device=x.device)
+        self.encode_into(x, X, t, thr, drown)
+        return X, t, thr
+
+    def encode_into(self, x, X, t, thr, drown=0.0):
+        """Same as :meth:`encode` into caller-owned output tensors (no allocation in the timed path)."""
+        B, S, C = x.shape
+        K = S // self.filters_n
+        with torch.cuda.device(x.device):
+            _lib.check(self._lib.ac_encode_fused(self.mdct._plan(x.device), self.psy._plan(x.device), _host.ptr(x),
+                                                 _host.ptr(X), _host.ptr(t), _host.ptr(thr), float(drown), B, K, C,
+                                                 _host.stream_ptr(x.device)))
+
+    def decode(self, X):
+        """X [B, K', N, C] -> x [B, (K'+1)*N, C]."""
+        return self.mdct.inverse_transform(X)
+
+    def decode_into(self, X, x):
+        B, Kp, N, C = X.shape
+        with torch.cuda.device(X.device):
+            _lib.check(self._lib.ac_mdct_inverse(self.mdct._plan(X.device), _host.ptr(X), _host.ptr(x), B, Kp, C,
+                                                 _host.stream_ptr(X.device)))
+
+
+class StreamingMDCT:
+    """Chunked analysis / synthesis with device-resident overlap state (BASELINE config 5).
+
+    Feeding consecutive chunks of ``k`` blocks gives, frame for frame, the one-shot ``transform`` /
+    ``inverse_transform`` result: analysis frame ``i`` of a chunk pairs block ``i`` with block ``i-1``
+    (the stored last block of the previous chunk for ``i = 0``); synthesis block ``i`` overlap-adds
+    frame ``i`` with the stored aliased half of the previous frame.
+    """
+
+    def __init__(self, mdct: MDCTransformer, batches_n, channels_n, device=None):
+        self.mdct = mdct
+        self.B, self.C = int(batches_n), int(channels_n)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._lib = _lib.load()
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ac_stream_create(mdct._plan(self.device), self.B, self.C, ctypes.byref(handle)))
+        self._handle = handle
+
+    def close(self):
+        if self._handle is not None:
+            self._lib.ac_stream_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ac_stream_reset(self._handle, _host.stream_ptr(self.device)))
+
+    def transform_chunk(self, x_chunk):
+        """x_chunk [B, k*N, C] -> X [B, k, N, C]."""
+        x = _host.check_device_tensor(x_chunk, "x_chunk", self.mdct.compute_dtype, 3)
+        B, S, C = x.shape
+        N = self.mdct.filters_n
+        if (B, C) != (self.B, self.C) or S % N != 0:
+            raise ValueError("x_chunk must be [%d, k*%d, %d], got %s" % (self.B, N, self.C, tuple(x.shape)))
+        k = S // N
+        X = torch.empty((B, k, N, C), dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(self._lib.ac_stream_forward(self._handle, _host.ptr(x), _host.ptr(X), k,
+                                                   _host.stream_ptr(x.device)))
+        return X
+
+    def inverse_chunk(self, X_chunk):
+        """X_chunk [B, k, N, C] -> x [B, k*N, C]."""
+        X = _host.check_device_tensor(X_chunk, "X_chunk", self.mdct.compute_dtype, 4)
+        B, k, N, C = X.shape
+        if (B, C, N) != (self.B, self.C, self.mdct.filters_n):
+            raise ValueError("X_chunk must be [%d, k, %d, %d], got %s" % (self.B, self.mdct.filters_n, self.C,
+                                                                         tuple(X.shape)))
+        x = torch.empty((B, k * N, C), dtype=X.dtype, device=X.device)
+        with torch.cuda.device(X.device):
+            _lib.check(self._lib.ac_stream_inverse(self._handle, _host.ptr(X), _host.ptr(x), k,
+                                                   _host.stream_ptr(X.device)))
+        return x

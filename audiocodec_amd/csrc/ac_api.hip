@@ -1,0 +1,428 @@
+// C ABI of libaudiocodec_amd.so (see include/audiocodec_amd.h).  gfx950 only.
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "ac_internal.h"
+
+namespace ac {
+
+static thread_local std::string g_err;
+int g_force_generic = 0;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+template <typename T>
+static int upload(const std::vector<T>& h, T** d) {
+  *d = nullptr;
+  const size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+  AC_HIP_CHECK(hipMalloc((void**)d, bytes));
+  if (!h.empty()) AC_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return AC_OK;
+}
+
+static int check_device(int device) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    set_error("no HIP device available");
+    return AC_ENODEV;
+  }
+  if (device < 0 || device >= count) {
+    set_error("device %d out of range (have %d)", device, count);
+    return AC_EINVAL;
+  }
+  return AC_OK;
+}
+
+static bool valid_window(int w) { return w == AC_WINDOW_VORBIS || w == AC_WINDOW_SINE || w == AC_WINDOW_RECT; }
+
+}  // namespace ac
+
+using namespace ac;
+
+extern "C" {
+
+int ac_version(void) { return AC_VERSION; }
+const char* ac_last_error(void) { return g_err.c_str(); }
+
+int ac_set_force_generic(int on) {
+  g_force_generic = on ? 1 : 0;
+  return AC_OK;
+}
+
+// ---- host-only builders ------------------------------------------------------------------------
+
+int ac_mdct_fold_coefficients_host(int N, int window, double* coef) {
+  AC_REQUIRE(N >= 2 && (N % 2) == 0, "number of filters used in mdct transformation needs to be even (got %d)", N);
+  AC_REQUIRE(valid_window(window), "unknown window id %d", window);
+  AC_REQUIRE(coef != nullptr, "coef is NULL");
+  FoldCoef c;
+  fold_coefficients(N, window, c);
+  const int h = N / 2;
+  const std::vector<double>* v[8] = {&c.a1, &c.a2, &c.a3, &c.a4, &c.s1, &c.s2, &c.s3, &c.s4};
+  for (int i = 0; i < 8; ++i) std::memcpy(coef + (size_t)i * h, v[i]->data(), h * sizeof(double));
+  return AC_OK;
+}
+
+int ac_mdct_dense_matrices_host(int N, int window, float* H, float* H_inv) {
+  AC_REQUIRE(N >= 2 && (N % 2) == 0, "number of filters used in mdct transformation needs to be even (got %d)", N);
+  AC_REQUIRE(valid_window(window), "unknown window id %d", window);
+  FoldCoef c;
+  fold_coefficients(N, window, c);
+  std::vector<double> w;
+  window_samples(N, window, w);
+  const int h = N / 2;
+  const size_t NN = (size_t)N * N;
+  if (H) {
+    // H[n, r, k] = F[r, k] d_n[k]; n = 0 uses columns k >= h (current block), n = 1 columns k < h
+    std::memset(H, 0, 2 * NN * sizeof(float));
+    for (int j = 0; j < h; ++j) {
+      H[0 * NN + (size_t)j * N + (h + j)] = (float)c.a1[j];                  // F[j, h+j]
+      H[0 * NN + (size_t)(N - 1 - j) * N + (h + j)] = (float)c.a2[j];        // F[N-1-j, h+j]
+      H[1 * NN + (size_t)(h - 1 - j) * N + j] = (float)c.a3[j];              // F[h-1-j, j]
+      H[1 * NN + (size_t)(h + j) * N + j] = (float)c.a4[j];                  // F[h+j, j]
+    }
+  }
+  if (H_inv) {
+    // H_inv[n, r, k] = e_n[r] Finv[r, k]; n = 0 rows r < h, n = 1 rows r >= h
+    std::memset(H_inv, 0, 2 * NN * sizeof(float));
+    for (int j = 0; j < h; ++j) {
+      H_inv[0 * NN + (size_t)(h - 1 - j) * N + j] = (float)c.s1[j];          // Finv[h-1-j, j]
+      H_inv[0 * NN + (size_t)(h - 1 - j) * N + (N - 1 - j)] = (float)c.s3[j];
+      H_inv[1 * NN + (size_t)(h + j) * N + j] = (float)c.s2[j];              // Finv[h+j, j]
+      H_inv[1 * NN + (size_t)(h + j) * N + (N - 1 - j)] = (float)c.s4[j];
+    }
+  }
+  return AC_OK;
+}
+
+int ac_psy_tables_host(int N, int M, double sample_rate, double alpha, float* W, float* W_inv, float* S,
+                       float* quiet, double* scalars) {
+  AC_REQUIRE(N >= 1 && M >= 1, "filter_bands_n (%d) and bark_bands_n (%d) must be positive", N, M);
+  AC_REQUIRE(sample_rate > 0 && alpha > 0, "sample_rate and alpha must be positive");
+  PsyTables t;
+  psy_tables(N, M, sample_rate, alpha, t);
+  if (W) for (size_t i = 0; i < t.W.size(); ++i) W[i] = (float)t.W[i];
+  if (W_inv) for (size_t i = 0; i < t.W_inv.size(); ++i) W_inv[i] = (float)t.W_inv[i];
+  if (S) for (size_t i = 0; i < t.S.size(); ++i) S[i] = (float)t.S[i];
+  if (quiet) for (size_t i = 0; i < t.quiet.size(); ++i) quiet[i] = (float)t.quiet[i];
+  if (scalars) {
+    scalars[0] = t.max_frequency;
+    scalars[1] = t.max_bark;
+    scalars[2] = t.bark_band_width;
+    scalars[3] = t.dB_MIN;
+  }
+  return AC_OK;
+}
+
+// ---- plans --------------------------------------------------------------------------------------
+
+int ac_mdct_plan_create(int N, int window, int device, ac_mdct_plan** out) {
+  AC_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  AC_REQUIRE(N >= 2 && (N % 2) == 0, "number of filters used in mdct transformation needs to be even (got %d)", N);
+  AC_REQUIRE(N <= 8192, "filters_n = %d not supported (max 8192)", N);
+  AC_REQUIRE(valid_window(window), "unknown window id %d", window);
+  int st = check_device(device);
+  if (st) return st;
+  DeviceGuard guard(device);
+  ac_mdct_plan* p = new (std::nothrow) ac_mdct_plan();
+  if (!p) {
+    set_error("out of host memory");
+    return AC_ENOMEM;
+  }
+  p->N = N;
+  p->window = window;
+  p->device = device;
+  FoldCoef c;
+  fold_coefficients(N, window, c);
+  const int h = N / 2;
+  std::vector<float> coef(8 * (size_t)h);
+  const std::vector<double>* v[8] = {&c.a1, &c.a2, &c.a3, &c.a4, &c.s1, &c.s2, &c.s3, &c.s4};
+  for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < h; ++j) coef[(size_t)i * h + j] = (float)(*v[i])[j];
+  std::vector<float> ctab(8 * (size_t)N);
+  for (size_t i = 0; i < ctab.size(); ++i) ctab[i] = (float)std::cos(3.14159265358979323846 * (double)i / (4.0 * N));
+  st = upload(coef, &p->d_coef);
+  if (!st) st = upload(ctab, &p->d_ctab);
+  if (!st && fast_mdct_supported(N)) {
+    st = fast_mdct_plan_init(p);
+    if (!st) p->fast = 1;
+  }
+  if (st) {
+    ac_mdct_plan_destroy(p);
+    return st;
+  }
+  *out = p;
+  return AC_OK;
+}
+
+int ac_mdct_plan_destroy(ac_mdct_plan* p) {
+  if (!p) return AC_OK;
+  DeviceGuard guard(p->device);
+  (void)hipFree(p->d_coef);
+  (void)hipFree(p->d_ctab);
+  (void)hipFree(p->d_fast);
+  delete p;
+  return AC_OK;
+}
+
+int ac_psy_plan_create(int N, int M, double sample_rate, double alpha, int device, ac_psy_plan** out) {
+  AC_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  AC_REQUIRE(N >= 1 && M >= 1, "filter_bands_n (%d) and bark_bands_n (%d) must be positive", N, M);
+  AC_REQUIRE(N <= 8192 && M <= 4096, "filter_bands_n = %d / bark_bands_n = %d not supported", N, M);
+  AC_REQUIRE(sample_rate > 0 && alpha > 0, "sample_rate and alpha must be positive");
+  int st = check_device(device);
+  if (st) return st;
+  DeviceGuard guard(device);
+  ac_psy_plan* p = new (std::nothrow) ac_psy_plan();
+  if (!p) {
+    set_error("out of host memory");
+    return AC_ENOMEM;
+  }
+  p->N = N;
+  p->M = M;
+  p->device = device;
+  p->sample_rate = sample_rate;
+  p->alpha = alpha;
+  psy_tables(N, M, sample_rate, alpha, p->host);
+  SparseRows wb, wi;
+  w_by_band(p->host, wb);
+  winv_by_bin(p->host, wi);
+  p->wb_max = wb.max_row;
+  p->wi_max = wi.max_row;
+  std::vector<float> S(p->host.S.size()), quiet(M);
+  for (size_t i = 0; i < S.size(); ++i) S[i] = (float)p->host.S[i];
+  for (int j = 0; j < M; ++j) quiet[j] = (float)p->host.quiet[j];
+  st = upload(wb.ptr, &p->d_wb_ptr);
+  if (!st) st = upload(wb.idx, &p->d_wb_idx);
+  if (!st) st = upload(wb.val, &p->d_wb_val);
+  if (!st) st = upload(wi.ptr, &p->d_wi_ptr);
+  if (!st) st = upload(wi.idx, &p->d_wi_idx);
+  if (!st) st = upload(wi.val, &p->d_wi_val);
+  if (!st) st = upload(S, &p->d_S);
+  if (!st) st = upload(quiet, &p->d_quiet);
+  if (!st) st = upload(p->host.beta, &p->d_beta);
+  if (!st && fast_psy_supported(p)) {
+    st = fast_psy_plan_init(p);
+    if (!st) p->fast = 1;
+  }
+  if (st) {
+    ac_psy_plan_destroy(p);
+    return st;
+  }
+  *out = p;
+  return AC_OK;
+}
+
+int ac_psy_plan_destroy(ac_psy_plan* p) {
+  if (!p) return AC_OK;
+  DeviceGuard guard(p->device);
+  (void)hipFree(p->d_wb_ptr);
+  (void)hipFree(p->d_wb_idx);
+  (void)hipFree(p->d_wb_val);
+  (void)hipFree(p->d_wi_ptr);
+  (void)hipFree(p->d_wi_idx);
+  (void)hipFree(p->d_wi_val);
+  (void)hipFree(p->d_S);
+  (void)hipFree(p->d_quiet);
+  (void)hipFree(p->d_beta);
+  (void)hipFree(p->d_fast);
+  delete p;
+  return AC_OK;
+}
+
+int ac_mdct_plan_is_fast(const ac_mdct_plan* p) { return p ? p->fast : 0; }
+int ac_psy_plan_is_fast(const ac_psy_plan* p) { return p ? p->fast : 0; }
+
+// ---- hot path -------------------------------------------------------------------------------------
+
+static int check_dims(int B, int K, int C) {
+  AC_REQUIRE(B >= 0 && K >= 0 && C >= 0, "negative dimension (B=%d, blocks=%d, C=%d)", B, K, C);
+  return AC_OK;
+}
+
+int ac_mdct_forward(const ac_mdct_plan* p, const float* x, float* X, int B, int K, int C, void* stream) {
+  AC_REQUIRE(p != nullptr, "plan is NULL");
+  int st = check_dims(B, K, C);
+  if (st) return st;
+  if (B == 0 || C == 0) return AC_OK;
+  AC_REQUIRE(X != nullptr && (x != nullptr || K == 0), "NULL tensor pointer");
+  DeviceGuard guard(p->device);
+  hipStream_t s = (hipStream_t)stream;
+  if (p->fast && !g_force_generic)
+    return launch_fwd_fast(p, nullptr, x, X, nullptr, nullptr, 0.f, nullptr, B, K, K + 1, C, s);
+  return launch_fwd_generic(p, x, X, nullptr, B, K, K + 1, C, s);
+}
+
+int ac_mdct_inverse(const ac_mdct_plan* p, const float* X, float* x, int B, int Kp, int C, void* stream) {
+  AC_REQUIRE(p != nullptr, "plan is NULL");
+  int st = check_dims(B, Kp, C);
+  if (st) return st;
+  if (B == 0 || C == 0) return AC_OK;
+  AC_REQUIRE(x != nullptr && (X != nullptr || Kp == 0), "NULL tensor pointer");
+  DeviceGuard guard(p->device);
+  hipStream_t s = (hipStream_t)stream;
+  if (p->fast && !g_force_generic) return launch_inv_fast(p, X, x, nullptr, nullptr, B, Kp, Kp + 1, C, s);
+  return launch_inv_generic(p, X, x, nullptr, nullptr, B, Kp, Kp + 1, C, s);
+}
+
+int ac_tonality(const ac_psy_plan* p, const float* X, float* t, int B, int F, int C, void* stream) {
+  AC_REQUIRE(p != nullptr, "plan is NULL");
+  int st = check_dims(B, F, C);
+  if (st) return st;
+  if (B == 0 || C == 0 || F == 0) return AC_OK;
+  AC_REQUIRE(X != nullptr && t != nullptr, "NULL tensor pointer");
+  DeviceGuard guard(p->device);
+  hipStream_t s = (hipStream_t)stream;
+  if (p->fast && !g_force_generic) return launch_psy_fast(p, X, nullptr, t, nullptr, 0.f, B, F, C, s);
+  return launch_tonality_generic(p, X, t, B, F, C, s);
+}
+
+int ac_mask_threshold(const ac_psy_plan* p, const float* X, const float* t, float drown, float* thr, int B, int F,
+                      int C, void* stream) {
+  AC_REQUIRE(p != nullptr, "plan is NULL");
+  int st = check_dims(B, F, C);
+  if (st) return st;
+  if (B == 0 || C == 0 || F == 0) return AC_OK;
+  AC_REQUIRE(X != nullptr && t != nullptr && thr != nullptr, "NULL tensor pointer");
+  DeviceGuard guard(p->device);
+  hipStream_t s = (hipStream_t)stream;
+  if (p->fast && !g_force_generic) return launch_psy_fast(p, X, t, nullptr, thr, drown, B, F, C, s);
+  return launch_threshold_generic(p, X, t, drown, thr, B, F, C, s);
+}
+
+int ac_encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr,
+                    float drown, int B, int K, int C, void* stream) {
+  AC_REQUIRE(mdct != nullptr && psy != nullptr, "plan is NULL");
+  AC_REQUIRE(mdct->N == psy->N, "mdct filters_n (%d) != psychoacoustic filter_bands_n (%d)", mdct->N, psy->N);
+  AC_REQUIRE(mdct->device == psy->device, "plans live on different devices");
+  int st = check_dims(B, K, C);
+  if (st) return st;
+  if (B == 0 || C == 0) return AC_OK;
+  AC_REQUIRE(X != nullptr && t != nullptr && thr != nullptr && (x != nullptr || K == 0), "NULL tensor pointer");
+  DeviceGuard guard(mdct->device);
+  hipStream_t s = (hipStream_t)stream;
+  if (mdct->fast && psy->fast && !g_force_generic)
+    return launch_fwd_fast(mdct, psy, x, X, t, thr, drown, nullptr, B, K, K + 1, C, s);
+  // un-fused composition for configurations the fused kernel does not cover
+  st = ac_mdct_forward(mdct, x, X, B, K, C, stream);
+  if (!st) st = ac_tonality(psy, X, t, B, K + 1, C, stream);
+  if (!st) st = ac_mask_threshold(psy, X, t, drown, thr, B, K + 1, C, stream);
+  return st;
+}
+
+// ---- streaming ---------------------------------------------------------------------------------------
+
+int ac_stream_create(const ac_mdct_plan* plan, int B, int C, ac_stream** out) {
+  AC_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  AC_REQUIRE(plan != nullptr, "plan is NULL");
+  AC_REQUIRE(B >= 1 && C >= 1, "B (%d) and C (%d) must be positive", B, C);
+  DeviceGuard guard(plan->device);
+  ac_stream* s = new (std::nothrow) ac_stream();
+  if (!s) {
+    set_error("out of host memory");
+    return AC_ENOMEM;
+  }
+  s->plan = plan;
+  s->B = B;
+  s->C = C;
+  const size_t nb = (size_t)B * plan->N * C * sizeof(float);
+  const size_t nt = (size_t)B * C * (plan->N / 2) * sizeof(float);
+  hipError_t e = hipMalloc((void**)&s->d_prev_block, nb);
+  if (e == hipSuccess) e = hipMalloc((void**)&s->d_tail, nt);
+  if (e == hipSuccess) e = hipMalloc((void**)&s->d_tail_tmp, nt);
+  if (e == hipSuccess) e = hipMemset(s->d_prev_block, 0, nb);
+  if (e == hipSuccess) e = hipMemset(s->d_tail, 0, nt);
+  if (e == hipSuccess) e = hipMemset(s->d_tail_tmp, 0, nt);
+  if (e != hipSuccess) {
+    set_error("stream state allocation failed: %s", hipGetErrorString(e));
+    ac_stream_destroy(s);
+    return e == hipErrorOutOfMemory ? AC_ENOMEM : AC_EHIP;
+  }
+  *out = s;
+  return AC_OK;
+}
+
+int ac_stream_reset(ac_stream* s, void* stream) {
+  AC_REQUIRE(s != nullptr, "stream is NULL");
+  DeviceGuard guard(s->plan->device);
+  const size_t nb = (size_t)s->B * s->plan->N * s->C * sizeof(float);
+  const size_t nt = (size_t)s->B * s->C * (s->plan->N / 2) * sizeof(float);
+  AC_HIP_CHECK(hipMemsetAsync(s->d_prev_block, 0, nb, (hipStream_t)stream));
+  AC_HIP_CHECK(hipMemsetAsync(s->d_tail, 0, nt, (hipStream_t)stream));
+  return AC_OK;
+}
+
+int ac_stream_destroy(ac_stream* s) {
+  if (!s) return AC_OK;
+  DeviceGuard guard(s->plan->device);
+  (void)hipFree(s->d_prev_block);
+  (void)hipFree(s->d_tail);
+  (void)hipFree(s->d_tail_tmp);
+  delete s;
+  return AC_OK;
+}
+
+int ac_stream_forward(ac_stream* s, const float* x_chunk, float* X, int k, void* stream) {
+  AC_REQUIRE(s != nullptr, "stream is NULL");
+  AC_REQUIRE(k >= 0, "negative chunk length %d", k);
+  if (k == 0) return AC_OK;
+  AC_REQUIRE(x_chunk != nullptr && X != nullptr, "NULL tensor pointer");
+  const ac_mdct_plan* p = s->plan;
+  DeviceGuard guard(p->device);
+  hipStream_t hs = (hipStream_t)stream;
+  int st;
+  if (p->fast && !g_force_generic)
+    st = launch_fwd_fast(p, nullptr, x_chunk, X, nullptr, nullptr, 0.f, s->d_prev_block, s->B, k, k, s->C, hs);
+  else
+    st = launch_fwd_generic(p, x_chunk, X, s->d_prev_block, s->B, k, k, s->C, hs);
+  if (st) return st;
+  // new state = last block of the chunk, per clip: B rows of N*C floats, source pitch k*N*C floats
+  const size_t row = (size_t)p->N * s->C * sizeof(float);
+  AC_HIP_CHECK(hipMemcpy2DAsync(s->d_prev_block, row, x_chunk + (size_t)(k - 1) * p->N * s->C, row * k, row,
+                                (size_t)s->B, hipMemcpyDeviceToDevice, hs));
+  return AC_OK;
+}
+
+int ac_stream_inverse(ac_stream* s, const float* X_chunk, float* x, int k, void* stream) {
+  AC_REQUIRE(s != nullptr, "stream is NULL");
+  AC_REQUIRE(k >= 0, "negative chunk length %d", k);
+  if (k == 0) return AC_OK;
+  AC_REQUIRE(X_chunk != nullptr && x != nullptr, "NULL tensor pointer");
+  const ac_mdct_plan* p = s->plan;
+  DeviceGuard guard(p->device);
+  hipStream_t hs = (hipStream_t)stream;
+  int st;
+  if (p->fast && !g_force_generic)
+    st = launch_inv_fast(p, X_chunk, x, s->d_tail, s->d_tail_tmp, s->B, k, k, s->C, hs);
+  else
+    st = launch_inv_generic(p, X_chunk, x, s->d_tail, s->d_tail_tmp, s->B, k, k, s->C, hs);
+  if (st) return st;
+  std::swap(s->d_tail, s->d_tail_tmp);
+  return AC_OK;
+}
+
+// ---- element-wise utilities ------------------------------------------------------------------------
+
+int ac_amplitude_to_db(const float* a, float* out, size_t n, int norm, void* stream) {
+  AC_REQUIRE(n == 0 || (a != nullptr && out != nullptr), "NULL tensor pointer");
+  return launch_db(a, out, n, norm, (hipStream_t)stream);
+}
+
+int ac_add_noise(const float* X, const float* thr, float* out, size_t n, uint64_t seed, void* stream) {
+  AC_REQUIRE(n == 0 || (X != nullptr && thr != nullptr && out != nullptr), "NULL tensor pointer");
+  return launch_add_noise(X, thr, out, n, seed, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,331 @@
+// Generic kernels: any even N, any channel count, any Bark-band count.  O(N^2) direct DCT-IV.
+// They are the path for sizes the wave-level FFT kernels (ac_fast.hip) do not cover and an
+// independent on-device cross-check for them.  gfx950 only.
+#include "ac_internal.h"
+
+namespace ac {
+
+static constexpr int kThreads = 256;
+static constexpr float kEps = 1e-14f;   // _INTENSITY_EPS, psychoacoustic.py:56
+
+// ------------------------------------------------------------------------------------------------
+// analysis: fold (mdctransformer.py:118,349-368 in closed form) + DCT-IV (:311-347) + scale (:125)
+// one workgroup per (signal = b*C + c, frame n)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_fwd_generic(const float* __restrict__ x, float* __restrict__ X,
+                                                          const float* __restrict__ prev_block,
+                                                          const float* __restrict__ coef,
+                                                          const float* __restrict__ ctab, int Kin, int F, int C,
+                                                          int N) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* v = smem;  // [N]
+  const int h = N >> 1;
+  const long long wg = blockIdx.x;
+  const int n = (int)(wg % F);
+  const long long sig = wg / F;
+  const int c = (int)(sig % C);
+  const long long b = sig / C;
+  const float* a1 = coef;
+  const float* a2 = coef + h;
+  const float* a3 = coef + 2 * h;
+  const float* a4 = coef + 3 * h;
+
+  const bool has_cur = n < Kin;
+  const float* xc = x + ((size_t)b * Kin + (size_t)n) * N * C + c;              // block n
+  const float* xp = nullptr;                                                       // block n-1
+  if (n >= 1) xp = x + ((size_t)b * Kin + (size_t)(n - 1)) * N * C + c;
+  else if (prev_block) xp = prev_block + (size_t)b * N * C + c;
+
+  for (int j = threadIdx.x; j < h; j += kThreads) {
+    float vc = 0.f, vp = 0.f;
+    if (has_cur) vc = a1[j] * xc[(size_t)j * C] + a2[j] * xc[(size_t)(N - 1 - j) * C];
+    if (xp) vp = a3[j] * xp[(size_t)(h - 1 - j) * C] + a4[j] * xp[(size_t)(h + j) * C];
+    v[h + j] = vc;
+    v[j] = vp;
+  }
+  __syncthreads();
+
+  const unsigned mod = 8u * (unsigned)N;
+  const double scale = 1.0 / ((double)N * 1.4142135623730951);   // 1/sqrt(4N) * sqrt(2/N)
+  float* Xo = X + (((size_t)b * F + (size_t)n) * N) * C + c;
+  for (int k = threadIdx.x; k < N; k += kThreads) {
+    const unsigned step = (unsigned)((2ull * (2ull * k + 1ull)) % mod);
+    unsigned idx = (unsigned)((2ull * k + 1ull) % mod);   // (2m+1)(2k+1) at m = 0
+    double acc = 0.0;
+    for (int m = 0; m < N; ++m) {
+      acc += (double)v[m] * (double)ctab[idx];
+      idx += step;
+      if (idx >= mod) idx -= mod;
+    }
+    Xo[(size_t)k * C] = (float)(acc * scale);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthesis: scale (mdctransformer.py:145) + DCT-IV + unfold/overlap-add (:148 in closed form)
+// one workgroup per (signal, output block n); block n = nblk only writes the new stream state
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_inv_generic(const float* __restrict__ X, float* __restrict__ x,
+                                                          const float* __restrict__ tail_in,
+                                                          float* __restrict__ tail_out,
+                                                          const float* __restrict__ coef,
+                                                          const float* __restrict__ ctab, int Kp, int nblk,
+                                                          int nwg_per_sig, int C, int N) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xn = smem;       // [N] frame n
+  float* Xm = smem + N;   // [N] frame n-1
+  const int h = N >> 1;
+  const long long wg = blockIdx.x;
+  const int n = (int)(wg % nwg_per_sig);
+  const long long sig = wg / nwg_per_sig;
+  const int c = (int)(sig % C);
+  const long long b = sig / C;
+  const float* s1 = coef + 4 * h;
+  const float* s2 = coef + 5 * h;
+  const float* s3 = coef + 6 * h;
+  const float* s4 = coef + 7 * h;
+
+  const bool has_n = n < Kp && n < nblk;   // the virtual state block (n == nblk) has no current frame
+  const bool has_m = n >= 1;
+  for (int k = threadIdx.x; k < N; k += kThreads) {
+    Xn[k] = has_n ? X[(((size_t)b * Kp + (size_t)n) * N + k) * C + c] : 0.f;
+    Xm[k] = has_m ? X[(((size_t)b * Kp + (size_t)(n - 1)) * N + k) * C + c] : 0.f;
+  }
+  __syncthreads();
+
+  const unsigned mod = 8u * (unsigned)N;
+  const double scale = 2.0 * 1.4142135623730951;   // sqrt(4N) * sqrt(2/N)
+  for (int j = threadIdx.x; j < h; j += kThreads) {
+    double a = 0.0, bb = 0.0;
+    if (has_n) {   // u_n[h-1-j]
+      const unsigned long long mm = 2ull * (unsigned)(h - 1 - j) + 1ull;
+      const unsigned step = (unsigned)((2ull * mm) % mod);
+      unsigned idx = (unsigned)(mm % mod);
+      for (int k = 0; k < N; ++k) {
+        a += (double)Xn[k] * (double)ctab[idx];
+        idx += step;
+        if (idx >= mod) idx -= mod;
+      }
+      a *= scale;
+    }
+    if (has_m) {   // u_{n-1}[h+j]
+      const unsigned long long mm = 2ull * (unsigned)(h + j) + 1ull;
+      const unsigned step = (unsigned)((2ull * mm) % mod);
+      unsigned idx = (unsigned)(mm % mod);
+      for (int k = 0; k < N; ++k) {
+        bb += (double)Xm[k] * (double)ctab[idx];
+        idx += step;
+        if (idx >= mod) idx -= mod;
+      }
+      bb *= scale;
+    } else if (tail_in) {
+      bb = (double)tail_in[((size_t)b * C + c) * h + j];
+    }
+    if (n < nblk) {
+      float* xo = x + (((size_t)b * nblk + (size_t)n) * N) * C + c;
+      xo[(size_t)j * C] = (float)((double)s1[j] * a + (double)s2[j] * bb);
+      xo[(size_t)(N - 1 - j) * C] = (float)((double)s3[j] * a + (double)s4[j] * bb);
+    } else if (tail_out) {
+      tail_out[((size_t)b * C + c) * h + j] = (float)bb;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tonality (psychoacoustic.py:102-120), one workgroup per (b, frame, c)
+// ------------------------------------------------------------------------------------------------
+__device__ inline float block_sum(float v, float* red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int w = 0; w < kThreads / 64; ++w) s += red[w];
+  return s;
+}
+
+__global__ __launch_bounds__(kThreads) void k_tonality_generic(const float* __restrict__ X, float* __restrict__ t,
+                                                               int C, int N) {
+  __shared__ float red[kThreads / 64];
+  const long long wg = blockIdx.x;   // (b*F + f)*C + c
+  const int c = (int)(wg % C);
+  const long long bf = wg / C;
+  const float* Xi = X + (size_t)bf * N * C + c;
+  float slog = 0.f, ssq = 0.f;
+  for (int k = threadIdx.x; k < N; k += kThreads) {
+    const float a = Xi[(size_t)k * C];
+    const float I = a * a;
+    slog += logf(fmaxf(kEps, I));
+    ssq += I;
+  }
+  slog = block_sum(slog, red);
+  ssq = block_sum(ssq, red);
+  if (threadIdx.x == 0) {
+    const float gm = expf(slog / (float)N);
+    const float am = ssq / (float)N + kEps;
+    const float sfm = 10.f * logf(gm / am) / 2.302585092994046f;
+    t[wg] = fminf(sfm / -60.f, 1.f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// global masking threshold (psychoacoustic.py:122-148 with :169-210, :301-331), factorised form
+// one workgroup per (b, frame, c)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_threshold_generic(
+    const float* __restrict__ X, const float* __restrict__ t, float* __restrict__ thr, float drown, float alpha,
+    const int32_t* __restrict__ wb_ptr, const int32_t* __restrict__ wb_idx, const float* __restrict__ wb_val,
+    const int32_t* __restrict__ wi_ptr, const int32_t* __restrict__ wi_idx, const float* __restrict__ wi_val,
+    const float* __restrict__ S, const float* __restrict__ quiet, const float* __restrict__ beta, int C, int N,
+    int M) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* I = smem;       // [N]
+  float* Q = smem + N;   // [M]
+  float* G = Q + M;      // [M]
+  const long long wg = blockIdx.x;
+  const int c = (int)(wg % C);
+  const long long bf = wg / C;
+  const float* Xi = X + (size_t)bf * N * C + c;
+  for (int k = threadIdx.x; k < N; k += kThreads) {
+    const float a = Xi[(size_t)k * C];
+    I[k] = a * a;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < M; j += kThreads) {   // _to_bark_intensity (:301-315)
+    float P = 0.f;
+    for (int e = wb_ptr[j]; e < wb_ptr[j + 1]; ++e) P += I[wb_idx[e]] * wb_val[e];
+    Q[j] = powf(fmaxf(kEps, P), alpha);               // (:206)
+  }
+  __syncthreads();
+  const float tt = t[wg];
+  for (int j = threadIdx.x; j < M; j += kThreads) {   // _masking_intensity_in_bark (:169-210)
+    float acc = 0.f;
+    for (int i = 0; i < M; ++i) acc += Q[i] * S[(size_t)i * M + j];
+    const float offset = (1.f - drown) * (tt * beta[j] + 9.f * tt + 5.5f);     // (:185-191)
+    const float fac = powf(10.f, -alpha * offset / 10.f);                       // (:197)
+    const float T = powf(fmaxf(kEps, fac * acc), 1.f / alpha);                  // (:208)
+    G[j] = fmaxf(T, quiet[j]);                                                  // (:144)
+  }
+  __syncthreads();
+  float* out = thr + (size_t)bf * N * C + c;
+  for (int k = threadIdx.x; k < N; k += kThreads) {   // _bark_intensity_to_freq_ampl (:317-331)
+    float acc = 0.f;
+    for (int e = wi_ptr[k]; e < wi_ptr[k + 1]; ++e) acc += G[wi_idx[e]] * wi_val[e];
+    out[(size_t)k * C] = sqrtf(fmaxf(kEps, acc));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// element-wise utilities
+// ------------------------------------------------------------------------------------------------
+__global__ void k_db(const float* __restrict__ a, float* __restrict__ out, size_t n, int norm) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = a[i];
+    float dB = 10.f * logf(fmaxf(kEps, v * v)) / 2.302585092994046f + 120.f;   // psychoacoustic.py:83-85
+    if (norm) dB = (dB - (-20.f)) / (120.f - (-20.f));                          // :98-100
+    out[i] = dB;
+  }
+}
+
+// counter-based generator: two rounds of a 64-bit mix (splitmix64) -> Box-Muller
+__device__ inline uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__global__ void k_add_noise(const float* __restrict__ X, const float* __restrict__ thr, float* __restrict__ out,
+                            size_t n, uint64_t seed) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint64_t r = mix64(mix64(seed) ^ (uint64_t)i);
+    const float u1 = ((float)(uint32_t)(r >> 40) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
+    const float u2 = (float)(uint32_t)((r >> 8) & 0xFFFFFFu) * (1.0f / 16777216.0f);
+    const float g = sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+    out[i] = X[i] + thr[i] * (g * (1.0f / 6.0f));                                  // psychoacoustic.py:165-167
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static int check_grid(long long n) {
+  if (n <= 0) return 1;
+  if (n > 2147483647ll) {
+    set_error("problem too large for one launch (%lld workgroups)", n);
+    return AC_EINVAL;
+  }
+  return 0;
+}
+
+int launch_fwd_generic(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin,
+                       int F, int C, hipStream_t s) {
+  const long long nwg = (long long)B * C * F;
+  const int st = check_grid(nwg);
+  if (st) return st < 0 ? st : AC_OK;
+  const size_t lds = (size_t)p->N * sizeof(float);
+  AC_REQUIRE(lds <= 64 * 1024, "filters_n = %d too large for the generic kernel", p->N);
+  hipLaunchKernelGGL(k_fwd_generic, dim3((unsigned)nwg), dim3(kThreads), lds, s, x, X, prev_block, p->d_coef,
+                     p->d_ctab, Kin, F, C, p->N);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+int launch_inv_generic(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out,
+                       int B, int Kp, int nblk, int C, hipStream_t s) {
+  const int per_sig = nblk + (tail_out ? 1 : 0);
+  const long long nwg = (long long)B * C * per_sig;
+  const int st = check_grid(nwg);
+  if (st) return st < 0 ? st : AC_OK;
+  const size_t lds = 2 * (size_t)p->N * sizeof(float);
+  AC_REQUIRE(lds <= 64 * 1024, "filters_n = %d too large for the generic kernel", p->N);
+  hipLaunchKernelGGL(k_inv_generic, dim3((unsigned)nwg), dim3(kThreads), lds, s, X, x, tail_in, tail_out,
+                     p->d_coef, p->d_ctab, Kp, nblk, per_sig, C, p->N);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+int launch_tonality_generic(const ac_psy_plan* p, const float* X, float* t, int B, int F, int C, hipStream_t s) {
+  const long long nwg = (long long)B * F * C;
+  const int st = check_grid(nwg);
+  if (st) return st < 0 ? st : AC_OK;
+  hipLaunchKernelGGL(k_tonality_generic, dim3((unsigned)nwg), dim3(kThreads), 0, s, X, t, C, p->N);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+int launch_threshold_generic(const ac_psy_plan* p, const float* X, const float* t, float drown, float* thr, int B,
+                             int F, int C, hipStream_t s) {
+  const long long nwg = (long long)B * F * C;
+  const int st = check_grid(nwg);
+  if (st) return st < 0 ? st : AC_OK;
+  const size_t lds = ((size_t)p->N + 2 * (size_t)p->M) * sizeof(float);
+  AC_REQUIRE(lds <= 64 * 1024, "filter_bands_n = %d / bark_bands_n = %d too large for the generic kernel", p->N,
+             p->M);
+  hipLaunchKernelGGL(k_threshold_generic, dim3((unsigned)nwg), dim3(kThreads), lds, s, X, t, thr, drown,
+                     (float)p->alpha, p->d_wb_ptr, p->d_wb_idx, p->d_wb_val, p->d_wi_ptr, p->d_wi_idx, p->d_wi_val,
+                     p->d_S, p->d_quiet, p->d_beta, C, p->N, p->M);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+int launch_db(const float* a, float* out, size_t n, int norm, hipStream_t s) {
+  if (n == 0) return AC_OK;
+  const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_db, dim3(grid), dim3(256), 0, s, a, out, n, norm);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+int launch_add_noise(const float* X, const float* thr, float* out, size_t n, uint64_t seed, hipStream_t s) {
+  if (n == 0) return AC_OK;
+  const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_add_noise, dim3(grid), dim3(256), 0, s, X, thr, out, n, seed);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+}  // namespace ac

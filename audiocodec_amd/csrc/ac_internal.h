@@ -1,0 +1,114 @@
+// Internal declarations shared by the translation units of libaudiocodec_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "../../include/audiocodec_amd.h"
+#include "ac_tables.h"
+
+namespace ac {
+
+void set_error(const char* fmt, ...);
+
+#define AC_HIP_CHECK(expr)                                                                   \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      ac::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return AC_EHIP;                                                                        \
+    }                                                                                        \
+  } while (0)
+
+#define AC_REQUIRE(cond, ...)      \
+  do {                             \
+    if (!(cond)) {                 \
+      ac::set_error(__VA_ARGS__);  \
+      return AC_EINVAL;            \
+    }                              \
+  } while (0)
+
+// Makes `device` current for the lifetime of the guard (no-op when it already is).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != device) {
+      switched = (hipSetDevice(device) == hipSuccess);
+    }
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+extern int g_force_generic;
+
+}  // namespace ac
+
+// ---- plan objects ---------------------------------------------------------------------------
+
+struct ac_mdct_plan {
+  int N = 0, window = 0, device = 0;
+  int fast = 0;                // 1: wave-level FFT kernels available for this N
+  float* d_coef = nullptr;     // [8][N/2]  a1 a2 a3 a4 s1 s2 s3 s4
+  float* d_ctab = nullptr;     // [8N]      cos(pi i / (4N)), generic kernels
+  // fast-path tables (ac_fast.hip): per-FFT-element fold coefficients and twiddles
+  float* d_fast = nullptr;
+  size_t fast_bytes = 0;
+};
+
+struct ac_psy_plan {
+  int N = 0, M = 0, device = 0;
+  double sample_rate = 0, alpha = 0;
+  int fast = 0;                // 1: the fused wave-level epilogue supports this (N, M, table shape)
+  ac::PsyTables host;
+  int32_t* d_wb_ptr = nullptr; int32_t* d_wb_idx = nullptr; float* d_wb_val = nullptr; int wb_max = 0;
+  int32_t* d_wi_ptr = nullptr; int32_t* d_wi_idx = nullptr; float* d_wi_val = nullptr; int wi_max = 0;
+  float* d_S = nullptr;        // [M, M]
+  float* d_quiet = nullptr;    // [M]
+  float* d_beta = nullptr;     // [M]
+  // fast-path tables (ac_fast.hip)
+  float* d_fast = nullptr;
+  size_t fast_bytes = 0;
+};
+
+struct ac_stream {
+  const ac_mdct_plan* plan = nullptr;
+  int B = 0, C = 0;
+  float* d_prev_block = nullptr;   // analysis state  [B, N, C]
+  float* d_tail = nullptr;         // synthesis state [B, C, N/2]  (u_last[h .. N-1])
+  float* d_tail_tmp = nullptr;     // double buffer for the synthesis state
+};
+
+// ---- kernel launchers (each returns an AC_* status) -----------------------------------------
+namespace ac {
+
+// generic O(N^2) kernels: any even N, any C, any M
+int launch_fwd_generic(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin,
+                       int F, int C, hipStream_t s);
+int launch_inv_generic(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out,
+                       int B, int Kp, int nblk, int C, hipStream_t s);
+int launch_tonality_generic(const ac_psy_plan* p, const float* X, float* t, int B, int F, int C, hipStream_t s);
+int launch_threshold_generic(const ac_psy_plan* p, const float* X, const float* t, float drown, float* thr, int B,
+                             int F, int C, hipStream_t s);
+
+// wave-level FFT kernels (ac_fast.hip)
+bool fast_mdct_supported(int N);
+bool fast_psy_supported(const ac_psy_plan* p);
+int fast_mdct_plan_init(ac_mdct_plan* p);
+int fast_psy_plan_init(ac_psy_plan* p);
+// psy may be null (plain transform).  X/t/thr as in ac_encode_fused.
+int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr,
+                    float drown, const float* prev_block, int B, int Kin, int F, int C, hipStream_t s);
+int launch_inv_fast(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out, int B,
+                    int Kp, int nblk, int C, hipStream_t s);
+int launch_psy_fast(const ac_psy_plan* p, const float* X, const float* t_in, float* t_out, float* thr, float drown,
+                    int B, int F, int C, hipStream_t s);
+
+int launch_db(const float* a, float* out, size_t n, int norm, hipStream_t s);
+int launch_add_noise(const float* X, const float* thr, float* out, size_t n, uint64_t seed, hipStream_t s);
+
+}  // namespace ac

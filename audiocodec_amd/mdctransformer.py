@@ -1,0 +1,122 @@
+"""MDCT analysis / synthesis filter bank on MI355X.
+
+Drop-in for ``audiocodec.mdctransformer.MDCTransformer`` (reference
+``audiocodec/mdctransformer.py:12-368``): same constructor keywords, method names, tensor layouts
+and attribute names; tensors are ``torch`` tensors on a ROCm device instead of ``tf.Tensor``.
+The arithmetic is done by hand-written HIP kernels behind the C ABI of ``libaudiocodec_amd.so``;
+PyTorch only owns the device memory and the stream.
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _host, _lib
+
+
+class MDCTransformer:
+    def __init__(self, filters_n=1024, window_type="vorbis", compute_dtype=torch.float32,
+                 precompute_dtype=torch.float64):
+        """Same signature as the reference (``mdctransformer.py:13-14``).
+
+        :param filters_n:        number of filter bands (must be even, ``:26``)
+        :param window_type:      'sine', 'vorbis' (default); any other string or None selects the
+                                 rectangular window (``:199-211``; the reference crashes on None)
+        :param compute_dtype:    dtype of inputs and outputs; the HIP path supports float32
+        :param precompute_dtype: constants are always pre-computed in float64 on the host (the
+                                 reference's default, ``:14,31-35``); other values are rejected
+        """
+        assert (filters_n % 2) == 0, "number of filters used in mdct transformation needs to be even"
+        self.filters_n = int(filters_n)
+        self.window_type = window_type
+        self.compute_dtype = _host.as_torch_dtype(compute_dtype)
+        self.precompute_dtype = _host.as_torch_dtype(precompute_dtype)
+        _host.require_hip_compute_dtype(self.compute_dtype, "MDCTransformer")
+        if self.precompute_dtype != torch.float64:
+            raise NotImplementedError("constants are pre-computed in float64 only")
+        self._window = _lib.window_id(window_type)
+        self._lib = _lib.load()
+        self._H = None
+        self._H_inv = None
+        n, w, lib = self.filters_n, self._window, self._lib
+        self._plans = _host.PlanCache(self, lambda dev, out: lib.ac_mdct_plan_create(n, w, dev, out),
+                                      lib.ac_mdct_plan_destroy)
+
+    # ---- dense polyphase matrices, for attribute parity only (mdctransformer.py:58-59) -------------
+    def _dense(self):
+        if self._H is None:
+            n = self.filters_n
+            H = np.empty((2, n, n), dtype=np.float32)
+            Hi = np.empty((2, n, n), dtype=np.float32)
+            fp = ctypes.POINTER(ctypes.c_float)
+            _lib.check(self._lib.ac_mdct_dense_matrices_host(n, self._window, H.ctypes.data_as(fp),
+                                                             Hi.ctypes.data_as(fp)))
+            self._H, self._H_inv = torch.from_numpy(H), torch.from_numpy(Hi)
+        return self._H, self._H_inv
+
+    @property
+    def H(self):
+        """[2, N, N] analysis polyphase matrix (2N non-zeros); built lazily, never used by the kernels."""
+        return self._dense()[0]
+
+    @property
+    def H_inv(self):
+        """[2, N, N] synthesis polyphase matrix; built lazily, never used by the kernels."""
+        return self._dense()[1]
+
+    def fold_coefficients(self):
+        """The 8 x N/2 non-zeros of F and F^-1 in float64 (a1..a4, s1..s4; see include/audiocodec_amd.h)."""
+        h = self.filters_n // 2
+        coef = np.empty((8, h), dtype=np.float64)
+        _lib.check(self._lib.ac_mdct_fold_coefficients_host(
+            self.filters_n, self._window, coef.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+        return coef
+
+    def is_fast(self, device=None):
+        """True when this size runs the wave-level FFT kernels (else the generic O(N^2) kernels)."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        return bool(self._lib.ac_mdct_plan_is_fast(self._plans.get(dev)))
+
+    # ---- analysis ------------------------------------------------------------------------------------
+    def transform(self, x):
+        """MDCT analysis filter bank (reference ``transform``, ``mdctransformer.py:62-125``).
+
+        :param x: signal in -1..1, ``[batches_n, samples_n, channels_n]``, ``samples_n`` a multiple of
+                  ``filters_n`` (the reference's reshape raises otherwise, ``:287,295``; here ValueError)
+        :return:  ``[batches_n, blocks_n + 1, filters_n, channels_n]`` amplitudes in ]-1, 1[
+        """
+        x = _host.check_device_tensor(x, "x", self.compute_dtype, 3)
+        B, S, C = x.shape
+        N = self.filters_n
+        if S % N != 0:
+            raise ValueError("samples_n (%d) is not a multiple of filters_n (%d)" % (S, N))
+        K = S // N
+        X = torch.empty((B, K + 1, N, C), dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(self._lib.ac_mdct_forward(self._plans.get(x.device), _host.ptr(x), _host.ptr(X), B, K, C,
+                                                 _host.stream_ptr(x.device)))
+        return X
+
+    # ---- synthesis -----------------------------------------------------------------------------------
+    def inverse_transform(self, mdct_amplitudes):
+        """MDCT synthesis filter bank (reference ``inverse_transform``, ``mdctransformer.py:128-153``).
+
+        :param mdct_amplitudes: ``[batches_n, blocks_n, filters_n, channels_n]``
+        :return:                ``[batches_n, (blocks_n + 1) * filters_n, channels_n]``
+        """
+        X = _host.check_device_tensor(mdct_amplitudes, "mdct_amplitudes", self.compute_dtype, 4)
+        B, Kp, N, C = X.shape
+        if N != self.filters_n:
+            raise ValueError("axis 2 of mdct_amplitudes (%d) != filters_n (%d)" % (N, self.filters_n))
+        x = torch.empty((B, (Kp + 1) * N, C), dtype=X.dtype, device=X.device)
+        with torch.cuda.device(X.device):
+            _lib.check(self._lib.ac_mdct_inverse(self._plans.get(X.device), _host.ptr(X), _host.ptr(x), B, Kp, C,
+                                                 _host.stream_ptr(X.device)))
+        return x
+
+    # native handle for the fused / streaming entry points
+    def _plan(self, device):
+        return self._plans.get(device)

@@ -1,0 +1,154 @@
+"""Psychoacoustic masking model on MI355X.
+
+Drop-in for ``audiocodec.psychoacoustic.PsychoacousticModel`` (reference
+``audiocodec/psychoacoustic.py:13-339``): same constructor keywords, methods, layouts and
+attributes, on ``torch`` ROCm tensors.  Constants are pre-computed in float64 by the native
+library (host side), the per-frame model runs in hand-written HIP kernels.
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _host, _lib
+
+
+class PsychoacousticModel:
+    def __init__(self, sample_rate, filter_bands_n=1024, bark_bands_n=64, alpha=0.6,
+                 compute_dtype=torch.float32, precompute_dtype=torch.float64):
+        """Same signature as the reference (``psychoacoustic.py:14-15``).
+
+        :raises TypeError: when compute_dtype is not float64, float32 or bfloat16 (``:42-43``);
+                           of those the HIP path implements float32 (others: NotImplementedError)
+        """
+        self.alpha = alpha
+        self.sample_rate = sample_rate
+        self.bark_bands_n = int(bark_bands_n)
+        self.filter_bands_n = int(filter_bands_n)
+        compute_dtype = _host.as_torch_dtype(compute_dtype)
+        if compute_dtype not in (torch.float64, torch.float32, torch.bfloat16):
+            raise TypeError("compute_dtype of PsychoacousticModel should be float64, float32 or bfloat16")
+        self.compute_dtype = compute_dtype
+        _host.require_hip_compute_dtype(compute_dtype, "PsychoacousticModel")
+        if _host.as_torch_dtype(precompute_dtype) != torch.float64:
+            raise NotImplementedError("constants are pre-computed in float64 only")
+        self._lib = _lib.load()
+
+        N, M = self.filter_bands_n, self.bark_bands_n
+        W = np.empty((N, M), dtype=np.float32)
+        W_inv = np.empty((M, N), dtype=np.float32)
+        S = np.empty((M, M), dtype=np.float32)
+        quiet = np.empty((M,), dtype=np.float32)
+        scalars = np.empty((4,), dtype=np.float64)
+        fp = ctypes.POINTER(ctypes.c_float)
+        _lib.check(self._lib.ac_psy_tables_host(
+            N, M, float(sample_rate), float(alpha), W.ctypes.data_as(fp), W_inv.ctypes.data_as(fp),
+            S.ctypes.data_as(fp), quiet.ctypes.data_as(fp), scalars.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+        self._dB_MAX = torch.tensor(120.0, dtype=compute_dtype)                 # :52
+        self._INTENSITY_EPS = torch.tensor(1e-14, dtype=compute_dtype)          # :56
+        self._dB_MIN = torch.tensor(scalars[3], dtype=compute_dtype)            # :58  (= -20 dB)
+        self.max_frequency = torch.tensor(scalars[0], dtype=torch.float64)      # :61
+        self.max_bark = torch.tensor(scalars[1], dtype=torch.float64)           # :62
+        self.bark_band_width = torch.tensor(scalars[2], dtype=torch.float64)    # :63
+        self.W = torch.from_numpy(W)                                            # :66
+        self.W_inv = torch.from_numpy(W_inv)                                    # :67
+        self.quiet_threshold_intensity = torch.from_numpy(quiet).reshape(1, 1, M, 1)   # :68
+        self.spreading_matrix = torch.from_numpy(S)                             # :69
+
+        sr, al, lib = float(sample_rate), float(alpha), self._lib
+        self._plans = _host.PlanCache(self, lambda dev, out: lib.ac_psy_plan_create(N, M, sr, al, dev, out),
+                                      lib.ac_psy_plan_destroy)
+
+    def _plan(self, device):
+        return self._plans.get(device)
+
+    def is_fast(self, device=None):
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        return bool(self._lib.ac_psy_plan_is_fast(self._plans.get(dev)))
+
+    # ---- element-wise utilities -----------------------------------------------------------------
+    def _elementwise_db(self, mdct_amplitude, norm):
+        a = mdct_amplitude
+        if not isinstance(a, torch.Tensor):
+            raise TypeError("mdct_amplitude must be a torch.Tensor")
+        if a.dtype != self.compute_dtype:
+            raise ValueError("mdct_amplitude has dtype %s but compute_dtype is %s" % (a.dtype, self.compute_dtype))
+        if not a.is_cuda:
+            raise RuntimeError("mdct_amplitude lives on %s: no CPU fallback" % a.device)
+        a = a.contiguous()
+        out = torch.empty_like(a)
+        with torch.cuda.device(a.device):
+            _lib.check(self._lib.ac_amplitude_to_db(_host.ptr(a), _host.ptr(out), a.numel(), int(norm),
+                                                    _host.stream_ptr(a.device)))
+        return out
+
+    def amplitude_to_dB(self, mdct_amplitude):
+        """``amplitude_to_dB`` (``psychoacoustic.py:71-85``): [-1,1] amplitude -> dB in [_dB_MIN, _dB_MAX]."""
+        return self._elementwise_db(mdct_amplitude, False)
+
+    def amplitude_to_dB_norm(self, mdct_amplitude):
+        """``amplitude_to_dB_norm`` (``psychoacoustic.py:87-100``): dB scale normalised to [0, 1]."""
+        return self._elementwise_db(mdct_amplitude, True)
+
+    # ---- per-frame model -------------------------------------------------------------------------
+    def _check_spectrum(self, X, name="mdct_amplitudes"):
+        X = _host.check_device_tensor(X, name, self.compute_dtype, 4)
+        if X.shape[2] != self.filter_bands_n:
+            raise ValueError("axis 2 of %s (%d) != filter_bands_n (%d)" % (name, X.shape[2], self.filter_bands_n))
+        return X
+
+    def tonality(self, mdct_amplitudes):
+        """``tonality`` (``psychoacoustic.py:102-120``): [B, K, N, C] -> [B, K, 1, C] in [0, 1]."""
+        X = self._check_spectrum(mdct_amplitudes)
+        B, F, N, C = X.shape
+        t = torch.empty((B, F, 1, C), dtype=X.dtype, device=X.device)
+        with torch.cuda.device(X.device):
+            _lib.check(self._lib.ac_tonality(self._plans.get(X.device), _host.ptr(X), _host.ptr(t), B, F, C,
+                                             _host.stream_ptr(X.device)))
+        return t
+
+    def global_masking_threshold(self, mdct_amplitudes, tonality_per_block, drown=0.0):
+        """``global_masking_threshold`` (``psychoacoustic.py:122-148``): -> [B, K, N, C], strictly positive."""
+        X = self._check_spectrum(mdct_amplitudes)
+        B, F, N, C = X.shape
+        t = _host.check_device_tensor(tonality_per_block, "tonality_per_block", self.compute_dtype, 4)
+        if tuple(t.shape) != (B, F, 1, C):
+            raise ValueError("tonality_per_block must have shape %s, got %s" % ((B, F, 1, C), tuple(t.shape)))
+        if t.device != X.device:
+            raise ValueError("mdct_amplitudes and tonality_per_block live on different devices")
+        thr = torch.empty_like(X)
+        with torch.cuda.device(X.device):
+            _lib.check(self._lib.ac_mask_threshold(self._plans.get(X.device), _host.ptr(X), _host.ptr(t),
+                                                   float(drown), _host.ptr(thr), B, F, C,
+                                                   _host.stream_ptr(X.device)))
+        return thr
+
+    def add_noise(self, mdct_amplitudes, masking_threshold, seed=None):
+        """``add_noise`` (``psychoacoustic.py:150-167``): X + thr * Normal(0, 1/6).
+
+        The generator is counter-based (seed, element index); the stream differs from TensorFlow's, so
+        parity is statistical (mean 0, sigma = thr / 6).  ``seed=None`` draws one from torch's generator.
+        """
+        X = self._check_spectrum(mdct_amplitudes)
+        thr = _host.check_device_tensor(masking_threshold, "masking_threshold", self.compute_dtype, 4)
+        if thr.shape != X.shape or thr.device != X.device:
+            raise ValueError("masking_threshold must match mdct_amplitudes in shape and device")
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        out = torch.empty_like(X)
+        with torch.cuda.device(X.device):
+            _lib.check(self._lib.ac_add_noise(_host.ptr(X), _host.ptr(thr), _host.ptr(out), X.numel(),
+                                              int(seed) & (2 ** 64 - 1), _host.stream_ptr(X.device)))
+        return out
+
+    # ---- Bark scale (host precompute helpers, psychoacoustic.py:333-339) ------------------------------
+    def freq2bark(self, frequencies):
+        """Empirical Bark scale (``:333-335``)."""
+        return 6.0 * torch.asinh(torch.as_tensor(frequencies, dtype=torch.float64) / 600.0)
+
+    def bark2freq(self, bark_band):
+        """Empirical Bark scale (``:337-339``)."""
+        return 600.0 * torch.sinh(torch.as_tensor(bark_band, dtype=torch.float64) / 6.0)

@@ -1,0 +1,143 @@
+/*
+ * audiocodec_amd.h -- C ABI of the MI355X (gfx950) MDCT + psychoacoustic-masking library.
+ *
+ * The reference (korneelvdbroek/audiocodec) has no FFI: its boundary is the Python API of
+ * audiocodec/mdctransformer.py and audiocodec/psychoacoustic.py, whose arithmetic is delegated to
+ * TensorFlow ops.  Each entry point below replaces the TensorFlow op sequence of one reference
+ * method (cited as file:line into the reference tree); INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add to bind them.
+ *
+ * Conventions
+ *  - plain C types only; device pointers are raw HIP device addresses owned by the caller;
+ *  - tensor layouts are exactly the reference's, contiguous, float32, channels innermost:
+ *        PCM        x   [B, S, C]        S = K * N samples        (mdctransformer.py:104)
+ *        spectrum   X   [B, F, N, C]     F frames of N filters    (mdctransformer.py:105-107)
+ *        tonality   t   [B, F, 1, C]                              (psychoacoustic.py:110)
+ *        threshold  thr [B, F, N, C]                              (psychoacoustic.py:134-135)
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream); every call only
+ *    enqueues work and returns without synchronising; the library never allocates, frees or
+ *    synchronises caller memory and never changes the current device outside *_create;
+ *  - return value 0 = AC_OK, negative = error; ac_last_error() gives a thread-local message;
+ *  - plans are immutable after creation and may be shared between host threads and streams.
+ */
+#ifndef AUDIOCODEC_AMD_H
+#define AUDIOCODEC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AC_VERSION 100 /* 0.1.0 */
+
+enum {
+  AC_OK = 0,
+  AC_EINVAL = -1,  /* bad shape / size / argument                                   */
+  AC_EHIP = -2,    /* a HIP runtime call failed (message carries hipGetErrorString)  */
+  AC_ENOMEM = -3,  /* host or device allocation failed                               */
+  AC_ENODEV = -4,  /* no usable gfx950 device                                        */
+  AC_EUNSUPPORTED = -5
+};
+
+/* window_type of MDCTransformer.__init__ (mdctransformer.py:13,199-211) */
+enum { AC_WINDOW_VORBIS = 0, AC_WINDOW_SINE = 1, AC_WINDOW_RECT = 2 };
+
+typedef struct ac_mdct_plan ac_mdct_plan;
+typedef struct ac_psy_plan ac_psy_plan;
+typedef struct ac_stream ac_stream;
+
+int ac_version(void);
+const char* ac_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Host-only constant builders (fp64 precompute, no GPU needed).
+ * ---------------------------------------------------------------------------------------- */
+
+/* Non-zeros of the folding matrix F and of F^-1: replaces _filter_window_matrix / _polyphase_matrix /
+ * _inv_polyphase_matrix incl. tf.linalg.inv (mdctransformer.py:155-229).  Eight vectors of N/2 doubles
+ * written to coef[8*N/2] in the order a1 a2 a3 a4 s1 s2 s3 s4:
+ *   analysis   v[h+j] = a1[j] xc[j] + a2[j] xc[N-1-j],   v[j]       = a3[j] xp[h-1-j] + a4[j] xp[h+j]
+ *   synthesis  out[j] = s1[j] u_n[h-1-j] + s2[j] u_{n-1}[h+j],   out[N-1-j] = s3[j] u_n[h-1-j] + s4[j] u_{n-1}[h+j] */
+int ac_mdct_fold_coefficients_host(int N, int window, double* coef);
+
+/* Dense polyphase matrices exactly as the reference stores them: H, H_inv [2,N,N] float32
+ * (mdctransformer.py:58-59).  Never used by the kernels; for the Python attributes only. */
+int ac_mdct_dense_matrices_host(int N, int window, float* H, float* H_inv);
+
+/* Constants of PsychoacousticModel.__init__ (psychoacoustic.py:52-69): W [N,M], W_inv [M,N],
+ * spreading_matrix [M,M], quiet_threshold_intensity [M] as float32 (any pointer may be NULL) and
+ * scalars[4] = {max_frequency, max_bark, bark_band_width, dB_MIN} as double. */
+int ac_psy_tables_host(int N, int M, double sample_rate, double alpha,
+                       float* W, float* W_inv, float* S, float* quiet, double* scalars);
+
+/* ------------------------------------------------------------------------------------------
+ * Plans (own the device copies of the constant tables).
+ * ---------------------------------------------------------------------------------------- */
+
+/* MDCTransformer.__init__ (mdctransformer.py:13-59).  N even, >= 2. */
+int ac_mdct_plan_create(int N, int window, int device, ac_mdct_plan** out);
+int ac_mdct_plan_destroy(ac_mdct_plan* plan);
+
+/* PsychoacousticModel.__init__ (psychoacoustic.py:14-69). */
+int ac_psy_plan_create(int N, int M, double sample_rate, double alpha, int device, ac_psy_plan** out);
+int ac_psy_plan_destroy(ac_psy_plan* plan);
+
+/* 1 when the plan runs the wave-level FFT kernels, 0 when it runs the generic O(N^2) kernels. */
+int ac_mdct_plan_is_fast(const ac_mdct_plan* plan);
+int ac_psy_plan_is_fast(const ac_psy_plan* plan);
+
+/* Test/bench hook: force the generic kernels (1) or restore automatic selection (0). */
+int ac_set_force_generic(int on);
+
+/* ------------------------------------------------------------------------------------------
+ * Hot path.
+ * ---------------------------------------------------------------------------------------- */
+
+/* MDCTransformer.transform (mdctransformer.py:62-125):  x [B, K*N, C] -> X [B, K+1, N, C]. */
+int ac_mdct_forward(const ac_mdct_plan* plan, const float* x, float* X, int B, int K, int C, void* stream);
+
+/* MDCTransformer.inverse_transform (mdctransformer.py:128-153):  X [B, Kp, N, C] -> x [B, (Kp+1)*N, C]. */
+int ac_mdct_inverse(const ac_mdct_plan* plan, const float* X, float* x, int B, int Kp, int C, void* stream);
+
+/* PsychoacousticModel.tonality (psychoacoustic.py:102-120):  X [B, F, N, C] -> t [B, F, 1, C]. */
+int ac_tonality(const ac_psy_plan* plan, const float* X, float* t, int B, int F, int C, void* stream);
+
+/* PsychoacousticModel.global_masking_threshold (psychoacoustic.py:122-148, with 169-210, 301-331):
+ * X [B,F,N,C], t [B,F,1,C], drown in [0,1] -> thr [B,F,N,C]. */
+int ac_mask_threshold(const ac_psy_plan* plan, const float* X, const float* t, float drown, float* thr,
+                      int B, int F, int C, void* stream);
+
+/* Fused encode = transform -> tonality -> global_masking_threshold in one pass over the PCM
+ * (the composition of tests/test_psychoacoustic.py:38-41 + psychoacoustic.py:130-131).
+ * x [B,K*N,C] -> X [B,K+1,N,C], t [B,K+1,1,C], thr [B,K+1,N,C].  mdct N must equal psy N. */
+int ac_encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t,
+                    float* thr, float drown, int B, int K, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Streaming overlap-add (chunked transform with device-resident state).
+ * Analysis state: the last input block per (b,c) [B,N,C]; synthesis state: the aliased second half of
+ * the last DCT-IV output per (b,c) [B,C,N/2].  A fresh/reset stream starts from zero state, so the
+ * concatenation of chunk outputs equals the one-shot transform frame for frame.
+ * ---------------------------------------------------------------------------------------- */
+int ac_stream_create(const ac_mdct_plan* plan, int B, int C, ac_stream** out);
+int ac_stream_reset(ac_stream* s, void* stream);
+int ac_stream_destroy(ac_stream* s);
+/* x_chunk [B, k*N, C] -> X [B, k, N, C]  (frame i = blocks i-1, i; block -1 = state) */
+int ac_stream_forward(ac_stream* s, const float* x_chunk, float* X, int k, void* stream);
+/* X_chunk [B, k, N, C] -> x [B, k*N, C]  (block i = frames i, i-1; frame -1 = state) */
+int ac_stream_inverse(ac_stream* s, const float* X_chunk, float* x, int k, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Element-wise utilities of PsychoacousticModel (psychoacoustic.py:71-100, 150-167).
+ * ---------------------------------------------------------------------------------------- */
+/* amplitude_to_dB (norm = 0) / amplitude_to_dB_norm (norm = 1) on n floats. */
+int ac_amplitude_to_db(const float* a, float* out, size_t n, int norm, void* stream);
+/* add_noise: out = X + thr * Normal(0, 1/6), counter-based generator keyed by (seed, element index). */
+int ac_add_noise(const float* X, const float* thr, float* out, size_t n, uint64_t seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUDIOCODEC_AMD_H */

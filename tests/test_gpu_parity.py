@@ -1,0 +1,301 @@
+"""GPU (MI355X): parity of the HIP path -- called through the C ABI -- with the oracle and the golden
+vectors.  Tolerances (BASELINE.json north star / SURVEY 8(c)):
+  * MDCT coefficients: max_frame(|dX|_inf / |X|_inf) <= 1e-4 and rel-L2 <= 1e-4 vs the fp64 reference values
+  * tonality: |dt| <= 2e-5 absolute;  thresholds: element-wise relative <= 1e-4
+  * round trip PCM: <= 1 LSB of int16 (3.05e-5) and identical after rounding to int16
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_elem, rel_l2, rel_peak
+
+import audiocodec_amd
+from audiocodec_amd import _lib
+from oracle.audiocodec_oracle import MDCTOracle, PsychoOracle, sine_wav
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+LSB = 1.0 / 32768.0
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X (run with -m gpu on the GPU box)"
+    _lib.load()
+    yield
+    _lib.load().ac_set_force_generic(0)
+
+
+@pytest.fixture(params=["auto", "generic"])
+def path(request):
+    _lib.load().ac_set_force_generic(1 if request.param == "generic" else 0)
+    yield request.param
+    _lib.load().ac_set_force_generic(0)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+MDCT_CASES = [("mdct_n64_sine", 64, "vorbis"), ("mdct_n256_roundtrip", 256, "vorbis"),
+              ("mdct_n1024_rand_vorbis", 1024, "vorbis"), ("mdct_n1024_rand_sine", 1024, "sine"),
+              ("mdct_n2048_rand_vorbis", 2048, "vorbis"), ("mdct_n16_rand_vorbis", 16, "vorbis"),
+              ("mdct_n16_rand_sine", 16, "sine"), ("mdct_n16_rand_rect", 16, "rect"),
+              ("mdct_n12_rand_vorbis", 12, "vorbis")]
+
+
+@pytest.mark.parametrize("name,N,wt", MDCT_CASES)
+def test_mdct_golden(golden, path, name, N, wt):
+    g = golden(name)
+    m = audiocodec_amd.MDCTransformer(N, window_type=wt)
+    X = host(m.transform(dev(g["x"])))
+    assert X.shape == g["X_ref64"].shape and X.dtype == np.float32
+    assert rel_peak(X, g["X_ref64"]) <= TOL
+    assert rel_l2(X, g["X_ref64"]) <= TOL
+    if "xhat_ref64" in g:
+        xh = host(m.inverse_transform(dev(g["X_ref32"])))
+        assert xh.shape == g["xhat_ref64"].shape
+        assert np.max(np.abs(xh - g["xhat_ref64"])) <= LSB
+
+
+def test_known_answer_vector(golden, path):
+    """tests/test_mdctransformer.py:39-54"""
+    g = golden("mdct_n64_sine")
+    X = host(audiocodec_amd.MDCTransformer(64).transform(dev(g["x"])))
+    a = g["known_answer_frame1_first10"]
+    assert np.all(X[0, 1, :10, 0] - a < 1e-6)
+    assert np.max(np.abs(X[0, 1, :10, 0] - a)) < 2e-6
+
+
+def test_inverse_identity_like_reference(path):
+    """tests/test_mdctransformer.py:19-37"""
+    N = 256
+    x = sine_wav(0.8, 880, sample_rate=16000, duration_sec=1.0)
+    x = x[:, : N * (x.shape[1] // N)]
+    m = audiocodec_amd.MDCTransformer(N)
+    xh = host(m.inverse_transform(m.transform(dev(x))))
+    assert np.max(np.abs(x - xh[:, N:-N])) < 1e-5
+
+
+def test_shape_like_reference(path):
+    """tests/test_mdctransformer.py:56-75"""
+    x = torch.randn(128, 10 * 64, 2, device="cuda")
+    X = audiocodec_amd.MDCTransformer(64).transform(x)
+    assert tuple(X.shape) == (128, 11, 64, 2)
+
+
+@pytest.mark.parametrize("B,K,C,N", [(3, 5, 2, 1024), (2, 3, 1, 1024), (2, 4, 3, 1024), (1, 1, 2, 1024),
+                                     (5, 7, 2, 256), (2, 2, 5, 64), (1, 3, 2, 2048), (2, 37, 2, 1024)])
+def test_mdct_random_vs_oracle(path, B, K, C, N):
+    rng = np.random.default_rng(B * 1000 + K * 10 + C)
+    x = rng.uniform(-1, 1, (B, K * N, C)).astype(np.float32)
+    m = audiocodec_amd.MDCTransformer(N)
+    o = MDCTOracle(N, "vorbis", np.float64)
+    X = host(m.transform(dev(x)))
+    Xo = o.transform(x.astype(np.float64))
+    assert rel_peak(X, Xo) <= TOL and rel_l2(X, Xo) <= TOL
+    xh = host(m.inverse_transform(dev(X)))
+    assert xh.shape == (B, (K + 2) * N, C)
+    assert np.max(np.abs(xh[:, N:-N] - x)) <= LSB
+    assert np.array_equal(np.round(xh[:, N:-N] * 32767), np.round(x * 32767)) or \
+        np.max(np.abs(np.round(xh[:, N:-N] * 32767) - np.round(x * 32767))) <= 1
+    # head and tail blocks of the round trip are the aliased halves; compare with the oracle too
+    xo = o.inverse_transform(Xo)
+    assert np.max(np.abs(xh - xo)) <= LSB
+
+
+def test_int16_pcm_round_trip_exact(path):
+    """PCM that came from int16 survives encode -> decode bit-exactly after re-quantisation."""
+    rng = np.random.default_rng(7)
+    pcm = rng.integers(-32768, 32768, (4, 6 * 1024, 2), dtype=np.int16)
+    x = (pcm.astype(np.float32) / 32768.0)
+    m = audiocodec_amd.MDCTransformer(1024)
+    xh = host(m.inverse_transform(m.transform(dev(x))))[:, 1024:-1024]
+    assert np.max(np.abs(xh - x)) <= LSB
+    assert np.array_equal(np.round(xh * 32768.0).astype(np.int32), pcm.astype(np.int32))
+
+
+def test_empty_and_edge_shapes(path):
+    m = audiocodec_amd.MDCTransformer(64)
+    X = m.transform(torch.zeros(2, 0, 2, device="cuda"))
+    assert tuple(X.shape) == (2, 1, 64, 2) and float(X.abs().max()) == 0.0
+    assert tuple(m.transform(torch.zeros(0, 128, 2, device="cuda")).shape) == (0, 3, 64, 2)
+    x = m.inverse_transform(torch.zeros(1, 0, 64, 1, device="cuda"))
+    assert tuple(x.shape) == (1, 64, 1) and float(x.abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        m.transform(torch.zeros(1, 100, 1, device="cuda"))
+    with pytest.raises(ValueError):
+        m.transform(torch.zeros(1, 128, 1, device="cuda", dtype=torch.float64))
+    with pytest.raises(ValueError):
+        m.inverse_transform(torch.zeros(1, 2, 32, 1, device="cuda"))
+    # non-contiguous input is accepted (made contiguous), result identical
+    xs = torch.rand(2, 256, 4, device="cuda")[:, :, ::2]
+    assert torch.equal(m.transform(xs), m.transform(xs.contiguous()))
+
+
+def test_linearity_and_shift_properties(path):
+    """Size-independent properties: linearity and block-shift covariance of the analysis bank."""
+    N = 1024
+    m = audiocodec_amd.MDCTransformer(N)
+    x1 = torch.rand(2, 8 * N, 2, device="cuda") * 2 - 1
+    x2 = torch.rand(2, 8 * N, 2, device="cuda") * 2 - 1
+    lhs = m.transform(0.5 * x1 - 0.25 * x2)
+    rhs = 0.5 * m.transform(x1) - 0.25 * m.transform(x2)
+    assert float((lhs - rhs).abs().max()) < 2e-6
+    shifted = torch.cat([torch.zeros(2, N, 2, device="cuda"), x1], dim=1)
+    Xs = m.transform(shifted)
+    assert float(Xs[:, 0].abs().max()) == 0.0
+    assert torch.equal(Xs[:, 1:], m.transform(x1))
+
+
+# ---- psychoacoustic model ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("cfg,sr,N,M", [("psy_48000_1024_64_cases", 48000, 1024, 64),
+                                        ("psy_64_64_64_cases", 64, 64, 64)])
+def test_psy_golden(golden, path, cfg, sr, N, M):
+    g = golden(cfg)
+    p = audiocodec_amd.PsychoacousticModel(sr, filter_bands_n=N, bark_bands_n=M)
+    for key in [k for k in g if k.startswith("X_")]:
+        name = key[2:]
+        X = dev(g[key].astype(np.float32))
+        t_ref = g["t_%s_ref64" % name]
+        t = host(p.tonality(X))
+        assert t.shape == t_ref.shape
+        assert np.max(np.abs(t - t_ref)) <= 2e-5, name
+        for k2 in [k for k in g if k.startswith("thr_" + name) and k.endswith("ref64")]:
+            mid = k2[len("thr_" + name):-len("ref64")].strip("_")
+            drown = int(mid[1:]) / 10.0 if mid else 0.0
+            thr = host(p.global_masking_threshold(X, dev(t_ref.astype(np.float32)), drown))
+            assert rel_elem(thr, g[k2]) <= TOL, (name, k2)
+            assert thr.min() >= 1e-7 * (1 - 1e-6)
+
+
+def test_tonality_like_reference(path):
+    """tests/test_psychoacoustic.py:32-65"""
+    N = 64
+    m = audiocodec_amd.MDCTransformer(N)
+    p = audiocodec_amd.PsychoacousticModel(sample_rate=N, filter_bands_n=N)
+    X = m.transform(dev(sine_wav(0.8, 4, sample_rate=64, duration_sec=5.0)))
+    assert float(p.tonality(X)[0, 1]) == 1.0
+    x = torch.rand(10, 10 * N, 2, device="cuda") * 2 - 1
+    t = p.tonality(m.transform(x))
+    assert tuple(t.shape) == (10, 11, 1, 2)
+    assert float(t[0, 1:-1].mean()) < 0.1
+
+
+@pytest.mark.parametrize("sr,N,M,B,F,C", [(48000, 1024, 64, 3, 4, 2), (48000, 1024, 64, 2, 3, 1), (48000, 1024, 64, 1, 2, 3),
+                                          (44100, 256, 48, 2, 5, 2), (32768, 64, 64, 2, 3, 2), (48000, 2048, 64, 1, 2, 2)])
+def test_psy_random_vs_oracle(path, sr, N, M, B, F, C):
+    rng = np.random.default_rng(F * 100 + C)
+    env = np.logspace(-5, 0, N).reshape(1, 1, N, 1)
+    X = (rng.uniform(-1, 1, (B, F, N, C)) * env * rng.uniform(1e-3, 1, (B, F, 1, C))).astype(np.float32)
+    X[0, 0, :, 0] = 0.0
+    p = audiocodec_amd.PsychoacousticModel(sr, filter_bands_n=N, bark_bands_n=M)
+    o = PsychoOracle(sr, N, M, compute_dtype=np.float64)
+    t = host(p.tonality(dev(X)))
+    to = o.tonality(X.astype(np.float64))
+    assert np.max(np.abs(t - to)) <= 2e-5
+    for drown in (0.0, 0.3, 1.0):
+        thr = host(p.global_masking_threshold(dev(X), dev(to.astype(np.float32)), drown))
+        assert rel_elem(thr, o.global_masking_threshold(X.astype(np.float64), to, drown)) <= TOL
+
+
+@pytest.mark.parametrize("B,K,C", [(3, 5, 2), (2, 4, 1), (1, 3, 3), (2, 37, 2)])
+def test_encode_fused_equals_unfused_and_oracle(path, B, K, C):
+    N = 1024
+    rng = np.random.default_rng(11 + B)
+    x = rng.uniform(-1, 1, (B, K * N, C)).astype(np.float32)
+    x[0, : 2 * N, 0] *= 1e-3
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    X, t, thr = codec.encode(dev(x), drown=0.2)
+    Xu = codec.mdct.transform(dev(x))
+    tu = codec.psy.tonality(Xu)
+    thru = codec.psy.global_masking_threshold(Xu, tu, 0.2)
+    assert float((X - Xu).abs().max()) <= 1e-6
+    assert float((t - tu).abs().max()) <= 2e-5
+    assert float(((thr - thru).abs() / thru).max()) <= TOL
+    om, op = MDCTOracle(N, "vorbis", np.float64), PsychoOracle(48000, N, 64, compute_dtype=np.float64)
+    Xo = om.transform(x.astype(np.float64))
+    to = op.tonality(Xo)
+    thro = op.global_masking_threshold(Xo, to, 0.2)
+    assert rel_peak(host(X), Xo) <= TOL
+    assert np.max(np.abs(host(t) - to)) <= 2e-5
+    assert rel_elem(host(thr), thro) <= 2e-4      # threshold of the GPU's own X and t (two rounding sources)
+    xh = host(codec.decode(X))
+    assert np.max(np.abs(xh[:, N:-N] - x)) <= LSB
+
+
+def test_db_and_noise(golden, path):
+    g = golden("db_utils")
+    p = audiocodec_amd.PsychoacousticModel(48000)
+    a = dev(g["a"])
+    np.testing.assert_allclose(host(p.amplitude_to_dB(a)), g["dB_ref64"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(host(p.amplitude_to_dB_norm(a)), g["dBn_ref64"], rtol=0, atol=2e-6)
+    X = torch.zeros(4, 8, 1024, 2, device="cuda")
+    thr = torch.full_like(X, 0.3)
+    y = p.add_noise(X, thr, seed=5)
+    assert abs(float(y.mean())) < 5e-4 and abs(float(y.std()) - 0.05) < 5e-4
+    assert torch.equal(y, p.add_noise(X, thr, seed=5)) and not torch.equal(y, p.add_noise(X, thr, seed=6))
+    assert float((y.abs() > 0.3).float().mean()) < 0.01
+
+
+# ---- streaming ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("N,C,chunks", [(1024, 2, (3, 1, 4, 2)), (256, 1, (2, 2, 5)), (1024, 1, (5, 3))])
+def test_streaming_equals_one_shot(path, N, C, chunks):
+    B, K = 2, sum(chunks)
+    x = torch.rand(B, K * N, C, device="cuda") * 2 - 1
+    m = audiocodec_amd.MDCTransformer(N)
+    X_full = m.transform(x)                       # [B, K+1, N, C]
+    st = audiocodec_amd.StreamingMDCT(m, B, C)
+    outs, pos = [], 0
+    for k in chunks:
+        outs.append(st.transform_chunk(x[:, pos * N:(pos + k) * N]))
+        pos += k
+    outs.append(st.transform_chunk(torch.zeros(B, N, C, device="cuda")))   # flush: tail frame
+    X_stream = torch.cat(outs, dim=1)
+    assert torch.equal(X_stream, X_full)
+    x_full = m.inverse_transform(X_full)          # [B, (K+2) N, C]
+    st.reset()
+    outs, pos = [], 0
+    for k in chunks + (1,):
+        outs.append(st.inverse_chunk(X_full[:, pos:pos + k]))
+        pos += k
+    outs.append(st.inverse_chunk(torch.zeros(B, 1, N, C, device="cuda")))
+    x_stream = torch.cat(outs, dim=1)
+    assert float((x_stream - x_full).abs().max()) <= 1e-6
+    assert float((x_stream[:, N:-N] - x).abs().max()) <= LSB
+    st.close()
+
+
+def test_full_size_properties(path):
+    """BASELINE config 2 shape (B=256 stereo, K=46, N=1024): size-independent properties only."""
+    if path == "generic":
+        pytest.skip("O(N^2) kernels: full size covered on the fast path")
+    N, B, K, C = 1024, 256, 46, 2
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    x = torch.rand(B, K * N, C, device="cuda", generator=g) * 2 - 1
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    X, t, thr = codec.encode(x)
+    xh = codec.decode(X)
+    assert float((xh[:, N:-N] - x).abs().max()) <= LSB
+    assert torch.equal(torch.round(xh[:, N:-N] * 32767), torch.round(x * 32767)) or \
+        float((torch.round(xh[:, N:-N] * 32767) - torch.round(x * 32767)).abs().max()) <= 1
+    assert float(t.min()) >= -1e-6 and float(t.max()) <= 1.0
+    assert float(thr.min()) >= 1e-7 * (1 - 1e-6) and bool(torch.isfinite(thr).all())
+    # every clip is independent: a clip processed alone gives the same bits
+    X1, t1, thr1 = codec.encode(x[17:18])
+    assert torch.equal(X1, X[17:18]) and torch.equal(thr1, thr[17:18]) and torch.equal(t1, t[17:18])
+    # parity on a sample of clips against the oracle
+    om, op = MDCTOracle(N, "vorbis", np.float64), PsychoOracle(48000, N, 64, compute_dtype=np.float64)
+    xs = host(x[:2]).astype(np.float64)
+    Xo = om.transform(xs)
+    assert rel_peak(host(X[:2]), Xo) <= TOL
+    assert rel_elem(host(thr[:2]), op.global_masking_threshold(Xo, op.tonality(Xo))) <= 2e-4

@@ -1,0 +1,177 @@
+"""CPU: host logic of the product -- the C-ABI library loads and exports every symbol the header declares,
+host-side constant builders match the golden tables, argument validation, sharding helpers (gloo, world 2)."""
+
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+import audiocodec_amd
+from audiocodec_amd import _lib
+from audiocodec_amd.dist import clip_range
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "audiocodec_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ac_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_header_symbol():
+    lib = _lib.load()
+    syms = _header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), "libaudiocodec_amd.so does not export %s" % s
+    assert sorted(_lib.PROTOTYPES) == syms, "ctypes prototypes and header disagree"
+    assert lib.ac_version() == 100
+
+
+def test_library_contains_gfx950_code_object():
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-S", _lib.LIB_PATH], capture_output=True, text=True)
+    assert ".hip_fatbin" in out.stdout
+    data = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in data
+
+
+@pytest.mark.parametrize("N,wt", [(8, "vorbis"), (16, "sine"), (16, "rect"), (12, "vorbis")])
+def test_dense_matrices_match_oracle(N, wt):
+    from oracle.audiocodec_oracle import MDCTOracle
+    m = audiocodec_amd.MDCTransformer(N, window_type=wt)
+    o = MDCTOracle(N, wt, np.float64)
+    np.testing.assert_allclose(m.H.numpy(), o.dense_H().astype(np.float32), atol=1e-7)
+    np.testing.assert_allclose(m.H_inv.numpy(), o.dense_H_inv().astype(np.float32), atol=1e-6)
+    assert m.H.shape == (2, N, N) and int((m.H != 0).sum()) <= 2 * N
+
+
+def test_dense_H_matches_reference_golden(golden):
+    g = golden("mdct_n8_H")
+    m = audiocodec_amd.MDCTransformer(8)
+    np.testing.assert_allclose(m.H.numpy(), g["H"].astype(np.float32), atol=1e-7)
+    np.testing.assert_allclose(m.H_inv.numpy(), g["H_inv"].astype(np.float32), atol=1e-6)
+
+
+@pytest.mark.parametrize("N,wt", [(1024, "vorbis"), (1024, "sine"), (64, "rect"), (2048, "Vorbis")])
+def test_fold_coefficients_match_oracle(N, wt):
+    from oracle.audiocodec_oracle import fold_coefficients
+    c = audiocodec_amd.MDCTransformer(N, window_type=wt).fold_coefficients()
+    o = fold_coefficients(N, wt)
+    for i, k in enumerate(["a1", "a2", "a3", "a4", "s1", "s2", "s3", "s4"]):
+        np.testing.assert_allclose(c[i], o[k], rtol=1e-12, atol=1e-15)
+
+
+def _dense(idx, val, shape):
+    m = np.zeros(shape)
+    m[idx[:, 0], idx[:, 1]] = val
+    return m
+
+
+@pytest.mark.parametrize("sr,N,M", [(48000, 1024, 64), (48000, 2048, 64), (32768, 64, 64), (44100, 256, 48)])
+def test_psy_tables_match_reference_golden(golden, sr, N, M):
+    g = golden("psy_%d_%d_%d_tables" % (sr, N, M))
+    p = audiocodec_amd.PsychoacousticModel(sr, filter_bands_n=N, bark_bands_n=M)
+    np.testing.assert_array_equal(p.W.numpy(), _dense(g["W_idx"], g["W_val"], (N, M)).astype(np.float32))
+    np.testing.assert_array_equal(p.W_inv.numpy(), _dense(g["W_inv_idx"], g["W_inv_val"], (M, N)).astype(np.float32))
+    np.testing.assert_allclose(p.spreading_matrix.numpy(), g["S"].astype(np.float32), rtol=2e-7)
+    np.testing.assert_allclose(p.quiet_threshold_intensity.numpy().reshape(-1), g["quiet"].astype(np.float32), rtol=2e-7)
+    assert abs(float(p.max_bark) - float(g["max_bark"])) < 1e-13
+    assert abs(float(p.bark_band_width) - float(g["bark_band_width"])) < 1e-14
+    assert float(p._dB_MIN) == -20.0
+    assert tuple(p.quiet_threshold_intensity.shape) == (1, 1, M, 1)
+
+
+def test_energy_conservation_like_reference():
+    """tests/test_psychoacoustic.py:14-30 on the product's tables"""
+    p = audiocodec_amd.PsychoacousticModel(sample_rate=32768, filter_bands_n=64)
+    assert float(torch.sum(torch.abs(torch.sum(p.W, dim=1) - 1.0))) < 1e-6
+    assert float(torch.sum(torch.abs(torch.sum(p.W_inv, dim=1) - 1.0))) < 1e-6
+
+
+def test_constructor_validation():
+    with pytest.raises(AssertionError):
+        audiocodec_amd.MDCTransformer(7)
+    with pytest.raises(TypeError):
+        audiocodec_amd.PsychoacousticModel(48000, compute_dtype=torch.float16)
+    with pytest.raises(NotImplementedError):
+        audiocodec_amd.PsychoacousticModel(48000, compute_dtype=torch.float64)
+    assert audiocodec_amd.MDCTransformer(8, window_type=None)._window == 2
+    assert audiocodec_amd.MDCTransformer(8, window_type="SINE")._window == 1
+    assert audiocodec_amd.MDCTransformer(8, window_type="hann")._window == 2
+    lib = _lib.load()
+    out = ctypes.c_void_p()
+    assert lib.ac_mdct_plan_create(7, 0, 0, ctypes.byref(out)) == _lib.AC_EINVAL
+    assert b"even" in lib.ac_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(lib.ac_mdct_fold_coefficients_host(8, 9, (ctypes.c_double * 32)()))
+
+
+def test_no_cpu_fallback():
+    m = audiocodec_amd.MDCTransformer(64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.transform(torch.zeros(1, 128, 1))
+    with pytest.raises(ValueError):
+        m.transform(torch.zeros(1, 128, 1, dtype=torch.float64))
+    p = audiocodec_amd.PsychoacousticModel(48000, 64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        p.tonality(torch.zeros(1, 2, 64, 1))
+    import audiocodec_amd.mdctransformer as prod
+    src = open(prod.__file__).read() + open(audiocodec_amd.psychoacoustic.__file__).read()
+    assert "oracle" not in src
+
+
+def test_import_path_shim():
+    from audiocodec.mdctransformer import MDCTransformer
+    from audiocodec import psychoacoustic
+    assert MDCTransformer is audiocodec_amd.MDCTransformer
+    assert psychoacoustic.PsychoacousticModel is audiocodec_amd.PsychoacousticModel
+
+
+def test_clip_range_partitions():
+    for B in (0, 1, 7, 256, 4096):
+        for W in (1, 2, 3, 8):
+            spans = [clip_range(B, r, W) for r in range(W)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(W - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert clip_range(4096, 3, 8) == (1536, 2048)
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+from audiocodec_amd import dist as acd
+from oracle.audiocodec_oracle import MDCTOracle
+rank, world, _ = acd.init_process_group("gloo")
+B = 6
+x = np.random.default_rng(1234).uniform(-1, 1, (B, 4 * 64, 2)).astype(np.float32)   # same on every rank
+lo, hi = acd.clip_range(B, rank, world)
+X = MDCTOracle(64).transform(x[lo:hi])            # the shard this rank owns (CPU stand-in for the HIP call)
+frames, checksum = acd.reduce_scalars([float((hi - lo) * 2 * 4), float(np.sum(X.astype(np.float64)))], "sum")
+tmax, = acd.reduce_scalars([1.0 + rank], "max")
+if rank == 0:
+    full = float(np.sum(MDCTOracle(64).transform(x).astype(np.float64)))
+    assert frames == B * 2 * 4, frames
+    assert abs(checksum - full) < 1e-9, (checksum, full)
+    assert tmax == float(world)
+    print("OK", frames, tmax)
+"""
+
+
+def test_sharding_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29713")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29713", str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "OK 48.0 2.0" in out.stdout

@@ -1,0 +1,166 @@
+"""CPU: pin the oracle (oracle/audiocodec_oracle.py) against the golden vectors generated from the
+reference's own source (oracle/gen_golden.py) and against every assertion of the reference's 7 tests."""
+
+import numpy as np
+import pytest
+
+from conftest import rel_elem, rel_l2, rel_peak
+from oracle.audiocodec_oracle import MDCTOracle, PsychoOracle, sine_wav
+
+# the reference multiplies the DCT by a float32-rounded sqrt(2) (mdctransformer.py:347): a 1.7e-8
+# relative scale offset between its fp64 evaluation and exact arithmetic
+REF_SQRT2_REL = 2e-8
+
+MDCT_CASES = [("mdct_n64_sine", 64, "vorbis"), ("mdct_n256_roundtrip", 256, "vorbis"),
+              ("mdct_n1024_rand_vorbis", 1024, "vorbis"), ("mdct_n1024_rand_sine", 1024, "sine"),
+              ("mdct_n2048_rand_vorbis", 2048, "vorbis"), ("mdct_n16_rand_vorbis", 16, "vorbis"),
+              ("mdct_n16_rand_sine", 16, "sine"), ("mdct_n16_rand_rect", 16, "rect"),
+              ("mdct_n12_rand_vorbis", 12, "vorbis")]
+
+
+@pytest.mark.parametrize("name,N,wt", MDCT_CASES)
+@pytest.mark.parametrize("dense", [False, True])
+def test_mdct_oracle_fp64_matches_reference(golden, name, N, wt, dense):
+    g = golden(name)
+    o = MDCTOracle(N, wt, np.float64)
+    X = o.transform(g["x"].astype(np.float64), dense=dense)
+    assert X.shape == g["X_ref64"].shape
+    assert rel_peak(X, g["X_ref64"]) < REF_SQRT2_REL
+    if "xhat_ref64" in g:
+        xh = o.inverse_transform(g["X_ref64"], dense=dense)
+        assert np.max(np.abs(xh - g["xhat_ref64"])) < REF_SQRT2_REL * max(1.0, np.max(np.abs(g["xhat_ref64"])))
+
+
+@pytest.mark.parametrize("name,N,wt", MDCT_CASES)
+def test_mdct_oracle_fp32_within_reference_envelope(golden, name, N, wt):
+    g = golden(name)
+    o = MDCTOracle(N, wt, np.float32)
+    X = o.transform(g["x"])
+    assert X.dtype == np.float32
+    assert rel_peak(X, g["X_ref64"]) < 2e-6
+    assert rel_peak(X, g["X_ref32"]) < 2e-6
+    if "xhat_ref64" in g:
+        xh = o.inverse_transform(X)
+        assert np.max(np.abs(xh - g["xhat_ref64"])) < 3e-6
+
+
+def test_known_answer_vector(golden):
+    """tests/test_mdctransformer.py:39-54 -- the only real-TensorFlow numbers in the reference."""
+    g = golden("mdct_n64_sine")
+    x = sine_wav(0.8, 4, sample_rate=64, duration_sec=4.0)
+    x = x[:, : 64 * (x.shape[1] // 64)]
+    np.testing.assert_array_equal(x, g["x"])
+    for dt in (np.float32, np.float64):
+        X = MDCTOracle(64, "vorbis", dt).transform(x.astype(dt))
+        a = g["known_answer_frame1_first10"]
+        assert np.all(X[0, 1, :10, 0] - a < 1e-6)            # the reference's one-sided assertion (:54)
+        assert np.max(np.abs(X[0, 1, :10, 0] - a)) < 1e-6    # and two-sided
+
+
+def test_inverse_identity_like_reference():
+    """tests/test_mdctransformer.py:19-37"""
+    N = 256
+    x = sine_wav(0.8, 880, sample_rate=16000, duration_sec=1.0)
+    x = x[:, : N * (x.shape[1] // N)]
+    o = MDCTOracle(N)
+    xh = o.inverse_transform(o.transform(x))
+    assert np.max(np.abs(x - xh[:, N:-N])) < 1e-5
+
+
+def test_shape_like_reference():
+    """tests/test_mdctransformer.py:56-75"""
+    x = np.random.default_rng(0).standard_normal((128, 10 * 64, 2)).astype(np.float32)
+    assert MDCTOracle(64).transform(x).shape == (128, 11, 64, 2)
+
+
+def test_ragged_input_raises():
+    with pytest.raises(ValueError):
+        MDCTOracle(64).transform(np.zeros((1, 100, 1), np.float32))
+
+
+def test_dense_matrices(golden):
+    g = golden("mdct_n8_H")
+    o = MDCTOracle(8, "vorbis", np.float64)
+    np.testing.assert_allclose(o.dense_H(), g["H"], atol=1e-15)
+    np.testing.assert_allclose(o.dense_H_inv(), g["H_inv"], atol=1e-14)
+
+
+def _dense(idx, val, shape):
+    m = np.zeros(shape)
+    m[idx[:, 0], idx[:, 1]] = val
+    return m
+
+
+@pytest.mark.parametrize("sr,N,M", [(48000, 1024, 64), (48000, 2048, 64), (32768, 64, 64), (44100, 256, 48)])
+def test_psy_tables(golden, sr, N, M):
+    g = golden("psy_%d_%d_%d_tables" % (sr, N, M))
+    p = PsychoOracle(sr, N, M, compute_dtype=np.float64)
+    np.testing.assert_allclose(p.W64, _dense(g["W_idx"], g["W_val"], (N, M)), atol=1e-15)
+    np.testing.assert_allclose(p.W_inv64, _dense(g["W_inv_idx"], g["W_inv_val"], (M, N)), atol=1e-15)
+    np.testing.assert_allclose(p.spreading64, g["S"], rtol=1e-13)
+    np.testing.assert_allclose(p.quiet64.reshape(-1), g["quiet"], rtol=1e-13)
+    assert abs(p.max_bark - g["max_bark"]) < 1e-14
+    assert float(p._dB_MIN) == float(g["dB_MIN"]) == -20.0
+
+
+def test_energy_conservation_like_reference():
+    """tests/test_psychoacoustic.py:14-30"""
+    p = PsychoOracle(32768, 64)
+    assert np.sum(np.abs(np.sum(p.W, axis=1) - 1.0)) < 1e-6
+    assert np.sum(np.abs(np.sum(p.W_inv, axis=1) - 1.0)) < 1e-6
+
+
+def test_tonality_like_reference():
+    """tests/test_psychoacoustic.py:32-65"""
+    N = 64
+    m = MDCTOracle(N)
+    p = PsychoOracle(N, N)
+    X = m.transform(sine_wav(0.8, 4, sample_rate=64, duration_sec=5.0))
+    assert p.tonality(X)[0, 1] == 1.0
+    x = np.random.default_rng(3).uniform(-1, 1, (10, 10 * N, 2)).astype(np.float32)
+    t = p.tonality(m.transform(x))
+    assert t.shape == (10, 11, 1, 2)
+    assert np.mean(t[0, 1:-1]) < 0.1
+
+
+@pytest.mark.parametrize("cfg,sr,N,M", [("psy_48000_1024_64_cases", 48000, 1024, 64), ("psy_64_64_64_cases", 64, 64, 64)])
+@pytest.mark.parametrize("dt,tag,tol", [(np.float64, "ref64", 1e-13), (np.float32, "ref32", 3e-6)])
+def test_psy_cases(golden, cfg, sr, N, M, dt, tag, tol):
+    g = golden(cfg)
+    p = PsychoOracle(sr, N, M, compute_dtype=dt)
+    for key in [k for k in g if k.startswith("X_")]:
+        name = key[2:]
+        X = g[key].astype(dt)
+        t_ref = g["t_%s_%s" % (name, tag)]
+        t = p.tonality(X)
+        assert np.max(np.abs(t - t_ref)) < max(tol, 1e-6 if dt == np.float32 else 0)
+        for k2 in [k for k in g if k.startswith("thr_" + name) and k.endswith(tag)]:
+            mid = k2[len("thr_" + name):-len(tag)].strip("_")
+            drown = int(mid[1:]) / 10.0 if mid else 0.0
+            for dense in (False, True):
+                thr = p.global_masking_threshold(X, t_ref.astype(dt), drown, dense=dense)
+                assert rel_elem(thr, g[k2]) < tol
+
+
+def test_probe_values_from_survey(golden):
+    """SURVEY.md 8(c) fixture 5: all-zero and single-bin-delta spectra at 48 kHz / 1024 / 64."""
+    p = PsychoOracle(48000, 1024, 64)
+    Xz = np.zeros((1, 1, 1024, 1), np.float32)
+    t = p.tonality(Xz)
+    thr = p.global_masking_threshold(Xz, t)
+    assert abs(float(t.reshape(-1)[0])) < 2e-6
+    assert abs(thr.min() - 1.78e-7) < 1e-9 and abs(thr.max() - 0.134587) < 1e-6
+    Xd = np.zeros((1, 1, 1024, 1), np.float32)
+    Xd[0, 0, 100, 0] = 0.5
+    t = p.tonality(Xd)
+    assert float(t.reshape(-1)[0]) == 1.0
+    assert abs(p.global_masking_threshold(Xd, t)[0, 0, 100, 0] - 0.00807218) < 1e-7
+    assert abs(p.global_masking_threshold(Xd, t, drown=1.0)[0, 0, 100, 0] - 0.181141) < 1e-5
+
+
+def test_db_utils(golden):
+    g = golden("db_utils")
+    p = PsychoOracle(48000)
+    np.testing.assert_allclose(p.amplitude_to_dB(g["a"]), g["dB_ref32"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(p.amplitude_to_dB_norm(g["a"]), g["dBn_ref32"], rtol=0, atol=1e-6)
+    assert p.amplitude_to_dB(np.float32(0.0)) == -20.0 and p.amplitude_to_dB(np.float32(1.0)) == 120.0
