@@ -1,11 +1,870 @@
-// placeholder: wave-level FFT kernels land here
+// Wave-level kernels for filters_n = 1024 on gfx950 (MI355X).
+//
+// One 64-lane wavefront owns one "strip": a pair of channels of one clip over a run of consecutive
+// frames, and walks it in time.  Both channels ride in the two halves of 64-bit register pairs
+// (v2f = (c0, c1)), so twiddles, window coefficients, addresses and LDS traffic are shared.  Per step:
+//
+//   PCM block (coalesced 16-B loads) -> LDS (parity-split, XOR-swizzled) -> window fold with the
+//   half that aliases into the NEXT frame carried in registers -> pre-twiddle -> 512-point complex FFT
+//   as three in-register radix-8 passes with two conflict-free LDS transposes -> post-twiddle ->
+//   natural-order staging in LDS -> coalesced 16-B stores of X; the psychoacoustic epilogue
+//   (tonality, Bark sums, spreading, threshold) runs on the staged frame before the next block.
+//
+// Index maps, swizzles and their bank behaviour are emulated lane by lane in tools/emulate_wave_fft.py.
+// Reference formulas: mdctransformer.py:62-153 (closed forms in SURVEY.md App. A), psychoacoustic.py:102-210,301-331.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
 #include "ac_internal.h"
+
 namespace ac {
-bool fast_mdct_supported(int) { return false; }
-bool fast_psy_supported(const ac_psy_plan*) { return false; }
-int fast_mdct_plan_init(ac_mdct_plan*) { return AC_OK; }
-int fast_psy_plan_init(ac_psy_plan*) { return AC_OK; }
-int launch_fwd_fast(const ac_mdct_plan*, const ac_psy_plan*, const float*, float*, float*, float*, float, const float*, int, int, int, int, hipStream_t) { set_error("fast path not built"); return AC_EUNSUPPORTED; }
-int launch_inv_fast(const ac_mdct_plan*, const float*, float*, const float*, float*, int, int, int, int, hipStream_t) { set_error("fast path not built"); return AC_EUNSUPPORTED; }
-int launch_psy_fast(const ac_psy_plan*, const float*, const float*, float*, float*, float, int, int, int, hipStream_t) { set_error("fast path not built"); return AC_EUNSUPPORTED; }
+namespace {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int FN = 1024;            // filters_n served by this file
+constexpr int FH = FN / 2;          // complex FFT points per frame (= 64 lanes x 8 registers)
+constexpr int WAVES = 4;            // waves (independent strips) per workgroup
+constexpr int WAVE_LDS = 8192;      // bytes of LDS per wave
+constexpr float kEps = 1e-14f;      // _INTENSITY_EPS, psychoacoustic.py:56
+
+// ---- mdct table layout (floats) in ac_mdct_plan::d_fast ------------------------------------------
+constexpr int T_PRE = 0;                  // [8][64] float2  exp(-i pi (e + 1/4) / N), e = lane + 64 r
+constexpr int T_P1 = T_PRE + 1024;        // [8][64] float2  W512^(lane k0)
+constexpr int T_P2 = T_P1 + 1024;         // [8][64] float2  W64^((lane & 7) k1)
+constexpr int T_POSTF = T_P2 + 1024;      // [8][64] float2  exp(-i pi k / N) / (N sqrt 2)
+constexpr int T_POSTI = T_POSTF + 1024;   // [8][64] float2  exp(-i pi k / N) * 2 sqrt 2
+constexpr int T_FOLD = T_POSTI + 1024;    // [8][64] float4  (cE, cO, kE, kO) of element e
+constexpr int T_SYN = T_FOLD + 2048;      // [8][64] float4  (s1, s2, s3, s4) at j(k)
+constexpr int T_TOTAL = T_SYN + 2048;
+
+// ---- psy table layout (32-bit words) in ac_psy_plan::d_fast --------------------------------------
+constexpr int PB_F0 = 0, PB_N = 64, PB_WF = 128, PB_WL = 192, PB_QUIET = 256, PB_BETA = 320, PB_RHO = 384,
+              PB_U0 = 448, PB_U1 = 512;
+constexpr int P_IDX = 576;                // [4][64] uint32: entry index bytes of the 16 bins a lane owns
+constexpr int P_G = P_IDX + 256;          // [128] spreading prototype g
+constexpr int P_TOTAL = P_G + 128;
+
+struct C2 {   // one complex value for both channels of the pair
+  v2f re, im;
+};
+
+__device__ __forceinline__ void wave_sync() {
+  // LDS operations of one wave execute in order; this only pins the compiler's ordering of
+  // cross-lane communication through LDS
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+__device__ __forceinline__ int swz(int q) { return q ^ ((q >> 3) & 7); }
+
+__device__ __forceinline__ C2 cmul(const C2& x, const float2 w) {
+  C2 r;
+  r.re = x.re * w.x - x.im * w.y;
+  r.im = x.re * w.y + x.im * w.x;
+  return r;
+}
+__device__ __forceinline__ C2 cadd(const C2& a, const C2& b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ C2 csub(const C2& a, const C2& b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ C2 mul_mi(const C2& a) { return {a.im, -a.re}; }   // a * (-i)
+
+// 8-point DFT (forward sign) of the eight registers, outputs in natural order
+__device__ __forceinline__ void dft8(C2 (&x)[8]) {
+  constexpr float R = 0.70710678118654752440f;
+  C2 a0 = cadd(x[0], x[4]), a4 = csub(x[0], x[4]);
+  C2 a1 = cadd(x[1], x[5]), a5 = csub(x[1], x[5]);
+  C2 a2 = cadd(x[2], x[6]), a6 = csub(x[2], x[6]);
+  C2 a3 = cadd(x[3], x[7]), a7 = csub(x[3], x[7]);
+  a5 = {(a5.re + a5.im) * R, (a5.im - a5.re) * R};     // * W8^1
+  a6 = mul_mi(a6);                                      // * W8^2
+  a7 = {(a7.im - a7.re) * R, -(a7.re + a7.im) * R};    // * W8^3
+  {
+    C2 c0 = cadd(a0, a2), c2 = csub(a0, a2), c1 = cadd(a1, a3), c3 = mul_mi(csub(a1, a3));
+    x[0] = cadd(c0, c1);
+    x[4] = csub(c0, c1);
+    x[2] = cadd(c2, c3);
+    x[6] = csub(c2, c3);
+  }
+  {
+    C2 c0 = cadd(a4, a6), c2 = csub(a4, a6), c1 = cadd(a5, a7), c3 = mul_mi(csub(a5, a7));
+    x[1] = cadd(c0, c1);
+    x[5] = csub(c0, c1);
+    x[3] = cadd(c2, c3);
+    x[7] = csub(c2, c3);
+  }
+}
+
+__device__ __forceinline__ void lds_put(char* buf, int idx16, const C2& v) {
+  *reinterpret_cast<v4f*>(buf + 16 * idx16) = v4f{v.re.x, v.re.y, v.im.x, v.im.y};
+}
+__device__ __forceinline__ C2 lds_get(const char* buf, int idx16) {
+  const v4f t = *reinterpret_cast<const v4f*>(buf + 16 * idx16);
+  return {v2f{t.x, t.y}, v2f{t.z, t.w}};
+}
+
+// 512-point FFT of z[r] = element (lane + 64 r); result z[k2] = bin k = (lane>>3) + 8 (lane&7) + 64 k2
+__device__ __forceinline__ void fft512(C2 (&z)[8], char* buf, const float* __restrict__ tab, int lane) {
+  const int a = lane >> 3, m0 = lane & 7;
+  const int flip = (a & 1) << 3;
+  dft8(z);
+#pragma unroll
+  for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], reinterpret_cast<const float2*>(tab + T_P1)[k * 64 + lane]);
+  wave_sync();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) lds_put(buf, (k * 64 + lane) ^ ((k & 1) << 3), z[k]);
+  wave_sync();
+#pragma unroll
+  for (int r = 0; r < 8; ++r) z[r] = lds_get(buf, (a * 64 + 8 * r + m0) ^ flip);
+  dft8(z);
+#pragma unroll
+  for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], reinterpret_cast<const float2*>(tab + T_P2)[k * 64 + lane]);
+  wave_sync();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) lds_put(buf, a * 64 + ((k * 8 + (m0 ^ k)) ^ flip), z[k]);
+  wave_sync();
+#pragma unroll
+  for (int r = 0; r < 8; ++r) z[r] = lds_get(buf, a * 64 + ((m0 * 8 + (r ^ m0)) ^ flip));
+  dft8(z);
+}
+
+// natural-order staging: sample / coefficient f of both channels lives in the even (f = 2q) or odd
+// (f = 2q + 1) array at 8-byte slot swz(q)
+__device__ __forceinline__ v2f& slotE(char* buf, int q) { return *reinterpret_cast<v2f*>(buf + 8 * swz(q)); }
+__device__ __forceinline__ v2f& slotO(char* buf, int q) { return *reinterpret_cast<v2f*>(buf + 4096 + 8 * swz(q)); }
+
+// ---- global <-> register movement of one natural-order row of N values x channel pair ---------------
+// CMODE 0: exactly two channels (interleaved, 16-byte vectors); CMODE 1: any channel count, pair (c0, c0+1)
+template <int CMODE>
+__device__ __forceinline__ void load_row(const float* __restrict__ row, int C, int c0, bool has1, int lane,
+                                         v4f (&v)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = 64 * i + lane;
+    if (CMODE == 0) {
+      v[i] = reinterpret_cast<const v4f*>(row)[q];
+    } else {
+      const float* p = row + (size_t)(2 * q) * C + c0;
+      v[i].x = p[0];
+      v[i].z = p[C];
+      v[i].y = has1 ? p[1] : 0.f;
+      v[i].w = has1 ? p[C + 1] : 0.f;
+    }
+  }
+}
+
+template <int CMODE>
+__device__ __forceinline__ void store_row(float* __restrict__ row, int C, int c0, bool has1, int lane,
+                                          const v4f (&v)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = 64 * i + lane;
+    if (CMODE == 0) {
+      reinterpret_cast<v4f*>(row)[q] = v[i];
+    } else {
+      float* p = row + (size_t)(2 * q) * C + c0;
+      p[0] = v[i].x;
+      p[C] = v[i].z;
+      if (has1) {
+        p[1] = v[i].y;
+        p[C + 1] = v[i].w;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void stage_row(char* buf, int lane, const v4f (&v)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = 64 * i + lane;
+    slotE(buf, q) = v2f{v[i].x, v[i].y};
+    slotO(buf, q) = v2f{v[i].z, v[i].w};
+  }
+}
+
+__device__ __forceinline__ void unstage_row(char* buf, int lane, v4f (&v)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = 64 * i + lane;
+    const v2f e = slotE(buf, q), o = slotO(buf, q);
+    v[i] = v4f{e.x, e.y, o.x, o.y};
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }     // v_log_f32
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }    // v_exp_f32
+__device__ __forceinline__ v2f log2v(v2f x) { return v2f{fast_log2(x.x), fast_log2(x.y)}; }
+__device__ __forceinline__ v2f exp2v(v2f x) { return v2f{fast_exp2(x.x), fast_exp2(x.y)}; }
+__device__ __forceinline__ v2f maxv(v2f a, float b) { return v2f{fmaxf(a.x, b), fmaxf(a.y, b)}; }
+
+// ------------------------------------------------------------------------------------------------------
+// psychoacoustic epilogue on one frame (both channels) held in natural order: xq[i] = (X[2q], X[2q+1]) x (c0, c1),
+// q = 64 i + lane.  tonality: psychoacoustic.py:102-120; threshold: :122-148 with :169-210 (factorised,
+// SURVEY App. A.3) and :301-331 (Bark mapping as per-band ranges / per-bin entry lookups).
+// ------------------------------------------------------------------------------------------------------
+struct PsyParams {
+  const uint32_t* tab;   // ac_psy_plan::d_fast
+  float alpha, inv_alpha, drown;
+  int maxn;              // widest Bark band in bins
+};
+
+template <bool WANT_T, bool WANT_THR>
+__device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* buf, const float* g_lds, const PsyParams& pp,
+                                          int lane, v2f& t, v4f (&thr)[8]) {
+  v4f Iq[8];
+  v2f slog = {0.f, 0.f}, ssq = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    Iq[i] = xq[i] * xq[i];
+    if (WANT_T) {
+      ssq += v2f{Iq[i].x, Iq[i].y} + v2f{Iq[i].z, Iq[i].w};
+      slog += log2v(maxv(v2f{Iq[i].x, Iq[i].y}, kEps)) + log2v(maxv(v2f{Iq[i].z, Iq[i].w}, kEps));
+    }
+  }
+  if (WANT_T) {
+    slog.x = wave_sum(slog.x);
+    slog.y = wave_sum(slog.y);
+    ssq.x = wave_sum(ssq.x);
+    ssq.y = wave_sum(ssq.y);
+    const v2f am = ssq * (1.0f / FN) + kEps;
+    // sfm = 10 log10(gm / am) with gm = exp(mean ln I)  ==  10 log10(2) (mean log2 I - log2 am)
+    const v2f sfm = 3.0102999566398120f * (slog * (1.0f / FN) - log2v(am));
+    const v2f tt = sfm * (-1.0f / 60.0f);
+    t = v2f{fminf(tt.x, 1.0f), fminf(tt.y, 1.0f)};
+  }
+  if (!WANT_THR) return;
+
+  const uint32_t* tab = pp.tab;
+  wave_sync();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) *reinterpret_cast<v4f*>(buf + 16 * (64 * i + lane)) = Iq[i];   // I[f] at byte 8 f
+  wave_sync();
+
+  // P_j = sum_f I_f W[f, j]: lane = Bark band; W is 1 on interior bins, wf / wl on the two edge bins (:312-313)
+  const int f0 = (int)tab[PB_F0 + lane], nb = (int)tab[PB_N + lane];
+  const float wf = __uint_as_float(tab[PB_WF + lane]), wl = __uint_as_float(tab[PB_WL + lane]);
+  const char* bp = buf + 8 * f0;
+  v2f P = {0.f, 0.f};
+  for (int it = 0; it < pp.maxn; ++it) {
+    if (it < nb) {
+      const v2f I = *reinterpret_cast<const v2f*>(bp + 8 * it);
+      const float w = (it == 0) ? wf : ((it == nb - 1) ? wl : 1.0f);
+      P += I * w;
+    }
+  }
+  const v2f Q = exp2v(pp.alpha * log2v(maxv(P, kEps)));   // max(eps, P)^alpha  (:206)
+  wave_sync();
+  *reinterpret_cast<v2f*>(buf + 8 * lane) = Q;
+  wave_sync();
+  // sum_i Q_i S[i, j], S[i, j] = g[64 - i + j]  (:205-207 with the offset factor pulled out of the sum)
+  v2f acc = {0.f, 0.f};
+  const float* gp = g_lds + 64 + lane;
+#pragma unroll 8
+  for (int i = 0; i < 64; ++i) {
+    const v2f qi = *reinterpret_cast<const v2f*>(buf + 8 * i);
+    acc += qi * gp[-i];
+  }
+  const float beta = __uint_as_float(tab[PB_BETA + lane]), quiet = __uint_as_float(tab[PB_QUIET + lane]);
+  const v2f offset = (1.0f - pp.drown) * (t * beta + 9.0f * t + 5.5f);                       // (:185-191)
+  const v2f fac = exp2v(offset * (-pp.alpha * 0.33219280948873623f));                        // 10^(-alpha O / 10)
+  const v2f T = exp2v(pp.inv_alpha * log2v(maxv(fac * acc, kEps)));                           // (:208)
+  const v2f G = maxv(T, quiet);                                                               // (:144)
+  v2f Gn;
+  Gn.x = __shfl_down(G.x, 1, 64);
+  Gn.y = __shfl_down(G.y, 1, 64);
+  // thr^2 of the bins of band j: interior bins G_j rho_j; the bin shared with band j+1 G_j u0 + G_{j+1} u1 (:330)
+  const float rho = __uint_as_float(tab[PB_RHO + lane]), u0 = __uint_as_float(tab[PB_U0 + lane]),
+              u1 = __uint_as_float(tab[PB_U1 + lane]);
+  const v2f A0 = G * rho, A1 = G * u0 + Gn * u1;
+  wave_sync();
+  *reinterpret_cast<v4f*>(buf + 16 * lane) = v4f{A0.x, A0.y, A1.x, A1.y};   // entry e at byte 8 e
+  wave_sync();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t w = tab[P_IDX + (i >> 1) * 64 + lane] >> (16 * (i & 1));
+    const v2f a0 = *reinterpret_cast<const v2f*>(buf + 8 * (w & 0xffu));
+    const v2f a1 = *reinterpret_cast<const v2f*>(buf + 8 * ((w >> 8) & 0xffu));
+    thr[i] = v4f{__builtin_sqrtf(fmaxf(a0.x, kEps)), __builtin_sqrtf(fmaxf(a0.y, kEps)),
+                 __builtin_sqrtf(fmaxf(a1.x, kEps)), __builtin_sqrtf(fmaxf(a1.y, kEps))};   // (:331)
+  }
+  wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// analysis (+ fused epilogue)
+// ------------------------------------------------------------------------------------------------------
+struct FwdArgs {
+  const float* x;            // [B, Kin*N, C]
+  float* X;                  // [B, F, N, C]
+  float* t;                  // [B, F, 1, C]   (PSY)
+  float* thr;                // [B, F, N, C]   (PSY)
+  const float* prev_block;   // [B, N, C] or null
+  const float* tab;          // mdct tables
+  PsyParams psy;
+  int B, Kin, F, C, CP, seglen, nseg;
+  long long ntasks;
+};
+
+// fold one staged block: cur = part of this frame, carry' = part aliasing into the next frame
+__device__ __forceinline__ void fold_block(char* buf, const float* __restrict__ tab, int lane, v2f (&cur)[8],
+                                           v2f (&nxt)[8]) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int e = lane + 64 * r;
+    const v2f xe = slotE(buf, (e + 256) & 511);
+    const v2f xo = slotO(buf, (767 - e) & 511);
+    const float4 cf = reinterpret_cast<const float4*>(tab + T_FOLD)[r * 64 + lane];
+    cur[r] = cf.x * xe + cf.y * xo;
+    nxt[r] = cf.z * xe + cf.w * xo;
+  }
+}
+
+template <int CMODE, bool PSY>
+__global__ __launch_bounds__(WAVES * 64) void k_fwd_fast(FwdArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[WAVES * WAVE_LDS];
+  __shared__ float g_lds[128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (PSY) {
+    if (threadIdx.x < 128) g_lds[threadIdx.x] = __uint_as_float(a.psy.tab[P_G + threadIdx.x]);
+    __syncthreads();
+  }
+  const long long task = (long long)blockIdx.x * WAVES + wave;
+  if (task >= a.ntasks) return;
+  char* buf = lds + wave * WAVE_LDS;
+  const int sgm = (int)(task % a.nseg);
+  const long long pair = task / a.nseg;
+  const int cp = (int)(pair % a.CP);
+  const long long b = pair / a.CP;
+  const int C = a.C, c0 = 2 * cp;
+  const bool has1 = (c0 + 1) < C;
+  const int n0 = sgm * a.seglen;
+  const int n1 = min(a.F, n0 + a.seglen);
+  const float* tab = a.tab;
+  const size_t blk = (size_t)FN * C;   // floats per block / frame row over all channels
+
+  v2f carry[8];
+  v4f row[8];
+  {
+    // carry of the block before the strip: block n0-1 of x, the stream state, or zero
+    const float* src = nullptr;
+    if (n0 >= 1) src = a.x + ((size_t)b * a.Kin + (size_t)(n0 - 1)) * blk;
+    else if (a.prev_block) src = a.prev_block + (size_t)b * blk;
+    if (src) {
+      load_row<CMODE>(src, C, c0, has1, lane, row);
+      stage_row(buf, lane, row);
+      wave_sync();
+      v2f dummy[8];
+      fold_block(buf, tab, lane, dummy, carry);
+      wave_sync();
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) carry[r] = v2f{0.f, 0.f};
+    }
+  }
+
+  for (int n = n0; n < n1; ++n) {
+    // defeat loop-invariant hoisting of the table loads (they would pin >100 VGPRs across the walk)
+    asm volatile("" : "+s"(tab));
+    v2f cur[8], nxt[8];
+    if (n < a.Kin) {
+      load_row<CMODE>(a.x + ((size_t)b * a.Kin + (size_t)n) * blk, C, c0, has1, lane, row);
+      stage_row(buf, lane, row);
+      wave_sync();
+      fold_block(buf, tab, lane, cur, nxt);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        cur[r] = v2f{0.f, 0.f};
+        nxt[r] = v2f{0.f, 0.f};
+      }
+    }
+    C2 z[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      // element e = lane + 64 r: v[2e] + i v[N-1-2e]; for e < 256 the real part comes from the previous block
+      const C2 v = (r < 4) ? C2{carry[r], cur[r]} : C2{cur[r], carry[r]};
+      z[r] = cmul(v, reinterpret_cast<const float2*>(tab + T_PRE)[r * 64 + lane]);
+      carry[r] = nxt[r];
+    }
+    fft512(z, buf, tab, lane);
+    wave_sync();
+    {
+      const int k_lo = (lane >> 3) + 8 * (lane & 7);
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) {
+        const int k = k_lo + 64 * k2;
+        const C2 r = cmul(z[k2], reinterpret_cast<const float2*>(tab + T_POSTF)[k2 * 64 + lane]);
+        slotE(buf, k) = r.re;          // X[2k]
+        slotO(buf, 511 - k) = -r.im;   // X[N-1-2k]
+      }
+    }
+    wave_sync();
+    unstage_row(buf, lane, row);
+    const size_t frame = (size_t)b * a.F + (size_t)n;
+    store_row<CMODE>(a.X + frame * blk, C, c0, has1, lane, row);
+    if (PSY) {
+      v2f tt;
+      v4f th[8];
+      psy_stage<true, true>(row, buf, g_lds, a.psy, lane, tt, th);
+      store_row<CMODE>(a.thr + frame * blk, C, c0, has1, lane, th);
+      if (lane == 0) {
+        a.t[frame * C + c0] = tt.x;
+        if (has1) a.t[frame * C + c0 + 1] = tt.y;
+      }
+    } else {
+      wave_sync();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// synthesis
+// ------------------------------------------------------------------------------------------------------
+struct InvArgs {
+  const float* X;          // [B, Kp, N, C]
+  float* x;                // [B, nblk*N, C]
+  const float* tail_in;    // [B, C, N/2] or null
+  float* tail_out;         // [B, C, N/2] or null
+  const float* tab;
+  int B, Kp, nblk, C, CP, seglen, nseg;
+  long long ntasks;
+};
+
+// DCT-IV of the staged frame: returns (now, nxt) per output element k
+__device__ __forceinline__ void idct_frame(char* buf, const float* __restrict__ tab, int lane, v2f (&now)[8],
+                                           v2f (&nxt)[8]) {
+  C2 z[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int e = lane + 64 * r;
+    const C2 v = {slotE(buf, e), slotO(buf, 511 - e)};   // X[2e] + i X[N-1-2e]
+    z[r] = cmul(v, reinterpret_cast<const float2*>(tab + T_PRE)[r * 64 + lane]);
+  }
+  fft512(z, buf, tab, lane);
+#pragma unroll
+  for (int k2 = 0; k2 < 8; ++k2) {
+    const C2 r = cmul(z[k2], reinterpret_cast<const float2*>(tab + T_POSTI)[k2 * 64 + lane]);
+    // u[2k] = Re, u[N-1-2k] = -Im; k < 256 (k2 < 4): u[2k] belongs to this block, u[N-1-2k] to the next
+    if (k2 < 4) {
+      now[k2] = r.re;
+      nxt[k2] = -r.im;
+    } else {
+      now[k2] = -r.im;
+      nxt[k2] = r.re;
+    }
+  }
+}
+
+template <int CMODE>
+__global__ __launch_bounds__(WAVES * 64) void k_inv_fast(InvArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[WAVES * WAVE_LDS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long task = (long long)blockIdx.x * WAVES + wave;
+  if (task >= a.ntasks) return;
+  char* buf = lds + wave * WAVE_LDS;
+  const int sgm = (int)(task % a.nseg);
+  const long long pair = task / a.nseg;
+  const int cp = (int)(pair % a.CP);
+  const long long b = pair / a.CP;
+  const int C = a.C, c0 = 2 * cp;
+  const bool has1 = (c0 + 1) < C;
+  const int n0 = sgm * a.seglen;
+  const int n1 = min(a.nblk, n0 + a.seglen);
+  const float* tab = a.tab;
+  const size_t blk = (size_t)FN * C;
+  const int k_lo = (lane >> 3) + 8 * (lane & 7);
+
+  v2f carry[8];
+  v4f row[8];
+  if (n0 >= 1) {
+    // aliased half of frame n0-1 (always an existing frame: n0-1 < Kp)
+    load_row<CMODE>(a.X + ((size_t)b * a.Kp + (size_t)(n0 - 1)) * blk, C, c0, has1, lane, row);
+    stage_row(buf, lane, row);
+    wave_sync();
+    v2f dummy[8];
+    idct_frame(buf, tab, lane, dummy, carry);
+    wave_sync();
+  } else if (a.tail_in) {
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) {
+      const int k = k_lo + 64 * k2;
+      const int j = (k2 < 4) ? (511 - 2 * k) : (2 * k - 512);
+      carry[k2].x = a.tail_in[((size_t)b * C + c0) * FH + j];
+      carry[k2].y = has1 ? a.tail_in[((size_t)b * C + c0 + 1) * FH + j] : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) carry[r] = v2f{0.f, 0.f};
+  }
+
+  for (int n = n0; n < n1; ++n) {
+    asm volatile("" : "+s"(tab));
+    v2f now[8], nxt[8];
+    if (n < a.Kp) {
+      load_row<CMODE>(a.X + ((size_t)b * a.Kp + (size_t)n) * blk, C, c0, has1, lane, row);
+      stage_row(buf, lane, row);
+      wave_sync();
+      idct_frame(buf, tab, lane, now, nxt);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        now[r] = v2f{0.f, 0.f};
+        nxt[r] = v2f{0.f, 0.f};
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) {
+      const int k = k_lo + 64 * k2;
+      const float4 sc = reinterpret_cast<const float4*>(tab + T_SYN)[k2 * 64 + lane];
+      const v2f o1 = sc.x * now[k2] + sc.y * carry[k2];   // out[j]
+      const v2f o2 = sc.z * now[k2] + sc.w * carry[k2];   // out[N-1-j]
+      // k < 256: j = 511 - 2k (odd), N-1-j = 512 + 2k (even); else j = 2k - 512 (even), N-1-j = 1535 - 2k (odd)
+      slotE(buf, (k + 256) & 511) = (k2 < 4) ? o2 : o1;
+      slotO(buf, (767 - k) & 511) = (k2 < 4) ? o1 : o2;
+      carry[k2] = nxt[k2];
+    }
+    wave_sync();
+    unstage_row(buf, lane, row);
+    store_row<CMODE>(a.x + ((size_t)b * a.nblk + (size_t)n) * blk, C, c0, has1, lane, row);
+    wave_sync();
+  }
+
+  if (a.tail_out && n1 == a.nblk) {
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) {
+      const int k = k_lo + 64 * k2;
+      const int j = (k2 < 4) ? (511 - 2 * k) : (2 * k - 512);
+      a.tail_out[((size_t)b * C + c0) * FH + j] = carry[k2].x;
+      if (has1) a.tail_out[((size_t)b * C + c0 + 1) * FH + j] = carry[k2].y;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// stand-alone tonality / threshold on a spectrum in HBM: one wave per (b, frame, channel pair)
+// ------------------------------------------------------------------------------------------------------
+struct PsyArgs {
+  const float* X;
+  const float* t_in;
+  float* t_out;
+  float* thr;
+  PsyParams psy;
+  int C, CP;
+  long long ntasks;   // B * F * CP
+};
+
+template <int CMODE, bool WANT_T, bool WANT_THR>
+__global__ __launch_bounds__(WAVES * 64) void k_psy_fast(PsyArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[WAVES * WAVE_LDS];
+  __shared__ float g_lds[128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < 128) g_lds[threadIdx.x] = __uint_as_float(a.psy.tab[P_G + threadIdx.x]);
+  __syncthreads();
+  const long long task = (long long)blockIdx.x * WAVES + wave;
+  if (task >= a.ntasks) return;
+  char* buf = lds + wave * WAVE_LDS;
+  const int cp = (int)(task % a.CP);
+  const long long frame = task / a.CP;
+  const int C = a.C, c0 = 2 * cp;
+  const bool has1 = (c0 + 1) < C;
+  const size_t blk = (size_t)FN * C;
+  v4f row[8], th[8];
+  load_row<CMODE>(a.X + (size_t)frame * blk, C, c0, has1, lane, row);
+  v2f tt = {0.f, 0.f};
+  if (!WANT_T) {
+    tt.x = a.t_in[(size_t)frame * C + c0];
+    tt.y = has1 ? a.t_in[(size_t)frame * C + c0 + 1] : 0.f;
+  }
+  psy_stage<WANT_T, WANT_THR>(row, buf, g_lds, a.psy, lane, tt, th);
+  if (WANT_T && lane == 0) {
+    a.t_out[(size_t)frame * C + c0] = tt.x;
+    if (has1) a.t_out[(size_t)frame * C + c0 + 1] = tt.y;
+  }
+  if (WANT_THR) store_row<CMODE>(a.thr + (size_t)frame * blk, C, c0, has1, lane, th);
+}
+
+// strips: enough waves to fill the chip several times over, long enough to amortise the one-block halo
+int pick_seglen(long long pairs, int frames) {
+  const long long total = pairs * (long long)frames;
+  long long s = (total + 8191) / 8192;
+  if (s < 4) s = 4;
+  if (s > frames) s = frames;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+PsyParams psy_params(const ac_psy_plan* p, float drown) {
+  PsyParams pp;
+  pp.tab = reinterpret_cast<const uint32_t*>(p->d_fast);
+  pp.alpha = (float)p->alpha;
+  pp.inv_alpha = (float)(1.0 / p->alpha);
+  pp.drown = drown;
+  pp.maxn = p->wb_max;
+  return pp;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------
+bool fast_mdct_supported(int N) { return N == FN; }
+
+int fast_mdct_plan_init(ac_mdct_plan* p) {
+  const int N = p->N, h = N / 2;
+  FoldCoef c;
+  fold_coefficients(N, p->window, c);
+  std::vector<float> t(T_TOTAL, 0.f);
+  const double pi = 3.14159265358979323846;
+  for (int r = 0; r < 8; ++r) {
+    for (int l = 0; l < 64; ++l) {
+      const int i = r * 64 + l;
+      const int e = l + 64 * r;                                   // input element of (lane, register)
+      const int k = (l >> 3) + 8 * (l & 7) + 64 * r;              // output bin of (lane, register)
+      double ang = -pi * (e + 0.25) / N;
+      t[T_PRE + 2 * i] = (float)std::cos(ang);
+      t[T_PRE + 2 * i + 1] = (float)std::sin(ang);
+      ang = -2.0 * pi * (double)(l * r) / 512.0;
+      t[T_P1 + 2 * i] = (float)std::cos(ang);
+      t[T_P1 + 2 * i + 1] = (float)std::sin(ang);
+      ang = -2.0 * pi * (double)((l & 7) * r) / 64.0;
+      t[T_P2 + 2 * i] = (float)std::cos(ang);
+      t[T_P2 + 2 * i + 1] = (float)std::sin(ang);
+      ang = -pi * (double)k / N;
+      const double sf = 1.0 / (N * std::sqrt(2.0)), si = 2.0 * std::sqrt(2.0);
+      t[T_POSTF + 2 * i] = (float)(std::cos(ang) * sf);
+      t[T_POSTF + 2 * i + 1] = (float)(std::sin(ang) * sf);
+      t[T_POSTI + 2 * i] = (float)(std::cos(ang) * si);
+      t[T_POSTI + 2 * i + 1] = (float)(std::sin(ang) * si);
+      double cE, cO, kE, kO;
+      if (e < h / 2) {   // e < 256: samples 512+2e (even) / 511-2e (odd); current part = v[N-1-2e], carry = v'[2e]
+        const int jc = h - 1 - 2 * e, jk = 2 * e;
+        cE = c.a2[jc]; cO = c.a1[jc]; kE = c.a4[jk]; kO = c.a3[jk];
+      } else {           // samples 2p (even) / N-1-2p (odd), p = e-256: current part = v[2e], carry = v'[N-1-2e]
+        const int pidx = e - h / 2;
+        const int jc = 2 * pidx, jk = h - 1 - 2 * pidx;
+        cE = c.a1[jc]; cO = c.a2[jc]; kE = c.a3[jk]; kO = c.a4[jk];
+      }
+      t[T_FOLD + 4 * i + 0] = (float)cE;
+      t[T_FOLD + 4 * i + 1] = (float)cO;
+      t[T_FOLD + 4 * i + 2] = (float)kE;
+      t[T_FOLD + 4 * i + 3] = (float)kO;
+      const int j = (k < h / 2) ? (h - 1 - 2 * k) : (2 * k - h);
+      t[T_SYN + 4 * i + 0] = (float)c.s1[j];
+      t[T_SYN + 4 * i + 1] = (float)c.s2[j];
+      t[T_SYN + 4 * i + 2] = (float)c.s3[j];
+      t[T_SYN + 4 * i + 3] = (float)c.s4[j];
+    }
+  }
+  p->fast_bytes = t.size() * sizeof(float);
+  AC_HIP_CHECK(hipMalloc((void**)&p->d_fast, p->fast_bytes));
+  AC_HIP_CHECK(hipMemcpy(p->d_fast, t.data(), p->fast_bytes, hipMemcpyHostToDevice));
+  return AC_OK;
+}
+
+// The fused epilogue needs: N = 1024, 64 Bark bands (lane = band), every band a contiguous bin range whose
+// interior weights are exactly 1, every bin overlapping at most two (adjacent) bands, and a per-band constant
+// W_inv on the bins that belong to one band only.
+static bool build_psy_fast(const ac_psy_plan* p, std::vector<uint32_t>* out) {
+  const PsyTables& t = p->host;
+  const int N = t.N, M = t.M;
+  if (N != FN || M != 64) return false;
+  auto Wf = [&](int f, int j) { return (float)t.W[(size_t)f * M + j]; };
+  auto Vf = [&](int j, int f) { return (float)t.W_inv[(size_t)j * N + f]; };
+  std::vector<uint32_t> w(P_TOTAL, 0u);
+  auto putf = [&](int idx, float v) { uint32_t u; memcpy(&u, &v, 4); w[idx] = u; };
+  std::vector<int> first(M), last(M);
+  for (int j = 0; j < M; ++j) {
+    int f0 = -1, f1 = -1;
+    for (int f = 0; f < N; ++f)
+      if (Wf(f, j) != 0.f) {
+        if (f0 < 0) f0 = f;
+        f1 = f;
+      }
+    if (f0 < 0) return false;
+    for (int f = f0; f <= f1; ++f) {
+      if (Wf(f, j) == 0.f) return false;
+      if (f > f0 && f < f1 && Wf(f, j) != 1.0f) return false;
+    }
+    first[j] = f0;
+    last[j] = f1;
+    if (f1 - f0 + 1 > 255) return false;
+    w[PB_F0 + j] = (uint32_t)f0;
+    w[PB_N + j] = (uint32_t)(f1 - f0 + 1);
+    putf(PB_WF + j, Wf(f0, j));
+    putf(PB_WL + j, Wf(f1, j));
+    putf(PB_QUIET + j, (float)t.quiet[j]);
+    putf(PB_BETA + j, t.beta[j]);
+  }
+  // bins -> entries; nnz pattern of W and W_inv is identical (same overlap)
+  std::vector<int> entry(N, -1);
+  std::vector<float> rho(M, 0.f), u0(M, 0.f), u1(M, 0.f);
+  std::vector<bool> have_rho(M, false);
+  for (int f = 0; f < N; ++f) {
+    int cnt = 0, jf = -1;
+    for (int j = 0; j < M; ++j)
+      if (Vf(j, f) != 0.f) {
+        if (cnt == 0) jf = j;
+        ++cnt;
+      }
+    if (cnt == 1) {
+      const float v = Vf(jf, f);
+      if (!have_rho[jf]) {
+        rho[jf] = v;
+        have_rho[jf] = true;
+      } else if (std::fabs(v - rho[jf]) > 1e-6f * rho[jf]) {
+        return false;
+      }
+      entry[f] = 2 * jf;
+    } else if (cnt == 2 && Vf(jf + 1, f) != 0.f && jf + 1 < M) {
+      if (u0[jf] != 0.f || u1[jf] != 0.f) return false;   // one shared bin per band boundary
+      u0[jf] = Vf(jf, f);
+      u1[jf] = Vf(jf + 1, f);
+      entry[f] = 2 * jf + 1;
+    } else {
+      return false;
+    }
+  }
+  for (int j = 0; j < M; ++j) {
+    putf(PB_RHO + j, rho[j]);
+    putf(PB_U0 + j, u0[j]);
+    putf(PB_U1 + j, u1[j]);
+  }
+  for (int l = 0; l < 64; ++l)
+    for (int i = 0; i < 8; ++i) {
+      const int q = 64 * i + l;
+      const uint32_t e0 = (uint32_t)entry[2 * q], e1 = (uint32_t)entry[2 * q + 1];
+      w[P_IDX + (i >> 1) * 64 + l] |= (e0 | (e1 << 8)) << (16 * (i & 1));
+    }
+  for (int i = 0; i < 128; ++i) putf(P_G + i, (float)t.g[i]);
+  if (out) *out = w;
+  return true;
+}
+
+bool fast_psy_supported(const ac_psy_plan* p) { return build_psy_fast(p, nullptr); }
+
+int fast_psy_plan_init(ac_psy_plan* p) {
+  std::vector<uint32_t> w;
+  if (!build_psy_fast(p, &w)) {
+    set_error("internal: fused epilogue not supported for this configuration");
+    return AC_EUNSUPPORTED;
+  }
+  p->fast_bytes = w.size() * sizeof(uint32_t);
+  AC_HIP_CHECK(hipMalloc((void**)&p->d_fast, p->fast_bytes));
+  AC_HIP_CHECK(hipMemcpy(p->d_fast, w.data(), p->fast_bytes, hipMemcpyHostToDevice));
+  return AC_OK;
+}
+
+static int grid_for(long long ntasks, unsigned* grid) {
+  const long long g = (ntasks + WAVES - 1) / WAVES;
+  if (g > 2147483647ll) {
+    set_error("problem too large for one launch (%lld workgroups)", g);
+    return AC_EINVAL;
+  }
+  *grid = (unsigned)g;
+  return AC_OK;
+}
+
+int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr,
+                    float drown, const float* prev_block, int B, int Kin, int F, int C, hipStream_t s) {
+  if (B <= 0 || C <= 0 || F <= 0) return AC_OK;
+  FwdArgs a;
+  a.x = x;
+  a.X = X;
+  a.t = t;
+  a.thr = thr;
+  a.prev_block = prev_block;
+  a.tab = p->d_fast;
+  if (psy) a.psy = psy_params(psy, drown);
+  else a.psy = PsyParams{nullptr, 0.f, 0.f, 0.f, 0};
+  a.B = B;
+  a.Kin = Kin;
+  a.F = F;
+  a.C = C;
+  a.CP = (C + 1) / 2;
+  a.seglen = pick_seglen((long long)B * a.CP, F);
+  a.nseg = (F + a.seglen - 1) / a.seglen;
+  a.ntasks = (long long)B * a.CP * a.nseg;
+  unsigned grid;
+  int st = grid_for(a.ntasks, &grid);
+  if (st) return st;
+  const dim3 blk(WAVES * 64);
+  if (C == 2) {
+    if (psy) hipLaunchKernelGGL((k_fwd_fast<0, true>), dim3(grid), blk, 0, s, a);
+    else hipLaunchKernelGGL((k_fwd_fast<0, false>), dim3(grid), blk, 0, s, a);
+  } else {
+    if (psy) hipLaunchKernelGGL((k_fwd_fast<1, true>), dim3(grid), blk, 0, s, a);
+    else hipLaunchKernelGGL((k_fwd_fast<1, false>), dim3(grid), blk, 0, s, a);
+  }
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+int launch_inv_fast(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out, int B,
+                    int Kp, int nblk, int C, hipStream_t s) {
+  if (B <= 0 || C <= 0 || nblk <= 0) return AC_OK;
+  InvArgs a;
+  a.X = X;
+  a.x = x;
+  a.tail_in = tail_in;
+  a.tail_out = tail_out;
+  a.tab = p->d_fast;
+  a.B = B;
+  a.Kp = Kp;
+  a.nblk = nblk;
+  a.C = C;
+  a.CP = (C + 1) / 2;
+  a.seglen = pick_seglen((long long)B * a.CP, nblk);
+  a.nseg = (nblk + a.seglen - 1) / a.seglen;
+  a.ntasks = (long long)B * a.CP * a.nseg;
+  unsigned grid;
+  int st = grid_for(a.ntasks, &grid);
+  if (st) return st;
+  const dim3 blk(WAVES * 64);
+  if (C == 2) hipLaunchKernelGGL((k_inv_fast<0>), dim3(grid), blk, 0, s, a);
+  else hipLaunchKernelGGL((k_inv_fast<1>), dim3(grid), blk, 0, s, a);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+int launch_psy_fast(const ac_psy_plan* p, const float* X, const float* t_in, float* t_out, float* thr, float drown,
+                    int B, int F, int C, hipStream_t s) {
+  if (B <= 0 || C <= 0 || F <= 0) return AC_OK;
+  PsyArgs a;
+  a.X = X;
+  a.t_in = t_in;
+  a.t_out = t_out;
+  a.thr = thr;
+  a.psy = psy_params(p, drown);
+  a.C = C;
+  a.CP = (C + 1) / 2;
+  a.ntasks = (long long)B * F * a.CP;
+  unsigned grid;
+  int st = grid_for(a.ntasks, &grid);
+  if (st) return st;
+  const dim3 blk(WAVES * 64);
+  const bool want_t = (t_out != nullptr), want_thr = (thr != nullptr);
+  if (want_t && !want_thr) {
+    if (C == 2) hipLaunchKernelGGL((k_psy_fast<0, true, false>), dim3(grid), blk, 0, s, a);
+    else hipLaunchKernelGGL((k_psy_fast<1, true, false>), dim3(grid), blk, 0, s, a);
+  } else if (!want_t && want_thr) {
+    if (C == 2) hipLaunchKernelGGL((k_psy_fast<0, false, true>), dim3(grid), blk, 0, s, a);
+    else hipLaunchKernelGGL((k_psy_fast<1, false, true>), dim3(grid), blk, 0, s, a);
+  } else if (want_t && want_thr) {
+    if (C == 2) hipLaunchKernelGGL((k_psy_fast<0, true, true>), dim3(grid), blk, 0, s, a);
+    else hipLaunchKernelGGL((k_psy_fast<1, true, true>), dim3(grid), blk, 0, s, a);
+  }
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+}  // namespace ac

@@ -112,6 +112,7 @@ void psy_tables(int N, int M, double sample_rate, double alpha, PsyTables& t) {
     const double f = 15.81 + 7.5 * (z + 0.474) - 17.5 * std::sqrt(1.0 + std::pow(z + 0.474, 2.0));
     g[i] = std::pow(10.0, alpha * f / 10.0);                                 // :223
   }
+  t.g = g;
   t.S.resize((size_t)M * M);
   for (int row = 0; row < M; ++row)
     for (int col = 0; col < M; ++col) t.S[(size_t)row * M + col] = g[M - row + col];   // :227-228

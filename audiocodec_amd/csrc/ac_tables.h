@@ -26,6 +26,7 @@ struct PsyTables {
   std::vector<double> S;      // [M, M]   psychoacoustic.py:212-230
   std::vector<double> quiet;  // [M]      psychoacoustic.py:232-255
   std::vector<float> beta;    // [M]      linspace(0, max_bark, M) in float32, psychoacoustic.py:187-189
+  std::vector<double> g;      // [2M]     spreading prototype, S[i][j] = g[M - i + j]  (psychoacoustic.py:223-228)
 };
 void psy_tables(int N, int M, double sample_rate, double alpha, PsyTables& t);
 
