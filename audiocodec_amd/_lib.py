@@ -11,7 +11,7 @@ import threading
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libaudiocodec_amd.so")
+LIB_PATH = os.environ.get("AUDIOCODEC_AMD_LIB") or os.path.join(_HERE, "lib", "libaudiocodec_amd.so")
 
 AC_OK = 0
 AC_EINVAL, AC_EHIP, AC_ENOMEM, AC_ENODEV, AC_EUNSUPPORTED = -1, -2, -3, -4, -5

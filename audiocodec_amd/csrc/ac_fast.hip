@@ -23,22 +23,26 @@ namespace {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const float* gtab_t;   // LDS-resident table image
 
 constexpr int FN = 1024;            // filters_n served by this file
 constexpr int FH = FN / 2;          // complex FFT points per frame (= 64 lanes x 8 registers)
 constexpr int WAVES = 4;            // waves (independent strips) per workgroup
 constexpr int WAVE_LDS = 8192;      // bytes of LDS per wave
 constexpr float kEps = 1e-14f;      // _INTENSITY_EPS, psychoacoustic.py:56
+#ifndef AC_WPE
+#define AC_WPE 2                    // minimum waves per SIMD the register allocator must leave room for
+#endif
 
-// ---- mdct table layout (floats) in ac_mdct_plan::d_fast ------------------------------------------
-constexpr int T_PRE = 0;                  // [8][64] float2  exp(-i pi (e + 1/4) / N), e = lane + 64 r
-constexpr int T_P1 = T_PRE + 1024;        // [8][64] float2  W512^(lane k0)
-constexpr int T_P2 = T_P1 + 1024;         // [8][64] float2  W64^((lane & 7) k1)
-constexpr int T_POSTF = T_P2 + 1024;      // [8][64] float2  exp(-i pi k / N) / (N sqrt 2)
-constexpr int T_POSTI = T_POSTF + 1024;   // [8][64] float2  exp(-i pi k / N) * 2 sqrt 2
-constexpr int T_FOLD = T_POSTI + 1024;    // [8][64] float4  (cE, cO, kE, kO) of element e
-constexpr int T_SYN = T_FOLD + 2048;      // [8][64] float4  (s1, s2, s3, s4) at j(k)
-constexpr int T_TOTAL = T_SYN + 2048;
+// ---- mdct tables: two images in ac_mdct_plan::d_fast (analysis at 0, synthesis at I_TOTAL floats); the kernel
+// copies its image into LDS once per workgroup, so the walk loop touches HBM only for PCM / spectra ---------
+constexpr int I_PRE = 0;                  // [8][64] float2  exp(-i pi (e + 1/4) / N), e = lane + 64 r
+constexpr int I_P1 = I_PRE + 1024;        // [8][64] float2  W512^(lane k0)
+constexpr int I_P2 = I_P1 + 1024;         // [8][8]  float2  W64^(m0 k1)
+constexpr int I_POST = I_P2 + 128;        // [8][64] float2  exp(-i pi k / N) * (1/(N sqrt 2) | 2 sqrt 2)
+constexpr int I_COEF = I_POST + 1024;     // [8][64] float4  fold (cE, cO, kE, kO)(e) | unfold (s1..s4)(j(k))
+constexpr int I_TOTAL = I_COEF + 2048;    // 5248 floats = 20 992 bytes
+constexpr int TAB_LDS = I_TOTAL * 4;
 
 // ---- psy table layout (32-bit words) in ac_psy_plan::d_fast --------------------------------------
 constexpr int PB_F0 = 0, PB_N = 64, PB_WF = 128, PB_WL = 192, PB_QUIET = 256, PB_BETA = 320, PB_RHO = 384,
@@ -61,7 +65,7 @@ __device__ __forceinline__ void wave_sync() {
 
 __device__ __forceinline__ int swz(int q) { return q ^ ((q >> 3) & 7); }
 
-__device__ __forceinline__ C2 cmul(const C2& x, const float2 w) {
+__device__ __forceinline__ C2 cmul(const C2& x, const v2f w) {
   C2 r;
   r.re = x.re * w.x - x.im * w.y;
   r.im = x.re * w.y + x.im * w.x;
@@ -106,12 +110,12 @@ __device__ __forceinline__ C2 lds_get(const char* buf, int idx16) {
 }
 
 // 512-point FFT of z[r] = element (lane + 64 r); result z[k2] = bin k = (lane>>3) + 8 (lane&7) + 64 k2
-__device__ __forceinline__ void fft512(C2 (&z)[8], char* buf, const float* __restrict__ tab, int lane) {
+__device__ __forceinline__ void fft512(C2 (&z)[8], char* buf, gtab_t tab, int lane) {
   const int a = lane >> 3, m0 = lane & 7;
   const int flip = (a & 1) << 3;
   dft8(z);
 #pragma unroll
-  for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], reinterpret_cast<const float2*>(tab + T_P1)[k * 64 + lane]);
+  for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], reinterpret_cast<const v2f*>(tab + I_P1)[k * 64 + lane]);
   wave_sync();
 #pragma unroll
   for (int k = 0; k < 8; ++k) lds_put(buf, (k * 64 + lane) ^ ((k & 1) << 3), z[k]);
@@ -120,7 +124,7 @@ __device__ __forceinline__ void fft512(C2 (&z)[8], char* buf, const float* __res
   for (int r = 0; r < 8; ++r) z[r] = lds_get(buf, (a * 64 + 8 * r + m0) ^ flip);
   dft8(z);
 #pragma unroll
-  for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], reinterpret_cast<const float2*>(tab + T_P2)[k * 64 + lane]);
+  for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], reinterpret_cast<const v2f*>(tab + I_P2)[k * 8 + m0]);
   wave_sync();
 #pragma unroll
   for (int k = 0; k < 8; ++k) lds_put(buf, a * 64 + ((k * 8 + (m0 ^ k)) ^ flip), z[k]);
@@ -251,14 +255,16 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* buf, const f
   // P_j = sum_f I_f W[f, j]: lane = Bark band; W is 1 on interior bins, wf / wl on the two edge bins (:312-313)
   const int f0 = (int)tab[PB_F0 + lane], nb = (int)tab[PB_N + lane];
   const float wf = __uint_as_float(tab[PB_WF + lane]), wl = __uint_as_float(tab[PB_WL + lane]);
+  // every lane reads unconditionally (index clamped into its own band) so the reads pipeline; bins past the
+  // band's end get weight 0
   const char* bp = buf + 8 * f0;
+  const int last = nb - 1;
   v2f P = {0.f, 0.f};
+#pragma unroll 4
   for (int it = 0; it < pp.maxn; ++it) {
-    if (it < nb) {
-      const v2f I = *reinterpret_cast<const v2f*>(bp + 8 * it);
-      const float w = (it == 0) ? wf : ((it == nb - 1) ? wl : 1.0f);
-      P += I * w;
-    }
+    const v2f I = *reinterpret_cast<const v2f*>(bp + 8 * min(it, last));
+    const float w = (it == 0) ? wf : ((it < last) ? 1.0f : ((it == last) ? wl : 0.0f));
+    P += I * w;
   }
   const v2f Q = exp2v(pp.alpha * log2v(maxv(P, kEps)));   // max(eps, P)^alpha  (:206)
   wave_sync();
@@ -314,31 +320,41 @@ struct FwdArgs {
 };
 
 // fold one staged block: cur = part of this frame, carry' = part aliasing into the next frame
-__device__ __forceinline__ void fold_block(char* buf, const float* __restrict__ tab, int lane, v2f (&cur)[8],
+__device__ __forceinline__ void fold_block(char* buf, gtab_t tab, int lane, v2f (&cur)[8],
                                            v2f (&nxt)[8]) {
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     const int e = lane + 64 * r;
     const v2f xe = slotE(buf, (e + 256) & 511);
     const v2f xo = slotO(buf, (767 - e) & 511);
-    const float4 cf = reinterpret_cast<const float4*>(tab + T_FOLD)[r * 64 + lane];
+    const v4f cf = reinterpret_cast<const v4f*>(tab + I_COEF)[r * 64 + lane];
     cur[r] = cf.x * xe + cf.y * xo;
     nxt[r] = cf.z * xe + cf.w * xo;
   }
 }
 
+// copies the table image (and the spreading prototype) into the workgroup's LDS; every thread takes part
+__device__ __forceinline__ void load_tables(char* lds, const float* __restrict__ image, const uint32_t* psy_tab) {
+  v4f* dst = reinterpret_cast<v4f*>(lds + WAVES * WAVE_LDS);
+  const v4f* src = reinterpret_cast<const v4f*>(image);
+  for (int i = threadIdx.x; i < I_TOTAL / 4; i += WAVES * 64) dst[i] = src[i];
+  if (psy_tab && threadIdx.x < 128)
+    reinterpret_cast<float*>(lds + WAVES * WAVE_LDS + TAB_LDS)[threadIdx.x] = __uint_as_float(psy_tab[P_G + threadIdx.x]);
+  __syncthreads();
+}
+
 template <int CMODE, bool PSY>
-__global__ __launch_bounds__(WAVES * 64) void k_fwd_fast(FwdArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[WAVES * WAVE_LDS];
-  __shared__ float g_lds[128];
+__global__ __launch_bounds__(WAVES * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
+  // one LDS object: [4 x 8 KB wave buffers | table image | g]; a single array keeps every table read in the loop
+  // (the wave-buffer stores may alias it), so no table value is pinned in registers across the walk
+  __shared__ __attribute__((aligned(16))) char lds[WAVES * WAVE_LDS + TAB_LDS + 512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (PSY) {
-    if (threadIdx.x < 128) g_lds[threadIdx.x] = __uint_as_float(a.psy.tab[P_G + threadIdx.x]);
-    __syncthreads();
-  }
+  load_tables(lds, a.tab, PSY ? a.psy.tab : nullptr);
   const long long task = (long long)blockIdx.x * WAVES + wave;
   if (task >= a.ntasks) return;
   char* buf = lds + wave * WAVE_LDS;
+  gtab_t tab = reinterpret_cast<const float*>(lds + WAVES * WAVE_LDS);
+  const float* g_lds = reinterpret_cast<const float*>(lds + WAVES * WAVE_LDS + TAB_LDS);
   const int sgm = (int)(task % a.nseg);
   const long long pair = task / a.nseg;
   const int cp = (int)(pair % a.CP);
@@ -347,18 +363,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_fwd_fast(FwdArgs a) {
   const bool has1 = (c0 + 1) < C;
   const int n0 = sgm * a.seglen;
   const int n1 = min(a.F, n0 + a.seglen);
-  const float* tab = a.tab;
   const size_t blk = (size_t)FN * C;   // floats per block / frame row over all channels
+  const float* xb = a.x + (size_t)b * a.Kin * blk;
 
   v2f carry[8];
-  v4f row[8];
+  v4f row[8], ahead[8];   // ahead = the next PCM block, in flight while the current frame is transformed
   {
     // carry of the block before the strip: block n0-1 of x, the stream state, or zero
     const float* src = nullptr;
-    if (n0 >= 1) src = a.x + ((size_t)b * a.Kin + (size_t)(n0 - 1)) * blk;
+    if (n0 >= 1) src = xb + (size_t)(n0 - 1) * blk;
     else if (a.prev_block) src = a.prev_block + (size_t)b * blk;
+    if (src) load_row<CMODE>(src, C, c0, has1, lane, row);
+    if (n0 < a.Kin) load_row<CMODE>(xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
     if (src) {
-      load_row<CMODE>(src, C, c0, has1, lane, row);
       stage_row(buf, lane, row);
       wave_sync();
       v2f dummy[8];
@@ -371,12 +388,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_fwd_fast(FwdArgs a) {
   }
 
   for (int n = n0; n < n1; ++n) {
-    // defeat loop-invariant hoisting of the table loads (they would pin >100 VGPRs across the walk)
-    asm volatile("" : "+s"(tab));
     v2f cur[8], nxt[8];
     if (n < a.Kin) {
-      load_row<CMODE>(a.x + ((size_t)b * a.Kin + (size_t)n) * blk, C, c0, has1, lane, row);
-      stage_row(buf, lane, row);
+      stage_row(buf, lane, ahead);
+      if (n + 1 < n1 && n + 1 < a.Kin) load_row<CMODE>(xb + (size_t)(n + 1) * blk, C, c0, has1, lane, ahead);
       wave_sync();
       fold_block(buf, tab, lane, cur, nxt);
     } else {
@@ -391,7 +406,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_fwd_fast(FwdArgs a) {
     for (int r = 0; r < 8; ++r) {
       // element e = lane + 64 r: v[2e] + i v[N-1-2e]; for e < 256 the real part comes from the previous block
       const C2 v = (r < 4) ? C2{carry[r], cur[r]} : C2{cur[r], carry[r]};
-      z[r] = cmul(v, reinterpret_cast<const float2*>(tab + T_PRE)[r * 64 + lane]);
+      z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + I_PRE)[r * 64 + lane]);
       carry[r] = nxt[r];
     }
     fft512(z, buf, tab, lane);
@@ -401,7 +416,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_fwd_fast(FwdArgs a) {
 #pragma unroll
       for (int k2 = 0; k2 < 8; ++k2) {
         const int k = k_lo + 64 * k2;
-        const C2 r = cmul(z[k2], reinterpret_cast<const float2*>(tab + T_POSTF)[k2 * 64 + lane]);
+        const C2 r = cmul(z[k2], reinterpret_cast<const v2f*>(tab + I_POST)[k2 * 64 + lane]);
         slotE(buf, k) = r.re;          // X[2k]
         slotO(buf, 511 - k) = -r.im;   // X[N-1-2k]
       }
@@ -439,19 +454,19 @@ struct InvArgs {
 };
 
 // DCT-IV of the staged frame: returns (now, nxt) per output element k
-__device__ __forceinline__ void idct_frame(char* buf, const float* __restrict__ tab, int lane, v2f (&now)[8],
+__device__ __forceinline__ void idct_frame(char* buf, gtab_t tab, int lane, v2f (&now)[8],
                                            v2f (&nxt)[8]) {
   C2 z[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     const int e = lane + 64 * r;
     const C2 v = {slotE(buf, e), slotO(buf, 511 - e)};   // X[2e] + i X[N-1-2e]
-    z[r] = cmul(v, reinterpret_cast<const float2*>(tab + T_PRE)[r * 64 + lane]);
+    z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + I_PRE)[r * 64 + lane]);
   }
   fft512(z, buf, tab, lane);
 #pragma unroll
   for (int k2 = 0; k2 < 8; ++k2) {
-    const C2 r = cmul(z[k2], reinterpret_cast<const float2*>(tab + T_POSTI)[k2 * 64 + lane]);
+    const C2 r = cmul(z[k2], reinterpret_cast<const v2f*>(tab + I_POST)[k2 * 64 + lane]);
     // u[2k] = Re, u[N-1-2k] = -Im; k < 256 (k2 < 4): u[2k] belongs to this block, u[N-1-2k] to the next
     if (k2 < 4) {
       now[k2] = r.re;
@@ -464,12 +479,14 @@ __device__ __forceinline__ void idct_frame(char* buf, const float* __restrict__ 
 }
 
 template <int CMODE>
-__global__ __launch_bounds__(WAVES * 64) void k_inv_fast(InvArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[WAVES * WAVE_LDS];
+__global__ __launch_bounds__(WAVES * 64, AC_WPE) void k_inv_fast(InvArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[WAVES * WAVE_LDS + TAB_LDS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  load_tables(lds, a.tab + I_TOTAL, nullptr);
   const long long task = (long long)blockIdx.x * WAVES + wave;
   if (task >= a.ntasks) return;
   char* buf = lds + wave * WAVE_LDS;
+  gtab_t tab = reinterpret_cast<const float*>(lds + WAVES * WAVE_LDS);
   const int sgm = (int)(task % a.nseg);
   const long long pair = task / a.nseg;
   const int cp = (int)(pair % a.CP);
@@ -478,15 +495,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_inv_fast(InvArgs a) {
   const bool has1 = (c0 + 1) < C;
   const int n0 = sgm * a.seglen;
   const int n1 = min(a.nblk, n0 + a.seglen);
-  const float* tab = a.tab;
   const size_t blk = (size_t)FN * C;
   const int k_lo = (lane >> 3) + 8 * (lane & 7);
+  const float* Xb = a.X + (size_t)b * a.Kp * blk;
 
   v2f carry[8];
-  v4f row[8];
+  v4f row[8], ahead[8];   // ahead = the next frame, in flight while the current one is transformed
+  if (n0 >= 1) load_row<CMODE>(Xb + (size_t)(n0 - 1) * blk, C, c0, has1, lane, row);
+  if (n0 < a.Kp) load_row<CMODE>(Xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
   if (n0 >= 1) {
     // aliased half of frame n0-1 (always an existing frame: n0-1 < Kp)
-    load_row<CMODE>(a.X + ((size_t)b * a.Kp + (size_t)(n0 - 1)) * blk, C, c0, has1, lane, row);
     stage_row(buf, lane, row);
     wave_sync();
     v2f dummy[8];
@@ -506,11 +524,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_inv_fast(InvArgs a) {
   }
 
   for (int n = n0; n < n1; ++n) {
-    asm volatile("" : "+s"(tab));
     v2f now[8], nxt[8];
     if (n < a.Kp) {
-      load_row<CMODE>(a.X + ((size_t)b * a.Kp + (size_t)n) * blk, C, c0, has1, lane, row);
-      stage_row(buf, lane, row);
+      stage_row(buf, lane, ahead);
+      if (n + 1 < n1 && n + 1 < a.Kp) load_row<CMODE>(Xb + (size_t)(n + 1) * blk, C, c0, has1, lane, ahead);
       wave_sync();
       idct_frame(buf, tab, lane, now, nxt);
     } else {
@@ -524,7 +541,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_inv_fast(InvArgs a) {
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) {
       const int k = k_lo + 64 * k2;
-      const float4 sc = reinterpret_cast<const float4*>(tab + T_SYN)[k2 * 64 + lane];
+      const v4f sc = reinterpret_cast<const v4f*>(tab + I_COEF)[k2 * 64 + lane];
       const v2f o1 = sc.x * now[k2] + sc.y * carry[k2];   // out[j]
       const v2f o2 = sc.z * now[k2] + sc.w * carry[k2];   // out[N-1-j]
       // k < 256: j = 511 - 2k (odd), N-1-j = 512 + 2k (even); else j = 2k - 512 (even), N-1-j = 1535 - 2k (odd)
@@ -563,10 +580,10 @@ struct PsyArgs {
 };
 
 template <int CMODE, bool WANT_T, bool WANT_THR>
-__global__ __launch_bounds__(WAVES * 64) void k_psy_fast(PsyArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[WAVES * WAVE_LDS];
-  __shared__ float g_lds[128];
+__global__ __launch_bounds__(WAVES * 64, AC_WPE) void k_psy_fast(PsyArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[WAVES * WAVE_LDS + 512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* g_lds = reinterpret_cast<float*>(lds + WAVES * WAVE_LDS);
   if (threadIdx.x < 128) g_lds[threadIdx.x] = __uint_as_float(a.psy.tab[P_G + threadIdx.x]);
   __syncthreads();
   const long long task = (long long)blockIdx.x * WAVES + wave;
@@ -623,28 +640,34 @@ int fast_mdct_plan_init(ac_mdct_plan* p) {
   const int N = p->N, h = N / 2;
   FoldCoef c;
   fold_coefficients(N, p->window, c);
-  std::vector<float> t(T_TOTAL, 0.f);
+  std::vector<float> t(2 * I_TOTAL, 0.f);
+  float* tf = t.data();              // analysis image
+  float* ti = t.data() + I_TOTAL;    // synthesis image
   const double pi = 3.14159265358979323846;
+  auto put2 = [](float* base, int i, double re, double im) {
+    base[2 * i] = (float)re;
+    base[2 * i + 1] = (float)im;
+  };
   for (int r = 0; r < 8; ++r) {
     for (int l = 0; l < 64; ++l) {
       const int i = r * 64 + l;
       const int e = l + 64 * r;                                   // input element of (lane, register)
       const int k = (l >> 3) + 8 * (l & 7) + 64 * r;              // output bin of (lane, register)
       double ang = -pi * (e + 0.25) / N;
-      t[T_PRE + 2 * i] = (float)std::cos(ang);
-      t[T_PRE + 2 * i + 1] = (float)std::sin(ang);
+      put2(tf + I_PRE, i, std::cos(ang), std::sin(ang));
+      put2(ti + I_PRE, i, std::cos(ang), std::sin(ang));
       ang = -2.0 * pi * (double)(l * r) / 512.0;
-      t[T_P1 + 2 * i] = (float)std::cos(ang);
-      t[T_P1 + 2 * i + 1] = (float)std::sin(ang);
-      ang = -2.0 * pi * (double)((l & 7) * r) / 64.0;
-      t[T_P2 + 2 * i] = (float)std::cos(ang);
-      t[T_P2 + 2 * i + 1] = (float)std::sin(ang);
+      put2(tf + I_P1, i, std::cos(ang), std::sin(ang));
+      put2(ti + I_P1, i, std::cos(ang), std::sin(ang));
+      if (l < 8) {
+        ang = -2.0 * pi * (double)(l * r) / 64.0;                 // [k1 = r][m0 = l]
+        put2(tf + I_P2, r * 8 + l, std::cos(ang), std::sin(ang));
+        put2(ti + I_P2, r * 8 + l, std::cos(ang), std::sin(ang));
+      }
       ang = -pi * (double)k / N;
       const double sf = 1.0 / (N * std::sqrt(2.0)), si = 2.0 * std::sqrt(2.0);
-      t[T_POSTF + 2 * i] = (float)(std::cos(ang) * sf);
-      t[T_POSTF + 2 * i + 1] = (float)(std::sin(ang) * sf);
-      t[T_POSTI + 2 * i] = (float)(std::cos(ang) * si);
-      t[T_POSTI + 2 * i + 1] = (float)(std::sin(ang) * si);
+      put2(tf + I_POST, i, std::cos(ang) * sf, std::sin(ang) * sf);
+      put2(ti + I_POST, i, std::cos(ang) * si, std::sin(ang) * si);
       double cE, cO, kE, kO;
       if (e < h / 2) {   // e < 256: samples 512+2e (even) / 511-2e (odd); current part = v[N-1-2e], carry = v'[2e]
         const int jc = h - 1 - 2 * e, jk = 2 * e;
@@ -654,15 +677,15 @@ int fast_mdct_plan_init(ac_mdct_plan* p) {
         const int jc = 2 * pidx, jk = h - 1 - 2 * pidx;
         cE = c.a1[jc]; cO = c.a2[jc]; kE = c.a3[jk]; kO = c.a4[jk];
       }
-      t[T_FOLD + 4 * i + 0] = (float)cE;
-      t[T_FOLD + 4 * i + 1] = (float)cO;
-      t[T_FOLD + 4 * i + 2] = (float)kE;
-      t[T_FOLD + 4 * i + 3] = (float)kO;
+      tf[I_COEF + 4 * i + 0] = (float)cE;
+      tf[I_COEF + 4 * i + 1] = (float)cO;
+      tf[I_COEF + 4 * i + 2] = (float)kE;
+      tf[I_COEF + 4 * i + 3] = (float)kO;
       const int j = (k < h / 2) ? (h - 1 - 2 * k) : (2 * k - h);
-      t[T_SYN + 4 * i + 0] = (float)c.s1[j];
-      t[T_SYN + 4 * i + 1] = (float)c.s2[j];
-      t[T_SYN + 4 * i + 2] = (float)c.s3[j];
-      t[T_SYN + 4 * i + 3] = (float)c.s4[j];
+      ti[I_COEF + 4 * i + 0] = (float)c.s1[j];
+      ti[I_COEF + 4 * i + 1] = (float)c.s2[j];
+      ti[I_COEF + 4 * i + 2] = (float)c.s3[j];
+      ti[I_COEF + 4 * i + 3] = (float)c.s4[j];
     }
   }
   p->fast_bytes = t.size() * sizeof(float);

@@ -1,0 +1,38 @@
+#!/usr/bin/env python
+"""Per-entry-point timings on the bench workload (design aid; not the contract bench)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import audiocodec_amd
+
+N = 1024
+B, K, C = int(os.environ.get("B", 256)), int(os.environ.get("K", 468)), 2
+dev = torch.device("cuda")
+x = torch.rand((B, K * N, C), device=dev) * 2 - 1
+codec = audiocodec_amd.AudioCodec(48000, N)
+X = torch.empty((B, K + 1, N, C), device=dev); t = torch.empty((B, K + 1, 1, C), device=dev)
+thr = torch.empty_like(X); xh = torch.empty((B, (K + 2) * N, C), device=dev)
+frames = B * C * K
+
+def timeit(fn, n=10):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+rows = [
+    ("encode_fused", lambda: codec.encode_into(x, X, t, thr), 12292),
+    ("transform", lambda: codec.mdct.transform(x), 8192),
+    ("inverse", lambda: codec.decode_into(X, xh), 8192),
+    ("tonality", lambda: codec.psy.tonality(X), 4100),
+    ("threshold", lambda: codec.psy.global_masking_threshold(X, t), 8196),
+    ("torch copy X (1R:1W)", lambda: thr.copy_(X), 8192),
+    ("torch fill X (0R:1W)", lambda: thr.fill_(1.0), 4096),
+    ("torch sum X (1R:0W)", lambda: X.sum(), 4096),
+]
+for name, fn, bpf in rows:
+    ms = timeit(fn)
+    print("%-24s %8.3f ms   %7.0f GB/s (algorithmic %d B/frame)" % (name, ms, bpf * frames / ms / 1e6, bpf))
