@@ -28,7 +28,10 @@ typedef const float* gtab_t;   // LDS-resident table image
 constexpr int FN = 1024;            // filters_n served by this file
 constexpr int FH = FN / 2;          // complex FFT points per frame (= 64 lanes x 8 registers)
 constexpr int WAVES = 4;            // waves (independent strips) per workgroup
-constexpr int WAVE_LDS = 8192;      // bytes of LDS per wave
+constexpr int WAVE_LDS = 8192;      // bytes of LDS per wave (transform only)
+constexpr int WAVE_LDS_PSY = 9232;  // + 128 chunk sums + one zero slot for the psychoacoustic epilogue
+constexpr int S8_OFF = 8192;        // chunk sums (8 bins each) behind the wave's 8 KB
+constexpr int ZERO_OFF = S8_OFF + 1024;
 constexpr float kEps = 1e-14f;      // _INTENSITY_EPS, psychoacoustic.py:56
 #ifndef AC_WPE
 #define AC_WPE 2                    // minimum waves per SIMD the register allocator must leave room for
@@ -45,11 +48,18 @@ constexpr int I_TOTAL = I_COEF + 2048;    // 5248 floats = 20 992 bytes
 constexpr int TAB_LDS = I_TOTAL * 4;
 
 // ---- psy table layout (32-bit words) in ac_psy_plan::d_fast --------------------------------------
-constexpr int PB_F0 = 0, PB_N = 64, PB_WF = 128, PB_WL = 192, PB_QUIET = 256, PB_BETA = 320, PB_RHO = 384,
-              PB_U0 = 448, PB_U1 = 512;
-constexpr int P_IDX = 576;                // [4][64] uint32: entry index bytes of the 16 bins a lane owns
-constexpr int P_G = P_IDX + 256;          // [128] spreading prototype g
-constexpr int P_TOTAL = P_G + 128;
+// per-lane (= per Bark band) constants, read once per wave
+constexpr int PB_EDGE = 0, PB_WF = 64, PB_WL = 128, PB_QUIET = 192, PB_BETA = 256, PB_RHO = 320, PB_U0 = 384,
+              PB_U1 = 448;
+constexpr int P_IDX = 512;                // [4][64] uint32: entry index bytes of the 16 bins a lane owns
+// image copied into LDS once per workgroup
+constexpr int P_IMG = P_IDX + 256;
+constexpr int PL_G = 0;                   // [128]     spreading prototype g
+constexpr int PL_LST = 128;               // [12][64]  gather lists: two 16-bit LDS byte offsets per word
+constexpr int PL_HALF = 12;               // list length / 2
+constexpr int P_IMG_WORDS = PL_LST + PL_HALF * 64;
+constexpr int PSY_LDS = P_IMG_WORDS * 4;
+constexpr int P_TOTAL = P_IMG + P_IMG_WORDS;
 
 struct C2 {   // one complex value for both channels of the pair
   v2f re, im;
@@ -197,9 +207,18 @@ __device__ __forceinline__ void unstage_row(char* buf, int lane, v4f (&v)[8]) {
   }
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_xadd(float v) {   // v + v[lane permuted by a DPP row pattern]
+  const int iv = __builtin_bit_cast(int, v);
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  v = dpp_xadd<0xB1>(v);    // quad_perm [1,0,3,2]  (lane ^ 1)
+  v = dpp_xadd<0x4E>(v);    // quad_perm [2,3,0,1]  (lane ^ 2)
+  v = dpp_xadd<0x141>(v);   // row_half_mirror      (other quad of the 8)
+  v = dpp_xadd<0x140>(v);   // row_mirror           (other half of the 16)
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
   return v;
 }
 
@@ -217,11 +236,11 @@ __device__ __forceinline__ v2f maxv(v2f a, float b) { return v2f{fmaxf(a.x, b), 
 struct PsyParams {
   const uint32_t* tab;   // ac_psy_plan::d_fast
   float alpha, inv_alpha, drown;
-  int maxn;              // widest Bark band in bins
 };
 
+// buf = the wave's LDS region (WAVE_LDS_PSY bytes), pimg = the workgroup's copy of the psy image (g + gather lists)
 template <bool WANT_T, bool WANT_THR>
-__device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* buf, const float* g_lds, const PsyParams& pp,
+__device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* buf, const uint32_t* pimg, const PsyParams& pp,
                                           int lane, v2f& t, v4f (&thr)[8]) {
   v4f Iq[8];
   v2f slog = {0.f, 0.f}, ssq = {0.f, 0.f};
@@ -248,36 +267,53 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* buf, const f
 
   const uint32_t* tab = pp.tab;
   wave_sync();
+  // intensities in natural order: granule q = (I[2q], I[2q+1]) x (c0, c1) at byte 16 (q ^ ((q >> 4) & 3))
+  {
+    const int lsw = lane ^ ((lane >> 4) & 3);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) *reinterpret_cast<v4f*>(buf + 16 * (64 * i + lane)) = Iq[i];   // I[f] at byte 8 f
-  wave_sync();
-
-  // P_j = sum_f I_f W[f, j]: lane = Bark band; W is 1 on interior bins, wf / wl on the two edge bins (:312-313)
-  const int f0 = (int)tab[PB_F0 + lane], nb = (int)tab[PB_N + lane];
-  const float wf = __uint_as_float(tab[PB_WF + lane]), wl = __uint_as_float(tab[PB_WL + lane]);
-  // every lane reads unconditionally (index clamped into its own band) so the reads pipeline; bins past the
-  // band's end get weight 0
-  const char* bp = buf + 8 * f0;
-  const int last = nb - 1;
-  v2f P = {0.f, 0.f};
-#pragma unroll 4
-  for (int it = 0; it < pp.maxn; ++it) {
-    const v2f I = *reinterpret_cast<const v2f*>(bp + 8 * min(it, last));
-    const float w = (it == 0) ? wf : ((it < last) ? 1.0f : ((it == last) ? wl : 0.0f));
-    P += I * w;
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<v4f*>(buf + 16 * (64 * i + lsw)) = Iq[i];
   }
+  wave_sync();
+  // sums over aligned chunks of 8 bins (4 granules): lane c owns chunks c and c + 64
+  {
+    const int x = (lane >> 2) & 3;
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) {
+      const char* cb = buf + 64 * (lane + 64 * i2);
+      const v4f g0 = *reinterpret_cast<const v4f*>(cb + 16 * (0 ^ x)), g1 = *reinterpret_cast<const v4f*>(cb + 16 * (1 ^ x)),
+                g2 = *reinterpret_cast<const v4f*>(cb + 16 * (2 ^ x)), g3 = *reinterpret_cast<const v4f*>(cb + 16 * (3 ^ x));
+      const v4f s = (g0 + g1) + (g2 + g3);
+      *reinterpret_cast<v2f*>(buf + S8_OFF + 8 * (lane + 64 * i2)) = v2f{s.x + s.z, s.y + s.w};
+    }
+  }
+  wave_sync();
+  // P_j = sum_f I_f W[f, j]  (:312-313): lane = Bark band; the two edge bins carry weights wf / wl, the interior
+  // (weight 1) is gathered as single bins + 8-bin chunk sums through a host-built list of LDS offsets
+  const uint32_t edge = tab[PB_EDGE + lane];
+  const float wf = __uint_as_float(tab[PB_WF + lane]), wl = __uint_as_float(tab[PB_WL + lane]);
+  v2f P0 = *reinterpret_cast<const v2f*>(buf + (edge & 0xffffu)) * wf;
+  v2f P1 = *reinterpret_cast<const v2f*>(buf + (edge >> 16)) * wl;
+#pragma unroll
+  for (int hlf = 0; hlf < PL_HALF; ++hlf) {
+    const uint32_t w = pimg[PL_LST + hlf * 64 + lane];
+    P0 += *reinterpret_cast<const v2f*>(buf + (w & 0xffffu));
+    P1 += *reinterpret_cast<const v2f*>(buf + (w >> 16));
+  }
+  const v2f P = P0 + P1;
   const v2f Q = exp2v(pp.alpha * log2v(maxv(P, kEps)));   // max(eps, P)^alpha  (:206)
   wave_sync();
   *reinterpret_cast<v2f*>(buf + 8 * lane) = Q;
   wave_sync();
   // sum_i Q_i S[i, j], S[i, j] = g[64 - i + j]  (:205-207 with the offset factor pulled out of the sum)
-  v2f acc = {0.f, 0.f};
-  const float* gp = g_lds + 64 + lane;
+  v2f acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+  const float* gp = reinterpret_cast<const float*>(pimg + PL_G) + 64 + lane;
 #pragma unroll 8
-  for (int i = 0; i < 64; ++i) {
-    const v2f qi = *reinterpret_cast<const v2f*>(buf + 8 * i);
-    acc += qi * gp[-i];
+  for (int i = 0; i < 64; i += 2) {
+    const v4f qq = *reinterpret_cast<const v4f*>(buf + 8 * i);   // Q_i, Q_{i+1} (broadcast read)
+    acc0 += v2f{qq.x, qq.y} * gp[-i];
+    acc1 += v2f{qq.z, qq.w} * gp[-i - 1];
   }
+  const v2f acc = acc0 + acc1;
   const float beta = __uint_as_float(tab[PB_BETA + lane]), quiet = __uint_as_float(tab[PB_QUIET + lane]);
   const v2f offset = (1.0f - pp.drown) * (t * beta + 9.0f * t + 5.5f);                       // (:185-191)
   const v2f fac = exp2v(offset * (-pp.alpha * 0.33219280948873623f));                        // 10^(-alpha O / 10)
@@ -298,8 +334,9 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* buf, const f
     const uint32_t w = tab[P_IDX + (i >> 1) * 64 + lane] >> (16 * (i & 1));
     const v2f a0 = *reinterpret_cast<const v2f*>(buf + 8 * (w & 0xffu));
     const v2f a1 = *reinterpret_cast<const v2f*>(buf + 8 * ((w >> 8) & 0xffu));
-    thr[i] = v4f{__builtin_sqrtf(fmaxf(a0.x, kEps)), __builtin_sqrtf(fmaxf(a0.y, kEps)),
-                 __builtin_sqrtf(fmaxf(a1.x, kEps)), __builtin_sqrtf(fmaxf(a1.y, kEps))};   // (:331)
+    // v_sqrt_f32 (1 ulp); arguments are >= 1e-14, far from the denormal range   (:331)
+    thr[i] = v4f{__builtin_amdgcn_sqrtf(fmaxf(a0.x, kEps)), __builtin_amdgcn_sqrtf(fmaxf(a0.y, kEps)),
+                 __builtin_amdgcn_sqrtf(fmaxf(a1.x, kEps)), __builtin_amdgcn_sqrtf(fmaxf(a1.y, kEps))};
   }
   wave_sync();
 }
@@ -333,13 +370,16 @@ __device__ __forceinline__ void fold_block(char* buf, gtab_t tab, int lane, v2f 
   }
 }
 
-// copies the table image (and the spreading prototype) into the workgroup's LDS; every thread takes part
+// copies the table image (and the psy image) into the workgroup's LDS; every thread takes part
+template <int WSTRIDE>
 __device__ __forceinline__ void load_tables(char* lds, const float* __restrict__ image, const uint32_t* psy_tab) {
-  v4f* dst = reinterpret_cast<v4f*>(lds + WAVES * WAVE_LDS);
+  v4f* dst = reinterpret_cast<v4f*>(lds + WAVES * WSTRIDE);
   const v4f* src = reinterpret_cast<const v4f*>(image);
   for (int i = threadIdx.x; i < I_TOTAL / 4; i += WAVES * 64) dst[i] = src[i];
-  if (psy_tab && threadIdx.x < 128)
-    reinterpret_cast<float*>(lds + WAVES * WAVE_LDS + TAB_LDS)[threadIdx.x] = __uint_as_float(psy_tab[P_G + threadIdx.x]);
+  if (psy_tab) {
+    uint32_t* pd = reinterpret_cast<uint32_t*>(lds + WAVES * WSTRIDE + TAB_LDS);
+    for (int i = threadIdx.x; i < P_IMG_WORDS; i += WAVES * 64) pd[i] = psy_tab[P_IMG + i];
+  }
   __syncthreads();
 }
 
@@ -347,14 +387,16 @@ template <int CMODE, bool PSY>
 __global__ __launch_bounds__(WAVES * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
   // one LDS object: [4 x 8 KB wave buffers | table image | g]; a single array keeps every table read in the loop
   // (the wave-buffer stores may alias it), so no table value is pinned in registers across the walk
-  __shared__ __attribute__((aligned(16))) char lds[WAVES * WAVE_LDS + TAB_LDS + 512];
+  constexpr int WSTRIDE = PSY ? WAVE_LDS_PSY : WAVE_LDS;
+  __shared__ __attribute__((aligned(16))) char lds[WAVES * WSTRIDE + TAB_LDS + (PSY ? PSY_LDS : 0)];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  load_tables(lds, a.tab, PSY ? a.psy.tab : nullptr);
+  load_tables<WSTRIDE>(lds, a.tab, PSY ? a.psy.tab : nullptr);
   const long long task = (long long)blockIdx.x * WAVES + wave;
   if (task >= a.ntasks) return;
-  char* buf = lds + wave * WAVE_LDS;
-  gtab_t tab = reinterpret_cast<const float*>(lds + WAVES * WAVE_LDS);
-  const float* g_lds = reinterpret_cast<const float*>(lds + WAVES * WAVE_LDS + TAB_LDS);
+  char* buf = lds + wave * WSTRIDE;
+  gtab_t tab = reinterpret_cast<const float*>(lds + WAVES * WSTRIDE);
+  const uint32_t* pimg = reinterpret_cast<const uint32_t*>(lds + WAVES * WSTRIDE + TAB_LDS);
+  if (PSY) *reinterpret_cast<v2f*>(buf + ZERO_OFF) = v2f{0.f, 0.f};   // the gather lists' padding slot
   const int sgm = (int)(task % a.nseg);
   const long long pair = task / a.nseg;
   const int cp = (int)(pair % a.CP);
@@ -428,7 +470,7 @@ __global__ __launch_bounds__(WAVES * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
     if (PSY) {
       v2f tt;
       v4f th[8];
-      psy_stage<true, true>(row, buf, g_lds, a.psy, lane, tt, th);
+      psy_stage<true, true>(row, buf, pimg, a.psy, lane, tt, th);
       store_row<CMODE>(a.thr + frame * blk, C, c0, has1, lane, th);
       if (lane == 0) {
         a.t[frame * C + c0] = tt.x;
@@ -482,7 +524,7 @@ template <int CMODE>
 __global__ __launch_bounds__(WAVES * 64, AC_WPE) void k_inv_fast(InvArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[WAVES * WAVE_LDS + TAB_LDS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  load_tables(lds, a.tab + I_TOTAL, nullptr);
+  load_tables<WAVE_LDS>(lds, a.tab + I_TOTAL, nullptr);
   const long long task = (long long)blockIdx.x * WAVES + wave;
   if (task >= a.ntasks) return;
   char* buf = lds + wave * WAVE_LDS;
@@ -581,14 +623,17 @@ struct PsyArgs {
 
 template <int CMODE, bool WANT_T, bool WANT_THR>
 __global__ __launch_bounds__(WAVES * 64, AC_WPE) void k_psy_fast(PsyArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[WAVES * WAVE_LDS + 512];
+  __shared__ __attribute__((aligned(16))) char lds[WAVES * WAVE_LDS_PSY + PSY_LDS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* g_lds = reinterpret_cast<float*>(lds + WAVES * WAVE_LDS);
-  if (threadIdx.x < 128) g_lds[threadIdx.x] = __uint_as_float(a.psy.tab[P_G + threadIdx.x]);
-  __syncthreads();
+  uint32_t* pimg = reinterpret_cast<uint32_t*>(lds + WAVES * WAVE_LDS_PSY);
+  if (WANT_THR) {
+    for (int i = threadIdx.x; i < P_IMG_WORDS; i += WAVES * 64) pimg[i] = a.psy.tab[P_IMG + i];
+    __syncthreads();
+  }
   const long long task = (long long)blockIdx.x * WAVES + wave;
   if (task >= a.ntasks) return;
-  char* buf = lds + wave * WAVE_LDS;
+  char* buf = lds + wave * WAVE_LDS_PSY;
+  if (WANT_THR) *reinterpret_cast<v2f*>(buf + ZERO_OFF) = v2f{0.f, 0.f};
   const int cp = (int)(task % a.CP);
   const long long frame = task / a.CP;
   const int C = a.C, c0 = 2 * cp;
@@ -601,7 +646,7 @@ __global__ __launch_bounds__(WAVES * 64, AC_WPE) void k_psy_fast(PsyArgs a) {
     tt.x = a.t_in[(size_t)frame * C + c0];
     tt.y = has1 ? a.t_in[(size_t)frame * C + c0 + 1] : 0.f;
   }
-  psy_stage<WANT_T, WANT_THR>(row, buf, g_lds, a.psy, lane, tt, th);
+  psy_stage<WANT_T, WANT_THR>(row, buf, pimg, a.psy, lane, tt, th);
   if (WANT_T && lane == 0) {
     a.t_out[(size_t)frame * C + c0] = tt.x;
     if (has1) a.t_out[(size_t)frame * C + c0 + 1] = tt.y;
@@ -625,7 +670,6 @@ PsyParams psy_params(const ac_psy_plan* p, float drown) {
   pp.alpha = (float)p->alpha;
   pp.inv_alpha = (float)(1.0 / p->alpha);
   pp.drown = drown;
-  pp.maxn = p->wb_max;
   return pp;
 }
 
@@ -720,13 +764,27 @@ static bool build_psy_fast(const ac_psy_plan* p, std::vector<uint32_t>* out) {
     }
     first[j] = f0;
     last[j] = f1;
-    if (f1 - f0 + 1 > 255) return false;
-    w[PB_F0 + j] = (uint32_t)f0;
-    w[PB_N + j] = (uint32_t)(f1 - f0 + 1);
+    // LDS byte offset of I[f] in the wave buffer (granule swizzle of psy_stage)
+    auto addrI = [](int f) { const int q = f >> 1; return (uint32_t)(16 * (q ^ ((q >> 4) & 3)) + 8 * (f & 1)); };
+    w[PB_EDGE + j] = addrI(f0) | (addrI(f1) << 16);
     putf(PB_WF + j, Wf(f0, j));
-    putf(PB_WL + j, Wf(f1, j));
+    putf(PB_WL + j, (f1 > f0) ? Wf(f1, j) : 0.f);
     putf(PB_QUIET + j, (float)t.quiet[j]);
     putf(PB_BETA + j, t.beta[j]);
+    // interior bins f0+1 .. f1-1 (weight 1): single bins up to an 8-aligned boundary, whole chunks, single bins
+    std::vector<uint32_t> lst;
+    for (int f = f0 + 1; f <= f1 - 1;) {
+      if ((f & 7) == 0 && f + 7 <= f1 - 1) {
+        lst.push_back((uint32_t)(S8_OFF + 8 * (f >> 3)));
+        f += 8;
+      } else {
+        lst.push_back(addrI(f));
+        f += 1;
+      }
+    }
+    if ((int)lst.size() > 2 * PL_HALF) return false;
+    lst.resize(2 * PL_HALF, (uint32_t)ZERO_OFF);
+    for (int hlf = 0; hlf < PL_HALF; ++hlf) w[P_IMG + PL_LST + hlf * 64 + j] = lst[2 * hlf] | (lst[2 * hlf + 1] << 16);
   }
   // bins -> entries; nnz pattern of W and W_inv is identical (same overlap)
   std::vector<int> entry(N, -1);
@@ -768,7 +826,7 @@ static bool build_psy_fast(const ac_psy_plan* p, std::vector<uint32_t>* out) {
       const uint32_t e0 = (uint32_t)entry[2 * q], e1 = (uint32_t)entry[2 * q + 1];
       w[P_IDX + (i >> 1) * 64 + l] |= (e0 | (e1 << 8)) << (16 * (i & 1));
     }
-  for (int i = 0; i < 128; ++i) putf(P_G + i, (float)t.g[i]);
+  for (int i = 0; i < 128; ++i) putf(P_IMG + PL_G + i, (float)t.g[i]);
   if (out) *out = w;
   return true;
 }
@@ -808,7 +866,7 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const float* 
   a.prev_block = prev_block;
   a.tab = p->d_fast;
   if (psy) a.psy = psy_params(psy, drown);
-  else a.psy = PsyParams{nullptr, 0.f, 0.f, 0.f, 0};
+  else a.psy = PsyParams{nullptr, 0.f, 0.f, 0.f};
   a.B = B;
   a.Kin = Kin;
   a.F = F;
