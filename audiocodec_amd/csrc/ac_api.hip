@@ -153,7 +153,7 @@ int ac_mdct_plan_create(int N, int window, int device, ac_mdct_plan** out) {
   for (size_t i = 0; i < ctab.size(); ++i) ctab[i] = (float)std::cos(3.14159265358979323846 * (double)i / (4.0 * N));
   st = upload(coef, &p->d_coef);
   if (!st) st = upload(ctab, &p->d_ctab);
-  if (!st && fast_mdct_supported(N)) {
+  if (!st && fast_mdct_supported(N, window)) {
     st = fast_mdct_plan_init(p);
     if (!st) p->fast = 1;
   }

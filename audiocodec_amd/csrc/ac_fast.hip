@@ -2,17 +2,26 @@
 //
 // One 64-lane wavefront owns one "strip": a pair of channels of one clip over a run of consecutive
 // frames, and walks it in time.  Both channels ride in the two halves of 64-bit register pairs
-// (v2f = (c0, c1)), so twiddles, window coefficients, addresses and LDS traffic are shared.  Per step:
+// (v2f = (c0, c1)), so twiddles, window coefficients, addresses and LDS traffic are shared.
 //
-//   PCM block (coalesced 16-B loads) -> LDS (parity-split, XOR-swizzled) -> window fold with the
-//   half that aliases into the NEXT frame carried in registers -> pre-twiddle -> 512-point complex FFT
-//   as three in-register radix-8 passes with two conflict-free LDS transposes -> post-twiddle ->
-//   natural-order staging in LDS -> coalesced 16-B stores of X; the psychoacoustic epilogue
-//   (tonality, Bark sums, spreading, threshold) runs on the staged frame before the next block.
+// Data movement per frame (both channels), q = 64 i + lane being the 16-byte granule (x[2q], x[2q+1]) x (c0, c1)
+// that lane `lane` loads / stores with one coalesced 16-byte access per i:
+//   * FFT element e = lane + 64 r needs the even sample of granule q = e + 256 (same lane, another register) and
+//     the odd sample of granule 767 - e (lane 63 - lane): only the odd halves cross lanes, through one
+//     lane-reversal exchange in LDS (8 ds_write_b64 + 8 ds_read_b64);
+//   * window fold with two coefficients per element (Princen-Bradley windows: the 2x2 fold blocks are
+//     rotations), the half that aliases into the NEXT frame carried in registers;
+//   * pre-twiddle -> 512-point complex FFT as three in-register radix-8 passes with two padded, conflict-free LDS
+//     exchanges whose addresses are one per-lane base + an immediate -> post-twiddle; the output bin of
+//     (lane, register k2) is lane + 64 k2, so the even coefficients X[2k] are already where the store wants
+//     them and only the odd ones (X[N-1-2k]) take the lane-reversal exchange again;
+//   * coalesced 16-byte stores of X; the psychoacoustic epilogue (tonality, Bark sums, spreading, threshold)
+//     runs on the frame in registers before the next block.
 //
-// Index maps, swizzles and their bank behaviour are emulated lane by lane in tools/emulate_wave_fft.py.
+// Index maps and their bank behaviour are emulated lane by lane in tools/emulate_wave_fft.py.
 // Reference formulas: mdctransformer.py:62-153 (closed forms in SURVEY.md App. A), psychoacoustic.py:102-210,301-331.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -27,39 +36,41 @@ typedef const float* gtab_t;   // LDS-resident table image
 
 constexpr int FN = 1024;            // filters_n served by this file
 constexpr int FH = FN / 2;          // complex FFT points per frame (= 64 lanes x 8 registers)
-constexpr int WAVES = 4;            // waves (independent strips) per workgroup
-constexpr int WAVE_LDS = 8192;      // bytes of LDS per wave (transform only)
-constexpr int WAVE_LDS_PSY = 9232;  // + 128 chunk sums + one zero slot for the psychoacoustic epilogue
-constexpr int S8_OFF = 8192;        // chunk sums (8 bins each) behind the wave's 8 KB
-constexpr int ZERO_OFF = S8_OFF + 1024;
-constexpr float kEps = 1e-14f;      // _INTENSITY_EPS, psychoacoustic.py:56
-#ifndef AC_WPE
-#define AC_WPE 2                    // minimum waves per SIMD the register allocator must leave room for
+#ifndef AC_WAVES_PSY
+#define AC_WAVES_PSY 6              // waves (independent strips) per workgroup, fused encode
 #endif
+#ifndef AC_WAVES
+#define AC_WAVES 4                  // waves per workgroup, plain transform / inverse / stand-alone psycho
+#endif
+#ifndef AC_WPE
+#define AC_WPE 3                    // waves per SIMD the register allocator must leave room for
+#endif
+constexpr int WAVE_LDS = 9216;      // bytes of LDS per wave: 576 x 16-byte elements (8 rows of 64 + 8 pad)
+constexpr int S8_OFF = 8192;        // psycho: 128 chunk sums (8 bins each) behind the 8 KB intensity image
+constexpr int ZERO_OFF = 9216;      // psycho: one zero slot (padding target of the gather lists)
+constexpr int WAVE_LDS_PSY = 9232;
+constexpr float kEps = 1e-14f;      // _INTENSITY_EPS, psychoacoustic.py:56
 
 // ---- mdct tables: two images in ac_mdct_plan::d_fast (analysis at 0, synthesis at I_TOTAL floats); the kernel
 // copies its image into LDS once per workgroup, so the walk loop touches HBM only for PCM / spectra ---------
 constexpr int I_PRE = 0;                  // [8][64] float2  exp(-i pi (e + 1/4) / N), e = lane + 64 r
 constexpr int I_P1 = I_PRE + 1024;        // [8][64] float2  W512^(lane k0)
-constexpr int I_P2 = I_P1 + 1024;         // [8][8]  float2  W64^(m0 k1)
-constexpr int I_POST = I_P2 + 128;        // [8][64] float2  exp(-i pi k / N) * (1/(N sqrt 2) | 2 sqrt 2)
-constexpr int I_COEF = I_POST + 1024;     // [8][64] float4  fold (cE, cO, kE, kO)(e) | unfold (s1..s4)(j(k))
-constexpr int I_TOTAL = I_COEF + 2048;    // 5248 floats = 20 992 bytes
+constexpr int I_P2 = I_P1 + 1024;         // [8][8]  float2  W64^(e0 k1)
+constexpr int I_POST = I_P2 + 128;        // [8][64] float2  exp(-i pi k / N) * (1/(N sqrt 2) | 2 sqrt 2), k = lane + 64 k2
+constexpr int I_COEF = I_POST + 1024;     // [8][64] float2  fold (A, B)(e) | unfold (a, b)(k)
+constexpr int I_TOTAL = I_COEF + 1024;    // 4224 floats = 16 896 bytes
 constexpr int TAB_LDS = I_TOTAL * 4;
 
-// ---- psy table layout (32-bit words) in ac_psy_plan::d_fast --------------------------------------
-// per-lane (= per Bark band) constants, read once per wave
-constexpr int PB_EDGE = 0, PB_WF = 64, PB_WL = 128, PB_QUIET = 192, PB_BETA = 256, PB_RHO = 320, PB_U0 = 384,
-              PB_U1 = 448;
-constexpr int P_IDX = 512;                // [4][64] uint32: entry index bytes of the 16 bins a lane owns
-// image copied into LDS once per workgroup
-constexpr int P_IMG = P_IDX + 256;
+// ---- psy image (32-bit words) in ac_psy_plan::d_fast, copied into LDS once per workgroup -------------------
 constexpr int PL_G = 0;                   // [128]     spreading prototype g
 constexpr int PL_LST = 128;               // [12][64]  gather lists: two 16-bit LDS byte offsets per word
 constexpr int PL_HALF = 12;               // list length / 2
-constexpr int P_IMG_WORDS = PL_LST + PL_HALF * 64;
-constexpr int PSY_LDS = P_IMG_WORDS * 4;
-constexpr int P_TOTAL = P_IMG + P_IMG_WORDS;
+constexpr int PL_BAND = PL_LST + PL_HALF * 64;   // [2][64] x 4 words: per-lane (= per Bark band) constants
+//   group 0: edge offsets (lo | hi << 16), wf, wl, quiet        group 1: beta, rho, u0, u1
+constexpr int PL_IDX = PL_BAND + 512;     // [2][64] x 4 words: byte offsets (lo | hi << 16) of the threshold entries
+//   of the two bins of granule 64 i + lane, word i
+constexpr int P_TOTAL = PL_IDX + 512;     // 1920 words = 7680 bytes
+constexpr int PSY_LDS = P_TOTAL * 4;
 
 struct C2 {   // one complex value for both channels of the pair
   v2f re, im;
@@ -72,8 +83,6 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-
-__device__ __forceinline__ int swz(int q) { return q ^ ((q >> 3) & 7); }
 
 __device__ __forceinline__ C2 cmul(const C2& x, const v2f w) {
   C2 r;
@@ -111,43 +120,72 @@ __device__ __forceinline__ void dft8(C2 (&x)[8]) {
   }
 }
 
-__device__ __forceinline__ void lds_put(char* buf, int idx16, const C2& v) {
-  *reinterpret_cast<v4f*>(buf + 16 * idx16) = v4f{v.re.x, v.re.y, v.im.x, v.im.y};
+__device__ __forceinline__ void lds_put(char* p, const C2& v) {
+  *reinterpret_cast<v4f*>(p) = v4f{v.re.x, v.re.y, v.im.x, v.im.y};
 }
-__device__ __forceinline__ C2 lds_get(const char* buf, int idx16) {
-  const v4f t = *reinterpret_cast<const v4f*>(buf + 16 * idx16);
+__device__ __forceinline__ C2 lds_get(const char* p) {
+  const v4f t = *reinterpret_cast<const v4f*>(p);
   return {v2f{t.x, t.y}, v2f{t.z, t.w}};
 }
 
-// 512-point FFT of z[r] = element (lane + 64 r); result z[k2] = bin k = (lane>>3) + 8 (lane&7) + 64 k2
+// 512-point FFT of z[r] = element (lane + 64 r); result z[k2] = bin lane + 64 k2.
+// Element index e = e0 + 8 e1 + 64 e2 (lane = e0 + 8 e1, register e2), bin k = k0 + 8 k1 + 64 k2.
+//   pass 1 over e2 -> k0, twiddle W512^(lane k0); exchange 1: row k0 (72 elements of 16 B: 64 + 8 pad), column lane;
+//   lane (a = k0, m0 = e0) reads e1 = 0..7 at a 72 + 8 e1 + m0
+//   pass 2 over e1 -> k1, twiddle W64^(e0 k1);    exchange 2: element (k0, k1, e0) at 9 (k0 + 8 k1) + e0;
+//   lane k0 + 8 k1 reads its 8 consecutive e0      pass 3 over e0 -> k2.
+// Both exchanges are bank-conflict-free under the gfx950 lane-group rules (tools/emulate_wave_fft.py).
 __device__ __forceinline__ void fft512(C2 (&z)[8], char* buf, gtab_t tab, int lane) {
   const int a = lane >> 3, m0 = lane & 7;
-  const int flip = (a & 1) << 3;
   dft8(z);
 #pragma unroll
   for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], reinterpret_cast<const v2f*>(tab + I_P1)[k * 64 + lane]);
   wave_sync();
+  {
+    char* w1 = buf + 16 * lane;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) lds_put(buf, (k * 64 + lane) ^ ((k & 1) << 3), z[k]);
+    for (int k = 0; k < 8; ++k) lds_put(w1 + 1152 * k, z[k]);
+  }
   wave_sync();
+  {
+    const char* r1 = buf + 16 * (a * 72 + m0);
 #pragma unroll
-  for (int r = 0; r < 8; ++r) z[r] = lds_get(buf, (a * 64 + 8 * r + m0) ^ flip);
+    for (int r = 0; r < 8; ++r) z[r] = lds_get(r1 + 128 * r);
+  }
   dft8(z);
 #pragma unroll
   for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], reinterpret_cast<const v2f*>(tab + I_P2)[k * 8 + m0]);
   wave_sync();
+  {
+    char* w2 = buf + 16 * (9 * a + m0);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) lds_put(buf, a * 64 + ((k * 8 + (m0 ^ k)) ^ flip), z[k]);
+    for (int k = 0; k < 8; ++k) lds_put(w2 + 1152 * k, z[k]);
+  }
   wave_sync();
+  {
+    const char* r2 = buf + 144 * lane;
 #pragma unroll
-  for (int r = 0; r < 8; ++r) z[r] = lds_get(buf, a * 64 + ((m0 * 8 + (r ^ m0)) ^ flip));
+    for (int r = 0; r < 8; ++r) z[r] = lds_get(r2 + 16 * r);
+  }
   dft8(z);
 }
 
-// natural-order staging: sample / coefficient f of both channels lives in the even (f = 2q) or odd
-// (f = 2q + 1) array at 8-byte slot swz(q)
-__device__ __forceinline__ v2f& slotE(char* buf, int q) { return *reinterpret_cast<v2f*>(buf + 8 * swz(q)); }
-__device__ __forceinline__ v2f& slotO(char* buf, int q) { return *reinterpret_cast<v2f*>(buf + 4096 + 8 * swz(q)); }
+// lane-reversal exchange of eight (c0, c1) pairs: afterwards out[i] = in[(OFS - i) & 7] of lane 63 - lane
+template <int OFS>
+__device__ __forceinline__ void rev_exchange(char* buf, int lane, const v2f (&in)[8], v2f (&out)[8]) {
+  wave_sync();
+  {
+    char* w = buf + 8 * (63 - lane);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) *reinterpret_cast<v2f*>(w + 512 * c) = in[c];
+  }
+  wave_sync();
+  {
+    const char* r = buf + 8 * lane;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = *reinterpret_cast<const v2f*>(r + 512 * ((OFS - i) & 7));
+  }
+}
 
 // ---- global <-> register movement of one natural-order row of N values x channel pair ---------------
 // CMODE 0: exactly two channels (interleaved, 16-byte vectors); CMODE 1: any channel count, pair (c0, c0+1)
@@ -189,37 +227,21 @@ __device__ __forceinline__ void store_row(float* __restrict__ row, int C, int c0
   }
 }
 
-__device__ __forceinline__ void stage_row(char* buf, int lane, const v4f (&v)[8]) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int q = 64 * i + lane;
-    slotE(buf, q) = v2f{v[i].x, v[i].y};
-    slotO(buf, q) = v2f{v[i].z, v[i].w};
-  }
-}
-
-__device__ __forceinline__ void unstage_row(char* buf, int lane, v4f (&v)[8]) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int q = 64 * i + lane;
-    const v2f e = slotE(buf, q), o = slotO(buf, q);
-    v[i] = v4f{e.x, e.y, o.x, o.y};
-  }
-}
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_xadd(float v) {   // v + v[lane permuted by a DPP row pattern]
+// wave-wide sum, result uniform (scalar register): xor butterflies inside each row of 16 lanes, then the two
+// row broadcasts of the DPP unit; no LDS traffic
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {   // v + v[lane permuted by a DPP pattern] on the enabled rows
   const int iv = __builtin_bit_cast(int, v);
-  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, CTRL, 0xf, 0xf, false));
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, iv, CTRL, ROW_MASK, 0xf, false));
 }
 __device__ __forceinline__ float wave_sum(float v) {
-  v = dpp_xadd<0xB1>(v);    // quad_perm [1,0,3,2]  (lane ^ 1)
-  v = dpp_xadd<0x4E>(v);    // quad_perm [2,3,0,1]  (lane ^ 2)
-  v = dpp_xadd<0x141>(v);   // row_half_mirror      (other quad of the 8)
-  v = dpp_xadd<0x140>(v);   // row_mirror           (other half of the 16)
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
+  v = dpp_add<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]  (lane ^ 1)
+  v = dpp_add<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]  (lane ^ 2)
+  v = dpp_add<0x141, 0xf>(v);   // row_half_mirror      (other quad of the 8)
+  v = dpp_add<0x140, 0xf>(v);   // row_mirror           (other half of the 16): every lane holds its row's sum
+  v = dpp_add<0x142, 0xa>(v);   // row_bcast15 into rows 1, 3: row 1 = r0 + r1, row 3 = r2 + r3
+  v = dpp_add<0x143, 0xc>(v);   // row_bcast31 into rows 2, 3: row 3 = total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }     // v_log_f32
@@ -238,18 +260,26 @@ struct PsyParams {
   float alpha, inv_alpha, drown;
 };
 
-// buf = the wave's LDS region (WAVE_LDS_PSY bytes), pimg = the workgroup's copy of the psy image (g + gather lists)
+// buf = the wave's LDS region (WAVE_LDS_PSY bytes), pimg = the workgroup's copy of the psy image
 template <bool WANT_T, bool WANT_THR>
 __device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* buf, const uint32_t* pimg, const PsyParams& pp,
                                           int lane, v2f& t, v4f (&thr)[8]) {
-  v4f Iq[8];
+  if (WANT_THR) wave_sync();
   v2f slog = {0.f, 0.f}, ssq = {0.f, 0.f};
+  {
+    const int lsw = lane ^ ((lane >> 4) & 3);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    Iq[i] = xq[i] * xq[i];
-    if (WANT_T) {
-      ssq += v2f{Iq[i].x, Iq[i].y} + v2f{Iq[i].z, Iq[i].w};
-      slog += log2v(maxv(v2f{Iq[i].x, Iq[i].y}, kEps)) + log2v(maxv(v2f{Iq[i].z, Iq[i].w}, kEps));
+    for (int i = 0; i < 8; ++i) {
+      const v4f I = xq[i] * xq[i];
+      // intensities in natural order: granule q = (I[2q], I[2q+1]) x (c0, c1) at byte 16 (q ^ ((q >> 4) & 3))
+      if (WANT_THR) *reinterpret_cast<v4f*>(buf + 16 * lsw + 1024 * i) = I;
+      if (WANT_T) {
+        const v2f ie = v2f{I.x, I.y}, io = v2f{I.z, I.w};
+        ssq += ie + io;
+        // ln max(eps, a) + ln max(eps, b) = ln(max(eps, a) max(eps, b)): one v_log per two bins; the product stays
+        // in the normal float range for |X| < 1e9 (>= 1e-28)
+        slog += log2v(maxv(ie, kEps) * maxv(io, kEps));
+      }
     }
   }
   if (WANT_T) {
@@ -265,34 +295,28 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* buf, const u
   }
   if (!WANT_THR) return;
 
-  const uint32_t* tab = pp.tab;
-  wave_sync();
-  // intensities in natural order: granule q = (I[2q], I[2q+1]) x (c0, c1) at byte 16 (q ^ ((q >> 4) & 3))
-  {
-    const int lsw = lane ^ ((lane >> 4) & 3);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<v4f*>(buf + 16 * (64 * i + lsw)) = Iq[i];
-  }
   wave_sync();
   // sums over aligned chunks of 8 bins (4 granules): lane c owns chunks c and c + 64
   {
     const int x = (lane >> 2) & 3;
+    const char* cb = buf + 64 * lane;
+    const int o0 = 16 * x, o1 = 16 * (1 ^ x), o2 = 16 * (2 ^ x), o3 = 16 * (3 ^ x);
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2) {
-      const char* cb = buf + 64 * (lane + 64 * i2);
-      const v4f g0 = *reinterpret_cast<const v4f*>(cb + 16 * (0 ^ x)), g1 = *reinterpret_cast<const v4f*>(cb + 16 * (1 ^ x)),
-                g2 = *reinterpret_cast<const v4f*>(cb + 16 * (2 ^ x)), g3 = *reinterpret_cast<const v4f*>(cb + 16 * (3 ^ x));
+      const char* c2 = cb + 4096 * i2;
+      const v4f g0 = *reinterpret_cast<const v4f*>(c2 + o0), g1 = *reinterpret_cast<const v4f*>(c2 + o1),
+                g2 = *reinterpret_cast<const v4f*>(c2 + o2), g3 = *reinterpret_cast<const v4f*>(c2 + o3);
       const v4f s = (g0 + g1) + (g2 + g3);
-      *reinterpret_cast<v2f*>(buf + S8_OFF + 8 * (lane + 64 * i2)) = v2f{s.x + s.z, s.y + s.w};
+      *reinterpret_cast<v2f*>(buf + S8_OFF + 8 * lane + 512 * i2) = v2f{s.x + s.z, s.y + s.w};
     }
   }
   wave_sync();
   // P_j = sum_f I_f W[f, j]  (:312-313): lane = Bark band; the two edge bins carry weights wf / wl, the interior
   // (weight 1) is gathered as single bins + 8-bin chunk sums through a host-built list of LDS offsets
-  const uint32_t edge = tab[PB_EDGE + lane];
-  const float wf = __uint_as_float(tab[PB_WF + lane]), wl = __uint_as_float(tab[PB_WL + lane]);
-  v2f P0 = *reinterpret_cast<const v2f*>(buf + (edge & 0xffffu)) * wf;
-  v2f P1 = *reinterpret_cast<const v2f*>(buf + (edge >> 16)) * wl;
+  const v4f bc0 = reinterpret_cast<const v4f*>(pimg + PL_BAND)[lane];        // edge, wf, wl, quiet
+  const uint32_t edge = __float_as_uint(bc0.x);
+  v2f P0 = *reinterpret_cast<const v2f*>(buf + (edge & 0xffffu)) * bc0.y;
+  v2f P1 = *reinterpret_cast<const v2f*>(buf + (edge >> 16)) * bc0.z;
 #pragma unroll
   for (int hlf = 0; hlf < PL_HALF; ++hlf) {
     const uint32_t w = pimg[PL_LST + hlf * 64 + lane];
@@ -314,31 +338,52 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* buf, const u
     acc1 += v2f{qq.z, qq.w} * gp[-i - 1];
   }
   const v2f acc = acc0 + acc1;
-  const float beta = __uint_as_float(tab[PB_BETA + lane]), quiet = __uint_as_float(tab[PB_QUIET + lane]);
-  const v2f offset = (1.0f - pp.drown) * (t * beta + 9.0f * t + 5.5f);                       // (:185-191)
-  const v2f fac = exp2v(offset * (-pp.alpha * 0.33219280948873623f));                        // 10^(-alpha O / 10)
-  const v2f T = exp2v(pp.inv_alpha * log2v(maxv(fac * acc, kEps)));                           // (:208)
-  const v2f G = maxv(T, quiet);                                                               // (:144)
+  const v4f bc1 = reinterpret_cast<const v4f*>(pimg + PL_BAND)[64 + lane];   // beta, rho, u0, u1
+  const v2f offset = (1.0f - pp.drown) * (t * bc1.x + 9.0f * t + 5.5f);                        // (:185-191)
+  const v2f fac = exp2v(offset * (-pp.alpha * 0.33219280948873623f));                          // 10^(-alpha O / 10)
+  const v2f T = exp2v(pp.inv_alpha * log2v(maxv(fac * acc, kEps)));                             // (:208)
+  const v2f G = maxv(T, bc0.w);                                                                 // (:144)
   v2f Gn;
-  Gn.x = __shfl_down(G.x, 1, 64);
-  Gn.y = __shfl_down(G.y, 1, 64);
-  // thr^2 of the bins of band j: interior bins G_j rho_j; the bin shared with band j+1 G_j u0 + G_{j+1} u1 (:330)
-  const float rho = __uint_as_float(tab[PB_RHO + lane]), u0 = __uint_as_float(tab[PB_U0 + lane]),
-              u1 = __uint_as_float(tab[PB_U1 + lane]);
-  const v2f A0 = G * rho, A1 = G * u0 + Gn * u1;
-  wave_sync();
-  *reinterpret_cast<v4f*>(buf + 16 * lane) = v4f{A0.x, A0.y, A1.x, A1.y};   // entry e at byte 8 e
-  wave_sync();
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const uint32_t w = tab[P_IDX + (i >> 1) * 64 + lane] >> (16 * (i & 1));
-    const v2f a0 = *reinterpret_cast<const v2f*>(buf + 8 * (w & 0xffu));
-    const v2f a1 = *reinterpret_cast<const v2f*>(buf + 8 * ((w >> 8) & 0xffu));
-    // v_sqrt_f32 (1 ulp); arguments are >= 1e-14, far from the denormal range   (:331)
-    thr[i] = v4f{__builtin_amdgcn_sqrtf(fmaxf(a0.x, kEps)), __builtin_amdgcn_sqrtf(fmaxf(a0.y, kEps)),
-                 __builtin_amdgcn_sqrtf(fmaxf(a1.x, kEps)), __builtin_amdgcn_sqrtf(fmaxf(a1.y, kEps))};
+  {
+    // G of band j + 1 (lane + 1): wave_shr:1 would shift the wrong way; row_shl within rows + fix-up is no shorter
+    Gn.x = __shfl_down(G.x, 1, 64);
+    Gn.y = __shfl_down(G.y, 1, 64);
   }
+  // thr of the bins of band j: interior bins sqrt(max(eps, G_j rho_j)); the bin shared with band j+1
+  // sqrt(max(eps, G_j u0 + G_{j+1} u1))  (:330-331) -- one value per entry, not per bin
+  const v2f A0 = maxv(G * bc1.y, kEps), A1 = maxv(G * bc1.z + Gn * bc1.w, kEps);
   wave_sync();
+  // v_sqrt_f32 (1 ulp); arguments are >= 1e-14, far from the denormal range
+  *reinterpret_cast<v4f*>(buf + 16 * lane) = v4f{__builtin_amdgcn_sqrtf(A0.x), __builtin_amdgcn_sqrtf(A0.y),
+                                                 __builtin_amdgcn_sqrtf(A1.x), __builtin_amdgcn_sqrtf(A1.y)};   // entry e at byte 8 e
+  wave_sync();
+  {
+    const v4f ia = reinterpret_cast<const v4f*>(pimg + PL_IDX)[lane], ib = reinterpret_cast<const v4f*>(pimg + PL_IDX)[64 + lane];
+    const uint32_t iw[8] = {__float_as_uint(ia.x), __float_as_uint(ia.y), __float_as_uint(ia.z), __float_as_uint(ia.w),
+                            __float_as_uint(ib.x), __float_as_uint(ib.y), __float_as_uint(ib.z), __float_as_uint(ib.w)};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const v2f a0 = *reinterpret_cast<const v2f*>(buf + (iw[i] & 0xffffu));
+      const v2f a1 = *reinterpret_cast<const v2f*>(buf + (iw[i] >> 16));
+      thr[i] = v4f{a0.x, a0.y, a1.x, a1.y};
+    }
+  }
+}
+
+// copies the table image (and the psy image) into the workgroup's LDS behind the wave buffers; every thread takes part
+template <int NW, int WSTRIDE>
+__device__ __forceinline__ void load_tables(char* lds, const float* __restrict__ image, const uint32_t* psy_tab) {
+  if (image) {
+    v4f* dst = reinterpret_cast<v4f*>(lds + NW * WSTRIDE);
+    const v4f* src = reinterpret_cast<const v4f*>(image);
+    for (int i = threadIdx.x; i < I_TOTAL / 4; i += NW * 64) dst[i] = src[i];
+  }
+  if (psy_tab) {
+    uint4* pd = reinterpret_cast<uint4*>(lds + NW * WSTRIDE + (image ? TAB_LDS : 0));
+    const uint4* ps = reinterpret_cast<const uint4*>(psy_tab);
+    for (int i = threadIdx.x; i < P_TOTAL / 4; i += NW * 64) pd[i] = ps[i];
+  }
+  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -356,46 +401,39 @@ struct FwdArgs {
   long long ntasks;
 };
 
-// fold one staged block: cur = part of this frame, carry' = part aliasing into the next frame
-__device__ __forceinline__ void fold_block(char* buf, gtab_t tab, int lane, v2f (&cur)[8],
+// fold one block held in natural order: cur = part of this frame, nxt = part aliasing into the next frame.
+// Element e = lane + 64 r takes the even sample of granule e + 256 (this lane, register (r + 4) & 7) and the odd
+// sample of granule 767 - e (lane 63 - lane, register (3 - r) & 7).  With (A, B) = COEF[e]:
+//   r < 4:  cur = B xo - A xe      r >= 4:  cur = A xe - B xo      nxt = B xe + A xo      
+template <bool WANT_CUR>
+__device__ __forceinline__ void fold_block(const v4f (&blk)[8], char* buf, gtab_t tab, int lane, v2f (&cur)[8],
                                            v2f (&nxt)[8]) {
+  v2f xo_in[8], xo[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) xo_in[c] = v2f{blk[c].z, blk[c].w};
+  rev_exchange<3>(buf, lane, xo_in, xo);
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
-    const int e = lane + 64 * r;
-    const v2f xe = slotE(buf, (e + 256) & 511);
-    const v2f xo = slotO(buf, (767 - e) & 511);
-    const v4f cf = reinterpret_cast<const v4f*>(tab + I_COEF)[r * 64 + lane];
-    cur[r] = cf.x * xe + cf.y * xo;
-    nxt[r] = cf.z * xe + cf.w * xo;
+    const v4f& g = blk[(r + 4) & 7];
+    const v2f xe = v2f{g.x, g.y};
+    const v2f ab = reinterpret_cast<const v2f*>(tab + I_COEF)[r * 64 + lane];
+    if (WANT_CUR) cur[r] = (r < 4) ? (ab.y * xo[r] - ab.x * xe) : (ab.x * xe - ab.y * xo[r]);
+    nxt[r] = ab.y * xe + ab.x * xo[r];
   }
 }
 
-// copies the table image (and the psy image) into the workgroup's LDS; every thread takes part
-template <int WSTRIDE>
-__device__ __forceinline__ void load_tables(char* lds, const float* __restrict__ image, const uint32_t* psy_tab) {
-  v4f* dst = reinterpret_cast<v4f*>(lds + WAVES * WSTRIDE);
-  const v4f* src = reinterpret_cast<const v4f*>(image);
-  for (int i = threadIdx.x; i < I_TOTAL / 4; i += WAVES * 64) dst[i] = src[i];
-  if (psy_tab) {
-    uint32_t* pd = reinterpret_cast<uint32_t*>(lds + WAVES * WSTRIDE + TAB_LDS);
-    for (int i = threadIdx.x; i < P_IMG_WORDS; i += WAVES * 64) pd[i] = psy_tab[P_IMG + i];
-  }
-  __syncthreads();
-}
-
-template <int CMODE, bool PSY>
-__global__ __launch_bounds__(WAVES * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
-  // one LDS object: [4 x 8 KB wave buffers | table image | g]; a single array keeps every table read in the loop
-  // (the wave-buffer stores may alias it), so no table value is pinned in registers across the walk
+template <int CMODE, bool PSY, int NW>
+__global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
+  // one LDS object: [NW wave buffers | table image | psy image]
   constexpr int WSTRIDE = PSY ? WAVE_LDS_PSY : WAVE_LDS;
-  __shared__ __attribute__((aligned(16))) char lds[WAVES * WSTRIDE + TAB_LDS + (PSY ? PSY_LDS : 0)];
+  __shared__ __attribute__((aligned(16))) char lds[NW * WSTRIDE + TAB_LDS + (PSY ? PSY_LDS : 0)];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  load_tables<WSTRIDE>(lds, a.tab, PSY ? a.psy.tab : nullptr);
-  const long long task = (long long)blockIdx.x * WAVES + wave;
+  load_tables<NW, WSTRIDE>(lds, a.tab, PSY ? a.psy.tab : nullptr);
+  const long long task = (long long)blockIdx.x * NW + wave;
   if (task >= a.ntasks) return;
   char* buf = lds + wave * WSTRIDE;
-  gtab_t tab = reinterpret_cast<const float*>(lds + WAVES * WSTRIDE);
-  const uint32_t* pimg = reinterpret_cast<const uint32_t*>(lds + WAVES * WSTRIDE + TAB_LDS);
+  gtab_t tab = reinterpret_cast<const float*>(lds + NW * WSTRIDE);
+  const uint32_t* pimg = reinterpret_cast<const uint32_t*>(lds + NW * WSTRIDE + TAB_LDS);
   if (PSY) *reinterpret_cast<v2f*>(buf + ZERO_OFF) = v2f{0.f, 0.f};   // the gather lists' padding slot
   const int sgm = (int)(task % a.nseg);
   const long long pair = task / a.nseg;
@@ -409,62 +447,62 @@ __global__ __launch_bounds__(WAVES * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
   const float* xb = a.x + (size_t)b * a.Kin * blk;
 
   v2f carry[8];
-  v4f row[8], ahead[8];   // ahead = the next PCM block, in flight while the current frame is transformed
+  v4f ahead[8];   // the next PCM block, in flight while the current frame is transformed
   {
     // carry of the block before the strip: block n0-1 of x, the stream state, or zero
     const float* src = nullptr;
     if (n0 >= 1) src = xb + (size_t)(n0 - 1) * blk;
     else if (a.prev_block) src = a.prev_block + (size_t)b * blk;
-    if (src) load_row<CMODE>(src, C, c0, has1, lane, row);
-    if (n0 < a.Kin) load_row<CMODE>(xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
     if (src) {
-      stage_row(buf, lane, row);
-      wave_sync();
+      v4f row[8];
+      load_row<CMODE>(src, C, c0, has1, lane, row);
+      if (n0 < a.Kin) load_row<CMODE>(xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
       v2f dummy[8];
-      fold_block(buf, tab, lane, dummy, carry);
-      wave_sync();
+      fold_block<false>(row, buf, tab, lane, dummy, carry);
     } else {
+      if (n0 < a.Kin) load_row<CMODE>(xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
 #pragma unroll
       for (int r = 0; r < 8; ++r) carry[r] = v2f{0.f, 0.f};
     }
   }
 
   for (int n = n0; n < n1; ++n) {
-    v2f cur[8], nxt[8];
+    C2 z[8];
     if (n < a.Kin) {
-      stage_row(buf, lane, ahead);
+      v2f cur[8], nxt[8];
+      fold_block<true>(ahead, buf, tab, lane, cur, nxt);
       if (n + 1 < n1 && n + 1 < a.Kin) load_row<CMODE>(xb + (size_t)(n + 1) * blk, C, c0, has1, lane, ahead);
-      wave_sync();
-      fold_block(buf, tab, lane, cur, nxt);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        // element e = lane + 64 r: v[2e] + i v[N-1-2e]; for e < 256 the real part comes from the previous block
+        const C2 v = (r < 4) ? C2{carry[r], cur[r]} : C2{cur[r], carry[r]};
+        z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + I_PRE)[r * 64 + lane]);
+        carry[r] = nxt[r];
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        cur[r] = v2f{0.f, 0.f};
-        nxt[r] = v2f{0.f, 0.f};
+        const v2f zero = v2f{0.f, 0.f};
+        const C2 v = (r < 4) ? C2{carry[r], zero} : C2{zero, carry[r]};
+        z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + I_PRE)[r * 64 + lane]);
+        carry[r] = zero;
       }
-    }
-    C2 z[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      // element e = lane + 64 r: v[2e] + i v[N-1-2e]; for e < 256 the real part comes from the previous block
-      const C2 v = (r < 4) ? C2{carry[r], cur[r]} : C2{cur[r], carry[r]};
-      z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + I_PRE)[r * 64 + lane]);
-      carry[r] = nxt[r];
     }
     fft512(z, buf, tab, lane);
-    wave_sync();
+    v4f row[8];
     {
-      const int k_lo = (lane >> 3) + 8 * (lane & 7);
+      // bin k = lane + 64 k2: X[2k] = Re (granule k, this lane), X[N-1-2k] = -Im (granule 511 - k, lane 63 - lane)
+      v2f xe[8], xo_in[8], xo[8];
 #pragma unroll
       for (int k2 = 0; k2 < 8; ++k2) {
-        const int k = k_lo + 64 * k2;
         const C2 r = cmul(z[k2], reinterpret_cast<const v2f*>(tab + I_POST)[k2 * 64 + lane]);
-        slotE(buf, k) = r.re;          // X[2k]
-        slotO(buf, 511 - k) = -r.im;   // X[N-1-2k]
+        xe[k2] = r.re;
+        xo_in[k2] = -r.im;
       }
+      rev_exchange<7>(buf, lane, xo_in, xo);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) row[i] = v4f{xe[i].x, xe[i].y, xo[i].x, xo[i].y};
     }
-    wave_sync();
-    unstage_row(buf, lane, row);
     const size_t frame = (size_t)b * a.F + (size_t)n;
     store_row<CMODE>(a.X + frame * blk, C, c0, has1, lane, row);
     if (PSY) {
@@ -476,8 +514,6 @@ __global__ __launch_bounds__(WAVES * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
         a.t[frame * C + c0] = tt.x;
         if (has1) a.t[frame * C + c0 + 1] = tt.y;
       }
-    } else {
-      wave_sync();
     }
   }
 }
@@ -495,15 +531,21 @@ struct InvArgs {
   long long ntasks;
 };
 
-// DCT-IV of the staged frame: returns (now, nxt) per output element k
-__device__ __forceinline__ void idct_frame(char* buf, gtab_t tab, int lane, v2f (&now)[8],
+// DCT-IV of one frame held in natural order: returns (now, nxt) per output element k = lane + 64 k2.
+// Element e = lane + 64 r is X[2e] (granule e, this lane) + i X[N-1-2e] (granule 511 - e, lane 63 - lane).
+__device__ __forceinline__ void idct_frame(const v4f (&frm)[8], char* buf, gtab_t tab, int lane, v2f (&now)[8],
                                            v2f (&nxt)[8]) {
   C2 z[8];
+  {
+    v2f xo_in[8], xo[8];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int e = lane + 64 * r;
-    const C2 v = {slotE(buf, e), slotO(buf, 511 - e)};   // X[2e] + i X[N-1-2e]
-    z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + I_PRE)[r * 64 + lane]);
+    for (int c = 0; c < 8; ++c) xo_in[c] = v2f{frm[c].z, frm[c].w};
+    rev_exchange<7>(buf, lane, xo_in, xo);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const C2 v = {v2f{frm[r].x, frm[r].y}, xo[r]};
+      z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + I_PRE)[r * 64 + lane]);
+    }
   }
   fft512(z, buf, tab, lane);
 #pragma unroll
@@ -520,15 +562,15 @@ __device__ __forceinline__ void idct_frame(char* buf, gtab_t tab, int lane, v2f 
   }
 }
 
-template <int CMODE>
-__global__ __launch_bounds__(WAVES * 64, AC_WPE) void k_inv_fast(InvArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[WAVES * WAVE_LDS + TAB_LDS];
+template <int CMODE, int NW>
+__global__ __launch_bounds__(NW * 64, AC_WPE) void k_inv_fast(InvArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS + TAB_LDS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  load_tables<WAVE_LDS>(lds, a.tab + I_TOTAL, nullptr);
-  const long long task = (long long)blockIdx.x * WAVES + wave;
+  load_tables<NW, WAVE_LDS>(lds, a.tab + I_TOTAL, nullptr);
+  const long long task = (long long)blockIdx.x * NW + wave;
   if (task >= a.ntasks) return;
   char* buf = lds + wave * WAVE_LDS;
-  gtab_t tab = reinterpret_cast<const float*>(lds + WAVES * WAVE_LDS);
+  gtab_t tab = reinterpret_cast<const float*>(lds + NW * WAVE_LDS);
   const int sgm = (int)(task % a.nseg);
   const long long pair = task / a.nseg;
   const int cp = (int)(pair % a.CP);
@@ -538,40 +580,38 @@ __global__ __launch_bounds__(WAVES * 64, AC_WPE) void k_inv_fast(InvArgs a) {
   const int n0 = sgm * a.seglen;
   const int n1 = min(a.nblk, n0 + a.seglen);
   const size_t blk = (size_t)FN * C;
-  const int k_lo = (lane >> 3) + 8 * (lane & 7);
   const float* Xb = a.X + (size_t)b * a.Kp * blk;
 
   v2f carry[8];
-  v4f row[8], ahead[8];   // ahead = the next frame, in flight while the current one is transformed
-  if (n0 >= 1) load_row<CMODE>(Xb + (size_t)(n0 - 1) * blk, C, c0, has1, lane, row);
-  if (n0 < a.Kp) load_row<CMODE>(Xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
+  v4f ahead[8];   // the next frame, in flight while the current one is transformed
   if (n0 >= 1) {
     // aliased half of frame n0-1 (always an existing frame: n0-1 < Kp)
-    stage_row(buf, lane, row);
-    wave_sync();
+    v4f row[8];
+    load_row<CMODE>(Xb + (size_t)(n0 - 1) * blk, C, c0, has1, lane, row);
+    if (n0 < a.Kp) load_row<CMODE>(Xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
     v2f dummy[8];
-    idct_frame(buf, tab, lane, dummy, carry);
-    wave_sync();
-  } else if (a.tail_in) {
-#pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) {
-      const int k = k_lo + 64 * k2;
-      const int j = (k2 < 4) ? (511 - 2 * k) : (2 * k - 512);
-      carry[k2].x = a.tail_in[((size_t)b * C + c0) * FH + j];
-      carry[k2].y = has1 ? a.tail_in[((size_t)b * C + c0 + 1) * FH + j] : 0.f;
-    }
+    idct_frame(row, buf, tab, lane, dummy, carry);
   } else {
+    if (n0 < a.Kp) load_row<CMODE>(Xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
+    if (a.tail_in) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) carry[r] = v2f{0.f, 0.f};
+      for (int k2 = 0; k2 < 8; ++k2) {
+        const int k = lane + 64 * k2;
+        const int j = (k2 < 4) ? (511 - 2 * k) : (2 * k - 512);
+        carry[k2].x = a.tail_in[((size_t)b * C + c0) * FH + j];
+        carry[k2].y = has1 ? a.tail_in[((size_t)b * C + c0 + 1) * FH + j] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) carry[r] = v2f{0.f, 0.f};
+    }
   }
 
   for (int n = n0; n < n1; ++n) {
     v2f now[8], nxt[8];
     if (n < a.Kp) {
-      stage_row(buf, lane, ahead);
+      idct_frame(ahead, buf, tab, lane, now, nxt);
       if (n + 1 < n1 && n + 1 < a.Kp) load_row<CMODE>(Xb + (size_t)(n + 1) * blk, C, c0, has1, lane, ahead);
-      wave_sync();
-      idct_frame(buf, tab, lane, now, nxt);
     } else {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
@@ -579,28 +619,32 @@ __global__ __launch_bounds__(WAVES * 64, AC_WPE) void k_inv_fast(InvArgs a) {
         nxt[r] = v2f{0.f, 0.f};
       }
     }
-    wave_sync();
+    v4f row[8];
+    {
+      // with (a, b) = COEF[k]: o1 = a now + b carry -> out[j], o2 = b now - a carry -> out[N-1-j]  
+      // k < 256: j = 511 - 2k (odd: granule 255 - k, lane 63 - lane), N-1-j = 512 + 2k (even: granule 256 + k, this lane)
+      // else     j = 2k - 512 (even: granule k - 256, this lane),     N-1-j = 1535 - 2k (odd: granule 767 - k)
+      v2f xe[8], xo_in[8], xo[8];
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) {
-      const int k = k_lo + 64 * k2;
-      const v4f sc = reinterpret_cast<const v4f*>(tab + I_COEF)[k2 * 64 + lane];
-      const v2f o1 = sc.x * now[k2] + sc.y * carry[k2];   // out[j]
-      const v2f o2 = sc.z * now[k2] + sc.w * carry[k2];   // out[N-1-j]
-      // k < 256: j = 511 - 2k (odd), N-1-j = 512 + 2k (even); else j = 2k - 512 (even), N-1-j = 1535 - 2k (odd)
-      slotE(buf, (k + 256) & 511) = (k2 < 4) ? o2 : o1;
-      slotO(buf, (767 - k) & 511) = (k2 < 4) ? o1 : o2;
-      carry[k2] = nxt[k2];
+      for (int k2 = 0; k2 < 8; ++k2) {
+        const v2f ab = reinterpret_cast<const v2f*>(tab + I_COEF)[k2 * 64 + lane];
+        const v2f o1 = ab.x * now[k2] + ab.y * carry[k2];
+        const v2f o2 = ab.y * now[k2] - ab.x * carry[k2];
+        xe[(k2 + 4) & 7] = (k2 < 4) ? o2 : o1;
+        xo_in[k2] = (k2 < 4) ? o1 : o2;
+        carry[k2] = nxt[k2];
+      }
+      rev_exchange<3>(buf, lane, xo_in, xo);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) row[i] = v4f{xe[i].x, xe[i].y, xo[i].x, xo[i].y};
     }
-    wave_sync();
-    unstage_row(buf, lane, row);
     store_row<CMODE>(a.x + ((size_t)b * a.nblk + (size_t)n) * blk, C, c0, has1, lane, row);
-    wave_sync();
   }
 
   if (a.tail_out && n1 == a.nblk) {
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) {
-      const int k = k_lo + 64 * k2;
+      const int k = lane + 64 * k2;
       const int j = (k2 < 4) ? (511 - 2 * k) : (2 * k - 512);
       a.tail_out[((size_t)b * C + c0) * FH + j] = carry[k2].x;
       if (has1) a.tail_out[((size_t)b * C + c0 + 1) * FH + j] = carry[k2].y;
@@ -621,16 +665,13 @@ struct PsyArgs {
   long long ntasks;   // B * F * CP
 };
 
-template <int CMODE, bool WANT_T, bool WANT_THR>
-__global__ __launch_bounds__(WAVES * 64, AC_WPE) void k_psy_fast(PsyArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[WAVES * WAVE_LDS_PSY + PSY_LDS];
+template <int CMODE, bool WANT_T, bool WANT_THR, int NW>
+__global__ __launch_bounds__(NW * 64, AC_WPE) void k_psy_fast(PsyArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS_PSY + PSY_LDS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t* pimg = reinterpret_cast<uint32_t*>(lds + WAVES * WAVE_LDS_PSY);
-  if (WANT_THR) {
-    for (int i = threadIdx.x; i < P_IMG_WORDS; i += WAVES * 64) pimg[i] = a.psy.tab[P_IMG + i];
-    __syncthreads();
-  }
-  const long long task = (long long)blockIdx.x * WAVES + wave;
+  const uint32_t* pimg = reinterpret_cast<const uint32_t*>(lds + NW * WAVE_LDS_PSY);
+  if (WANT_THR) load_tables<NW, WAVE_LDS_PSY>(lds, nullptr, a.psy.tab);
+  const long long task = (long long)blockIdx.x * NW + wave;
   if (task >= a.ntasks) return;
   char* buf = lds + wave * WAVE_LDS_PSY;
   if (WANT_THR) *reinterpret_cast<v2f*>(buf + ZERO_OFF) = v2f{0.f, 0.f};
@@ -657,8 +698,16 @@ __global__ __launch_bounds__(WAVES * 64, AC_WPE) void k_psy_fast(PsyArgs a) {
 // strips: enough waves to fill the chip several times over, long enough to amortise the one-block halo
 int pick_seglen(long long pairs, int frames) {
   const long long total = pairs * (long long)frames;
-  long long s = (total + 8191) / 8192;
-  if (s < 4) s = 4;
+  static const long long target = [] {
+    const char* e = getenv("AC_TARGET_WAVES");   // tuning hook
+    return e ? atoll(e) : 8192ll;
+  }();
+  long long s = (total + target - 1) / target;
+  static const long long smin = [] {
+    const char* e = getenv("AC_MIN_SEGLEN");   // tuning hook
+    return e ? atoll(e) : 4ll;
+  }();
+  if (s < smin) s = smin;
   if (s > frames) s = frames;
   if (s < 1) s = 1;
   return (int)s;
@@ -678,12 +727,13 @@ PsyParams psy_params(const ac_psy_plan* p, float drown) {
 // ------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------
-bool fast_mdct_supported(int N) { return N == FN; }
-
-int fast_mdct_plan_init(ac_mdct_plan* p) {
-  const int N = p->N, h = N / 2;
+// Builds the two table images; false when the window's fold blocks are not rotations (the rectangular
+// "window", mdctransformer.py:209-211), which the two-coefficient fold cannot express.
+static bool build_mdct_fast(int N, int window, std::vector<float>* out) {
+  if (N != FN) return false;
+  const int h = N / 2;
   FoldCoef c;
-  fold_coefficients(N, p->window, c);
+  fold_coefficients(N, window, c);
   std::vector<float> t(2 * I_TOTAL, 0.f);
   float* tf = t.data();              // analysis image
   float* ti = t.data() + I_TOTAL;    // synthesis image
@@ -692,11 +742,13 @@ int fast_mdct_plan_init(ac_mdct_plan* p) {
     base[2 * i] = (float)re;
     base[2 * i + 1] = (float)im;
   };
+  // the reference's lower-right quadrant (1 - w[N+j] w[N-1-j]) / w[j] carries ~1e-10 of fp64 cancellation noise
+  auto same = [](double x, double y) { return std::fabs(x - y) <= 1e-8; };
   for (int r = 0; r < 8; ++r) {
     for (int l = 0; l < 64; ++l) {
       const int i = r * 64 + l;
       const int e = l + 64 * r;                                   // input element of (lane, register)
-      const int k = (l >> 3) + 8 * (l & 7) + 64 * r;              // output bin of (lane, register)
+      const int k = l + 64 * r;                                   // output bin of (lane, register)
       double ang = -pi * (e + 0.25) / N;
       put2(tf + I_PRE, i, std::cos(ang), std::sin(ang));
       put2(ti + I_PRE, i, std::cos(ang), std::sin(ang));
@@ -704,7 +756,7 @@ int fast_mdct_plan_init(ac_mdct_plan* p) {
       put2(tf + I_P1, i, std::cos(ang), std::sin(ang));
       put2(ti + I_P1, i, std::cos(ang), std::sin(ang));
       if (l < 8) {
-        ang = -2.0 * pi * (double)(l * r) / 64.0;                 // [k1 = r][m0 = l]
+        ang = -2.0 * pi * (double)(l * r) / 64.0;                 // [k1 = r][e0 = l]
         put2(tf + I_P2, r * 8 + l, std::cos(ang), std::sin(ang));
         put2(ti + I_P2, r * 8 + l, std::cos(ang), std::sin(ang));
       }
@@ -712,25 +764,36 @@ int fast_mdct_plan_init(ac_mdct_plan* p) {
       const double sf = 1.0 / (N * std::sqrt(2.0)), si = 2.0 * std::sqrt(2.0);
       put2(tf + I_POST, i, std::cos(ang) * sf, std::sin(ang) * sf);
       put2(ti + I_POST, i, std::cos(ang) * si, std::sin(ang) * si);
+      // analysis fold of element e (see fold_block): current-frame part cE xe + cO xo, carried part kE xe + kO xo
       double cE, cO, kE, kO;
-      if (e < h / 2) {   // e < 256: samples 512+2e (even) / 511-2e (odd); current part = v[N-1-2e], carry = v'[2e]
+      if (e < h / 2) {   // samples 512+2e (even) / 511-2e (odd); current part = v[N-1-2e], carry = v'[2e]
         const int jc = h - 1 - 2 * e, jk = 2 * e;
         cE = c.a2[jc]; cO = c.a1[jc]; kE = c.a4[jk]; kO = c.a3[jk];
+        if (!same(cE, -kO) || !same(cO, kE)) return false;        // (-A, B, B, A)
       } else {           // samples 2p (even) / N-1-2p (odd), p = e-256: current part = v[2e], carry = v'[N-1-2e]
         const int pidx = e - h / 2;
         const int jc = 2 * pidx, jk = h - 1 - 2 * pidx;
         cE = c.a1[jc]; cO = c.a2[jc]; kE = c.a3[jk]; kO = c.a4[jk];
+        if (!same(cE, kO) || !same(cO, -kE)) return false;        // (A, -B, B, A)
       }
-      tf[I_COEF + 4 * i + 0] = (float)cE;
-      tf[I_COEF + 4 * i + 1] = (float)cO;
-      tf[I_COEF + 4 * i + 2] = (float)kE;
-      tf[I_COEF + 4 * i + 3] = (float)kO;
+      put2(tf + I_COEF, i, kO, kE);                                // (A, B)
+      // synthesis unfold of output element k (see k_inv_fast): o1 = s1 now + s2 carry, o2 = s3 now + s4 carry
       const int j = (k < h / 2) ? (h - 1 - 2 * k) : (2 * k - h);
-      ti[I_COEF + 4 * i + 0] = (float)c.s1[j];
-      ti[I_COEF + 4 * i + 1] = (float)c.s2[j];
-      ti[I_COEF + 4 * i + 2] = (float)c.s3[j];
-      ti[I_COEF + 4 * i + 3] = (float)c.s4[j];
+      if (!same(c.s3[j], c.s2[j]) || !same(c.s4[j], -c.s1[j])) return false;   // (a, b, b, -a)
+      put2(ti + I_COEF, i, c.s1[j], c.s2[j]);
     }
+  }
+  if (out) *out = t;
+  return true;
+}
+
+bool fast_mdct_supported(int N, int window) { return build_mdct_fast(N, window, nullptr); }
+
+int fast_mdct_plan_init(ac_mdct_plan* p) {
+  std::vector<float> t;
+  if (!build_mdct_fast(p->N, p->window, &t)) {
+    set_error("internal: wave-level kernels not supported for this configuration");
+    return AC_EUNSUPPORTED;
   }
   p->fast_bytes = t.size() * sizeof(float);
   AC_HIP_CHECK(hipMalloc((void**)&p->d_fast, p->fast_bytes));
@@ -749,7 +812,7 @@ static bool build_psy_fast(const ac_psy_plan* p, std::vector<uint32_t>* out) {
   auto Vf = [&](int j, int f) { return (float)t.W_inv[(size_t)j * N + f]; };
   std::vector<uint32_t> w(P_TOTAL, 0u);
   auto putf = [&](int idx, float v) { uint32_t u; memcpy(&u, &v, 4); w[idx] = u; };
-  std::vector<int> first(M), last(M);
+  auto band = [](int group, int j, int word) { return PL_BAND + 4 * (group * 64 + j) + word; };
   for (int j = 0; j < M; ++j) {
     int f0 = -1, f1 = -1;
     for (int f = 0; f < N; ++f)
@@ -762,15 +825,13 @@ static bool build_psy_fast(const ac_psy_plan* p, std::vector<uint32_t>* out) {
       if (Wf(f, j) == 0.f) return false;
       if (f > f0 && f < f1 && Wf(f, j) != 1.0f) return false;
     }
-    first[j] = f0;
-    last[j] = f1;
     // LDS byte offset of I[f] in the wave buffer (granule swizzle of psy_stage)
     auto addrI = [](int f) { const int q = f >> 1; return (uint32_t)(16 * (q ^ ((q >> 4) & 3)) + 8 * (f & 1)); };
-    w[PB_EDGE + j] = addrI(f0) | (addrI(f1) << 16);
-    putf(PB_WF + j, Wf(f0, j));
-    putf(PB_WL + j, (f1 > f0) ? Wf(f1, j) : 0.f);
-    putf(PB_QUIET + j, (float)t.quiet[j]);
-    putf(PB_BETA + j, t.beta[j]);
+    w[band(0, j, 0)] = addrI(f0) | (addrI(f1) << 16);
+    putf(band(0, j, 1), Wf(f0, j));
+    putf(band(0, j, 2), (f1 > f0) ? Wf(f1, j) : 0.f);
+    putf(band(0, j, 3), (float)t.quiet[j]);
+    putf(band(1, j, 0), t.beta[j]);
     // interior bins f0+1 .. f1-1 (weight 1): single bins up to an 8-aligned boundary, whole chunks, single bins
     std::vector<uint32_t> lst;
     for (int f = f0 + 1; f <= f1 - 1;) {
@@ -784,7 +845,7 @@ static bool build_psy_fast(const ac_psy_plan* p, std::vector<uint32_t>* out) {
     }
     if ((int)lst.size() > 2 * PL_HALF) return false;
     lst.resize(2 * PL_HALF, (uint32_t)ZERO_OFF);
-    for (int hlf = 0; hlf < PL_HALF; ++hlf) w[P_IMG + PL_LST + hlf * 64 + j] = lst[2 * hlf] | (lst[2 * hlf + 1] << 16);
+    for (int hlf = 0; hlf < PL_HALF; ++hlf) w[PL_LST + hlf * 64 + j] = lst[2 * hlf] | (lst[2 * hlf + 1] << 16);
   }
   // bins -> entries; nnz pattern of W and W_inv is identical (same overlap)
   std::vector<int> entry(N, -1);
@@ -806,7 +867,7 @@ static bool build_psy_fast(const ac_psy_plan* p, std::vector<uint32_t>* out) {
         return false;
       }
       entry[f] = 2 * jf;
-    } else if (cnt == 2 && Vf(jf + 1, f) != 0.f && jf + 1 < M) {
+    } else if (cnt == 2 && jf + 1 < M && Vf(jf + 1, f) != 0.f) {
       if (u0[jf] != 0.f || u1[jf] != 0.f) return false;   // one shared bin per band boundary
       u0[jf] = Vf(jf, f);
       u1[jf] = Vf(jf + 1, f);
@@ -816,17 +877,18 @@ static bool build_psy_fast(const ac_psy_plan* p, std::vector<uint32_t>* out) {
     }
   }
   for (int j = 0; j < M; ++j) {
-    putf(PB_RHO + j, rho[j]);
-    putf(PB_U0 + j, u0[j]);
-    putf(PB_U1 + j, u1[j]);
+    putf(band(1, j, 1), rho[j]);
+    putf(band(1, j, 2), u0[j]);
+    putf(band(1, j, 3), u1[j]);
   }
+  // threshold entry e lives at byte 8 e of the wave buffer; word i of lane l = offsets of bins 2q, 2q+1, q = 64 i + l
   for (int l = 0; l < 64; ++l)
     for (int i = 0; i < 8; ++i) {
       const int q = 64 * i + l;
-      const uint32_t e0 = (uint32_t)entry[2 * q], e1 = (uint32_t)entry[2 * q + 1];
-      w[P_IDX + (i >> 1) * 64 + l] |= (e0 | (e1 << 8)) << (16 * (i & 1));
+      const uint32_t e0 = 8u * (uint32_t)entry[2 * q], e1 = 8u * (uint32_t)entry[2 * q + 1];
+      w[PL_IDX + 4 * ((i >> 2) * 64 + l) + (i & 3)] = e0 | (e1 << 16);
     }
-  for (int i = 0; i < 128; ++i) putf(P_IMG + PL_G + i, (float)t.g[i]);
+  for (int i = 0; i < 128; ++i) putf(PL_G + i, (float)t.g[i]);
   if (out) *out = w;
   return true;
 }
@@ -845,8 +907,8 @@ int fast_psy_plan_init(ac_psy_plan* p) {
   return AC_OK;
 }
 
-static int grid_for(long long ntasks, unsigned* grid) {
-  const long long g = (ntasks + WAVES - 1) / WAVES;
+static int grid_for(long long ntasks, int nw, unsigned* grid) {
+  const long long g = (ntasks + nw - 1) / nw;
   if (g > 2147483647ll) {
     set_error("problem too large for one launch (%lld workgroups)", g);
     return AC_EINVAL;
@@ -876,15 +938,16 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const float* 
   a.nseg = (F + a.seglen - 1) / a.seglen;
   a.ntasks = (long long)B * a.CP * a.nseg;
   unsigned grid;
-  int st = grid_for(a.ntasks, &grid);
+  int st = grid_for(a.ntasks, psy ? AC_WAVES_PSY : AC_WAVES, &grid);
   if (st) return st;
-  const dim3 blk(WAVES * 64);
-  if (C == 2) {
-    if (psy) hipLaunchKernelGGL((k_fwd_fast<0, true>), dim3(grid), blk, 0, s, a);
-    else hipLaunchKernelGGL((k_fwd_fast<0, false>), dim3(grid), blk, 0, s, a);
+  if (psy) {
+    const dim3 blk(AC_WAVES_PSY * 64);
+    if (C == 2) hipLaunchKernelGGL((k_fwd_fast<0, true, AC_WAVES_PSY>), dim3(grid), blk, 0, s, a);
+    else hipLaunchKernelGGL((k_fwd_fast<1, true, AC_WAVES_PSY>), dim3(grid), blk, 0, s, a);
   } else {
-    if (psy) hipLaunchKernelGGL((k_fwd_fast<1, true>), dim3(grid), blk, 0, s, a);
-    else hipLaunchKernelGGL((k_fwd_fast<1, false>), dim3(grid), blk, 0, s, a);
+    const dim3 blk(AC_WAVES * 64);
+    if (C == 2) hipLaunchKernelGGL((k_fwd_fast<0, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
+    else hipLaunchKernelGGL((k_fwd_fast<1, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
   }
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
@@ -908,11 +971,11 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, float* x, const float
   a.nseg = (nblk + a.seglen - 1) / a.seglen;
   a.ntasks = (long long)B * a.CP * a.nseg;
   unsigned grid;
-  int st = grid_for(a.ntasks, &grid);
+  int st = grid_for(a.ntasks, AC_WAVES, &grid);
   if (st) return st;
-  const dim3 blk(WAVES * 64);
-  if (C == 2) hipLaunchKernelGGL((k_inv_fast<0>), dim3(grid), blk, 0, s, a);
-  else hipLaunchKernelGGL((k_inv_fast<1>), dim3(grid), blk, 0, s, a);
+  const dim3 blk(AC_WAVES * 64);
+  if (C == 2) hipLaunchKernelGGL((k_inv_fast<0, AC_WAVES>), dim3(grid), blk, 0, s, a);
+  else hipLaunchKernelGGL((k_inv_fast<1, AC_WAVES>), dim3(grid), blk, 0, s, a);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }
@@ -930,19 +993,19 @@ int launch_psy_fast(const ac_psy_plan* p, const float* X, const float* t_in, flo
   a.CP = (C + 1) / 2;
   a.ntasks = (long long)B * F * a.CP;
   unsigned grid;
-  int st = grid_for(a.ntasks, &grid);
+  int st = grid_for(a.ntasks, AC_WAVES, &grid);
   if (st) return st;
-  const dim3 blk(WAVES * 64);
+  const dim3 blk(AC_WAVES * 64);
   const bool want_t = (t_out != nullptr), want_thr = (thr != nullptr);
   if (want_t && !want_thr) {
-    if (C == 2) hipLaunchKernelGGL((k_psy_fast<0, true, false>), dim3(grid), blk, 0, s, a);
-    else hipLaunchKernelGGL((k_psy_fast<1, true, false>), dim3(grid), blk, 0, s, a);
+    if (C == 2) hipLaunchKernelGGL((k_psy_fast<0, true, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
+    else hipLaunchKernelGGL((k_psy_fast<1, true, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
   } else if (!want_t && want_thr) {
-    if (C == 2) hipLaunchKernelGGL((k_psy_fast<0, false, true>), dim3(grid), blk, 0, s, a);
-    else hipLaunchKernelGGL((k_psy_fast<1, false, true>), dim3(grid), blk, 0, s, a);
+    if (C == 2) hipLaunchKernelGGL((k_psy_fast<0, false, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
+    else hipLaunchKernelGGL((k_psy_fast<1, false, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
   } else if (want_t && want_thr) {
-    if (C == 2) hipLaunchKernelGGL((k_psy_fast<0, true, true>), dim3(grid), blk, 0, s, a);
-    else hipLaunchKernelGGL((k_psy_fast<1, true, true>), dim3(grid), blk, 0, s, a);
+    if (C == 2) hipLaunchKernelGGL((k_psy_fast<0, true, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
+    else hipLaunchKernelGGL((k_psy_fast<1, true, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
   }
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;

@@ -96,7 +96,7 @@ int launch_threshold_generic(const ac_psy_plan* p, const float* X, const float* 
                              int F, int C, hipStream_t s);
 
 // wave-level FFT kernels (ac_fast.hip)
-bool fast_mdct_supported(int N);
+bool fast_mdct_supported(int N, int window);
 bool fast_psy_supported(const ac_psy_plan* p);
 int fast_mdct_plan_init(ac_mdct_plan* p);
 int fast_psy_plan_init(ac_psy_plan* p);

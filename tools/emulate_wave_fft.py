@@ -52,69 +52,56 @@ def cycles(kind, byte_addr):
     return total
 
 
-# ---------------- exchange index maps (units: 16-byte elements, 512 per wave buffer) -----------------
+# ---------------- exchange index maps (units: 16-byte elements, 576 per wave buffer = 9216 B) ----------
+# Every map is (one per-lane base) + (a compile-time multiple of the register index), so each exchange
+# costs one address VGPR and the register index rides in the instruction's immediate offset.
 def ex1_write(k0, m):            # after pass 1: lane m, register k0
-    return (k0 * 64 + m) ^ ((k0 & 1) << 3)
+    return k0 * 72 + m
 
 
-def ex1_read(l, r):              # lane (a = l>>3, m0 = l&7) reads m1 = r of FFT #a
+def ex1_read(l, r):              # lane (a = l>>3 = k0, m0 = l&7 = e0) reads e1 = r
     a, m0 = l >> 3, l & 7
-    return (a * 64 + 8 * r + m0) ^ ((a & 1) << 3)
+    return a * 72 + 8 * r + m0
 
 
-def ex2_write(l, k1):            # lane (a, m0), register k1
+def ex2_write(l, k1):            # lane (a = k0, m0 = e0), register k1 -> row of reader lane k0 + 8 k1, column e0
     a, m0 = l >> 3, l & 7
-    return a * 64 + ((k1 * 8 + (m0 ^ k1)) ^ ((a & 1) << 3))
+    return k1 * 72 + 9 * a + m0
 
 
-def ex2_read(l, r):              # lane (a, b) reads m0 = r
-    a, b = l >> 3, l & 7
-    return a * 64 + ((b * 8 + (r ^ b)) ^ ((a & 1) << 3))
+def ex2_read(l, r):              # lane l = k0 + 8 k1 reads e0 = r
+    return 9 * l + r
 
 
-def nat_slot(f):                 # natural-order staging: 8-byte slot of coefficient / sample f (both channels)
-    q = f >> 1
-    return ((q ^ ((q >> 3) & 7)) << 1) | (f & 1)
+def rev_write(l, c):             # lane-reversal exchange (8-byte slots): lane l writes register c
+    return (63 - l) + 64 * c
+
+
+def rev_read(l, i):
+    return l + 64 * i
 
 
 def check_banks():
     worst = {}
-    for k0 in range(8):
-        worst["ex1 write_b128"] = max(worst.get("ex1 write_b128", 0), cycles("write_b128", 16 * ex1_write(k0, lane)))
     for r in range(8):
+        worst["ex1 write_b128"] = max(worst.get("ex1 write_b128", 0), cycles("write_b128", 16 * ex1_write(r, lane)))
         worst["ex1 read_b128"] = max(worst.get("ex1 read_b128", 0), cycles("read_b128", 16 * ex1_read(lane, r)))
         worst["ex2 write_b128"] = max(worst.get("ex2 write_b128", 0), cycles("write_b128", 16 * ex2_write(lane, r)))
         worst["ex2 read_b128"] = max(worst.get("ex2 read_b128", 0), cycles("read_b128", 16 * ex2_read(lane, r)))
-    a, b = lane >> 3, lane & 7
-    for k2 in range(8):
-        k = a + 8 * b + 64 * k2
-        worst["nat write_b64 (even f)"] = max(worst.get("nat write_b64 (even f)", 0), cycles("write_b64", 8 * nat_slot(2 * k)))
-        worst["nat write_b64 (odd f)"] = max(worst.get("nat write_b64 (odd f)", 0), cycles("write_b64", 8 * nat_slot(N - 1 - 2 * k)))
-    for i in range(8):
-        q = 64 * i + lane
-        worst["nat read_b128"] = max(worst.get("nat read_b128", 0), cycles("read_b128", 8 * nat_slot(2 * q)))
-        worst["nat write_b128 (linear)"] = max(worst.get("nat write_b128 (linear)", 0), cycles("write_b128", 8 * nat_slot(2 * q)))
-    # fold reads: element e = m + 64 r reads samples po / pe (8-byte slots)
-    for r in range(8):
-        e = lane + 64 * r
-        if r < 4:
-            po, pe = 511 - 2 * e, 512 + 2 * e
-        else:
-            p = e - 256
-            pe, po = 2 * p, 1023 - 2 * p
-        worst["fold read_b64 (odd)"] = max(worst.get("fold read_b64 (odd)", 0), cycles("read_b64", 8 * nat_slot(po)))
-        worst["fold read_b64 (even)"] = max(worst.get("fold read_b64 (even)", 0), cycles("read_b64", 8 * nat_slot(pe)))
+        worst["rev write_b64"] = max(worst.get("rev write_b64", 0), cycles("write_b64", 8 * rev_write(lane, r)))
+        worst["rev read_b64"] = max(worst.get("rev read_b64", 0), cycles("read_b64", 8 * rev_read(lane, r)))
     ideal = {"write_b128": 8, "read_b128": 4, "write_b64": 4, "read_b64": 2}
     for k, v in worst.items():
         kind = [t for t in ideal if t in k][0]
         print("  %-28s %2d cycles (conflict-free = %d)" % (k, v, ideal[kind]))
-    # all maps must be bijections on 0..511
-    for fn in (ex1_write, ex2_write):
-        s = sorted(int(fn(l, r)) if fn is ex2_write else int(fn(r, l)) for l in range(64) for r in range(8))
-        assert s == list(range(512)), fn.__name__
-    for fn in (ex1_read, ex2_read):
-        assert sorted(int(fn(l, r)) for l in range(64) for r in range(8)) == list(range(512)), fn.__name__
-    assert sorted(int(nat_slot(f)) for f in range(N)) == list(range(N))
+    for fn in (ex1_write,):
+        s = sorted(int(fn(r, l)) for l in range(64) for r in range(8))
+        assert len(set(s)) == 512 and max(s) < 576, fn.__name__
+    for fn in (ex1_read, ex2_write, ex2_read):
+        s = sorted(int(fn(l, r)) for l in range(64) for r in range(8))
+        assert len(set(s)) == 512 and max(s) < 576, fn.__name__
+    assert sorted(int(ex1_write(r, l)) for l in range(64) for r in range(8)) == sorted(int(ex1_read(l, r)) for l in range(64) for r in range(8))
+    assert sorted(int(ex2_write(l, r)) for l in range(64) for r in range(8)) == sorted(int(ex2_read(l, r)) for l in range(64) for r in range(8))
 
 
 # ---------------- the FFT on lanes ---------------------------------------------------------------------
@@ -126,9 +113,8 @@ def radix8(regs):                # regs [64, 8] -> DFT over the register axis
 
 
 def fft512_on_wave(t):
-    """t [64 lanes, 8 regs] with element e = lane + 64 r.  Returns regs with X[k], k = a + 8 b + 64 k2 in lane
-    (a = l>>3, b = l&7), register k2."""
-    lds = np.zeros(512, complex)
+    """t [64 lanes, 8 regs] with element e = lane + 64 r.  Returns regs with X[k], k = lane + 64 k2 in register k2."""
+    lds = np.zeros(576, complex)
     y = radix8(t)                                                     # pass 1 over r -> k0
     y = y * np.exp(-2j * np.pi * lane[:, None] * np.arange(8)[None, :] / 512)       # W512^{m k0}
     for k0 in range(8):
@@ -138,13 +124,12 @@ def fft512_on_wave(t):
     z = z * np.exp(-2j * np.pi * (lane & 7)[:, None] * np.arange(8)[None, :] / 64)  # W64^{m0 k1}
     for k1 in range(8):
         lds[ex2_write(lane, k1)] = z[:, k1]
-    z = np.stack([lds[ex2_read(lane, r)] for r in range(8)], axis=1)  # lane (a, b), reg m0
+    z = np.stack([lds[ex2_read(lane, r)] for r in range(8)], axis=1)  # lane k0 + 8 k1, reg e0
     return radix8(z)                                                  # pass 3 over m0 -> k2
 
 
 def out_index():
-    a, b = lane >> 3, lane & 7
-    return a[:, None] + 8 * b[:, None] + 64 * np.arange(8)[None, :]   # k of (lane, reg)
+    return lane[:, None] + 64 * np.arange(8)[None, :]                 # k of (lane, reg)
 
 
 # ---------------- fold tables ---------------------------------------------------------------------------
