@@ -142,6 +142,8 @@ int ac_mdct_plan_create(int N, int window, int device, ac_mdct_plan** out) {
   p->N = N;
   p->window = window;
   p->device = device;
+  if (hipDeviceGetAttribute(&p->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || p->cus <= 0)
+    p->cus = 256;
   FoldCoef c;
   fold_coefficients(N, window, c);
   const int h = N / 2;

@@ -37,7 +37,7 @@ typedef const float* gtab_t;   // LDS-resident table image
 constexpr int FN = 1024;            // filters_n served by this file
 constexpr int FH = FN / 2;          // complex FFT points per frame (= 64 lanes x 8 registers)
 #ifndef AC_WAVES_PSY
-#define AC_WAVES_PSY 6              // waves (independent strips) per workgroup, fused encode
+#define AC_WAVES_PSY 4              // waves per workgroup, fused encode (LDS: three workgroups per CU)
 #endif
 #ifndef AC_WAVES
 #define AC_WAVES 4                  // waves per workgroup, plain transform / inverse / stand-alone psycho
@@ -54,23 +54,25 @@ constexpr float kEps = 1e-14f;      // _INTENSITY_EPS, psychoacoustic.py:56
 // ---- mdct tables: two images in ac_mdct_plan::d_fast (analysis at 0, synthesis at I_TOTAL floats); the kernel
 // copies its image into LDS once per workgroup, so the walk loop touches HBM only for PCM / spectra ---------
 constexpr int I_PRE = 0;                  // [8][64] float2  exp(-i pi (e + 1/4) / N), e = lane + 64 r
-constexpr int I_P1 = I_PRE + 1024;        // [8][64] float2  W512^(lane k0)
-constexpr int I_P2 = I_P1 + 1024;         // [8][8]  float2  W64^(e0 k1)
+constexpr int I_P2 = I_PRE + 1024;        // [8][8]  float2  W64^(e0 k1)
 constexpr int I_POST = I_P2 + 128;        // [8][64] float2  exp(-i pi k / N) * (1/(N sqrt 2) | 2 sqrt 2), k = lane + 64 k2
 constexpr int I_COEF = I_POST + 1024;     // [8][64] float2  fold (A, B)(e) | unfold (a, b)(k)
-constexpr int I_TOTAL = I_COEF + 1024;    // 4224 floats = 16 896 bytes
-constexpr int TAB_LDS = I_TOTAL * 4;
+constexpr int I_LDS = I_COEF + 1024;      // 3200 floats = 12 800 bytes live in LDS
+constexpr int I_P1 = I_LDS;               // [8][64] float2  W512^(lane k0): seven per lane, held in registers
+constexpr int I_TOTAL = I_P1 + 1024;      // 4224 floats per image in global memory
+constexpr int TAB_LDS = I_LDS * 4;
 
 // ---- psy image (32-bit words) in ac_psy_plan::d_fast, copied into LDS once per workgroup -------------------
 constexpr int PL_G = 0;                   // [128]     spreading prototype g
 constexpr int PL_LST = 128;               // [12][64]  gather lists: two 16-bit LDS byte offsets per word
 constexpr int PL_HALF = 12;               // list length / 2
-constexpr int PL_BAND = PL_LST + PL_HALF * 64;   // [2][64] x 4 words: per-lane (= per Bark band) constants
+constexpr int PL_LDS = PL_LST + PL_HALF * 64;    // 896 words = 3584 bytes live in LDS; the rest is held in registers
+constexpr int PL_BAND = PL_LDS;           // [2][64] x 4 words: per-lane (= per Bark band) constants
 //   group 0: edge offsets (lo | hi << 16), wf, wl, quiet        group 1: beta, rho, u0, u1
 constexpr int PL_IDX = PL_BAND + 512;     // [2][64] x 4 words: byte offsets (lo | hi << 16) of the threshold entries
 //   of the two bins of granule 64 i + lane, word i
-constexpr int P_TOTAL = PL_IDX + 512;     // 1920 words = 7680 bytes
-constexpr int PSY_LDS = P_TOTAL * 4;
+constexpr int P_TOTAL = PL_IDX + 512;     // 1920 words in global memory
+constexpr int PSY_LDS = PL_LDS * 4;
 
 struct C2 {   // one complex value for both channels of the pair
   v2f re, im;
@@ -135,11 +137,11 @@ __device__ __forceinline__ C2 lds_get(const char* p) {
 //   pass 2 over e1 -> k1, twiddle W64^(e0 k1);    exchange 2: element (k0, k1, e0) at 9 (k0 + 8 k1) + e0;
 //   lane k0 + 8 k1 reads its 8 consecutive e0      pass 3 over e0 -> k2.
 // Both exchanges are bank-conflict-free under the gfx950 lane-group rules (tools/emulate_wave_fft.py).
-__device__ __forceinline__ void fft512(C2 (&z)[8], char* buf, gtab_t tab, int lane) {
+__device__ __forceinline__ void fft512(C2 (&z)[8], char* buf, gtab_t tab, const v2f (&p1)[8], int lane) {
   const int a = lane >> 3, m0 = lane & 7;
   dft8(z);
 #pragma unroll
-  for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], reinterpret_cast<const v2f*>(tab + I_P1)[k * 64 + lane]);
+  for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], p1[k]);
   wave_sync();
   {
     char* w1 = buf + 16 * lane;
@@ -168,6 +170,13 @@ __device__ __forceinline__ void fft512(C2 (&z)[8], char* buf, gtab_t tab, int la
     for (int r = 0; r < 8; ++r) z[r] = lds_get(r2 + 16 * r);
   }
   dft8(z);
+}
+
+// the lane's seven pass-1 twiddles W512^(lane k), k = 1..7, from the image in global memory
+__device__ __forceinline__ void load_p1(const float* __restrict__ image, int lane, v2f (&p1)[8]) {
+  p1[0] = v2f{1.f, 0.f};
+#pragma unroll
+  for (int k = 1; k < 8; ++k) p1[k] = reinterpret_cast<const v2f*>(image + I_P1)[k * 64 + lane];
 }
 
 // lane-reversal exchange of eight (c0, c1) pairs: afterwards out[i] = in[(OFS - i) & 7] of lane 63 - lane
@@ -260,10 +269,39 @@ struct PsyParams {
   float alpha, inv_alpha, drown;
 };
 
+// per-lane (= per Bark band) constants and the lane's threshold-entry offsets, held in registers
+struct PsyLane {
+  v4f bc0;   // edge offsets (lo | hi << 16), wf, wl, quiet
+  v4f bc1;   // beta, rho, u0, u1
+  v4f ia, ib;   // byte offsets (lo | hi << 16) of the entries of the two bins of granule 64 i + lane, i = 0..7
+};
+// wave_base = byte offset of the wave's buffer inside the workgroup's LDS object: the packed 16-bit offsets become
+// absolute, so unpacking one costs a single and / shift inside the loop
+__device__ __forceinline__ PsyLane load_psy_lane(const uint32_t* __restrict__ tab, int lane, uint32_t wave_base) {
+  PsyLane c;
+  c.bc0 = reinterpret_cast<const v4f*>(tab + PL_BAND)[lane];
+  c.bc1 = reinterpret_cast<const v4f*>(tab + PL_BAND)[64 + lane];
+  c.ia = reinterpret_cast<const v4f*>(tab + PL_IDX)[lane];
+  c.ib = reinterpret_cast<const v4f*>(tab + PL_IDX)[64 + lane];
+  const uint32_t both = wave_base * 0x10001u;
+  auto rebase = [both](float f) { return __uint_as_float(__float_as_uint(f) + both); };
+  c.bc0.x = rebase(c.bc0.x);
+  c.ia = v4f{rebase(c.ia.x), rebase(c.ia.y), rebase(c.ia.z), rebase(c.ia.w)};
+  c.ib = v4f{rebase(c.ib.x), rebase(c.ib.y), rebase(c.ib.z), rebase(c.ib.w)};
+  return c;
+}
+
+// keeps the unpacking of a loop-invariant word inside the loop (hoisted, the 16 addresses would cost 16 registers)
+__device__ __forceinline__ uint32_t in_loop(uint32_t w) {
+  asm volatile("" : "+v"(w));
+  return w;
+}
+
 // buf = the wave's LDS region (WAVE_LDS_PSY bytes), pimg = the workgroup's copy of the psy image
+// lds0 = base of the workgroup's LDS object (the absolute offsets of PsyLane count from it)
 template <bool WANT_T, bool WANT_THR>
-__device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* buf, const uint32_t* pimg, const PsyParams& pp,
-                                          int lane, v2f& t, v4f (&thr)[8]) {
+__device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* lds0, char* buf, const uint32_t* pimg,
+                                          const PsyLane& pc, const PsyParams& pp, int lane, v2f& t, v4f (&thr)[8]) {
   if (WANT_THR) wave_sync();
   v2f slog = {0.f, 0.f}, ssq = {0.f, 0.f};
   {
@@ -313,10 +351,10 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* buf, const u
   wave_sync();
   // P_j = sum_f I_f W[f, j]  (:312-313): lane = Bark band; the two edge bins carry weights wf / wl, the interior
   // (weight 1) is gathered as single bins + 8-bin chunk sums through a host-built list of LDS offsets
-  const v4f bc0 = reinterpret_cast<const v4f*>(pimg + PL_BAND)[lane];        // edge, wf, wl, quiet
-  const uint32_t edge = __float_as_uint(bc0.x);
-  v2f P0 = *reinterpret_cast<const v2f*>(buf + (edge & 0xffffu)) * bc0.y;
-  v2f P1 = *reinterpret_cast<const v2f*>(buf + (edge >> 16)) * bc0.z;
+  const v4f bc0 = pc.bc0;
+  const uint32_t edge = in_loop(__float_as_uint(bc0.x));
+  v2f P0 = *reinterpret_cast<const v2f*>(lds0 + (edge & 0xffffu)) * bc0.y;
+  v2f P1 = *reinterpret_cast<const v2f*>(lds0 + (edge >> 16)) * bc0.z;
 #pragma unroll
   for (int hlf = 0; hlf < PL_HALF; ++hlf) {
     const uint32_t w = pimg[PL_LST + hlf * 64 + lane];
@@ -338,7 +376,7 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* buf, const u
     acc1 += v2f{qq.z, qq.w} * gp[-i - 1];
   }
   const v2f acc = acc0 + acc1;
-  const v4f bc1 = reinterpret_cast<const v4f*>(pimg + PL_BAND)[64 + lane];   // beta, rho, u0, u1
+  const v4f bc1 = pc.bc1;
   const v2f offset = (1.0f - pp.drown) * (t * bc1.x + 9.0f * t + 5.5f);                        // (:185-191)
   const v2f fac = exp2v(offset * (-pp.alpha * 0.33219280948873623f));                          // 10^(-alpha O / 10)
   const v2f T = exp2v(pp.inv_alpha * log2v(maxv(fac * acc, kEps)));                             // (:208)
@@ -358,13 +396,14 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* buf, const u
                                                  __builtin_amdgcn_sqrtf(A1.x), __builtin_amdgcn_sqrtf(A1.y)};   // entry e at byte 8 e
   wave_sync();
   {
-    const v4f ia = reinterpret_cast<const v4f*>(pimg + PL_IDX)[lane], ib = reinterpret_cast<const v4f*>(pimg + PL_IDX)[64 + lane];
+    const v4f ia = pc.ia, ib = pc.ib;
     const uint32_t iw[8] = {__float_as_uint(ia.x), __float_as_uint(ia.y), __float_as_uint(ia.z), __float_as_uint(ia.w),
                             __float_as_uint(ib.x), __float_as_uint(ib.y), __float_as_uint(ib.z), __float_as_uint(ib.w)};
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const v2f a0 = *reinterpret_cast<const v2f*>(buf + (iw[i] & 0xffffu));
-      const v2f a1 = *reinterpret_cast<const v2f*>(buf + (iw[i] >> 16));
+      const uint32_t w = in_loop(iw[i]);
+      const v2f a0 = *reinterpret_cast<const v2f*>(lds0 + (w & 0xffffu));
+      const v2f a1 = *reinterpret_cast<const v2f*>(lds0 + (w >> 16));
       thr[i] = v4f{a0.x, a0.y, a1.x, a1.y};
     }
   }
@@ -376,12 +415,12 @@ __device__ __forceinline__ void load_tables(char* lds, const float* __restrict__
   if (image) {
     v4f* dst = reinterpret_cast<v4f*>(lds + NW * WSTRIDE);
     const v4f* src = reinterpret_cast<const v4f*>(image);
-    for (int i = threadIdx.x; i < I_TOTAL / 4; i += NW * 64) dst[i] = src[i];
+    for (int i = threadIdx.x; i < I_LDS / 4; i += NW * 64) dst[i] = src[i];
   }
   if (psy_tab) {
     uint4* pd = reinterpret_cast<uint4*>(lds + NW * WSTRIDE + (image ? TAB_LDS : 0));
     const uint4* ps = reinterpret_cast<const uint4*>(psy_tab);
-    for (int i = threadIdx.x; i < P_TOTAL / 4; i += NW * 64) pd[i] = ps[i];
+    for (int i = threadIdx.x; i < PL_LDS / 4; i += NW * 64) pd[i] = ps[i];
   }
   __syncthreads();
 }
@@ -395,33 +434,23 @@ struct FwdArgs {
   float* t;                  // [B, F, 1, C]   (PSY)
   float* thr;                // [B, F, N, C]   (PSY)
   const float* prev_block;   // [B, N, C] or null
-  const float* tab;          // mdct tables
+  const float* tab;          // mdct tables (analysis image)
   PsyParams psy;
-  int B, Kin, F, C, CP, seglen, nseg;
-  long long ntasks;
+  int B, Kin, F, C, CP;
+  int xcd;                   // 1: consecutive logical workgroups share an XCD (gridDim.x is a multiple of 8)
+  long long nframes;         // B * CP * F
 };
 
-// fold one block held in natural order: cur = part of this frame, nxt = part aliasing into the next frame.
-// Element e = lane + 64 r takes the even sample of granule e + 256 (this lane, register (r + 4) & 7) and the odd
-// sample of granule 767 - e (lane 63 - lane, register (3 - r) & 7).  With (A, B) = COEF[e]:
-//   r < 4:  cur = B xo - A xe      r >= 4:  cur = A xe - B xo      nxt = B xe + A xo      
-template <bool WANT_CUR>
-__device__ __forceinline__ void fold_block(const v4f (&blk)[8], char* buf, gtab_t tab, int lane, v2f (&cur)[8],
-                                           v2f (&nxt)[8]) {
-  v2f xo_in[8], xo[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) xo_in[c] = v2f{blk[c].z, blk[c].w};
-  rev_exchange<3>(buf, lane, xo_in, xo);
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const v4f& g = blk[(r + 4) & 7];
-    const v2f xe = v2f{g.x, g.y};
-    const v2f ab = reinterpret_cast<const v2f*>(tab + I_COEF)[r * 64 + lane];
-    if (WANT_CUR) cur[r] = (r < 4) ? (ab.y * xo[r] - ab.x * xe) : (ab.x * xe - ab.y * xo[r]);
-    nxt[r] = ab.y * xe + ab.x * xo[r];
-  }
-}
-
+// Analysis is frame-independent: frame n of a channel pair needs blocks n-1 and n of the PCM, and a wave that loads
+// both needs nothing from its neighbours.  Waves are persistent and deal the frames out in order -- wave w of W takes
+// frames w, w + W, w + 2W, ... -- so at any moment the chip reads one contiguous window of the PCM and writes one
+// contiguous window of each output tensor, which is what HBM rewards (tools/ubench_strips.hip: 10-15 % over per-wave
+// strips); block n-1 is the block the neighbouring wave loads as its block n, so the second read is an L2 hit.
+//
+// Element e = lane + 64 r of the FFT input takes, from each block, the even sample of granule e + 256 (this lane,
+// register (r + 4) & 7) and the odd sample of granule 767 - e (lane 63 - lane, register (3 - r) & 7).
+// With (A, B) = COEF[e]:  carried part (block n-1) = B xe + A xo;  current part (block n) = B xo - A xe (r < 4),
+// A xe - B xo (r >= 4)   (Princen-Bradley windows make the 2x2 fold blocks rotations).
 template <int CMODE, bool PSY, int NW>
 __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
   // one LDS object: [NW wave buffers | table image | psy image]
@@ -429,66 +458,74 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[NW * WSTRIDE + TAB_LDS + (PSY ? PSY_LDS : 0)];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   load_tables<NW, WSTRIDE>(lds, a.tab, PSY ? a.psy.tab : nullptr);
-  const long long task = (long long)blockIdx.x * NW + wave;
-  if (task >= a.ntasks) return;
   char* buf = lds + wave * WSTRIDE;
   gtab_t tab = reinterpret_cast<const float*>(lds + NW * WSTRIDE);
   const uint32_t* pimg = reinterpret_cast<const uint32_t*>(lds + NW * WSTRIDE + TAB_LDS);
   if (PSY) *reinterpret_cast<v2f*>(buf + ZERO_OFF) = v2f{0.f, 0.f};   // the gather lists' padding slot
-  const int sgm = (int)(task % a.nseg);
-  const long long pair = task / a.nseg;
-  const int cp = (int)(pair % a.CP);
-  const long long b = pair / a.CP;
-  const int C = a.C, c0 = 2 * cp;
-  const bool has1 = (c0 + 1) < C;
-  const int n0 = sgm * a.seglen;
-  const int n1 = min(a.F, n0 + a.seglen);
+  v2f p1[8];
+  load_p1(a.tab, lane, p1);
+  PsyLane pc;
+  if (PSY) pc = load_psy_lane(a.psy.tab, lane, (uint32_t)(wave * WSTRIDE));
+  int g = blockIdx.x;
+  if (a.xcd) g = (g & 7) * (gridDim.x >> 3) + (g >> 3);
+  const long long stride = (long long)gridDim.x * NW;
+  const int C = a.C;
   const size_t blk = (size_t)FN * C;   // floats per block / frame row over all channels
-  const float* xb = a.x + (size_t)b * a.Kin * blk;
 
-  v2f carry[8];
-  v4f ahead[8];   // the next PCM block, in flight while the current frame is transformed
-  {
-    // carry of the block before the strip: block n0-1 of x, the stream state, or zero
-    const float* src = nullptr;
-    if (n0 >= 1) src = xb + (size_t)(n0 - 1) * blk;
-    else if (a.prev_block) src = a.prev_block + (size_t)b * blk;
-    if (src) {
-      v4f row[8];
-      load_row<CMODE>(src, C, c0, has1, lane, row);
-      if (n0 < a.Kin) load_row<CMODE>(xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
-      v2f dummy[8];
-      fold_block<false>(row, buf, tab, lane, dummy, carry);
-    } else {
-      if (n0 < a.Kin) load_row<CMODE>(xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
-#pragma unroll
-      for (int r = 0; r < 8; ++r) carry[r] = v2f{0.f, 0.f};
-    }
-  }
+  for (long long f = (long long)g * NW + wave; f < a.nframes; f += stride) {
+    const int n = (int)(f % a.F);
+    const long long pair = f / a.F;
+    const int cp = (int)(pair % a.CP);
+    const long long b = pair / a.CP;
+    const int c0 = 2 * cp;
+    const bool has1 = (c0 + 1) < C;
+    const float* xb = a.x + (size_t)b * a.Kin * blk;
+    const float* pcur = (n < a.Kin) ? xb + (size_t)n * blk : nullptr;
+    const float* pprv = (n >= 1) ? xb + (size_t)(n - 1) * blk : (a.prev_block ? a.prev_block + (size_t)b * blk : nullptr);
 
-  for (int n = n0; n < n1; ++n) {
     C2 z[8];
-    if (n < a.Kin) {
-      v2f cur[8], nxt[8];
-      fold_block<true>(ahead, buf, tab, lane, cur, nxt);
-      if (n + 1 < n1 && n + 1 < a.Kin) load_row<CMODE>(xb + (size_t)(n + 1) * blk, C, c0, has1, lane, ahead);
+    {
+      v4f cb[8], pb[8];
+      if (pprv) {
+        load_row<CMODE>(pprv, C, c0, has1, lane, pb);
+      } else {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        // element e = lane + 64 r: v[2e] + i v[N-1-2e]; for e < 256 the real part comes from the previous block
-        const C2 v = (r < 4) ? C2{carry[r], cur[r]} : C2{cur[r], carry[r]};
-        z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + I_PRE)[r * 64 + lane]);
-        carry[r] = nxt[r];
+        for (int i = 0; i < 8; ++i) pb[i] = v4f{0.f, 0.f, 0.f, 0.f};
       }
-    } else {
+      if (pcur) {
+        load_row<CMODE>(pcur, C, c0, has1, lane, cb);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cb[i] = v4f{0.f, 0.f, 0.f, 0.f};
+      }
+      // lane-reversal exchange of the odd halves of both blocks: previous block in [0, 4 KB), current in [4 KB, 8 KB)
+      wave_sync();
+      {
+        char* w = buf + 8 * (63 - lane);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          *reinterpret_cast<v2f*>(w + 512 * c) = v2f{pb[c].z, pb[c].w};
+          *reinterpret_cast<v2f*>(w + 4096 + 512 * c) = v2f{cb[c].z, cb[c].w};
+        }
+      }
+      wave_sync();
+      const char* rd = buf + 8 * lane;
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        const v2f zero = v2f{0.f, 0.f};
-        const C2 v = (r < 4) ? C2{carry[r], zero} : C2{zero, carry[r]};
+        const v2f xop = *reinterpret_cast<const v2f*>(rd + 512 * ((3 - r) & 7));
+        const v2f xoc = *reinterpret_cast<const v2f*>(rd + 4096 + 512 * ((3 - r) & 7));
+        const v4f& gp = pb[(r + 4) & 7];
+        const v4f& gc = cb[(r + 4) & 7];
+        const v2f xep = v2f{gp.x, gp.y}, xec = v2f{gc.x, gc.y};
+        const v2f ab = reinterpret_cast<const v2f*>(tab + I_COEF)[r * 64 + lane];
+        const v2f carry = ab.y * xep + ab.x * xop;
+        const v2f cur = (r < 4) ? (ab.y * xoc - ab.x * xec) : (ab.x * xec - ab.y * xoc);
+        // element e = lane + 64 r: v[2e] + i v[N-1-2e]; for e < 256 the real part comes from the previous block
+        const C2 v = (r < 4) ? C2{carry, cur} : C2{cur, carry};
         z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + I_PRE)[r * 64 + lane]);
-        carry[r] = zero;
       }
     }
-    fft512(z, buf, tab, lane);
+    fft512(z, buf, tab, p1, lane);
     v4f row[8];
     {
       // bin k = lane + 64 k2: X[2k] = Re (granule k, this lane), X[N-1-2k] = -Im (granule 511 - k, lane 63 - lane)
@@ -508,7 +545,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
     if (PSY) {
       v2f tt;
       v4f th[8];
-      psy_stage<true, true>(row, buf, pimg, a.psy, lane, tt, th);
+      psy_stage<true, true>(row, lds, buf, pimg, pc, a.psy, lane, tt, th);
       store_row<CMODE>(a.thr + frame * blk, C, c0, has1, lane, th);
       if (lane == 0) {
         a.t[frame * C + c0] = tt.x;
@@ -533,8 +570,8 @@ struct InvArgs {
 
 // DCT-IV of one frame held in natural order: returns (now, nxt) per output element k = lane + 64 k2.
 // Element e = lane + 64 r is X[2e] (granule e, this lane) + i X[N-1-2e] (granule 511 - e, lane 63 - lane).
-__device__ __forceinline__ void idct_frame(const v4f (&frm)[8], char* buf, gtab_t tab, int lane, v2f (&now)[8],
-                                           v2f (&nxt)[8]) {
+__device__ __forceinline__ void idct_frame(const v4f (&frm)[8], char* buf, gtab_t tab, const v2f (&p1)[8], int lane,
+                                           v2f (&now)[8], v2f (&nxt)[8]) {
   C2 z[8];
   {
     v2f xo_in[8], xo[8];
@@ -547,7 +584,7 @@ __device__ __forceinline__ void idct_frame(const v4f (&frm)[8], char* buf, gtab_
       z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + I_PRE)[r * 64 + lane]);
     }
   }
-  fft512(z, buf, tab, lane);
+  fft512(z, buf, tab, p1, lane);
 #pragma unroll
   for (int k2 = 0; k2 < 8; ++k2) {
     const C2 r = cmul(z[k2], reinterpret_cast<const v2f*>(tab + I_POST)[k2 * 64 + lane]);
@@ -571,6 +608,8 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_inv_fast(InvArgs a) {
   if (task >= a.ntasks) return;
   char* buf = lds + wave * WAVE_LDS;
   gtab_t tab = reinterpret_cast<const float*>(lds + NW * WAVE_LDS);
+  v2f p1[8];
+  load_p1(a.tab + I_TOTAL, lane, p1);
   const int sgm = (int)(task % a.nseg);
   const long long pair = task / a.nseg;
   const int cp = (int)(pair % a.CP);
@@ -590,7 +629,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_inv_fast(InvArgs a) {
     load_row<CMODE>(Xb + (size_t)(n0 - 1) * blk, C, c0, has1, lane, row);
     if (n0 < a.Kp) load_row<CMODE>(Xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
     v2f dummy[8];
-    idct_frame(row, buf, tab, lane, dummy, carry);
+    idct_frame(row, buf, tab, p1, lane, dummy, carry);
   } else {
     if (n0 < a.Kp) load_row<CMODE>(Xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
     if (a.tail_in) {
@@ -610,7 +649,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_inv_fast(InvArgs a) {
   for (int n = n0; n < n1; ++n) {
     v2f now[8], nxt[8];
     if (n < a.Kp) {
-      idct_frame(ahead, buf, tab, lane, now, nxt);
+      idct_frame(ahead, buf, tab, p1, lane, now, nxt);
       if (n + 1 < n1 && n + 1 < a.Kp) load_row<CMODE>(Xb + (size_t)(n + 1) * blk, C, c0, has1, lane, ahead);
     } else {
 #pragma unroll
@@ -687,7 +726,9 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_psy_fast(PsyArgs a) {
     tt.x = a.t_in[(size_t)frame * C + c0];
     tt.y = has1 ? a.t_in[(size_t)frame * C + c0 + 1] : 0.f;
   }
-  psy_stage<WANT_T, WANT_THR>(row, buf, pimg, a.psy, lane, tt, th);
+  PsyLane pc;
+  if (WANT_THR) pc = load_psy_lane(a.psy.tab, lane, (uint32_t)(wave * WAVE_LDS_PSY));
+  psy_stage<WANT_T, WANT_THR>(row, lds, buf, pimg, pc, a.psy, lane, tt, th);
   if (WANT_T && lane == 0) {
     a.t_out[(size_t)frame * C + c0] = tt.x;
     if (has1) a.t_out[(size_t)frame * C + c0 + 1] = tt.y;
@@ -764,7 +805,7 @@ static bool build_mdct_fast(int N, int window, std::vector<float>* out) {
       const double sf = 1.0 / (N * std::sqrt(2.0)), si = 2.0 * std::sqrt(2.0);
       put2(tf + I_POST, i, std::cos(ang) * sf, std::sin(ang) * sf);
       put2(ti + I_POST, i, std::cos(ang) * si, std::sin(ang) * si);
-      // analysis fold of element e (see fold_block): current-frame part cE xe + cO xo, carried part kE xe + kO xo
+      // analysis fold of element e (see k_fwd_fast): current-frame part cE xe + cO xo, carried part kE xe + kO xo
       double cE, cO, kE, kO;
       if (e < h / 2) {   // samples 512+2e (even) / 511-2e (odd); current part = v[N-1-2e], carry = v'[2e]
         const int jc = h - 1 - 2 * e, jk = 2 * e;
@@ -917,6 +958,15 @@ static int grid_for(long long ntasks, int nw, unsigned* grid) {
   return AC_OK;
 }
 
+// workgroups of a persistent launch: enough to fill every CU at the kernel's occupancy, a multiple of 8 (XCDs)
+static unsigned persistent_grid(int cus, int wg_per_cu, long long ntasks, int nw) {
+  long long g = (long long)cus * wg_per_cu;
+  const long long need = (ntasks + nw - 1) / nw;
+  if (g > need) g = need;
+  g = (g + 7) / 8 * 8;
+  return (unsigned)g;
+}
+
 int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr,
                     float drown, const float* prev_block, int B, int Kin, int F, int C, hipStream_t s) {
   if (B <= 0 || C <= 0 || F <= 0) return AC_OK;
@@ -934,17 +984,17 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const float* 
   a.F = F;
   a.C = C;
   a.CP = (C + 1) / 2;
-  a.seglen = pick_seglen((long long)B * a.CP, F);
-  a.nseg = (F + a.seglen - 1) / a.seglen;
-  a.ntasks = (long long)B * a.CP * a.nseg;
-  unsigned grid;
-  int st = grid_for(a.ntasks, psy ? AC_WAVES_PSY : AC_WAVES, &grid);
-  if (st) return st;
+  a.nframes = (long long)B * a.CP * F;
+  static const int xcd = [] { const char* e = getenv("AC_XCD"); return e ? atoi(e) : 0; }();          // tuning hooks
+  static const int wgcu = [] { const char* e = getenv("AC_WG_PER_CU"); return e ? atoi(e) : 3; }();
+  a.xcd = xcd;
   if (psy) {
+    const unsigned grid = persistent_grid(p->cus, wgcu, a.nframes, AC_WAVES_PSY);
     const dim3 blk(AC_WAVES_PSY * 64);
     if (C == 2) hipLaunchKernelGGL((k_fwd_fast<0, true, AC_WAVES_PSY>), dim3(grid), blk, 0, s, a);
     else hipLaunchKernelGGL((k_fwd_fast<1, true, AC_WAVES_PSY>), dim3(grid), blk, 0, s, a);
   } else {
+    const unsigned grid = persistent_grid(p->cus, wgcu, a.nframes, AC_WAVES);
     const dim3 blk(AC_WAVES * 64);
     if (C == 2) hipLaunchKernelGGL((k_fwd_fast<0, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
     else hipLaunchKernelGGL((k_fwd_fast<1, false, AC_WAVES>), dim3(grid), blk, 0, s, a);

@@ -52,6 +52,7 @@ extern int g_force_generic;
 
 struct ac_mdct_plan {
   int N = 0, window = 0, device = 0;
+  int cus = 0;                 // compute units of the device (sizes the persistent launches)
   int fast = 0;                // 1: wave-level FFT kernels available for this N
   float* d_coef = nullptr;     // [8][N/2]  a1 a2 a3 a4 s1 s2 s3 s4
   float* d_ctab = nullptr;     // [8N]      cos(pi i / (4N)), generic kernels

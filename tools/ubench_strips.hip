@@ -105,6 +105,34 @@ __global__ __launch_bounds__(256) void k_strips_halo(const v4f* __restrict__ in,
   }
 }
 
+// pattern C: persistent waves; wave id w of W copies rows w, w + W, w + 2 W, ... and re-reads row r - 1 (HALO);
+// NT threads per workgroup, XCD: consecutive logical workgroups on one XCD
+template <int NT, bool HALO, bool XCD>
+__global__ __launch_bounds__(NT) void k_persist(const v4f* __restrict__ in, v4f* __restrict__ o1, v4f* __restrict__ o2,
+                                                long long nrows, int nwg) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int g = blockIdx.x;
+  if (XCD) g = (g & 7) * (nwg / 8) + (g >> 3);
+  const long long W = (long long)nwg * (NT / 64);
+  for (long long r = (long long)g * (NT / 64) + w; r < nrows; r += W) {
+    v4f cur[8], prv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cur[i] = in[r * 512 + 64 * i + lane];
+    if (HALO && r > 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) prv[i] = in[(r - 1) * 512 + 64 * i + lane];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) prv[i] = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      o1[r * 512 + 64 * i + lane] = cur[i] * 1.5f + prv[i];
+      o2[r * 512 + 64 * i + lane] = cur[i] + 1.0f;
+    }
+  }
+}
+
 int main() {
   const long long nrows = 256ll * 469;   // 8 KB rows: 984 MB per tensor (the bench workload's frame count)
   const size_t bytes = (size_t)nrows * 8192;
@@ -168,6 +196,41 @@ int main() {
         if (rep > 0 && ms < best) best = ms;
       }
       printf(" %-12.0f", (double)bytes * 3 / best / 1e6);
+    }
+    printf("\n");
+  }
+  printf("\npersistent waves, 1R2W + halo re-read, useful GB/s:\n%-28s %-10s %-10s\n", "config", "plain", "xcd");
+  for (int cfg = 0; cfg < 6; ++cfg) {
+    const int nwgs[6] = {256, 512, 768, 1024, 2048, 256};
+    const int nts[6] = {768, 384, 256, 256, 256, 1024};
+    char name[64];
+    snprintf(name, sizeof(name), "%d wg x %d threads", nwgs[cfg], nts[cfg]);
+    printf("%-28s", name);
+    for (int x = 0; x < 2; ++x) {
+      float best = 1e30f;
+      for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0);
+        const int nwg = nwgs[cfg];
+        if (nts[cfg] == 768) {
+          if (x) hipLaunchKernelGGL((k_persist<768, true, true>), dim3(nwg), dim3(768), 0, 0, in, o1, o2, nrows, nwg);
+          else hipLaunchKernelGGL((k_persist<768, true, false>), dim3(nwg), dim3(768), 0, 0, in, o1, o2, nrows, nwg);
+        } else if (nts[cfg] == 384) {
+          if (x) hipLaunchKernelGGL((k_persist<384, true, true>), dim3(nwg), dim3(384), 0, 0, in, o1, o2, nrows, nwg);
+          else hipLaunchKernelGGL((k_persist<384, true, false>), dim3(nwg), dim3(384), 0, 0, in, o1, o2, nrows, nwg);
+        } else if (nts[cfg] == 1024) {
+          if (x) hipLaunchKernelGGL((k_persist<1024, true, true>), dim3(nwg), dim3(1024), 0, 0, in, o1, o2, nrows, nwg);
+          else hipLaunchKernelGGL((k_persist<1024, true, false>), dim3(nwg), dim3(1024), 0, 0, in, o1, o2, nrows, nwg);
+        } else {
+          if (x) hipLaunchKernelGGL((k_persist<256, true, true>), dim3(nwg), dim3(256), 0, 0, in, o1, o2, nrows, nwg);
+          else hipLaunchKernelGGL((k_persist<256, true, false>), dim3(nwg), dim3(256), 0, 0, in, o1, o2, nrows, nwg);
+        }
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep > 0 && ms < best) best = ms;
+      }
+      printf(" %-10.0f", (double)bytes * 3 / best / 1e6);
     }
     printf("\n");
   }
