@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "ac_internal.h"
@@ -44,6 +45,9 @@ constexpr int FH = FN / 2;          // complex FFT points per frame (= 64 lanes 
 #endif
 #ifndef AC_WPE
 #define AC_WPE 3                    // waves per SIMD the register allocator must leave room for
+#endif
+#ifndef AC_PREFETCH
+#define AC_PREFETCH 0               // 1: the next frame's PCM is requested during the epilogue of the current one
 #endif
 constexpr int WAVE_LDS = 9216;      // bytes of LDS per wave: 576 x 16-byte elements (8 rows of 64 + 8 pad)
 constexpr int S8_OFF = 8192;        // psycho: 128 chunk sums (8 bins each) behind the 8 KB intensity image
@@ -299,9 +303,15 @@ __device__ __forceinline__ uint32_t in_loop(uint32_t w) {
 
 // buf = the wave's LDS region (WAVE_LDS_PSY bytes), pimg = the workgroup's copy of the psy image
 // lds0 = base of the workgroup's LDS object (the absolute offsets of PsyLane count from it)
-template <bool WANT_T, bool WANT_THR>
+// late() is called once, just before the per-bin thresholds are gathered into registers (the point of lowest register
+// pressure of the epilogue): the fused kernel issues the next frame's halo loads there
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+template <bool WANT_T, bool WANT_THR, typename Late = NoHook>
 __device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* lds0, char* buf, const uint32_t* pimg,
-                                          const PsyLane& pc, const PsyParams& pp, int lane, v2f& t, v4f (&thr)[8]) {
+                                          const PsyLane& pc, const PsyParams& pp, int lane, v2f& t, v4f (&thr)[8],
+                                          Late late = Late()) {
   if (WANT_THR) wave_sync();
   v2f slog = {0.f, 0.f}, ssq = {0.f, 0.f};
   {
@@ -395,6 +405,7 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* lds0, char* 
   *reinterpret_cast<v4f*>(buf + 16 * lane) = v4f{__builtin_amdgcn_sqrtf(A0.x), __builtin_amdgcn_sqrtf(A0.y),
                                                  __builtin_amdgcn_sqrtf(A1.x), __builtin_amdgcn_sqrtf(A1.y)};   // entry e at byte 8 e
   wave_sync();
+  late();
   {
     const v4f ia = pc.ia, ib = pc.ib;
     const uint32_t iw[8] = {__float_as_uint(ia.x), __float_as_uint(ia.y), __float_as_uint(ia.z), __float_as_uint(ia.w),
@@ -456,7 +467,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
   // one LDS object: [NW wave buffers | table image | psy image]
   constexpr int WSTRIDE = PSY ? WAVE_LDS_PSY : WAVE_LDS;
   __shared__ __attribute__((aligned(16))) char lds[NW * WSTRIDE + TAB_LDS + (PSY ? PSY_LDS : 0)];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   load_tables<NW, WSTRIDE>(lds, a.tab, PSY ? a.psy.tab : nullptr);
   char* buf = lds + wave * WSTRIDE;
   gtab_t tab = reinterpret_cast<const float*>(lds + NW * WSTRIDE);
@@ -468,35 +479,75 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
   if (PSY) pc = load_psy_lane(a.psy.tab, lane, (uint32_t)(wave * WSTRIDE));
   int g = blockIdx.x;
   if (a.xcd) g = (g & 7) * (gridDim.x >> 3) + (g >> 3);
-  const long long stride = (long long)gridDim.x * NW;
   const int C = a.C;
   const size_t blk = (size_t)FN * C;   // floats per block / frame row over all channels
+  // frame f = (pair, n); everything about it is wave-uniform and lives in scalar registers, advanced without divisions
+  const long long stride = (long long)gridDim.x * NW;
+  const long long f0 = (long long)g * NW + __builtin_amdgcn_readfirstlane(wave);
+  const long long dpair = stride / a.F;
+  const int dn = (int)(stride % a.F);
+  long long pair = f0 / a.F;
+  int n = (int)(f0 % a.F);
+  const long long npairs = (long long)a.B * a.CP;
+  const float* __restrict__ xin = a.x;
+  const float* __restrict__ xstate = a.prev_block;
 
-  for (long long f = (long long)g * NW + wave; f < a.nframes; f += stride) {
-    const int n = (int)(f % a.F);
-    const long long pair = f / a.F;
-    const int cp = (int)(pair % a.CP);
-    const long long b = pair / a.CP;
+  // loads block fn (WHICH 0) or block fn-1 (WHICH 1) of frame (pr, fn) in natural order.  A missing block (before the
+  // first / after the last) is loaded from a neighbouring, valid address and zeroed when it is consumed (returns false),
+  // so that the loads stay unconditional and nothing waits for them at the point of issue.
+  auto issue_loads = [&](auto which, long long pr, int fn, v4f (&dst)[8]) -> bool {
+    const int cp = (CMODE == 0) ? 0 : (int)(pr % a.CP);      // CMODE 0: exactly one channel pair
+    const long long b = (CMODE == 0) ? pr : pr / a.CP;
     const int c0 = 2 * cp;
     const bool has1 = (c0 + 1) < C;
-    const float* xb = a.x + (size_t)b * a.Kin * blk;
-    const float* pcur = (n < a.Kin) ? xb + (size_t)n * blk : nullptr;
-    const float* pprv = (n >= 1) ? xb + (size_t)(n - 1) * blk : (a.prev_block ? a.prev_block + (size_t)b * blk : nullptr);
+    const float* xb = xin + (size_t)b * a.Kin * blk;
+    const float* src;
+    bool ok;
+    if (decltype(which)::value == 0) {
+      ok = fn < a.Kin;
+      src = xb + (size_t)(ok ? fn : (a.Kin > 0 ? a.Kin - 1 : 0)) * blk;
+      if (a.Kin == 0) src = a.X;                                // no PCM at all: any mapped address
+    } else {
+      ok = (fn >= 1) || xstate;
+      src = (fn >= 1) ? xb + (size_t)(fn - 1) * blk : (xstate ? xstate + (size_t)b * blk : xb);
+      if (a.Kin == 0 && !(fn == 0 && xstate)) {
+        src = a.X;
+        ok = false;
+      }
+    }
+    load_row<CMODE>(src, C, c0, has1, lane, dst);
+    return ok;
+  };
+  constexpr std::integral_constant<int, 0> kCur{};
+  constexpr std::integral_constant<int, 1> kPrv{};
 
+  v4f cb[8], pb[8];   // block n and block n-1 of the frame being folded; refilled for the next frame during the epilogue
+  // vmcnt retires loads and stores in issue order, so a load issued behind a store cannot be consumed before that store
+  // has drained.  Each frame's loads are therefore issued ahead of the previous frame's stores: block n before the X
+  // stores, block n-1 (the neighbouring wave's block, an L2 hit most of the time) before the threshold stores.
+  bool cur_ok = true, prv_ok = true;
+  if (AC_PREFETCH && pair < npairs) {
+    cur_ok = issue_loads(kCur, pair, n, cb);
+    prv_ok = issue_loads(kPrv, pair, n, pb);
+  }
+  while (pair < npairs) {
+    if (!AC_PREFETCH) {
+      cur_ok = issue_loads(kCur, pair, n, cb);
+      prv_ok = issue_loads(kPrv, pair, n, pb);
+    }
+    const int cp = (CMODE == 0) ? 0 : (int)(pair % a.CP);
+    const long long b = (CMODE == 0) ? pair : pair / a.CP;
+    const int c0 = 2 * cp;
+    const bool has1 = (c0 + 1) < C;
     C2 z[8];
     {
-      v4f cb[8], pb[8];
-      if (pprv) {
-        load_row<CMODE>(pprv, C, c0, has1, lane, pb);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) pb[i] = v4f{0.f, 0.f, 0.f, 0.f};
-      }
-      if (pcur) {
-        load_row<CMODE>(pcur, C, c0, has1, lane, cb);
-      } else {
+      if (!cur_ok) {   // edge frames only (wave-uniform)
 #pragma unroll
         for (int i = 0; i < 8; ++i) cb[i] = v4f{0.f, 0.f, 0.f, 0.f};
+      }
+      if (!prv_ok) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pb[i] = v4f{0.f, 0.f, 0.f, 0.f};
       }
       // lane-reversal exchange of the odd halves of both blocks: previous block in [0, 4 KB), current in [4 KB, 8 KB)
       wave_sync();
@@ -541,11 +592,23 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
       for (int i = 0; i < 8; ++i) row[i] = v4f{xe[i].x, xe[i].y, xo[i].x, xo[i].y};
     }
     const size_t frame = (size_t)b * a.F + (size_t)n;
+    // next frame of this wave: its PCM is in flight while the epilogue of this one runs
+    pair += dpair;
+    n += dn;
+    if (n >= a.F) {
+      n -= a.F;
+      ++pair;
+    }
+    if (AC_PREFETCH && pair < npairs) cur_ok = issue_loads(kCur, pair, n, cb);
     store_row<CMODE>(a.X + frame * blk, C, c0, has1, lane, row);
+    auto halo = [&]() {
+      if (AC_PREFETCH && pair < npairs) prv_ok = issue_loads(kPrv, pair, n, pb);
+    };
+    if (!PSY) halo();
     if (PSY) {
       v2f tt;
       v4f th[8];
-      psy_stage<true, true>(row, lds, buf, pimg, pc, a.psy, lane, tt, th);
+      psy_stage<true, true>(row, lds, buf, pimg, pc, a.psy, lane, tt, th, halo);
       store_row<CMODE>(a.thr + frame * blk, C, c0, has1, lane, th);
       if (lane == 0) {
         a.t[frame * C + c0] = tt.x;
