@@ -449,6 +449,8 @@ struct FwdArgs {
   PsyParams psy;
   int B, Kin, F, C, CP;
   int xcd;                   // 1: consecutive logical workgroups share an XCD (gridDim.x is a multiple of 8)
+  int T;                     // > 0: workgroup g owns frames [g NW T, (g+1) NW T), wave w takes g NW T + w + NW t;
+                             // 0: persistent waves, wave w of W takes frames w, w + W, ...
   long long nframes;         // B * CP * F
 };
 
@@ -482,8 +484,9 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
   const int C = a.C;
   const size_t blk = (size_t)FN * C;   // floats per block / frame row over all channels
   // frame f = (pair, n); everything about it is wave-uniform and lives in scalar registers, advanced without divisions
-  const long long stride = (long long)gridDim.x * NW;
-  const long long f0 = (long long)g * NW + __builtin_amdgcn_readfirstlane(wave);
+  const long long stride = a.T > 0 ? (long long)NW : (long long)gridDim.x * NW;
+  const long long f0 = (a.T > 0 ? (long long)g * NW * a.T : (long long)g * NW) + wave;
+  int left = a.T > 0 ? a.T : 0x7fffffff;
   const long long dpair = stride / a.F;
   const int dn = (int)(stride % a.F);
   long long pair = f0 / a.F;
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
     cur_ok = issue_loads(kCur, pair, n, cb);
     prv_ok = issue_loads(kPrv, pair, n, pb);
   }
-  while (pair < npairs) {
+  while (pair < npairs && left > 0) {
     if (!AC_PREFETCH) {
       cur_ok = issue_loads(kCur, pair, n, cb);
       prv_ok = issue_loads(kPrv, pair, n, pb);
@@ -599,10 +602,11 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
       n -= a.F;
       ++pair;
     }
-    if (AC_PREFETCH && pair < npairs) cur_ok = issue_loads(kCur, pair, n, cb);
+    --left;
+    if (AC_PREFETCH && pair < npairs && left > 0) cur_ok = issue_loads(kCur, pair, n, cb);
     store_row<CMODE>(a.X + frame * blk, C, c0, has1, lane, row);
     auto halo = [&]() {
-      if (AC_PREFETCH && pair < npairs) prv_ok = issue_loads(kPrv, pair, n, pb);
+      if (AC_PREFETCH && pair < npairs && left > 0) prv_ok = issue_loads(kPrv, pair, n, pb);
     };
     if (!PSY) halo();
     if (PSY) {
@@ -665,23 +669,27 @@ __device__ __forceinline__ void idct_frame(const v4f (&frm)[8], char* buf, gtab_
 template <int CMODE, int NW>
 __global__ __launch_bounds__(NW * 64, AC_WPE) void k_inv_fast(InvArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS + TAB_LDS];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   load_tables<NW, WAVE_LDS>(lds, a.tab + I_TOTAL, nullptr);
-  const long long task = (long long)blockIdx.x * NW + wave;
-  if (task >= a.ntasks) return;
   char* buf = lds + wave * WAVE_LDS;
   gtab_t tab = reinterpret_cast<const float*>(lds + NW * WAVE_LDS);
   v2f p1[8];
   load_p1(a.tab + I_TOTAL, lane, p1);
+  const int C = a.C;
+  const size_t blk = (size_t)FN * C;
+  // Synthesis carries the aliased half of the previous frame's DCT-IV, so a wave walks a short strip of consecutive
+  // output blocks (the first one costs an extra DCT-IV of the frame before the strip).  Waves are persistent and take
+  // the strips in order -- strip w, w + W, ... -- so the chip works on one contiguous window of X and of the PCM.
+  const long long stride = (long long)gridDim.x * NW;
+  for (long long task = (long long)blockIdx.x * NW + wave; task < a.ntasks; task += stride) {
   const int sgm = (int)(task % a.nseg);
   const long long pair = task / a.nseg;
-  const int cp = (int)(pair % a.CP);
-  const long long b = pair / a.CP;
-  const int C = a.C, c0 = 2 * cp;
+  const int cp = (CMODE == 0) ? 0 : (int)(pair % a.CP);
+  const long long b = (CMODE == 0) ? pair : pair / a.CP;
+  const int c0 = 2 * cp;
   const bool has1 = (c0 + 1) < C;
   const int n0 = sgm * a.seglen;
   const int n1 = min(a.nblk, n0 + a.seglen);
-  const size_t blk = (size_t)FN * C;
   const float* Xb = a.X + (size_t)b * a.Kp * blk;
 
   v2f carry[8];
@@ -752,6 +760,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_inv_fast(InvArgs a) {
       if (has1) a.tail_out[((size_t)b * C + c0 + 1) * FH + j] = carry[k2].y;
     }
   }
+  }   // strips of this wave
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -799,22 +808,17 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_psy_fast(PsyArgs a) {
   if (WANT_THR) store_row<CMODE>(a.thr + (size_t)frame * blk, C, c0, has1, lane, th);
 }
 
-// strips: enough waves to fill the chip several times over, long enough to amortise the one-block halo
+// synthesis strips: short, so that the strips in flight cover a nearly contiguous window of memory (HBM rewards that
+// more than the extra DCT-IV per strip costs: measured 0.38 ms at 4 blocks against 0.42 ms at 15, B = 256, K = 468)
 int pick_seglen(long long pairs, int frames) {
-  const long long total = pairs * (long long)frames;
-  static const long long target = [] {
-    const char* e = getenv("AC_TARGET_WAVES");   // tuning hook
-    return e ? atoll(e) : 8192ll;
+  static const int fixed = [] {
+    const char* e = getenv("AC_SEGLEN");   // tuning hook
+    return e ? atoi(e) : 4;
   }();
-  long long s = (total + target - 1) / target;
-  static const long long smin = [] {
-    const char* e = getenv("AC_MIN_SEGLEN");   // tuning hook
-    return e ? atoll(e) : 4ll;
-  }();
-  if (s < smin) s = smin;
+  int s = fixed;
   if (s > frames) s = frames;
   if (s < 1) s = 1;
-  return (int)s;
+  return s;
 }
 
 PsyParams psy_params(const ac_psy_plan* p, float drown) {
@@ -1051,7 +1055,24 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const float* 
   static const int xcd = [] { const char* e = getenv("AC_XCD"); return e ? atoi(e) : 0; }();          // tuning hooks
   static const int wgcu = [] { const char* e = getenv("AC_WG_PER_CU"); return e ? atoi(e) : 3; }();
   a.xcd = xcd;
-  if (psy) {
+  // four frames per wave, workgroups dispatched in order (measured 0.603 ms against 0.615 ms for persistent waves,
+  // B = 256, K = 468: fresh workgroups keep the window of memory in flight contiguous); AC_FWD_T=0 = persistent
+  static const int tper = [] { const char* e = getenv("AC_FWD_T"); return e ? atoi(e) : 4; }();
+  a.T = tper;
+  if (tper > 0) {
+    const int nw = psy ? AC_WAVES_PSY : AC_WAVES;
+    const long long per = (long long)nw * tper;
+    long long g = (a.nframes + per - 1) / per;
+    g = (g + 7) / 8 * 8;
+    const dim3 blk(nw * 64);
+    if (psy) {
+      if (C == 2) hipLaunchKernelGGL((k_fwd_fast<0, true, AC_WAVES_PSY>), dim3((unsigned)g), blk, 0, s, a);
+      else hipLaunchKernelGGL((k_fwd_fast<1, true, AC_WAVES_PSY>), dim3((unsigned)g), blk, 0, s, a);
+    } else {
+      if (C == 2) hipLaunchKernelGGL((k_fwd_fast<0, false, AC_WAVES>), dim3((unsigned)g), blk, 0, s, a);
+      else hipLaunchKernelGGL((k_fwd_fast<1, false, AC_WAVES>), dim3((unsigned)g), blk, 0, s, a);
+    }
+  } else if (psy) {
     const unsigned grid = persistent_grid(p->cus, wgcu, a.nframes, AC_WAVES_PSY);
     const dim3 blk(AC_WAVES_PSY * 64);
     if (C == 2) hipLaunchKernelGGL((k_fwd_fast<0, true, AC_WAVES_PSY>), dim3(grid), blk, 0, s, a);
@@ -1083,9 +1104,10 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, float* x, const float
   a.seglen = pick_seglen((long long)B * a.CP, nblk);
   a.nseg = (nblk + a.seglen - 1) / a.seglen;
   a.ntasks = (long long)B * a.CP * a.nseg;
-  unsigned grid;
-  int st = grid_for(a.ntasks, AC_WAVES, &grid);
-  if (st) return st;
+  // one strip per wave by default (workgroups dispatched in order keep the window of memory in flight contiguous;
+  // persistent waves drift apart and measured slower here); AC_WG_PER_CU_INV > 0 makes the waves persistent
+  static const int wgcu = [] { const char* e = getenv("AC_WG_PER_CU_INV"); return e ? atoi(e) : 0; }();   // tuning hook
+  const unsigned grid = persistent_grid(wgcu > 0 ? p->cus : (1 << 20), wgcu > 0 ? wgcu : 1024, a.ntasks, AC_WAVES);
   const dim3 blk(AC_WAVES * 64);
   if (C == 2) hipLaunchKernelGGL((k_inv_fast<0, AC_WAVES>), dim3(grid), blk, 0, s, a);
   else hipLaunchKernelGGL((k_inv_fast<1, AC_WAVES>), dim3(grid), blk, 0, s, a);

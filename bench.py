@@ -18,6 +18,7 @@ channel, encode + decode both done (20 484 algorithmic bytes per frame).
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -37,47 +38,49 @@ DEC_BYTES = 4 * N + 4 * N                    # X in; PCM out                    
 HBM_PEAK_GBS = 8000.0                        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(seconds_target=12.0):
+def cpu_baseline(seconds=12.0):
     """The oracle (closed-form numpy/scipy restatement, oracle/audiocodec_oracle.py) timed on the host cores on a
-    bounded sample of the same workload: stereo clips of 46 blocks, encode + decode."""
-    from oracle.audiocodec_oracle import MDCTOracle, PsychoOracle
-    om, op = MDCTOracle(N, "vorbis", np.float32), PsychoOracle(48000, N, 64, compute_dtype=np.float32)
-    rng = np.random.default_rng(1234)
-    B, K, C = 8, 46, 2
-    x = rng.uniform(-1, 1, (B, K * N, C)).astype(np.float32)
-
-    def one():
-        X = om.transform(x)
-        t = op.tonality(X)
-        thr = op.global_masking_threshold(X, t)
-        xh = om.inverse_transform(X)
-        return thr, xh
-
-    one()
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        one()
-        reps += 1
-        el = time.perf_counter() - t0
-        if el >= seconds_target or reps >= 200:
-            break
-    frames = reps * B * C * K
+    bounded sample of the same workload: one single-threaded process per core (oracle/cpu_bench.py), each looping
+    encode + decode over stereo clips of 46 blocks for `seconds`; frames/s summed over the processes.  Runs before
+    this process touches the GPU (child processes are started from a GPU-free parent)."""
+    cores = max(1, min(os.cpu_count() or 1, 16))
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "oracle.cpu_bench", "--seconds", str(seconds)]
+    procs = [subprocess.Popen(cmd + ["--seed", str(i)], cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+             for i in range(cores)]
+    rate, frames = 0.0, 0
+    for p in procs:
+        out, _ = p.communicate(timeout=seconds * 6 + 120)
+        r = json.loads(out.strip().splitlines()[-1])
+        rate += r["frames"] / r["seconds"]
+        frames += r["frames"]
     # the reference-shaped flavour (dense [2,N,N] polyphase products, 2N-point DCT-III, dense Bark einsums,
-    # materialised 5-D masking tensor) on a smaller sample, for scale
-    xs = x[:2]
-    t1 = time.perf_counter()
-    Xd = om.transform(xs, dense=True)
-    td = op.tonality(Xd)
-    op.global_masking_threshold(Xd, td, dense=True)
-    om.inverse_transform(Xd, dense=True)
-    el_d = time.perf_counter() - t1
+    # materialised 5-D masking tensor) on one core, for scale
+    out = subprocess.run(cmd[:-1] + ["3", "--dense"], cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True,
+                         timeout=600).stdout
+    d = json.loads(out.strip().splitlines()[-1])
     return {
-        "value": frames / el, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
-        "sample": "%d x (B=%d stereo clips, K=%d blocks, N=%d) encode+decode, closed-form numpy/scipy oracle "
-                  "(scipy.fft workers=-1), %.1f s" % (reps, B, K, N, el),
-        "reference_shaped_value": (2 * C * K) / el_d,
-        "reference_shaped_sample": "1 x (B=2 stereo, K=%d) dense polyphase/DCT-III/einsum restatement, %.1f s" % (K, el_d),
+        "value": rate, "unit": "frames/s", "cores": cores, "kind": "port",
+        "sample": "%d single-threaded processes x %.0f s of (B=2 stereo clips, K=46 blocks, N=%d) encode+decode, "
+                  "closed-form numpy/scipy oracle; %d frames in total" % (cores, seconds, N, frames),
+        "reference_shaped_value_per_core": d["frames"] / d["seconds"],
+        "reference_shaped_sample": "1 process, dense polyphase / DCT-III / einsum restatement of the reference's op "
+                                   "sequence, %.1f s" % d["seconds"],
     }
+
+
+def measured_traffic():
+    """HBM bytes per launch of the fused encode kernel from the committed PMC passes (profiles/<round>/traffic.json:
+    FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE), or None."""
+    best = None
+    prof = os.path.join(ROOT, "profiles")
+    if os.path.isdir(prof):
+        for r in sorted(os.listdir(prof)):
+            f = os.path.join(prof, r, "traffic.json")
+            if os.path.exists(f):
+                with open(f) as fh:
+                    best = json.load(fh)
+    return best
 
 
 def main():
@@ -90,6 +93,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    rank, world, _ = acd.env_rank_world()
+    cpu = None
+    if world == 1 and args.gpus == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()          # before this process initialises the GPU
     rank, world, local_rank = acd.init_process_group("nccl" if args.gpus > 1 else None)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
@@ -137,6 +144,8 @@ def main():
     frames_total = frames_rank * world * args.steps
     value = frames_total / elapsed_max
     if rank == 0:
+        tr = measured_traffic() if (B, K) == (256, 468) else None
+        traffic = tr["encode"]["hbm_bytes_per_launch"] if tr else None
         enc_gbs = ENC_BYTES * frames_rank / (enc_ms * 1e-3) / 1e9
         dec_gbs = DEC_BYTES * frames_rank / (dec_ms * 1e-3) / 1e9
         out = {
@@ -148,16 +157,16 @@ def main():
                                    "(%.1f s), fused MDCT+tonality+masking encode then IMDCT decode" % (B, K, K * N / 48000.0),
                        "clips_per_gpu": B, "channels": C, "blocks": K, "filters_n": N, "sample_rate": 48000,
                        "sharding": "clips split across ranks, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_fwd_fast<0,true> (fused encode)",
+            "roofline": {"bound": "hbm", "kernel": "k_fwd_fast<0,true,4> (fused encode)",
                          "achieved": enc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": enc_gbs / HBM_PEAK_GBS,
-                         "traffic": None, "bytes_per_frame": ENC_BYTES, "frames_per_launch": frames_rank,
+                         "traffic": traffic, "bytes_per_frame": ENC_BYTES, "frames_per_launch": frames_rank,
                          "avg_launch_ms": enc_ms},
             "kernels": {"encode_ms": enc_ms, "encode_GBs": enc_gbs, "decode_ms": dec_ms, "decode_GBs": dec_gbs,
                         "step_frac_of_hbm_peak": (ENC_BYTES + DEC_BYTES) * (value / world) / (HBM_PEAK_GBS * 1e9)},
             "round_trip_max_abs_err": err,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
