@@ -46,6 +46,12 @@ constexpr int FH = FN / 2;          // complex FFT points per frame (= 64 lanes 
 #ifndef AC_WPE
 #define AC_WPE 3                    // waves per SIMD the register allocator must leave room for
 #endif
+#ifndef AC_NT_STORE
+#define AC_NT_STORE 1               // 1: streaming (non-temporal) stores of the output rows (measured +4 % on both kernels)
+#endif
+#ifndef AC_NT_LOAD
+#define AC_NT_LOAD 0                // bit 0: block n, bit 1: block n-1 of the analysis, bit 2: frames of the synthesis
+#endif
 #ifndef AC_PREFETCH
 #define AC_PREFETCH 0               // 1: the next frame's PCM is requested during the epilogue of the current one
 #endif
@@ -202,14 +208,15 @@ __device__ __forceinline__ void rev_exchange(char* buf, int lane, const v2f (&in
 
 // ---- global <-> register movement of one natural-order row of N values x channel pair ---------------
 // CMODE 0: exactly two channels (interleaved, 16-byte vectors); CMODE 1: any channel count, pair (c0, c0+1)
-template <int CMODE>
+template <int CMODE, bool NT = false>
 __device__ __forceinline__ void load_row(const float* __restrict__ row, int C, int c0, bool has1, int lane,
                                          v4f (&v)[8]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int q = 64 * i + lane;
     if (CMODE == 0) {
-      v[i] = reinterpret_cast<const v4f*>(row)[q];
+      if (NT) v[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(row) + q);
+      else v[i] = reinterpret_cast<const v4f*>(row)[q];
     } else {
       const float* p = row + (size_t)(2 * q) * C + c0;
       v[i].x = p[0];
@@ -227,7 +234,11 @@ __device__ __forceinline__ void store_row(float* __restrict__ row, int C, int c0
   for (int i = 0; i < 8; ++i) {
     const int q = 64 * i + lane;
     if (CMODE == 0) {
+#if AC_NT_STORE
+      __builtin_nontemporal_store(v[i], reinterpret_cast<v4f*>(row) + q);
+#else
       reinterpret_cast<v4f*>(row)[q] = v[i];
+#endif
     } else {
       float* p = row + (size_t)(2 * q) * C + c0;
       p[0] = v[i].x;
@@ -518,7 +529,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
         ok = false;
       }
     }
-    load_row<CMODE>(src, C, c0, has1, lane, dst);
+    load_row<CMODE, ((AC_NT_LOAD >> decltype(which)::value) & 1) != 0>(src, C, c0, has1, lane, dst);
     return ok;
   };
   constexpr std::integral_constant<int, 0> kCur{};
@@ -697,12 +708,12 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_inv_fast(InvArgs a) {
   if (n0 >= 1) {
     // aliased half of frame n0-1 (always an existing frame: n0-1 < Kp)
     v4f row[8];
-    load_row<CMODE>(Xb + (size_t)(n0 - 1) * blk, C, c0, has1, lane, row);
-    if (n0 < a.Kp) load_row<CMODE>(Xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
+    load_row<CMODE, (AC_NT_LOAD & 4) != 0>(Xb + (size_t)(n0 - 1) * blk, C, c0, has1, lane, row);
+    if (n0 < a.Kp) load_row<CMODE, (AC_NT_LOAD & 4) != 0>(Xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
     v2f dummy[8];
     idct_frame(row, buf, tab, p1, lane, dummy, carry);
   } else {
-    if (n0 < a.Kp) load_row<CMODE>(Xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
+    if (n0 < a.Kp) load_row<CMODE, (AC_NT_LOAD & 4) != 0>(Xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
     if (a.tail_in) {
 #pragma unroll
       for (int k2 = 0; k2 < 8; ++k2) {
@@ -721,7 +732,8 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_inv_fast(InvArgs a) {
     v2f now[8], nxt[8];
     if (n < a.Kp) {
       idct_frame(ahead, buf, tab, p1, lane, now, nxt);
-      if (n + 1 < n1 && n + 1 < a.Kp) load_row<CMODE>(Xb + (size_t)(n + 1) * blk, C, c0, has1, lane, ahead);
+      if (n + 1 < n1 && n + 1 < a.Kp)
+        load_row<CMODE, (AC_NT_LOAD & 4) != 0>(Xb + (size_t)(n + 1) * blk, C, c0, has1, lane, ahead);
     } else {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
