@@ -299,3 +299,48 @@ def test_full_size_properties(path):
     Xo = om.transform(xs)
     assert rel_peak(host(X[:2]), Xo) <= TOL
     assert rel_elem(host(thr[:2]), op.global_masking_threshold(Xo, op.tonality(Xo))) <= 2e-4
+
+
+def test_fast_path_selection():
+    """The wave-level kernels serve N = 1024 with a Princen-Bradley window; everything else runs the generic kernels
+    (the rectangular window's fold blocks are not rotations)."""
+    _lib.load().ac_set_force_generic(0)
+    assert audiocodec_amd.MDCTransformer(1024, "vorbis").is_fast()
+    assert audiocodec_amd.MDCTransformer(1024, "sine").is_fast()
+    assert not audiocodec_amd.MDCTransformer(1024, "rect").is_fast()
+    assert not audiocodec_amd.MDCTransformer(512).is_fast()
+    assert audiocodec_amd.PsychoacousticModel(48000, 1024, 64).is_fast()
+    assert not audiocodec_amd.PsychoacousticModel(48000, 2048, 64).is_fast()
+
+
+@pytest.mark.parametrize("wt", ["rect", None])
+def test_rect_window_n1024_vs_oracle(wt):
+    N, B, K, C = 1024, 2, 3, 2
+    x = np.random.default_rng(5).uniform(-1, 1, (B, K * N, C)).astype(np.float32)
+    m = audiocodec_amd.MDCTransformer(N, window_type=wt)
+    o = MDCTOracle(N, "rect", np.float64)
+    X = host(m.transform(dev(x)))
+    Xo = o.transform(x.astype(np.float64))
+    assert rel_peak(X, Xo) <= TOL and rel_l2(X, Xo) <= TOL
+    xh = host(m.inverse_transform(dev(X)))
+    assert np.max(np.abs(xh - o.inverse_transform(Xo))) <= 1e-4
+
+
+def test_streaming_config5_ten_minutes():
+    """BASELINE config 5: 10 min of 48 kHz stereo fed in chunks of 256 blocks through the device-resident overlap state;
+    every frame equals the one-shot transform and the round trip stays within 1 LSB."""
+    N, C, K, k = 1024, 2, 28125, 256
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand(1, K * N, C, device="cuda", generator=g) * 2 - 1
+    m = audiocodec_amd.MDCTransformer(N)
+    X_full = m.transform(x)
+    st = audiocodec_amd.StreamingMDCT(m, 1, C)
+    outs = [st.transform_chunk(x[:, p * N:min(K, p + k) * N]) for p in range(0, K, k)]
+    outs.append(st.transform_chunk(torch.zeros(1, N, C, device="cuda")))
+    X_stream = torch.cat(outs, dim=1)
+    assert torch.equal(X_stream, X_full)
+    st.reset()
+    outs = [st.inverse_chunk(X_stream[:, p:min(K + 1, p + k)]) for p in range(0, K + 1, k)]
+    x_stream = torch.cat(outs, dim=1)                   # [1, (K+1) N, C]: block 0 is the leading half-aliased block
+    assert float((x_stream[:, N:] - x).abs().max()) <= LSB
+    st.close()
