@@ -1,4 +1,5 @@
-// Wave-level kernels for filters_n = 1024 on gfx950 (MI355X).
+// Wave-level kernels for filters_n = 1024 and 2048 on gfx950 (MI355X); the description below is for 1024
+// (8 complex FFT points per lane), 2048 runs the same code with 16 (template parameter R).
 //
 // One 64-lane wavefront owns one "strip": a pair of channels of one clip over a run of consecutive
 // frames, and walks it in time.  Both channels ride in the two halves of 64-bit register pairs
@@ -35,8 +36,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const float* gtab_t;   // LDS-resident table image
 
-constexpr int FN = 1024;            // filters_n served by this file
-constexpr int FH = FN / 2;          // complex FFT points per frame (= 64 lanes x 8 registers)
+constexpr int PSY_FN = 1024;        // filter_bands_n of the wave-level psychoacoustic epilogue
 #ifndef AC_WAVES_PSY
 #define AC_WAVES_PSY 4              // waves per workgroup, fused encode (LDS: three workgroups per CU)
 #endif
@@ -52,25 +52,32 @@ constexpr int FH = FN / 2;          // complex FFT points per frame (= 64 lanes 
 #ifndef AC_NT_LOAD
 #define AC_NT_LOAD 0                // bit 0: block n, bit 1: block n-1 of the analysis, bit 2: frames of the synthesis
 #endif
-#ifndef AC_PREFETCH
-#define AC_PREFETCH 0               // 1: the next frame's PCM is requested during the epilogue of the current one
-#endif
 constexpr int WAVE_LDS = 9216;      // bytes of LDS per wave: 576 x 16-byte elements (8 rows of 64 + 8 pad)
 constexpr int S8_OFF = 8192;        // psycho: 128 chunk sums (8 bins each) behind the 8 KB intensity image
 constexpr int ZERO_OFF = 9216;      // psycho: one zero slot (padding target of the gather lists)
 constexpr int WAVE_LDS_PSY = 9232;
 constexpr float kEps = 1e-14f;      // _INTENSITY_EPS, psychoacoustic.py:56
 
-// ---- mdct tables: two images in ac_mdct_plan::d_fast (analysis at 0, synthesis at I_TOTAL floats); the kernel
-// copies its image into LDS once per workgroup, so the walk loop touches HBM only for PCM / spectra ---------
-constexpr int I_PRE = 0;                  // [8][64] float2  exp(-i pi (e + 1/4) / N), e = lane + 64 r
-constexpr int I_P2 = I_PRE + 1024;        // [8][8]  float2  W64^(e0 k1)
-constexpr int I_POST = I_P2 + 128;        // [8][64] float2  exp(-i pi k / N) * (1/(N sqrt 2) | 2 sqrt 2), k = lane + 64 k2
-constexpr int I_COEF = I_POST + 1024;     // [8][64] float2  fold (A, B)(e) | unfold (a, b)(k)
-constexpr int I_LDS = I_COEF + 1024;      // 3200 floats = 12 800 bytes live in LDS
-constexpr int I_P1 = I_LDS;               // [8][64] float2  W512^(lane k0): seven per lane, held in registers
-constexpr int I_TOTAL = I_P1 + 1024;      // 4224 floats per image in global memory
-constexpr int TAB_LDS = I_LDS * 4;
+// ---- geometry and mdct tables for R complex FFT points per lane: filters_n = 128 R (R = 8: 1024, R = 16: 2048).
+// Two table images in ac_mdct_plan::d_fast (analysis at 0, synthesis at I_TOTAL floats); the kernel copies the first
+// I_LDS floats of its image into LDS once per workgroup, so the frame loop touches HBM only for PCM / spectra.
+template <int R>
+struct Geo {
+  static constexpr int FH = 64 * R;                 // complex FFT points per frame
+  static constexpr int FN = 128 * R;                // filters_n
+  static constexpr int I_PRE = 0;                   // [R][64] float2  exp(-i pi (e + 1/4) / N), e = lane + 64 r
+  static constexpr int I_P2 = I_PRE + 128 * R;      // [8][8]  float2  W64^(e0 k1)
+  static constexpr int I_POST = I_P2 + 128;         // [R][64] float2  exp(-i pi k / N) * (1/(N sqrt 2) | 2 sqrt 2), k = lane + 64 j
+  static constexpr int I_COEF = I_POST + 128 * R;   // [R][64] float2  fold (A, B)(e) | unfold (a, b)(k)
+  static constexpr int I_LDS = I_COEF + 128 * R;    // floats that live in LDS (R = 8: 12 800 bytes)
+  static constexpr int I_P1 = I_LDS;                // [R][64] float2  W_{64R}^(lane k0): held in registers
+  static constexpr int I_TOTAL = I_P1 + 128 * R;    // floats per image in global memory
+  static constexpr int TAB_LDS = I_LDS * 4;
+};
+// waves per SIMD the register allocator must leave room for: the strided any-channel-count variants (CMODE 1) and the
+// 2048-filter kernels get the larger budget
+template <int R, int CMODE>
+constexpr int wpe() { return (R == 8 && CMODE == 0) ? AC_WPE : 2; }
 
 // ---- psy image (32-bit words) in ac_psy_plan::d_fast, copied into LDS once per workgroup -------------------
 constexpr int PL_G = 0;                   // [128]     spreading prototype g
@@ -140,98 +147,145 @@ __device__ __forceinline__ C2 lds_get(const char* p) {
   return {v2f{t.x, t.y}, v2f{t.z, t.w}};
 }
 
-// 512-point FFT of z[r] = element (lane + 64 r); result z[k2] = bin lane + 64 k2.
-// Element index e = e0 + 8 e1 + 64 e2 (lane = e0 + 8 e1, register e2), bin k = k0 + 8 k1 + 64 k2.
-//   pass 1 over e2 -> k0, twiddle W512^(lane k0); exchange 1: row k0 (72 elements of 16 B: 64 + 8 pad), column lane;
-//   lane (a = k0, m0 = e0) reads e1 = 0..7 at a 72 + 8 e1 + m0
-//   pass 2 over e1 -> k1, twiddle W64^(e0 k1);    exchange 2: element (k0, k1, e0) at 9 (k0 + 8 k1) + e0;
-//   lane k0 + 8 k1 reads its 8 consecutive e0      pass 3 over e0 -> k2.
-// Both exchanges are bank-conflict-free under the gfx950 lane-group rules (tools/emulate_wave_fft.py).
-__device__ __forceinline__ void fft512(C2 (&z)[8], char* buf, gtab_t tab, const v2f (&p1)[8], int lane) {
+// 16-point DFT (forward sign): two 8-point DFTs of the even / odd registers and one radix-2 stage
+__device__ __forceinline__ void dft16(C2 (&x)[16]) {
+  C2 e[8], o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    e[i] = x[2 * i];
+    o[i] = x[2 * i + 1];
+  }
+  dft8(e);
+  dft8(o);
+  constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, R2 = 0.70710678118654752440f;
+  const v2f w[8] = {v2f{1.f, 0.f}, v2f{c1, -s1}, v2f{R2, -R2}, v2f{s1, -c1},
+                    v2f{0.f, -1.f}, v2f{-s1, -c1}, v2f{-R2, -R2}, v2f{-c1, -s1}};   // W16^k
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const C2 t = (k == 0) ? o[0] : (k == 4) ? mul_mi(o[4]) : cmul(o[k], w[k]);
+    x[k] = cadd(e[k], t);
+    x[k + 8] = csub(e[k], t);
+  }
+}
+__device__ __forceinline__ void dft_regs(C2 (&x)[8]) { dft8(x); }
+__device__ __forceinline__ void dft_regs(C2 (&x)[16]) { dft16(x); }
+
+// 64R-point FFT of z[r] = element (lane + 64 r); result z[j] = bin lane + 64 j.
+// Element index e = e0 + 8 e1 + 64 r (lane = e0 + 8 e1), bin k = k0 + R (k1 + 8 k2), k0 = 8 beta + kappa.
+//   pass 1 over r -> k0 (radix R in registers), twiddle W_{64R}^(lane k0);
+//   per batch beta of eight k0: exchange 1: row kappa (72 elements of 16 B: 64 + 8 pad), column lane;
+//     lane (a = kappa, m0 = e0) reads e1 = 0..7 at a 72 + 8 e1 + m0;  pass 2 over e1 -> k1, twiddle W64^(e0 k1);
+//   per half h of the k1 (k1 = (64/R) h + kk): exchange 2: element (k0, kk, e0) at 9 (k0 + R kk) + e0;
+//     lane k0 + R kk reads its 8 consecutive e0;  pass 3 over e0 -> k2;  bin = lane + 64 (h + (R/8) k2).
+// Every exchange address is one per-lane base + an immediate, and every access is bank-conflict-free under the
+// gfx950 lane-group rules (tools/emulate_wave_fft.py emulates the maps for R = 8 and 16).
+template <int R>
+__device__ __forceinline__ void fft_wave(C2 (&z)[R], char* buf, gtab_t tab, const v2f (&p1)[R], int lane) {
+  constexpr int NB = R / 8;      // batches of eight 64-point FFTs
+  constexpr int Q = 64 / R;      // k1 values per exchange-2 half
   const int a = lane >> 3, m0 = lane & 7;
-  dft8(z);
+  dft_regs(z);
 #pragma unroll
-  for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], p1[k]);
-  wave_sync();
-  {
-    char* w1 = buf + 16 * lane;
+  for (int k = 1; k < R; ++k) z[k] = cmul(z[k], p1[k]);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) lds_put(w1 + 1152 * k, z[k]);
+  for (int beta = 0; beta < NB; ++beta) {
+    C2 y[8];
+    wave_sync();
+    {
+      char* w1 = buf + 16 * lane;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) lds_put(w1 + 1152 * k, z[8 * beta + k]);
+    }
+    wave_sync();
+    {
+      const char* r1 = buf + 16 * (a * 72 + m0);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) y[r] = lds_get(r1 + 128 * r);
+    }
+    dft8(y);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      z[8 * beta + k] = (k == 0) ? y[0] : cmul(y[k], reinterpret_cast<const v2f*>(tab + Geo<R>::I_P2)[k * 8 + m0]);
   }
-  wave_sync();
-  {
-    const char* r1 = buf + 16 * (a * 72 + m0);
+  C2 out[R];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) z[r] = lds_get(r1 + 128 * r);
+  for (int h = 0; h < NB; ++h) {
+    C2 y[8];
+    wave_sync();
+    {
+      char* w2 = buf + 16 * (9 * a + m0);
+#pragma unroll
+      for (int beta = 0; beta < NB; ++beta)
+#pragma unroll
+        for (int kk = 0; kk < Q; ++kk) lds_put(w2 + 16 * (72 * beta + 9 * R * kk), z[8 * beta + Q * h + kk]);
+    }
+    wave_sync();
+    {
+      const char* r2 = buf + 144 * lane;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) y[r] = lds_get(r2 + 16 * r);
+    }
+    dft8(y);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) out[h + NB * k2] = y[k2];
   }
-  dft8(z);
 #pragma unroll
-  for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], reinterpret_cast<const v2f*>(tab + I_P2)[k * 8 + m0]);
-  wave_sync();
-  {
-    char* w2 = buf + 16 * (9 * a + m0);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) lds_put(w2 + 1152 * k, z[k]);
-  }
-  wave_sync();
-  {
-    const char* r2 = buf + 144 * lane;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) z[r] = lds_get(r2 + 16 * r);
-  }
-  dft8(z);
+  for (int j = 0; j < R; ++j) z[j] = out[j];
 }
 
-// the lane's seven pass-1 twiddles W512^(lane k), k = 1..7, from the image in global memory
-__device__ __forceinline__ void load_p1(const float* __restrict__ image, int lane, v2f (&p1)[8]) {
+// the lane's pass-1 twiddles W_{64R}^(lane k), k = 1..R-1, from the image in global memory
+template <int R>
+__device__ __forceinline__ void load_p1(const float* __restrict__ image, int lane, v2f (&p1)[R]) {
   p1[0] = v2f{1.f, 0.f};
 #pragma unroll
-  for (int k = 1; k < 8; ++k) p1[k] = reinterpret_cast<const v2f*>(image + I_P1)[k * 64 + lane];
+  for (int k = 1; k < R; ++k) p1[k] = reinterpret_cast<const v2f*>(image + Geo<R>::I_P1)[k * 64 + lane];
 }
 
-// lane-reversal exchange of eight (c0, c1) pairs: afterwards out[i] = in[(OFS - i) & 7] of lane 63 - lane
-template <int OFS>
-__device__ __forceinline__ void rev_exchange(char* buf, int lane, const v2f (&in)[8], v2f (&out)[8]) {
+// lane-reversal exchange of R (c0, c1) pairs: afterwards out[i] = in[(OFS - i) mod R] of lane 63 - lane
+template <int OFS, int R>
+__device__ __forceinline__ void rev_exchange(char* buf, int lane, const v2f (&in)[R], v2f (&out)[R]) {
   wave_sync();
   {
     char* w = buf + 8 * (63 - lane);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) *reinterpret_cast<v2f*>(w + 512 * c) = in[c];
+    for (int c = 0; c < R; ++c) *reinterpret_cast<v2f*>(w + 512 * c) = in[c];
   }
   wave_sync();
   {
     const char* r = buf + 8 * lane;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) out[i] = *reinterpret_cast<const v2f*>(r + 512 * ((OFS - i) & 7));
+    for (int i = 0; i < R; ++i) out[i] = *reinterpret_cast<const v2f*>(r + 512 * ((OFS - i) & (R - 1)));
   }
 }
 
 // ---- global <-> register movement of one natural-order row of N values x channel pair ---------------
 // CMODE 0: exactly two channels (interleaved, 16-byte vectors); CMODE 1: any channel count, pair (c0, c0+1)
-template <int CMODE, bool NT = false>
+template <int CMODE, bool NT = false, int R = 8>
 __device__ __forceinline__ void load_row(const float* __restrict__ row, int C, int c0, bool has1, int lane,
-                                         v4f (&v)[8]) {
+                                         v4f (&v)[R]) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < R; ++i) {
     const int q = 64 * i + lane;
     if (CMODE == 0) {
       if (NT) v[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(row) + q);
       else v[i] = reinterpret_cast<const v4f*>(row)[q];
     } else {
-      const float* p = row + (size_t)(2 * q) * C + c0;
-      v[i].x = p[0];
-      v[i].z = p[C];
-      v[i].y = has1 ? p[1] : 0.f;
-      v[i].w = has1 ? p[C + 1] : 0.f;
+      // uniform base per register + four 32-bit lane offsets shared by all registers (keeps the addresses out of VGPRs)
+      const float* ri = row + (size_t)(128 * i) * C;
+      const int off = 2 * lane * C + c0;
+      v[i].x = ri[off];
+      v[i].z = ri[off + C];
+      v[i].y = has1 ? ri[off + 1] : 0.f;
+      v[i].w = has1 ? ri[off + C + 1] : 0.f;
     }
   }
 }
 
-template <int CMODE>
+template <int CMODE, int R = 8>
 __device__ __forceinline__ void store_row(float* __restrict__ row, int C, int c0, bool has1, int lane,
-                                          const v4f (&v)[8]) {
+                                          const v4f (&v)[R]) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < R; ++i) {
     const int q = 64 * i + lane;
     if (CMODE == 0) {
 #if AC_NT_STORE
@@ -240,12 +294,13 @@ __device__ __forceinline__ void store_row(float* __restrict__ row, int C, int c0
       reinterpret_cast<v4f*>(row)[q] = v[i];
 #endif
     } else {
-      float* p = row + (size_t)(2 * q) * C + c0;
-      p[0] = v[i].x;
-      p[C] = v[i].z;
+      float* ri = row + (size_t)(128 * i) * C;
+      const int off = 2 * lane * C + c0;
+      ri[off] = v[i].x;
+      ri[off + C] = v[i].z;
       if (has1) {
-        p[1] = v[i].y;
-        p[C + 1] = v[i].w;
+        ri[off + 1] = v[i].y;
+        ri[off + C + 1] = v[i].w;
       }
     }
   }
@@ -314,15 +369,9 @@ __device__ __forceinline__ uint32_t in_loop(uint32_t w) {
 
 // buf = the wave's LDS region (WAVE_LDS_PSY bytes), pimg = the workgroup's copy of the psy image
 // lds0 = base of the workgroup's LDS object (the absolute offsets of PsyLane count from it)
-// late() is called once, just before the per-bin thresholds are gathered into registers (the point of lowest register
-// pressure of the epilogue): the fused kernel issues the next frame's halo loads there
-struct NoHook {
-  __device__ __forceinline__ void operator()() const {}
-};
-template <bool WANT_T, bool WANT_THR, typename Late = NoHook>
+template <bool WANT_T, bool WANT_THR>
 __device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* lds0, char* buf, const uint32_t* pimg,
-                                          const PsyLane& pc, const PsyParams& pp, int lane, v2f& t, v4f (&thr)[8],
-                                          Late late = Late()) {
+                                          const PsyLane& pc, const PsyParams& pp, int lane, v2f& t, v4f (&thr)[8]) {
   if (WANT_THR) wave_sync();
   v2f slog = {0.f, 0.f}, ssq = {0.f, 0.f};
   {
@@ -346,9 +395,9 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* lds0, char* 
     slog.y = wave_sum(slog.y);
     ssq.x = wave_sum(ssq.x);
     ssq.y = wave_sum(ssq.y);
-    const v2f am = ssq * (1.0f / FN) + kEps;
+    const v2f am = ssq * (1.0f / PSY_FN) + kEps;
     // sfm = 10 log10(gm / am) with gm = exp(mean ln I)  ==  10 log10(2) (mean log2 I - log2 am)
-    const v2f sfm = 3.0102999566398120f * (slog * (1.0f / FN) - log2v(am));
+    const v2f sfm = 3.0102999566398120f * (slog * (1.0f / PSY_FN) - log2v(am));
     const v2f tt = sfm * (-1.0f / 60.0f);
     t = v2f{fminf(tt.x, 1.0f), fminf(tt.y, 1.0f)};
   }
@@ -416,7 +465,6 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* lds0, char* 
   *reinterpret_cast<v4f*>(buf + 16 * lane) = v4f{__builtin_amdgcn_sqrtf(A0.x), __builtin_amdgcn_sqrtf(A0.y),
                                                  __builtin_amdgcn_sqrtf(A1.x), __builtin_amdgcn_sqrtf(A1.y)};   // entry e at byte 8 e
   wave_sync();
-  late();
   {
     const v4f ia = pc.ia, ib = pc.ib;
     const uint32_t iw[8] = {__float_as_uint(ia.x), __float_as_uint(ia.y), __float_as_uint(ia.z), __float_as_uint(ia.w),
@@ -432,15 +480,15 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* lds0, char* 
 }
 
 // copies the table image (and the psy image) into the workgroup's LDS behind the wave buffers; every thread takes part
-template <int NW, int WSTRIDE>
+template <int NW, int WSTRIDE, int TABF>
 __device__ __forceinline__ void load_tables(char* lds, const float* __restrict__ image, const uint32_t* psy_tab) {
   if (image) {
     v4f* dst = reinterpret_cast<v4f*>(lds + NW * WSTRIDE);
     const v4f* src = reinterpret_cast<const v4f*>(image);
-    for (int i = threadIdx.x; i < I_LDS / 4; i += NW * 64) dst[i] = src[i];
+    for (int i = threadIdx.x; i < TABF / 4; i += NW * 64) dst[i] = src[i];
   }
   if (psy_tab) {
-    uint4* pd = reinterpret_cast<uint4*>(lds + NW * WSTRIDE + (image ? TAB_LDS : 0));
+    uint4* pd = reinterpret_cast<uint4*>(lds + NW * WSTRIDE + (image ? TABF * 4 : 0));
     const uint4* ps = reinterpret_cast<const uint4*>(psy_tab);
     for (int i = threadIdx.x; i < PL_LDS / 4; i += NW * 64) pd[i] = ps[i];
   }
@@ -475,25 +523,27 @@ struct FwdArgs {
 // register (r + 4) & 7) and the odd sample of granule 767 - e (lane 63 - lane, register (3 - r) & 7).
 // With (A, B) = COEF[e]:  carried part (block n-1) = B xe + A xo;  current part (block n) = B xo - A xe (r < 4),
 // A xe - B xo (r >= 4)   (Princen-Bradley windows make the 2x2 fold blocks rotations).
-template <int CMODE, bool PSY, int NW>
-__global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
+template <int R, int CMODE, bool PSY, int NW>
+__global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_fwd_fast(FwdArgs a) {
+  using G = Geo<R>;
+  static_assert(!PSY || R == 8, "the fused epilogue serves filter_bands_n = 1024");
   // one LDS object: [NW wave buffers | table image | psy image]
   constexpr int WSTRIDE = PSY ? WAVE_LDS_PSY : WAVE_LDS;
-  __shared__ __attribute__((aligned(16))) char lds[NW * WSTRIDE + TAB_LDS + (PSY ? PSY_LDS : 0)];
+  __shared__ __attribute__((aligned(16))) char lds[NW * WSTRIDE + G::TAB_LDS + (PSY ? PSY_LDS : 0)];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  load_tables<NW, WSTRIDE>(lds, a.tab, PSY ? a.psy.tab : nullptr);
+  load_tables<NW, WSTRIDE, G::I_LDS>(lds, a.tab, PSY ? a.psy.tab : nullptr);
   char* buf = lds + wave * WSTRIDE;
   gtab_t tab = reinterpret_cast<const float*>(lds + NW * WSTRIDE);
-  const uint32_t* pimg = reinterpret_cast<const uint32_t*>(lds + NW * WSTRIDE + TAB_LDS);
+  const uint32_t* pimg = reinterpret_cast<const uint32_t*>(lds + NW * WSTRIDE + G::TAB_LDS);
   if (PSY) *reinterpret_cast<v2f*>(buf + ZERO_OFF) = v2f{0.f, 0.f};   // the gather lists' padding slot
-  v2f p1[8];
-  load_p1(a.tab, lane, p1);
+  v2f p1[R];
+  load_p1<R>(a.tab, lane, p1);
   PsyLane pc;
   if (PSY) pc = load_psy_lane(a.psy.tab, lane, (uint32_t)(wave * WSTRIDE));
   int g = blockIdx.x;
   if (a.xcd) g = (g & 7) * (gridDim.x >> 3) + (g >> 3);
   const int C = a.C;
-  const size_t blk = (size_t)FN * C;   // floats per block / frame row over all channels
+  const size_t blk = (size_t)G::FN * C;   // floats per block / frame row over all channels
   // frame f = (pair, n); everything about it is wave-uniform and lives in scalar registers, advanced without divisions
   const long long stride = a.T > 0 ? (long long)NW : (long long)gridDim.x * NW;
   const long long f0 = (a.T > 0 ? (long long)g * NW * a.T : (long long)g * NW) + wave;
@@ -509,7 +559,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
   // loads block fn (WHICH 0) or block fn-1 (WHICH 1) of frame (pr, fn) in natural order.  A missing block (before the
   // first / after the last) is loaded from a neighbouring, valid address and zeroed when it is consumed (returns false),
   // so that the loads stay unconditional and nothing waits for them at the point of issue.
-  auto issue_loads = [&](auto which, long long pr, int fn, v4f (&dst)[8]) -> bool {
+  auto issue_loads = [&](auto which, long long pr, int fn, v4f (&dst)[R]) -> bool {
     const int cp = (CMODE == 0) ? 0 : (int)(pr % a.CP);      // CMODE 0: exactly one channel pair
     const long long b = (CMODE == 0) ? pr : pr / a.CP;
     const int c0 = 2 * cp;
@@ -529,46 +579,35 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
         ok = false;
       }
     }
-    load_row<CMODE, ((AC_NT_LOAD >> decltype(which)::value) & 1) != 0>(src, C, c0, has1, lane, dst);
+    load_row<CMODE, ((AC_NT_LOAD >> decltype(which)::value) & 1) != 0, R>(src, C, c0, has1, lane, dst);
     return ok;
   };
   constexpr std::integral_constant<int, 0> kCur{};
   constexpr std::integral_constant<int, 1> kPrv{};
+  auto zero_row = [](v4f (&v)[R]) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) v[i] = v4f{0.f, 0.f, 0.f, 0.f};
+  };
 
-  v4f cb[8], pb[8];   // block n and block n-1 of the frame being folded; refilled for the next frame during the epilogue
-  // vmcnt retires loads and stores in issue order, so a load issued behind a store cannot be consumed before that store
-  // has drained.  Each frame's loads are therefore issued ahead of the previous frame's stores: block n before the X
-  // stores, block n-1 (the neighbouring wave's block, an L2 hit most of the time) before the threshold stores.
-  bool cur_ok = true, prv_ok = true;
-  if (AC_PREFETCH && pair < npairs) {
-    cur_ok = issue_loads(kCur, pair, n, cb);
-    prv_ok = issue_loads(kPrv, pair, n, pb);
-  }
   while (pair < npairs && left > 0) {
-    if (!AC_PREFETCH) {
-      cur_ok = issue_loads(kCur, pair, n, cb);
-      prv_ok = issue_loads(kPrv, pair, n, pb);
-    }
     const int cp = (CMODE == 0) ? 0 : (int)(pair % a.CP);
     const long long b = (CMODE == 0) ? pair : pair / a.CP;
     const int c0 = 2 * cp;
     const bool has1 = (c0 + 1) < C;
-    C2 z[8];
-    {
-      if (!cur_ok) {   // edge frames only (wave-uniform)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) cb[i] = v4f{0.f, 0.f, 0.f, 0.f};
-      }
-      if (!prv_ok) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) pb[i] = v4f{0.f, 0.f, 0.f, 0.f};
-      }
-      // lane-reversal exchange of the odd halves of both blocks: previous block in [0, 4 KB), current in [4 KB, 8 KB)
+    C2 z[R];
+    if (R == 8) {
+      // both blocks in flight together; one lane-reversal exchange for the odd halves of both:
+      // previous block in [0, 4 KB), current block in [4 KB, 8 KB)
+      v4f cb[R], pb[R];
+      const bool cur_ok = issue_loads(kCur, pair, n, cb);
+      const bool prv_ok = issue_loads(kPrv, pair, n, pb);
+      if (!cur_ok) zero_row(cb);   // edge frames only (wave-uniform)
+      if (!prv_ok) zero_row(pb);
       wave_sync();
       {
         char* w = buf + 8 * (63 - lane);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < R; ++c) {
           *reinterpret_cast<v2f*>(w + 512 * c) = v2f{pb[c].z, pb[c].w};
           *reinterpret_cast<v2f*>(w + 4096 + 512 * c) = v2f{cb[c].z, cb[c].w};
         }
@@ -576,37 +615,72 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
       wave_sync();
       const char* rd = buf + 8 * lane;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const v2f xop = *reinterpret_cast<const v2f*>(rd + 512 * ((3 - r) & 7));
-        const v2f xoc = *reinterpret_cast<const v2f*>(rd + 4096 + 512 * ((3 - r) & 7));
-        const v4f& gp = pb[(r + 4) & 7];
-        const v4f& gc = cb[(r + 4) & 7];
+      for (int r = 0; r < R; ++r) {
+        const v2f xop = *reinterpret_cast<const v2f*>(rd + 512 * ((R / 2 - 1 - r) & (R - 1)));
+        const v2f xoc = *reinterpret_cast<const v2f*>(rd + 4096 + 512 * ((R / 2 - 1 - r) & (R - 1)));
+        const v4f& gp = pb[(r + R / 2) & (R - 1)];
+        const v4f& gc = cb[(r + R / 2) & (R - 1)];
         const v2f xep = v2f{gp.x, gp.y}, xec = v2f{gc.x, gc.y};
-        const v2f ab = reinterpret_cast<const v2f*>(tab + I_COEF)[r * 64 + lane];
+        const v2f ab = reinterpret_cast<const v2f*>(tab + G::I_COEF)[r * 64 + lane];
         const v2f carry = ab.y * xep + ab.x * xop;
-        const v2f cur = (r < 4) ? (ab.y * xoc - ab.x * xec) : (ab.x * xec - ab.y * xoc);
-        // element e = lane + 64 r: v[2e] + i v[N-1-2e]; for e < 256 the real part comes from the previous block
-        const C2 v = (r < 4) ? C2{carry, cur} : C2{cur, carry};
-        z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + I_PRE)[r * 64 + lane]);
+        const v2f cur = (r < R / 2) ? (ab.y * xoc - ab.x * xec) : (ab.x * xec - ab.y * xoc);
+        // element e = lane + 64 r: v[2e] + i v[N-1-2e]; for e < N/4 the real part comes from the previous block
+        const C2 v = (r < R / 2) ? C2{carry, cur} : C2{cur, carry};
+        z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + G::I_PRE)[r * 64 + lane]);
+      }
+    } else {
+      // larger frames: one block at a time (registers), each with its own lane-reversal exchange
+      v2f carry[R];
+      {
+        v4f pb[R];
+        const bool prv_ok = issue_loads(kPrv, pair, n, pb);
+        if (!prv_ok) zero_row(pb);
+        v2f xo_in[R], xo[R];
+#pragma unroll
+        for (int c = 0; c < R; ++c) xo_in[c] = v2f{pb[c].z, pb[c].w};
+        rev_exchange<R / 2 - 1, R>(buf, lane, xo_in, xo);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const v4f& gp = pb[(r + R / 2) & (R - 1)];
+          const v2f ab = reinterpret_cast<const v2f*>(tab + G::I_COEF)[r * 64 + lane];
+          carry[r] = ab.y * v2f{gp.x, gp.y} + ab.x * xo[r];
+        }
+      }
+      v4f cb[R];
+      const bool cur_ok = issue_loads(kCur, pair, n, cb);
+      if (!cur_ok) zero_row(cb);
+      v2f xo_in[R], xo[R];
+#pragma unroll
+      for (int c = 0; c < R; ++c) xo_in[c] = v2f{cb[c].z, cb[c].w};
+      rev_exchange<R / 2 - 1, R>(buf, lane, xo_in, xo);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const v4f& gc = cb[(r + R / 2) & (R - 1)];
+        const v2f xec = v2f{gc.x, gc.y};
+        const v2f ab = reinterpret_cast<const v2f*>(tab + G::I_COEF)[r * 64 + lane];
+        const v2f cur = (r < R / 2) ? (ab.y * xo[r] - ab.x * xec) : (ab.x * xec - ab.y * xo[r]);
+        const C2 v = (r < R / 2) ? C2{carry[r], cur} : C2{cur, carry[r]};
+        z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + G::I_PRE)[r * 64 + lane]);
       }
     }
-    fft512(z, buf, tab, p1, lane);
-    v4f row[8];
+    fft_wave<R>(z, buf, tab, p1, lane);
+    v4f row[R];
     {
-      // bin k = lane + 64 k2: X[2k] = Re (granule k, this lane), X[N-1-2k] = -Im (granule 511 - k, lane 63 - lane)
-      v2f xe[8], xo_in[8], xo[8];
+      // bin k = lane + 64 j: X[2k] = Re (granule k, this lane), X[N-1-2k] = -Im (granule N/2-1-k, lane 63 - lane)
+      v2f xe[R], xo_in[R], xo[R];
 #pragma unroll
-      for (int k2 = 0; k2 < 8; ++k2) {
-        const C2 r = cmul(z[k2], reinterpret_cast<const v2f*>(tab + I_POST)[k2 * 64 + lane]);
-        xe[k2] = r.re;
-        xo_in[k2] = -r.im;
+      for (int j = 0; j < R; ++j) {
+        const C2 r = cmul(z[j], reinterpret_cast<const v2f*>(tab + G::I_POST)[j * 64 + lane]);
+        xe[j] = r.re;
+        xo_in[j] = -r.im;
       }
-      rev_exchange<7>(buf, lane, xo_in, xo);
+      rev_exchange<R - 1, R>(buf, lane, xo_in, xo);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) row[i] = v4f{xe[i].x, xe[i].y, xo[i].x, xo[i].y};
+      for (int i = 0; i < R; ++i) row[i] = v4f{xe[i].x, xe[i].y, xo[i].x, xo[i].y};
     }
     const size_t frame = (size_t)b * a.F + (size_t)n;
-    // next frame of this wave: its PCM is in flight while the epilogue of this one runs
+    store_row<CMODE, R>(a.X + frame * blk, C, c0, has1, lane, row);
+    // next frame of this wave
     pair += dpair;
     n += dn;
     if (n >= a.F) {
@@ -614,16 +688,10 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_fast(FwdArgs a) {
       ++pair;
     }
     --left;
-    if (AC_PREFETCH && pair < npairs && left > 0) cur_ok = issue_loads(kCur, pair, n, cb);
-    store_row<CMODE>(a.X + frame * blk, C, c0, has1, lane, row);
-    auto halo = [&]() {
-      if (AC_PREFETCH && pair < npairs && left > 0) prv_ok = issue_loads(kPrv, pair, n, pb);
-    };
-    if (!PSY) halo();
-    if (PSY) {
+    if constexpr (PSY) {
       v2f tt;
       v4f th[8];
-      psy_stage<true, true>(row, lds, buf, pimg, pc, a.psy, lane, tt, th, halo);
+      psy_stage<true, true>(row, lds, buf, pimg, pc, a.psy, lane, tt, th);
       store_row<CMODE>(a.thr + frame * blk, C, c0, has1, lane, th);
       if (lane == 0) {
         a.t[frame * C + c0] = tt.x;
@@ -646,132 +714,139 @@ struct InvArgs {
   long long ntasks;
 };
 
-// DCT-IV of one frame held in natural order: returns (now, nxt) per output element k = lane + 64 k2.
-// Element e = lane + 64 r is X[2e] (granule e, this lane) + i X[N-1-2e] (granule 511 - e, lane 63 - lane).
-__device__ __forceinline__ void idct_frame(const v4f (&frm)[8], char* buf, gtab_t tab, const v2f (&p1)[8], int lane,
-                                           v2f (&now)[8], v2f (&nxt)[8]) {
-  C2 z[8];
+// DCT-IV of one frame held in natural order: returns (now, nxt) per output element k = lane + 64 j.
+// Element e = lane + 64 r is X[2e] (granule e, this lane) + i X[N-1-2e] (granule N/2-1-e, lane 63 - lane).
+template <int R>
+__device__ __forceinline__ void idct_frame(const v4f (&frm)[R], char* buf, gtab_t tab, const v2f (&p1)[R], int lane,
+                                           v2f (&now)[R], v2f (&nxt)[R]) {
+  using G = Geo<R>;
+  C2 z[R];
   {
-    v2f xo_in[8], xo[8];
+    v2f xo_in[R], xo[R];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) xo_in[c] = v2f{frm[c].z, frm[c].w};
-    rev_exchange<7>(buf, lane, xo_in, xo);
+    for (int c = 0; c < R; ++c) xo_in[c] = v2f{frm[c].z, frm[c].w};
+    rev_exchange<R - 1, R>(buf, lane, xo_in, xo);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < R; ++r) {
       const C2 v = {v2f{frm[r].x, frm[r].y}, xo[r]};
-      z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + I_PRE)[r * 64 + lane]);
+      z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + G::I_PRE)[r * 64 + lane]);
     }
   }
-  fft512(z, buf, tab, p1, lane);
+  fft_wave<R>(z, buf, tab, p1, lane);
 #pragma unroll
-  for (int k2 = 0; k2 < 8; ++k2) {
-    const C2 r = cmul(z[k2], reinterpret_cast<const v2f*>(tab + I_POST)[k2 * 64 + lane]);
-    // u[2k] = Re, u[N-1-2k] = -Im; k < 256 (k2 < 4): u[2k] belongs to this block, u[N-1-2k] to the next
-    if (k2 < 4) {
-      now[k2] = r.re;
-      nxt[k2] = -r.im;
+  for (int j = 0; j < R; ++j) {
+    const C2 r = cmul(z[j], reinterpret_cast<const v2f*>(tab + G::I_POST)[j * 64 + lane]);
+    // u[2k] = Re, u[N-1-2k] = -Im; k < N/4 (j < R/2): u[2k] belongs to this block, u[N-1-2k] to the next
+    if (j < R / 2) {
+      now[j] = r.re;
+      nxt[j] = -r.im;
     } else {
-      now[k2] = -r.im;
-      nxt[k2] = r.re;
+      now[j] = -r.im;
+      nxt[j] = r.re;
     }
   }
 }
 
-template <int CMODE, int NW>
-__global__ __launch_bounds__(NW * 64, AC_WPE) void k_inv_fast(InvArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS + TAB_LDS];
+template <int R, int CMODE, int NW>
+__global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_inv_fast(InvArgs a) {
+  using G = Geo<R>;
+  constexpr int FH = G::FH;
+  __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS + G::TAB_LDS];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  load_tables<NW, WAVE_LDS>(lds, a.tab + I_TOTAL, nullptr);
+  load_tables<NW, WAVE_LDS, G::I_LDS>(lds, a.tab + G::I_TOTAL, nullptr);
   char* buf = lds + wave * WAVE_LDS;
   gtab_t tab = reinterpret_cast<const float*>(lds + NW * WAVE_LDS);
-  v2f p1[8];
-  load_p1(a.tab + I_TOTAL, lane, p1);
+  v2f p1[R];
+  load_p1<R>(a.tab + G::I_TOTAL, lane, p1);
   const int C = a.C;
-  const size_t blk = (size_t)FN * C;
+  const size_t blk = (size_t)G::FN * C;
   // Synthesis carries the aliased half of the previous frame's DCT-IV, so a wave walks a short strip of consecutive
-  // output blocks (the first one costs an extra DCT-IV of the frame before the strip).  Waves are persistent and take
-  // the strips in order -- strip w, w + W, ... -- so the chip works on one contiguous window of X and of the PCM.
+  // output blocks (the first one costs an extra DCT-IV of the frame before the strip).  One strip per wave by default
+  // (workgroups dispatched in order keep the window of memory in flight contiguous); the loop serves persistent grids.
   const long long stride = (long long)gridDim.x * NW;
   for (long long task = (long long)blockIdx.x * NW + wave; task < a.ntasks; task += stride) {
-  const int sgm = (int)(task % a.nseg);
-  const long long pair = task / a.nseg;
-  const int cp = (CMODE == 0) ? 0 : (int)(pair % a.CP);
-  const long long b = (CMODE == 0) ? pair : pair / a.CP;
-  const int c0 = 2 * cp;
-  const bool has1 = (c0 + 1) < C;
-  const int n0 = sgm * a.seglen;
-  const int n1 = min(a.nblk, n0 + a.seglen);
-  const float* Xb = a.X + (size_t)b * a.Kp * blk;
+    const int sgm = (int)(task % a.nseg);
+    const long long pair = task / a.nseg;
+    const int cp = (CMODE == 0) ? 0 : (int)(pair % a.CP);
+    const long long b = (CMODE == 0) ? pair : pair / a.CP;
+    const int c0 = 2 * cp;
+    const bool has1 = (c0 + 1) < C;
+    const int n0 = sgm * a.seglen;
+    const int n1 = min(a.nblk, n0 + a.seglen);
+    const float* Xb = a.X + (size_t)b * a.Kp * blk;
+    constexpr bool NT = (AC_NT_LOAD & 4) != 0;
 
-  v2f carry[8];
-  v4f ahead[8];   // the next frame, in flight while the current one is transformed
-  if (n0 >= 1) {
-    // aliased half of frame n0-1 (always an existing frame: n0-1 < Kp)
-    v4f row[8];
-    load_row<CMODE, (AC_NT_LOAD & 4) != 0>(Xb + (size_t)(n0 - 1) * blk, C, c0, has1, lane, row);
-    if (n0 < a.Kp) load_row<CMODE, (AC_NT_LOAD & 4) != 0>(Xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
-    v2f dummy[8];
-    idct_frame(row, buf, tab, p1, lane, dummy, carry);
-  } else {
-    if (n0 < a.Kp) load_row<CMODE, (AC_NT_LOAD & 4) != 0>(Xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
-    if (a.tail_in) {
-#pragma unroll
-      for (int k2 = 0; k2 < 8; ++k2) {
-        const int k = lane + 64 * k2;
-        const int j = (k2 < 4) ? (511 - 2 * k) : (2 * k - 512);
-        carry[k2].x = a.tail_in[((size_t)b * C + c0) * FH + j];
-        carry[k2].y = has1 ? a.tail_in[((size_t)b * C + c0 + 1) * FH + j] : 0.f;
-      }
+    constexpr bool AHEAD = (R == 8);   // the next frame in flight while the current one is transformed
+    v2f carry[R];
+    v4f ahead[R];
+    if (n0 >= 1) {
+      // aliased half of frame n0-1 (always an existing frame: n0-1 < Kp)
+      v4f row[R];
+      load_row<CMODE, NT, R>(Xb + (size_t)(n0 - 1) * blk, C, c0, has1, lane, row);
+      if (AHEAD && n0 < a.Kp) load_row<CMODE, NT, R>(Xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
+      v2f dummy[R];
+      idct_frame<R>(row, buf, tab, p1, lane, dummy, carry);
     } else {
+      if (AHEAD && n0 < a.Kp) load_row<CMODE, NT, R>(Xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
+      if (a.tail_in) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) carry[r] = v2f{0.f, 0.f};
-    }
-  }
-
-  for (int n = n0; n < n1; ++n) {
-    v2f now[8], nxt[8];
-    if (n < a.Kp) {
-      idct_frame(ahead, buf, tab, p1, lane, now, nxt);
-      if (n + 1 < n1 && n + 1 < a.Kp)
-        load_row<CMODE, (AC_NT_LOAD & 4) != 0>(Xb + (size_t)(n + 1) * blk, C, c0, has1, lane, ahead);
-    } else {
+        for (int j2 = 0; j2 < R; ++j2) {
+          const int k = lane + 64 * j2;
+          const int j = (j2 < R / 2) ? (FH - 1 - 2 * k) : (2 * k - FH);
+          carry[j2].x = a.tail_in[((size_t)b * C + c0) * FH + j];
+          carry[j2].y = has1 ? a.tail_in[((size_t)b * C + c0 + 1) * FH + j] : 0.f;
+        }
+      } else {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        now[r] = v2f{0.f, 0.f};
-        nxt[r] = v2f{0.f, 0.f};
+        for (int r = 0; r < R; ++r) carry[r] = v2f{0.f, 0.f};
       }
     }
-    v4f row[8];
-    {
-      // with (a, b) = COEF[k]: o1 = a now + b carry -> out[j], o2 = b now - a carry -> out[N-1-j]  
-      // k < 256: j = 511 - 2k (odd: granule 255 - k, lane 63 - lane), N-1-j = 512 + 2k (even: granule 256 + k, this lane)
-      // else     j = 2k - 512 (even: granule k - 256, this lane),     N-1-j = 1535 - 2k (odd: granule 767 - k)
-      v2f xe[8], xo_in[8], xo[8];
-#pragma unroll
-      for (int k2 = 0; k2 < 8; ++k2) {
-        const v2f ab = reinterpret_cast<const v2f*>(tab + I_COEF)[k2 * 64 + lane];
-        const v2f o1 = ab.x * now[k2] + ab.y * carry[k2];
-        const v2f o2 = ab.y * now[k2] - ab.x * carry[k2];
-        xe[(k2 + 4) & 7] = (k2 < 4) ? o2 : o1;
-        xo_in[k2] = (k2 < 4) ? o1 : o2;
-        carry[k2] = nxt[k2];
-      }
-      rev_exchange<3>(buf, lane, xo_in, xo);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) row[i] = v4f{xe[i].x, xe[i].y, xo[i].x, xo[i].y};
-    }
-    store_row<CMODE>(a.x + ((size_t)b * a.nblk + (size_t)n) * blk, C, c0, has1, lane, row);
-  }
 
-  if (a.tail_out && n1 == a.nblk) {
+    for (int n = n0; n < n1; ++n) {
+      v2f now[R], nxt[R];
+      if (n < a.Kp) {
+        if (!AHEAD) load_row<CMODE, NT, R>(Xb + (size_t)n * blk, C, c0, has1, lane, ahead);
+        idct_frame<R>(ahead, buf, tab, p1, lane, now, nxt);
+        if (AHEAD && n + 1 < n1 && n + 1 < a.Kp)
+          load_row<CMODE, NT, R>(Xb + (size_t)(n + 1) * blk, C, c0, has1, lane, ahead);
+      } else {
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) {
-      const int k = lane + 64 * k2;
-      const int j = (k2 < 4) ? (511 - 2 * k) : (2 * k - 512);
-      a.tail_out[((size_t)b * C + c0) * FH + j] = carry[k2].x;
-      if (has1) a.tail_out[((size_t)b * C + c0 + 1) * FH + j] = carry[k2].y;
+        for (int r = 0; r < R; ++r) {
+          now[r] = v2f{0.f, 0.f};
+          nxt[r] = v2f{0.f, 0.f};
+        }
+      }
+      v4f row[R];
+      {
+        // with (a, b) = COEF[k]: o1 = a now + b carry -> out[j], o2 = b now - a carry -> out[N-1-j]  
+        // k < N/4: j = N/2-1 - 2k (odd: granule N/4-1-k, lane 63 - lane), N-1-j = N/2 + 2k (even: granule N/4+k, this lane)
+        // else     j = 2k - N/2 (even: granule k - N/4, this lane),       N-1-j = 3N/2-1 - 2k (odd: granule 3N/4-1-k)
+        v2f xe[R], xo_in[R], xo[R];
+#pragma unroll
+        for (int j2 = 0; j2 < R; ++j2) {
+          const v2f ab = reinterpret_cast<const v2f*>(tab + G::I_COEF)[j2 * 64 + lane];
+          const v2f o1 = ab.x * now[j2] + ab.y * carry[j2];
+          const v2f o2 = ab.y * now[j2] - ab.x * carry[j2];
+          xe[(j2 + R / 2) & (R - 1)] = (j2 < R / 2) ? o2 : o1;
+          xo_in[j2] = (j2 < R / 2) ? o1 : o2;
+          carry[j2] = nxt[j2];
+        }
+        rev_exchange<R / 2 - 1, R>(buf, lane, xo_in, xo);
+#pragma unroll
+        for (int i = 0; i < R; ++i) row[i] = v4f{xe[i].x, xe[i].y, xo[i].x, xo[i].y};
+      }
+      store_row<CMODE, R>(a.x + ((size_t)b * a.nblk + (size_t)n) * blk, C, c0, has1, lane, row);
     }
-  }
+
+    if (a.tail_out && n1 == a.nblk) {
+#pragma unroll
+      for (int j2 = 0; j2 < R; ++j2) {
+        const int k = lane + 64 * j2;
+        const int j = (j2 < R / 2) ? (FH - 1 - 2 * k) : (2 * k - FH);
+        a.tail_out[((size_t)b * C + c0) * FH + j] = carry[j2].x;
+        if (has1) a.tail_out[((size_t)b * C + c0 + 1) * FH + j] = carry[j2].y;
+      }
+    }
   }   // strips of this wave
 }
 
@@ -793,7 +868,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_psy_fast(PsyArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS_PSY + PSY_LDS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t* pimg = reinterpret_cast<const uint32_t*>(lds + NW * WAVE_LDS_PSY);
-  if (WANT_THR) load_tables<NW, WAVE_LDS_PSY>(lds, nullptr, a.psy.tab);
+  if (WANT_THR) load_tables<NW, WAVE_LDS_PSY, 0>(lds, nullptr, a.psy.tab);
   const long long task = (long long)blockIdx.x * NW + wave;
   if (task >= a.ntasks) return;
   char* buf = lds + wave * WAVE_LDS_PSY;
@@ -802,7 +877,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_psy_fast(PsyArgs a) {
   const long long frame = task / a.CP;
   const int C = a.C, c0 = 2 * cp;
   const bool has1 = (c0 + 1) < C;
-  const size_t blk = (size_t)FN * C;
+  const size_t blk = (size_t)PSY_FN * C;
   v4f row[8], th[8];
   load_row<CMODE>(a.X + (size_t)frame * blk, C, c0, has1, lane, row);
   v2f tt = {0.f, 0.f};
@@ -847,16 +922,16 @@ PsyParams psy_params(const ac_psy_plan* p, float drown) {
 // ------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------
-// Builds the two table images; false when the window's fold blocks are not rotations (the rectangular
-// "window", mdctransformer.py:209-211), which the two-coefficient fold cannot express.
-static bool build_mdct_fast(int N, int window, std::vector<float>* out) {
-  if (N != FN) return false;
+template <int R>
+static bool build_mdct_fast_R(int N, int window, std::vector<float>* out) {
+  using G = Geo<R>;
+  if (N != G::FN) return false;
   const int h = N / 2;
   FoldCoef c;
   fold_coefficients(N, window, c);
-  std::vector<float> t(2 * I_TOTAL, 0.f);
-  float* tf = t.data();              // analysis image
-  float* ti = t.data() + I_TOTAL;    // synthesis image
+  std::vector<float> t(2 * G::I_TOTAL, 0.f);
+  float* tf = t.data();                 // analysis image
+  float* ti = t.data() + G::I_TOTAL;    // synthesis image
   const double pi = 3.14159265358979323846;
   auto put2 = [](float* base, int i, double re, double im) {
     base[2 * i] = (float)re;
@@ -864,47 +939,56 @@ static bool build_mdct_fast(int N, int window, std::vector<float>* out) {
   };
   // the reference's lower-right quadrant (1 - w[N+j] w[N-1-j]) / w[j] carries ~1e-10 of fp64 cancellation noise
   auto same = [](double x, double y) { return std::fabs(x - y) <= 1e-8; };
-  for (int r = 0; r < 8; ++r) {
+  for (int r = 0; r < R; ++r) {
     for (int l = 0; l < 64; ++l) {
       const int i = r * 64 + l;
       const int e = l + 64 * r;                                   // input element of (lane, register)
       const int k = l + 64 * r;                                   // output bin of (lane, register)
       double ang = -pi * (e + 0.25) / N;
-      put2(tf + I_PRE, i, std::cos(ang), std::sin(ang));
-      put2(ti + I_PRE, i, std::cos(ang), std::sin(ang));
-      ang = -2.0 * pi * (double)(l * r) / 512.0;
-      put2(tf + I_P1, i, std::cos(ang), std::sin(ang));
-      put2(ti + I_P1, i, std::cos(ang), std::sin(ang));
-      if (l < 8) {
+      put2(tf + G::I_PRE, i, std::cos(ang), std::sin(ang));
+      put2(ti + G::I_PRE, i, std::cos(ang), std::sin(ang));
+      ang = -2.0 * pi * (double)(l * r) / (double)G::FH;          // W_{64R}^(lane k0), k0 = r
+      put2(tf + G::I_P1, i, std::cos(ang), std::sin(ang));
+      put2(ti + G::I_P1, i, std::cos(ang), std::sin(ang));
+      if (l < 8 && r < 8) {
         ang = -2.0 * pi * (double)(l * r) / 64.0;                 // [k1 = r][e0 = l]
-        put2(tf + I_P2, r * 8 + l, std::cos(ang), std::sin(ang));
-        put2(ti + I_P2, r * 8 + l, std::cos(ang), std::sin(ang));
+        put2(tf + G::I_P2, r * 8 + l, std::cos(ang), std::sin(ang));
+        put2(ti + G::I_P2, r * 8 + l, std::cos(ang), std::sin(ang));
       }
       ang = -pi * (double)k / N;
       const double sf = 1.0 / (N * std::sqrt(2.0)), si = 2.0 * std::sqrt(2.0);
-      put2(tf + I_POST, i, std::cos(ang) * sf, std::sin(ang) * sf);
-      put2(ti + I_POST, i, std::cos(ang) * si, std::sin(ang) * si);
+      put2(tf + G::I_POST, i, std::cos(ang) * sf, std::sin(ang) * sf);
+      put2(ti + G::I_POST, i, std::cos(ang) * si, std::sin(ang) * si);
       // analysis fold of element e (see k_fwd_fast): current-frame part cE xe + cO xo, carried part kE xe + kO xo
       double cE, cO, kE, kO;
-      if (e < h / 2) {   // samples 512+2e (even) / 511-2e (odd); current part = v[N-1-2e], carry = v'[2e]
+      if (e < h / 2) {   // samples N/2+2e (even) / N/2-1-2e (odd); current part = v[N-1-2e], carry = v'[2e]
         const int jc = h - 1 - 2 * e, jk = 2 * e;
         cE = c.a2[jc]; cO = c.a1[jc]; kE = c.a4[jk]; kO = c.a3[jk];
         if (!same(cE, -kO) || !same(cO, kE)) return false;        // (-A, B, B, A)
-      } else {           // samples 2p (even) / N-1-2p (odd), p = e-256: current part = v[2e], carry = v'[N-1-2e]
+      } else {           // samples 2p (even) / N-1-2p (odd), p = e-N/4: current part = v[2e], carry = v'[N-1-2e]
         const int pidx = e - h / 2;
         const int jc = 2 * pidx, jk = h - 1 - 2 * pidx;
         cE = c.a1[jc]; cO = c.a2[jc]; kE = c.a3[jk]; kO = c.a4[jk];
         if (!same(cE, kO) || !same(cO, -kE)) return false;        // (A, -B, B, A)
       }
-      put2(tf + I_COEF, i, kO, kE);                                // (A, B)
+      put2(tf + G::I_COEF, i, kO, kE);                             // (A, B)
       // synthesis unfold of output element k (see k_inv_fast): o1 = s1 now + s2 carry, o2 = s3 now + s4 carry
       const int j = (k < h / 2) ? (h - 1 - 2 * k) : (2 * k - h);
       if (!same(c.s3[j], c.s2[j]) || !same(c.s4[j], -c.s1[j])) return false;   // (a, b, b, -a)
-      put2(ti + I_COEF, i, c.s1[j], c.s2[j]);
+      put2(ti + G::I_COEF, i, c.s1[j], c.s2[j]);
     }
   }
   if (out) *out = t;
   return true;
+}
+
+// Builds the two table images; false when the size is not served (filters_n 1024 and 2048 are) or the window's fold
+// blocks are not rotations (the rectangular "window", mdctransformer.py:209-211), which the two-coefficient fold
+// cannot express.
+static bool build_mdct_fast(int N, int window, std::vector<float>* out) {
+  if (N == Geo<8>::FN) return build_mdct_fast_R<8>(N, window, out);
+  if (N == Geo<16>::FN) return build_mdct_fast_R<16>(N, window, out);
+  return false;
 }
 
 bool fast_mdct_supported(int N, int window) { return build_mdct_fast(N, window, nullptr); }
@@ -927,7 +1011,7 @@ int fast_mdct_plan_init(ac_mdct_plan* p) {
 static bool build_psy_fast(const ac_psy_plan* p, std::vector<uint32_t>* out) {
   const PsyTables& t = p->host;
   const int N = t.N, M = t.M;
-  if (N != FN || M != 64) return false;
+  if (N != PSY_FN || M != 64) return false;
   auto Wf = [&](int f, int j) { return (float)t.W[(size_t)f * M + j]; };
   auto Vf = [&](int j, int f) { return (float)t.W_inv[(size_t)j * N + f]; };
   std::vector<uint32_t> w(P_TOTAL, 0u);
@@ -1046,6 +1130,21 @@ static unsigned persistent_grid(int cus, int wg_per_cu, long long ntasks, int nw
   return (unsigned)g;
 }
 
+template <int R>
+static void launch_fwd_R(const FwdArgs& a, bool psy, int C, unsigned grid, hipStream_t s) {
+  if constexpr (R == 8) {
+    if (psy) {
+      const dim3 blk(AC_WAVES_PSY * 64);
+      if (C == 2) hipLaunchKernelGGL((k_fwd_fast<8, 0, true, AC_WAVES_PSY>), dim3(grid), blk, 0, s, a);
+      else hipLaunchKernelGGL((k_fwd_fast<8, 1, true, AC_WAVES_PSY>), dim3(grid), blk, 0, s, a);
+      return;
+    }
+  }
+  const dim3 blk(AC_WAVES * 64);
+  if (C == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
+  else hipLaunchKernelGGL((k_fwd_fast<R, 1, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
+}
+
 int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr,
                     float drown, const float* prev_block, int B, int Kin, int F, int C, hipStream_t s) {
   if (B <= 0 || C <= 0 || F <= 0) return AC_OK;
@@ -1064,37 +1163,30 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const float* 
   a.C = C;
   a.CP = (C + 1) / 2;
   a.nframes = (long long)B * a.CP * F;
-  static const int xcd = [] { const char* e = getenv("AC_XCD"); return e ? atoi(e) : 0; }();          // tuning hooks
+  // tuning hooks (read once): AC_XCD=1 groups consecutive workgroups per XCD; AC_FWD_T = frames per wave, workgroups
+  // dispatched in order (default 4: measured 0.603 ms against 0.615 ms for persistent waves, B = 256, K = 468 -- fresh
+  // workgroups keep the window of memory in flight contiguous); AC_FWD_T=0 = persistent waves, AC_WG_PER_CU per CU
+  static const int xcd = [] { const char* e = getenv("AC_XCD"); return e ? atoi(e) : 0; }();
   static const int wgcu = [] { const char* e = getenv("AC_WG_PER_CU"); return e ? atoi(e) : 3; }();
-  a.xcd = xcd;
-  // four frames per wave, workgroups dispatched in order (measured 0.603 ms against 0.615 ms for persistent waves,
-  // B = 256, K = 468: fresh workgroups keep the window of memory in flight contiguous); AC_FWD_T=0 = persistent
   static const int tper = [] { const char* e = getenv("AC_FWD_T"); return e ? atoi(e) : 4; }();
+  a.xcd = xcd;
   a.T = tper;
+  const int nw = psy ? AC_WAVES_PSY : AC_WAVES;
+  unsigned grid;
   if (tper > 0) {
-    const int nw = psy ? AC_WAVES_PSY : AC_WAVES;
     const long long per = (long long)nw * tper;
     long long g = (a.nframes + per - 1) / per;
     g = (g + 7) / 8 * 8;
-    const dim3 blk(nw * 64);
-    if (psy) {
-      if (C == 2) hipLaunchKernelGGL((k_fwd_fast<0, true, AC_WAVES_PSY>), dim3((unsigned)g), blk, 0, s, a);
-      else hipLaunchKernelGGL((k_fwd_fast<1, true, AC_WAVES_PSY>), dim3((unsigned)g), blk, 0, s, a);
-    } else {
-      if (C == 2) hipLaunchKernelGGL((k_fwd_fast<0, false, AC_WAVES>), dim3((unsigned)g), blk, 0, s, a);
-      else hipLaunchKernelGGL((k_fwd_fast<1, false, AC_WAVES>), dim3((unsigned)g), blk, 0, s, a);
+    if (g > 2147483647ll) {
+      set_error("problem too large for one launch (%lld workgroups)", g);
+      return AC_EINVAL;
     }
-  } else if (psy) {
-    const unsigned grid = persistent_grid(p->cus, wgcu, a.nframes, AC_WAVES_PSY);
-    const dim3 blk(AC_WAVES_PSY * 64);
-    if (C == 2) hipLaunchKernelGGL((k_fwd_fast<0, true, AC_WAVES_PSY>), dim3(grid), blk, 0, s, a);
-    else hipLaunchKernelGGL((k_fwd_fast<1, true, AC_WAVES_PSY>), dim3(grid), blk, 0, s, a);
+    grid = (unsigned)g;
   } else {
-    const unsigned grid = persistent_grid(p->cus, wgcu, a.nframes, AC_WAVES);
-    const dim3 blk(AC_WAVES * 64);
-    if (C == 2) hipLaunchKernelGGL((k_fwd_fast<0, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
-    else hipLaunchKernelGGL((k_fwd_fast<1, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
+    grid = persistent_grid(p->cus, wgcu, a.nframes, nw);
   }
+  if (p->N == Geo<8>::FN) launch_fwd_R<8>(a, psy != nullptr, C, grid, s);
+  else launch_fwd_R<16>(a, false, C, grid, s);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }
@@ -1119,10 +1211,20 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, float* x, const float
   // one strip per wave by default (workgroups dispatched in order keep the window of memory in flight contiguous;
   // persistent waves drift apart and measured slower here); AC_WG_PER_CU_INV > 0 makes the waves persistent
   static const int wgcu = [] { const char* e = getenv("AC_WG_PER_CU_INV"); return e ? atoi(e) : 0; }();   // tuning hook
-  const unsigned grid = persistent_grid(wgcu > 0 ? p->cus : (1 << 20), wgcu > 0 ? wgcu : 1024, a.ntasks, AC_WAVES);
+  const long long need = (a.ntasks + AC_WAVES - 1) / AC_WAVES;
+  if (need > 2147483647ll) {
+    set_error("problem too large for one launch (%lld workgroups)", need);
+    return AC_EINVAL;
+  }
+  const unsigned grid = wgcu > 0 ? persistent_grid(p->cus, wgcu, a.ntasks, AC_WAVES) : (unsigned)need;
   const dim3 blk(AC_WAVES * 64);
-  if (C == 2) hipLaunchKernelGGL((k_inv_fast<0, AC_WAVES>), dim3(grid), blk, 0, s, a);
-  else hipLaunchKernelGGL((k_inv_fast<1, AC_WAVES>), dim3(grid), blk, 0, s, a);
+  if (p->N == Geo<8>::FN) {
+    if (C == 2) hipLaunchKernelGGL((k_inv_fast<8, 0, AC_WAVES>), dim3(grid), blk, 0, s, a);
+    else hipLaunchKernelGGL((k_inv_fast<8, 1, AC_WAVES>), dim3(grid), blk, 0, s, a);
+  } else {
+    if (C == 2) hipLaunchKernelGGL((k_inv_fast<16, 0, AC_WAVES>), dim3(grid), blk, 0, s, a);
+    else hipLaunchKernelGGL((k_inv_fast<16, 1, AC_WAVES>), dim3(grid), blk, 0, s, a);
+  }
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }

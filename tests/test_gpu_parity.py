@@ -92,7 +92,8 @@ def test_shape_like_reference(path):
 
 
 @pytest.mark.parametrize("B,K,C,N", [(3, 5, 2, 1024), (2, 3, 1, 1024), (2, 4, 3, 1024), (1, 1, 2, 1024),
-                                     (5, 7, 2, 256), (2, 2, 5, 64), (1, 3, 2, 2048), (2, 37, 2, 1024)])
+                                     (5, 7, 2, 256), (2, 2, 5, 64), (1, 3, 2, 2048), (2, 37, 2, 1024),
+                                     (3, 9, 2, 2048), (2, 5, 1, 2048), (1, 6, 3, 2048)])
 def test_mdct_random_vs_oracle(path, B, K, C, N):
     rng = np.random.default_rng(B * 1000 + K * 10 + C)
     x = rng.uniform(-1, 1, (B, K * N, C)).astype(np.float32)
@@ -248,7 +249,8 @@ def test_db_and_noise(golden, path):
 
 # ---- streaming ------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("N,C,chunks", [(1024, 2, (3, 1, 4, 2)), (256, 1, (2, 2, 5)), (1024, 1, (5, 3))])
+@pytest.mark.parametrize("N,C,chunks", [(1024, 2, (3, 1, 4, 2)), (256, 1, (2, 2, 5)), (1024, 1, (5, 3)),
+                                        (2048, 2, (2, 5, 1))])
 def test_streaming_equals_one_shot(path, N, C, chunks):
     B, K = 2, sum(chunks)
     x = torch.rand(B, K * N, C, device="cuda") * 2 - 1
@@ -308,6 +310,8 @@ def test_fast_path_selection():
     assert audiocodec_amd.MDCTransformer(1024, "vorbis").is_fast()
     assert audiocodec_amd.MDCTransformer(1024, "sine").is_fast()
     assert not audiocodec_amd.MDCTransformer(1024, "rect").is_fast()
+    assert audiocodec_amd.MDCTransformer(2048, "vorbis").is_fast()
+    assert not audiocodec_amd.MDCTransformer(2048, "rect").is_fast()
     assert not audiocodec_amd.MDCTransformer(512).is_fast()
     assert audiocodec_amd.PsychoacousticModel(48000, 1024, 64).is_fast()
     assert not audiocodec_amd.PsychoacousticModel(48000, 2048, 64).is_fast()

@@ -223,3 +223,153 @@ if __name__ == "__main__":
         xo = o.inverse_transform(Xo.reshape(1, -1, N, 1))[0, :, 0]
         xw = synthesis_walk(Xo, wt)
         print("%-7s analysis err %.2e   synthesis err %.2e" % (wt, np.max(np.abs(Xw - Xo)), np.max(np.abs(xw - xo))))
+
+
+# ---------------- general R (complex points per lane): N = 128 R, FFT size 64 R -------------------------------------
+def fft_on_wave_R(t, R):
+    """t [64 lanes, R regs], element e = lane + 64 r.  Returns regs [64, R] with X[lane + 64 j] in register j.
+    pass 1: radix R over the registers -> k0; R/8 batches of eight 64-point FFTs (k0 = 8 beta + kappa) through
+    exchange 1 / pass 2; exchange 2 in R/8 halves h = k1 // (64 / R): reader lane k0 + R (k1 mod 64/R), pass 3."""
+    nb = R // 8
+    q = 64 // R
+    WR = np.exp(-2j * np.pi * np.arange(R)[:, None] * np.arange(R)[None, :] / R)
+    y = t @ WR
+    y = y * np.exp(-2j * np.pi * lane[:, None] * np.arange(R)[None, :] / (64 * R))
+    a, m0 = lane >> 3, lane & 7
+    z = np.zeros((64, R), complex)            # z[lane (kappa, e0), 8 beta + k1]
+    worst = {}
+    for beta in range(nb):
+        lds = np.zeros(576, complex)
+        for kap in range(8):
+            lds[ex1_write(kap, lane)] = y[:, 8 * beta + kap]
+        yy = np.stack([lds[ex1_read(lane, r)] for r in range(8)], axis=1)
+        zz = radix8(yy) * np.exp(-2j * np.pi * m0[:, None] * np.arange(8)[None, :] / 64)
+        z[:, 8 * beta:8 * beta + 8] = zz
+    out = np.zeros((64, R), complex)
+    for h in range(nb):
+        lds = np.zeros(576, complex)
+        for beta in range(nb):
+            for kk in range(q):               # k1 = q h + kk
+                addr = 9 * a + m0 + 72 * beta + 9 * R * kk
+                worst["ex2 write_b128"] = max(worst.get("ex2 write_b128", 0), cycles("write_b128", 16 * addr))
+                lds[addr] = z[:, 8 * beta + q * h + kk]
+        zz = np.stack([lds[9 * lane + r] for r in range(8)], axis=1)
+        res = radix8(zz)                      # over e0 -> k2
+        for k2 in range(8):
+            out[:, h + nb * k2] = res[:, k2]
+    return out, worst
+
+
+def check_R(R):
+    rng = np.random.default_rng(R)
+    t = rng.standard_normal((64, R)) + 1j * rng.standard_normal((64, R))
+    flat = np.zeros(64 * R, complex)
+    flat[lane[:, None] + 64 * np.arange(R)[None, :]] = t
+    ref = np.fft.fft(flat)
+    got, worst = fft_on_wave_R(t, R)
+    err = np.max(np.abs(got - ref[lane[:, None] + 64 * np.arange(R)[None, :]]))
+    print("R=%d: fft%d max err %.2e, bank cycles %s" % (R, 64 * R, err, worst))
+
+
+if __name__ == "__main__":
+    check_R(8)
+    check_R(16)
+
+
+# ---------------- lane-level walk for general R: fold / unfold index maps of the kernels ---------------------------
+def walks_R(R, window="vorbis"):
+    Nn, FHn = 128 * R, 64 * R
+    hh = Nn // 2
+    c = fold_coefficients(Nn, window)
+    rng = np.random.default_rng(7)
+    K = 3
+    x = rng.uniform(-1, 1, K * Nn)
+    o = MDCTOracle(Nn, window, np.float64)
+    Xo = o.transform(x.reshape(1, -1, 1))[0, :, :, 0]
+    xo_ref = o.inverse_transform(Xo.reshape(1, -1, Nn, 1))[0, :, 0]
+    reg = np.arange(R)
+    e_of = lane[:, None] + 64 * reg[None, :]
+    rev = 63 - lane
+    # analysis tables (A, B) = (kO, kE) as in build_mdct_fast
+    A = np.zeros((64, R)); B = np.zeros((64, R))
+    for l in range(64):
+        for r in range(R):
+            e = l + 64 * r
+            if e < hh // 2:
+                jk = 2 * e; A[l, r], B[l, r] = c["a3"][jk], c["a4"][jk]
+            else:
+                p = e - hh // 2; jk = hh - 1 - 2 * p; A[l, r], B[l, r] = c["a4"][jk], c["a3"][jk]
+    pre = np.exp(-1j * np.pi * (e_of + 0.25) / Nn)
+    kk = e_of                                  # output bin of (lane, reg)
+    post_f = np.exp(-1j * np.pi * kk / Nn) / (Nn * np.sqrt(2.0))
+    post_i = np.exp(-1j * np.pi * kk / Nn) * (2.0 * np.sqrt(2.0))
+
+    def natural(row):                          # row [N] -> E[lane, i], O[lane, i] for granule q = 64 i + lane
+        q = lane[:, None] + 64 * reg[None, :]
+        return row[2 * q], row[2 * q + 1]
+
+    def parts(block):                          # fold inputs of one block: xe[lane, r], xo[lane, r]
+        E, O = natural(block)
+        xe = E[:, (reg + R // 2) % R]
+        xo = O[rev][:, (R // 2 - 1 - reg) % R]
+        return xe, xo
+
+    Xw = np.zeros((K + 1, Nn))
+    for n in range(K + 1):
+        cur_blk = x[n * Nn:(n + 1) * Nn] if n < K else np.zeros(Nn)
+        prv_blk = x[(n - 1) * Nn:n * Nn] if n >= 1 else np.zeros(Nn)
+        xep, xop = parts(prv_blk)
+        xec, xoc = parts(cur_blk)
+        carry = B * xep + A * xop
+        lo = reg[None, :] < R // 2
+        cur = np.where(lo, B * xoc - A * xec, A * xec - B * xoc)
+        v = np.where(lo, carry + 1j * cur, cur + 1j * carry)
+        z, _ = fft_on_wave_R(v * pre, R)
+        r_ = z * post_f
+        E = r_.real
+        O = (-r_.imag)[rev][:, R - 1 - reg]
+        q = lane[:, None] + 64 * reg[None, :]
+        Xw[n, 2 * q] = E
+        Xw[n, 2 * q + 1] = O
+    err_a = np.max(np.abs(Xw - Xo))
+
+    # synthesis tables (a, b) = (s1[j], s2[j]), j = j(k)
+    a_ = np.zeros((64, R)); b_ = np.zeros((64, R))
+    for l in range(64):
+        for k2 in range(R):
+            k = l + 64 * k2
+            j = (hh - 1 - 2 * k) if k < hh // 2 else (2 * k - hh)
+            a_[l, k2], b_[l, k2] = c["s1"][j], c["s2"][j]
+    out = np.zeros((K + 2) * Nn)
+    carry = np.zeros((64, R))
+    for n in range(K + 2):
+        if n < K + 1:
+            E, O = natural(Xo[n])
+            v = E + 1j * O[rev][:, R - 1 - reg]
+            z, _ = fft_on_wave_R(v * pre, R)
+            r_ = z * post_i
+            lo = reg[None, :] < R // 2
+            now = np.where(lo, r_.real, -r_.imag)
+            nxt = np.where(lo, -r_.imag, r_.real)
+        else:
+            now = np.zeros((64, R)); nxt = np.zeros((64, R))
+        o1 = a_ * now + b_ * carry
+        o2 = b_ * now - a_ * carry
+        lo = reg[None, :] < R // 2
+        xe = np.zeros((64, R)); xo_in = np.where(lo, o1, o2)
+        xe[:, (reg + R // 2) % R] = np.where(lo, o2, o1)
+        xo = xo_in[rev][:, (R // 2 - 1 - reg) % R]
+        q = lane[:, None] + 64 * reg[None, :]
+        blk = np.zeros(Nn)
+        blk[2 * q] = xe
+        blk[2 * q + 1] = xo
+        out[n * Nn:(n + 1) * Nn] = blk
+        carry = nxt
+    err_s = np.max(np.abs(out - xo_ref))
+    print("R=%d %s: analysis err %.2e  synthesis err %.2e" % (R, window, err_a, err_s))
+
+
+if __name__ == "__main__":
+    for R_ in (8, 16):
+        for w_ in ("vorbis", "sine"):
+            walks_R(R_, w_)
