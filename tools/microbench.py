@@ -5,8 +5,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import audiocodec_amd
 
-N = 1024
-B, K, C = int(os.environ.get("B", 256)), int(os.environ.get("K", 468)), 2
+N = int(os.environ.get("N", 1024))
+B, K, C = int(os.environ.get("B", 256)), int(os.environ.get("K", 468 * 1024 // N)), int(os.environ.get("C", 2))
 dev = torch.device("cuda")
 x = torch.rand((B, K * N, C), device=dev) * 2 - 1
 codec = audiocodec_amd.AudioCodec(48000, N)
@@ -24,14 +24,14 @@ def timeit(fn, n=10):
     return e0.elapsed_time(e1) / n
 
 rows = [
-    ("encode_fused", lambda: codec.encode_into(x, X, t, thr), 12292),
-    ("transform", lambda: codec.mdct.transform(x), 8192),
-    ("inverse", lambda: codec.decode_into(X, xh), 8192),
-    ("tonality", lambda: codec.psy.tonality(X), 4100),
-    ("threshold", lambda: codec.psy.global_masking_threshold(X, t), 8196),
-    ("torch copy X (1R:1W)", lambda: thr.copy_(X), 8192),
-    ("torch fill X (0R:1W)", lambda: thr.fill_(1.0), 4096),
-    ("torch sum X (1R:0W)", lambda: X.sum(), 4096),
+    ("encode_fused", lambda: codec.encode_into(x, X, t, thr), 12 * N + 4),
+    ("transform", lambda: codec.mdct.transform(x), 8 * N),
+    ("inverse", lambda: codec.decode_into(X, xh), 8 * N),
+    ("tonality", lambda: codec.psy.tonality(X), 4 * N + 4),
+    ("threshold", lambda: codec.psy.global_masking_threshold(X, t), 8 * N + 4),
+    ("torch copy X (1R:1W)", lambda: thr.copy_(X), 8 * N),
+    ("torch fill X (0R:1W)", lambda: thr.fill_(1.0), 4 * N),
+    ("torch sum X (1R:0W)", lambda: X.sum(), 4 * N),
 ]
 for name, fn, bpf in rows:
     ms = timeit(fn)
