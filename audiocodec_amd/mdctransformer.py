@@ -17,6 +17,41 @@ import torch
 from . import _host, _lib
 
 
+class _TransformFn(torch.autograd.Function):
+    """Differentiable ``transform``.  The analysis bank T is linear; for Princen-Bradley windows the synthesis bank is
+    its scaled transpose (F^-1 = F^T and the DCT-IV is orthogonal), so
+    ``T^T g = inverse_transform(g)[:, N:-N] / (4 N)`` -- the backward pass is one launch of the synthesis kernel."""
+
+    @staticmethod
+    def forward(ctx, x, mdct):
+        ctx.mdct = mdct
+        return mdct._transform(x)
+
+    @staticmethod
+    def backward(ctx, gX):
+        m = ctx.mdct
+        m._require_adjoint()
+        N = m.filters_n
+        gx = m._inverse(gX.contiguous())[:, N:-N] / (4.0 * N)
+        return gx, None
+
+
+class _InverseFn(torch.autograd.Function):
+    """Differentiable ``inverse_transform``: ``S^T g = 4 N * transform(g)[:, 1:-1]`` (see ``_TransformFn``)."""
+
+    @staticmethod
+    def forward(ctx, X, mdct):
+        ctx.mdct = mdct
+        return mdct._inverse(X)
+
+    @staticmethod
+    def backward(ctx, gx):
+        m = ctx.mdct
+        m._require_adjoint()
+        gX = m._transform(gx.contiguous())[:, 1:-1] * (4.0 * m.filters_n)
+        return gX, None
+
+
 class MDCTransformer:
     def __init__(self, filters_n=1024, window_type="vorbis", compute_dtype=torch.float32,
                  precompute_dtype=torch.float64):
@@ -88,6 +123,16 @@ class MDCTransformer:
                   ``filters_n`` (the reference's reshape raises otherwise, ``:287,295``; here ValueError)
         :return:  ``[batches_n, blocks_n + 1, filters_n, channels_n]`` amplitudes in ]-1, 1[
         """
+        if isinstance(x, torch.Tensor) and x.requires_grad and torch.is_grad_enabled():
+            return _TransformFn.apply(x, self)
+        return self._transform(x)
+
+    def _require_adjoint(self):
+        if self._window == _lib.WINDOW_RECT:
+            raise NotImplementedError("backward needs a Princen-Bradley window ('vorbis' or 'sine'): the rectangular "
+                                      "window's synthesis bank is not the transpose of its analysis bank")
+
+    def _transform(self, x):
         x = _host.check_device_tensor(x, "x", self.compute_dtype, 3)
         B, S, C = x.shape
         N = self.filters_n
@@ -107,6 +152,11 @@ class MDCTransformer:
         :param mdct_amplitudes: ``[batches_n, blocks_n, filters_n, channels_n]``
         :return:                ``[batches_n, (blocks_n + 1) * filters_n, channels_n]``
         """
+        if isinstance(mdct_amplitudes, torch.Tensor) and mdct_amplitudes.requires_grad and torch.is_grad_enabled():
+            return _InverseFn.apply(mdct_amplitudes, self)
+        return self._inverse(mdct_amplitudes)
+
+    def _inverse(self, mdct_amplitudes):
         X = _host.check_device_tensor(mdct_amplitudes, "mdct_amplitudes", self.compute_dtype, 4)
         B, Kp, N, C = X.shape
         if N != self.filters_n:

@@ -348,3 +348,33 @@ def test_streaming_config5_ten_minutes():
     x_stream = torch.cat(outs, dim=1)                   # [1, (K+1) N, C]: block 0 is the leading half-aliased block
     assert float((x_stream[:, N:] - x).abs().max()) <= LSB
     st.close()
+
+
+@pytest.mark.parametrize("N,wt", [(1024, "vorbis"), (2048, "sine"), (64, "vorbis")])
+def test_autograd_of_the_filter_bank(path, N, wt):
+    """transform / inverse_transform are differentiable (the reference is usable inside a training graph,
+    psychoacoustic.py:311): the backward pass is the transposed bank, checked against <T x, g> = <x, T^T g>."""
+    B, K, C = 2, 4, 2
+    m = audiocodec_amd.MDCTransformer(N, window_type=wt)
+    x = (torch.rand(B, K * N, C, device="cuda") * 2 - 1).requires_grad_(True)
+    g = torch.randn(B, K + 1, N, C, device="cuda")
+    X = m.transform(x)
+    (X * g).sum().backward()
+    lhs = float((X.detach().double() * g.double()).sum())
+    rhs = float((x.detach().double() * x.grad.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
+    # independent check of the gradient itself: T^T g from the oracle's linear map applied to basis-free identity
+    o = MDCTOracle(N, wt, np.float64)
+    ref = o.inverse_transform(host(g).astype(np.float64))[:, N:-N] / (4.0 * N)
+    assert np.max(np.abs(host(x.grad) - ref)) <= 1e-5 * max(1.0, np.max(np.abs(ref)))
+    Xv = torch.randn(B, K, N, C, device="cuda").requires_grad_(True)
+    gy = torch.randn(B, (K + 1) * N, C, device="cuda")
+    y = m.inverse_transform(Xv)
+    (y * gy).sum().backward()
+    lhs = float((y.detach().double() * gy.double()).sum())
+    rhs = float((Xv.detach().double() * Xv.grad.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+    with pytest.raises(NotImplementedError):
+        mr = audiocodec_amd.MDCTransformer(64, window_type="rect")
+        xr = torch.rand(1, 128, 1, device="cuda", requires_grad=True)
+        mr.transform(xr).sum().backward()
