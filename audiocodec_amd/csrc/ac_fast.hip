@@ -76,8 +76,8 @@ struct Geo {
 };
 // waves per SIMD the register allocator must leave room for: the strided any-channel-count variants (CMODE 1) and the
 // 2048-filter kernels get the larger budget
-template <int R, int CMODE>
-constexpr int wpe() { return (R == 8 && CMODE == 0) ? AC_WPE : 2; }
+template <int R, int CMODE, bool PSY = false>
+constexpr int wpe() { return (R == 8 && CMODE != 1) ? AC_WPE : 2; }
 
 // ---- psy image (32-bit words) in ac_psy_plan::d_fast, copied into LDS once per workgroup -------------------
 constexpr int PL_G = 0;                   // [128]     spreading prototype g
@@ -258,49 +258,88 @@ __device__ __forceinline__ void rev_exchange(char* buf, int lane, const v2f (&in
   }
 }
 
-// ---- global <-> register movement of one natural-order row of N values x channel pair ---------------
-// CMODE 0: exactly two channels (interleaved, 16-byte vectors); CMODE 1: any channel count, pair (c0, c0+1)
+// ---- the two signals a wave transforms side by side, and global <-> register movement of one natural-order row ----
+// CMODE 0: exactly two channels: the pair is (clip b, channels 0 and 1), rows are interleaved 16-byte vectors.
+// CMODE 1: any channel count: signals s = b C + c are paired in order, (2p, 2p+1), across clip boundaries when C is
+//          odd (mono: two clips per wave), so no half of the packed registers idles except in one last odd pair;
+//          rows are read with stride C from one base pointer per signal.
+// CMODE 2: exactly one channel: as CMODE 1 with the two samples of a granule read / written as one 8-byte vector.
+struct Pair {
+  long long b0, b1;   // clips of the two signals
+  int c0, c1;         // their channels
+  bool has1;          // false: the second slot is the padding of an odd signal count
+};
+template <int CMODE>
+__device__ __forceinline__ Pair make_pair(long long p, int C, long long nsig) {
+  Pair q;
+  if (CMODE == 0) {
+    q.b0 = q.b1 = p;
+    q.c0 = 0;
+    q.c1 = 1;
+    q.has1 = true;
+  } else {
+    const long long s0 = 2 * p, s1 = s0 + 1;
+    q.has1 = s1 < nsig;
+    q.b0 = s0 / C;
+    q.c0 = (int)(s0 % C);
+    q.b1 = q.has1 ? s1 / C : q.b0;
+    q.c1 = q.has1 ? (int)(s1 % C) : q.c0;
+  }
+  return q;
+}
+// row of signal slot i of a [clips, rows_per_clip, N, C] tensor (floats per row over all channels = blk)
+__device__ __forceinline__ size_t row_off(long long b, long long rows_per_clip, long long row, size_t blk, int c) {
+  return ((size_t)b * (size_t)rows_per_clip + (size_t)row) * blk + (size_t)c;
+}
+
 template <int CMODE, bool NT = false, int R = 8>
-__device__ __forceinline__ void load_row(const float* __restrict__ row, int C, int c0, bool has1, int lane,
-                                         v4f (&v)[R]) {
+__device__ __forceinline__ void load_row(const float* __restrict__ r0, const float* __restrict__ r1, int C, bool has1,
+                                         int lane, v4f (&v)[R]) {
 #pragma unroll
   for (int i = 0; i < R; ++i) {
     const int q = 64 * i + lane;
     if (CMODE == 0) {
-      if (NT) v[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(row) + q);
-      else v[i] = reinterpret_cast<const v4f*>(row)[q];
+      if (NT) v[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(r0) + q);
+      else v[i] = reinterpret_cast<const v4f*>(r0)[q];
+    } else if (CMODE == 2) {
+      const v2f u = reinterpret_cast<const v2f*>(r0)[q];
+      const v2f w = has1 ? reinterpret_cast<const v2f*>(r1)[q] : v2f{0.f, 0.f};
+      v[i] = v4f{u.x, w.x, u.y, w.y};
     } else {
-      // uniform base per register + four 32-bit lane offsets shared by all registers (keeps the addresses out of VGPRs)
-      const float* ri = row + (size_t)(128 * i) * C;
-      const int off = 2 * lane * C + c0;
-      v[i].x = ri[off];
-      v[i].z = ri[off + C];
-      v[i].y = has1 ? ri[off + 1] : 0.f;
-      v[i].w = has1 ? ri[off + C + 1] : 0.f;
+      // uniform base per register + two 32-bit lane offsets shared by all registers (keeps the addresses out of VGPRs)
+      const size_t step = (size_t)(128 * i) * C;
+      const int off = 2 * lane * C;
+      v[i].x = r0[step + off];
+      v[i].z = r0[step + off + C];
+      v[i].y = has1 ? r1[step + off] : 0.f;
+      v[i].w = has1 ? r1[step + off + C] : 0.f;
     }
   }
 }
 
 template <int CMODE, int R = 8>
-__device__ __forceinline__ void store_row(float* __restrict__ row, int C, int c0, bool has1, int lane,
+__device__ __forceinline__ void store_row(float* __restrict__ r0, float* __restrict__ r1, int C, bool has1, int lane,
                                           const v4f (&v)[R]) {
 #pragma unroll
   for (int i = 0; i < R; ++i) {
     const int q = 64 * i + lane;
     if (CMODE == 0) {
 #if AC_NT_STORE
-      __builtin_nontemporal_store(v[i], reinterpret_cast<v4f*>(row) + q);
+      __builtin_nontemporal_store(v[i], reinterpret_cast<v4f*>(r0) + q);
 #else
-      reinterpret_cast<v4f*>(row)[q] = v[i];
+      reinterpret_cast<v4f*>(r0)[q] = v[i];
 #endif
+    } else if (CMODE == 2) {
+      reinterpret_cast<v2f*>(r0)[q] = v2f{v[i].x, v[i].z};
+      if (has1) reinterpret_cast<v2f*>(r1)[q] = v2f{v[i].y, v[i].w};
     } else {
-      float* ri = row + (size_t)(128 * i) * C;
-      const int off = 2 * lane * C + c0;
-      ri[off] = v[i].x;
-      ri[off + C] = v[i].z;
+      const size_t step = (size_t)(128 * i) * C;
+      const int off = 2 * lane * C;
+      r0[step + off] = v[i].x;
+      r0[step + off + C] = v[i].z;
       if (has1) {
-        ri[off + 1] = v[i].y;
-        ri[off + C + 1] = v[i].w;
+        r1[step + off] = v[i].y;
+        r1[step + off + C] = v[i].w;
       }
     }
   }
@@ -506,11 +545,12 @@ struct FwdArgs {
   const float* prev_block;   // [B, N, C] or null
   const float* tab;          // mdct tables (analysis image)
   PsyParams psy;
-  int B, Kin, F, C, CP;
+  int B, Kin, F, C;
+  long long npairs, nsig;    // wave tasks per frame index (see Pair) and B * C
   int xcd;                   // 1: consecutive logical workgroups share an XCD (gridDim.x is a multiple of 8)
   int T;                     // > 0: workgroup g owns frames [g NW T, (g+1) NW T), wave w takes g NW T + w + NW t;
                              // 0: persistent waves, wave w of W takes frames w, w + W, ...
-  long long nframes;         // B * CP * F
+  long long nframes;         // npairs * F
 };
 
 // Analysis is frame-independent: frame n of a channel pair needs blocks n-1 and n of the PCM, and a wave that loads
@@ -524,7 +564,7 @@ struct FwdArgs {
 // With (A, B) = COEF[e]:  carried part (block n-1) = B xe + A xo;  current part (block n) = B xo - A xe (r < 4),
 // A xe - B xo (r >= 4)   (Princen-Bradley windows make the 2x2 fold blocks rotations).
 template <int R, int CMODE, bool PSY, int NW>
-__global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_fwd_fast(FwdArgs a) {
+__global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY>())) void k_fwd_fast(FwdArgs a) {
   using G = Geo<R>;
   static_assert(!PSY || R == 8, "the fused epilogue serves filter_bands_n = 1024");
   // one LDS object: [NW wave buffers | table image | psy image]
@@ -552,7 +592,7 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_fwd_fast(FwdArgs
   const int dn = (int)(stride % a.F);
   long long pair = f0 / a.F;
   int n = (int)(f0 % a.F);
-  const long long npairs = (long long)a.B * a.CP;
+  const long long npairs = a.npairs;
   const float* __restrict__ xin = a.x;
   const float* __restrict__ xstate = a.prev_block;
 
@@ -560,26 +600,30 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_fwd_fast(FwdArgs
   // first / after the last) is loaded from a neighbouring, valid address and zeroed when it is consumed (returns false),
   // so that the loads stay unconditional and nothing waits for them at the point of issue.
   auto issue_loads = [&](auto which, long long pr, int fn, v4f (&dst)[R]) -> bool {
-    const int cp = (CMODE == 0) ? 0 : (int)(pr % a.CP);      // CMODE 0: exactly one channel pair
-    const long long b = (CMODE == 0) ? pr : pr / a.CP;
-    const int c0 = 2 * cp;
-    const bool has1 = (c0 + 1) < C;
-    const float* xb = xin + (size_t)b * a.Kin * blk;
-    const float* src;
+    const Pair q = make_pair<CMODE>(pr, C, a.nsig);
+    const float *s0, *s1;
     bool ok;
     if (decltype(which)::value == 0) {
       ok = fn < a.Kin;
-      src = xb + (size_t)(ok ? fn : (a.Kin > 0 ? a.Kin - 1 : 0)) * blk;
-      if (a.Kin == 0) src = a.X;                                // no PCM at all: any mapped address
+      const int blkidx = ok ? fn : (a.Kin > 0 ? a.Kin - 1 : 0);
+      s0 = xin + row_off(q.b0, a.Kin, blkidx, blk, q.c0);
+      s1 = xin + row_off(q.b1, a.Kin, blkidx, blk, q.c1);
     } else {
       ok = (fn >= 1) || xstate;
-      src = (fn >= 1) ? xb + (size_t)(fn - 1) * blk : (xstate ? xstate + (size_t)b * blk : xb);
-      if (a.Kin == 0 && !(fn == 0 && xstate)) {
-        src = a.X;
-        ok = false;
+      if (fn >= 1 || !xstate) {
+        const int blkidx = fn >= 1 ? fn - 1 : 0;
+        s0 = xin + row_off(q.b0, a.Kin, blkidx, blk, q.c0);
+        s1 = xin + row_off(q.b1, a.Kin, blkidx, blk, q.c1);
+      } else {
+        s0 = xstate + row_off(q.b0, 1, 0, blk, q.c0);
+        s1 = xstate + row_off(q.b1, 1, 0, blk, q.c1);
       }
     }
-    load_row<CMODE, ((AC_NT_LOAD >> decltype(which)::value) & 1) != 0, R>(src, C, c0, has1, lane, dst);
+    if (a.Kin == 0 && !(decltype(which)::value == 1 && fn == 0 && xstate)) {   // no PCM at all: any mapped address
+      s0 = s1 = a.X;
+      ok = false;
+    }
+    load_row<CMODE, ((AC_NT_LOAD >> decltype(which)::value) & 1) != 0, R>(s0, s1, C, q.has1, lane, dst);
     return ok;
   };
   constexpr std::integral_constant<int, 0> kCur{};
@@ -590,10 +634,7 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_fwd_fast(FwdArgs
   };
 
   while (pair < npairs && left > 0) {
-    const int cp = (CMODE == 0) ? 0 : (int)(pair % a.CP);
-    const long long b = (CMODE == 0) ? pair : pair / a.CP;
-    const int c0 = 2 * cp;
-    const bool has1 = (c0 + 1) < C;
+    const Pair pq = make_pair<CMODE>(pair, C, a.nsig);
     C2 z[R];
     if (R == 8) {
       // both blocks in flight together; one lane-reversal exchange for the odd halves of both:
@@ -678,8 +719,9 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_fwd_fast(FwdArgs
 #pragma unroll
       for (int i = 0; i < R; ++i) row[i] = v4f{xe[i].x, xe[i].y, xo[i].x, xo[i].y};
     }
-    const size_t frame = (size_t)b * a.F + (size_t)n;
-    store_row<CMODE, R>(a.X + frame * blk, C, c0, has1, lane, row);
+    const size_t o0 = row_off(pq.b0, a.F, n, blk, pq.c0), o1 = row_off(pq.b1, a.F, n, blk, pq.c1);
+    const size_t t0 = ((size_t)pq.b0 * a.F + (size_t)n) * C + pq.c0, t1 = ((size_t)pq.b1 * a.F + (size_t)n) * C + pq.c1;
+    store_row<CMODE, R>(a.X + o0, a.X + o1, C, pq.has1, lane, row);
     // next frame of this wave
     pair += dpair;
     n += dn;
@@ -692,10 +734,10 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_fwd_fast(FwdArgs
       v2f tt;
       v4f th[8];
       psy_stage<true, true>(row, lds, buf, pimg, pc, a.psy, lane, tt, th);
-      store_row<CMODE>(a.thr + frame * blk, C, c0, has1, lane, th);
+      store_row<CMODE>(a.thr + o0, a.thr + o1, C, pq.has1, lane, th);
       if (lane == 0) {
-        a.t[frame * C + c0] = tt.x;
-        if (has1) a.t[frame * C + c0 + 1] = tt.y;
+        a.t[t0] = tt.x;
+        if (pq.has1) a.t[t1] = tt.y;
       }
     }
   }
@@ -710,8 +752,9 @@ struct InvArgs {
   const float* tail_in;    // [B, C, N/2] or null
   float* tail_out;         // [B, C, N/2] or null
   const float* tab;
-  int B, Kp, nblk, C, CP, seglen, nseg;
-  long long ntasks;
+  int B, Kp, nblk, C, seglen, nseg;
+  long long npairs, nsig;  // see Pair
+  long long ntasks;        // npairs * nseg
 };
 
 // DCT-IV of one frame held in natural order: returns (now, nxt) per output element k = lane + 64 j.
@@ -766,14 +809,13 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_inv_fast(InvArgs
   const long long stride = (long long)gridDim.x * NW;
   for (long long task = (long long)blockIdx.x * NW + wave; task < a.ntasks; task += stride) {
     const int sgm = (int)(task % a.nseg);
-    const long long pair = task / a.nseg;
-    const int cp = (CMODE == 0) ? 0 : (int)(pair % a.CP);
-    const long long b = (CMODE == 0) ? pair : pair / a.CP;
-    const int c0 = 2 * cp;
-    const bool has1 = (c0 + 1) < C;
+    const Pair pq = make_pair<CMODE>(task / a.nseg, C, a.nsig);
+    const bool has1 = pq.has1;
     const int n0 = sgm * a.seglen;
     const int n1 = min(a.nblk, n0 + a.seglen);
-    const float* Xb = a.X + (size_t)b * a.Kp * blk;
+    const float* X0 = a.X + row_off(pq.b0, a.Kp, 0, blk, pq.c0);   // frame 0 of the two signals
+    const float* X1 = a.X + row_off(pq.b1, a.Kp, 0, blk, pq.c1);
+    const size_t ts0 = ((size_t)pq.b0 * C + pq.c0) * FH, ts1 = ((size_t)pq.b1 * C + pq.c1) * FH;   // stream state rows
     constexpr bool NT = (AC_NT_LOAD & 4) != 0;
 
     constexpr bool AHEAD = (R == 8);   // the next frame in flight while the current one is transformed
@@ -782,19 +824,19 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_inv_fast(InvArgs
     if (n0 >= 1) {
       // aliased half of frame n0-1 (always an existing frame: n0-1 < Kp)
       v4f row[R];
-      load_row<CMODE, NT, R>(Xb + (size_t)(n0 - 1) * blk, C, c0, has1, lane, row);
-      if (AHEAD && n0 < a.Kp) load_row<CMODE, NT, R>(Xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
+      load_row<CMODE, NT, R>(X0 + (size_t)(n0 - 1) * blk, X1 + (size_t)(n0 - 1) * blk, C, has1, lane, row);
+      if (AHEAD && n0 < a.Kp) load_row<CMODE, NT, R>(X0 + (size_t)n0 * blk, X1 + (size_t)n0 * blk, C, has1, lane, ahead);
       v2f dummy[R];
       idct_frame<R>(row, buf, tab, p1, lane, dummy, carry);
     } else {
-      if (AHEAD && n0 < a.Kp) load_row<CMODE, NT, R>(Xb + (size_t)n0 * blk, C, c0, has1, lane, ahead);
+      if (AHEAD && n0 < a.Kp) load_row<CMODE, NT, R>(X0 + (size_t)n0 * blk, X1 + (size_t)n0 * blk, C, has1, lane, ahead);
       if (a.tail_in) {
 #pragma unroll
         for (int j2 = 0; j2 < R; ++j2) {
           const int k = lane + 64 * j2;
           const int j = (j2 < R / 2) ? (FH - 1 - 2 * k) : (2 * k - FH);
-          carry[j2].x = a.tail_in[((size_t)b * C + c0) * FH + j];
-          carry[j2].y = has1 ? a.tail_in[((size_t)b * C + c0 + 1) * FH + j] : 0.f;
+          carry[j2].x = a.tail_in[ts0 + j];
+          carry[j2].y = has1 ? a.tail_in[ts1 + j] : 0.f;
         }
       } else {
 #pragma unroll
@@ -805,10 +847,10 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_inv_fast(InvArgs
     for (int n = n0; n < n1; ++n) {
       v2f now[R], nxt[R];
       if (n < a.Kp) {
-        if (!AHEAD) load_row<CMODE, NT, R>(Xb + (size_t)n * blk, C, c0, has1, lane, ahead);
+        if (!AHEAD) load_row<CMODE, NT, R>(X0 + (size_t)n * blk, X1 + (size_t)n * blk, C, has1, lane, ahead);
         idct_frame<R>(ahead, buf, tab, p1, lane, now, nxt);
         if (AHEAD && n + 1 < n1 && n + 1 < a.Kp)
-          load_row<CMODE, NT, R>(Xb + (size_t)(n + 1) * blk, C, c0, has1, lane, ahead);
+          load_row<CMODE, NT, R>(X0 + (size_t)(n + 1) * blk, X1 + (size_t)(n + 1) * blk, C, has1, lane, ahead);
       } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -835,7 +877,8 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_inv_fast(InvArgs
 #pragma unroll
         for (int i = 0; i < R; ++i) row[i] = v4f{xe[i].x, xe[i].y, xo[i].x, xo[i].y};
       }
-      store_row<CMODE, R>(a.x + ((size_t)b * a.nblk + (size_t)n) * blk, C, c0, has1, lane, row);
+      store_row<CMODE, R>(a.x + row_off(pq.b0, a.nblk, n, blk, pq.c0), a.x + row_off(pq.b1, a.nblk, n, blk, pq.c1), C, has1,
+                          lane, row);
     }
 
     if (a.tail_out && n1 == a.nblk) {
@@ -843,8 +886,8 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_inv_fast(InvArgs
       for (int j2 = 0; j2 < R; ++j2) {
         const int k = lane + 64 * j2;
         const int j = (j2 < R / 2) ? (FH - 1 - 2 * k) : (2 * k - FH);
-        a.tail_out[((size_t)b * C + c0) * FH + j] = carry[j2].x;
-        if (has1) a.tail_out[((size_t)b * C + c0 + 1) * FH + j] = carry[j2].y;
+        a.tail_out[ts0 + j] = carry[j2].x;
+        if (has1) a.tail_out[ts1 + j] = carry[j2].y;
       }
     }
   }   // strips of this wave
@@ -859,8 +902,9 @@ struct PsyArgs {
   float* t_out;
   float* thr;
   PsyParams psy;
-  int C, CP;
-  long long ntasks;   // B * F * CP
+  int C, F;
+  long long nsig;     // B * C
+  long long ntasks;   // npairs * F
 };
 
 template <int CMODE, bool WANT_T, bool WANT_THR, int NW>
@@ -873,26 +917,28 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_psy_fast(PsyArgs a) {
   if (task >= a.ntasks) return;
   char* buf = lds + wave * WAVE_LDS_PSY;
   if (WANT_THR) *reinterpret_cast<v2f*>(buf + ZERO_OFF) = v2f{0.f, 0.f};
-  const int cp = (int)(task % a.CP);
-  const long long frame = task / a.CP;
-  const int C = a.C, c0 = 2 * cp;
-  const bool has1 = (c0 + 1) < C;
+  const int f = (int)(task % a.F);
+  const int C = a.C;
+  const Pair pq = make_pair<CMODE>(task / a.F, C, a.nsig);
+  const bool has1 = pq.has1;
   const size_t blk = (size_t)PSY_FN * C;
+  const size_t o0 = row_off(pq.b0, a.F, f, blk, pq.c0), o1 = row_off(pq.b1, a.F, f, blk, pq.c1);
+  const size_t t0 = ((size_t)pq.b0 * a.F + (size_t)f) * C + pq.c0, t1 = ((size_t)pq.b1 * a.F + (size_t)f) * C + pq.c1;
   v4f row[8], th[8];
-  load_row<CMODE>(a.X + (size_t)frame * blk, C, c0, has1, lane, row);
+  load_row<CMODE>(a.X + o0, a.X + o1, C, has1, lane, row);
   v2f tt = {0.f, 0.f};
   if (!WANT_T) {
-    tt.x = a.t_in[(size_t)frame * C + c0];
-    tt.y = has1 ? a.t_in[(size_t)frame * C + c0 + 1] : 0.f;
+    tt.x = a.t_in[t0];
+    tt.y = has1 ? a.t_in[t1] : 0.f;
   }
   PsyLane pc;
   if (WANT_THR) pc = load_psy_lane(a.psy.tab, lane, (uint32_t)(wave * WAVE_LDS_PSY));
   psy_stage<WANT_T, WANT_THR>(row, lds, buf, pimg, pc, a.psy, lane, tt, th);
   if (WANT_T && lane == 0) {
-    a.t_out[(size_t)frame * C + c0] = tt.x;
-    if (has1) a.t_out[(size_t)frame * C + c0 + 1] = tt.y;
+    a.t_out[t0] = tt.x;
+    if (has1) a.t_out[t1] = tt.y;
   }
-  if (WANT_THR) store_row<CMODE>(a.thr + (size_t)frame * blk, C, c0, has1, lane, th);
+  if (WANT_THR) store_row<CMODE>(a.thr + o0, a.thr + o1, C, has1, lane, th);
 }
 
 // synthesis strips: short, so that the strips in flight cover a nearly contiguous window of memory (HBM rewards that
@@ -1136,12 +1182,14 @@ static void launch_fwd_R(const FwdArgs& a, bool psy, int C, unsigned grid, hipSt
     if (psy) {
       const dim3 blk(AC_WAVES_PSY * 64);
       if (C == 2) hipLaunchKernelGGL((k_fwd_fast<8, 0, true, AC_WAVES_PSY>), dim3(grid), blk, 0, s, a);
+      else if (C == 1) hipLaunchKernelGGL((k_fwd_fast<8, 2, true, AC_WAVES_PSY>), dim3(grid), blk, 0, s, a);
       else hipLaunchKernelGGL((k_fwd_fast<8, 1, true, AC_WAVES_PSY>), dim3(grid), blk, 0, s, a);
       return;
     }
   }
   const dim3 blk(AC_WAVES * 64);
   if (C == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
+  else if (C == 1) hipLaunchKernelGGL((k_fwd_fast<R, 2, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
   else hipLaunchKernelGGL((k_fwd_fast<R, 1, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
 }
 
@@ -1161,8 +1209,9 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const float* 
   a.Kin = Kin;
   a.F = F;
   a.C = C;
-  a.CP = (C + 1) / 2;
-  a.nframes = (long long)B * a.CP * F;
+  a.nsig = (long long)B * C;
+  a.npairs = (C == 2) ? (long long)B : (a.nsig + 1) / 2;
+  a.nframes = a.npairs * F;
   // tuning hooks (read once): AC_XCD=1 groups consecutive workgroups per XCD; AC_FWD_T = frames per wave, workgroups
   // dispatched in order (default 4: measured 0.603 ms against 0.615 ms for persistent waves, B = 256, K = 468 -- fresh
   // workgroups keep the window of memory in flight contiguous); AC_FWD_T=0 = persistent waves, AC_WG_PER_CU per CU
@@ -1204,10 +1253,11 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, float* x, const float
   a.Kp = Kp;
   a.nblk = nblk;
   a.C = C;
-  a.CP = (C + 1) / 2;
-  a.seglen = pick_seglen((long long)B * a.CP, nblk);
+  a.nsig = (long long)B * C;
+  a.npairs = (C == 2) ? (long long)B : (a.nsig + 1) / 2;
+  a.seglen = pick_seglen(a.npairs, nblk);
   a.nseg = (nblk + a.seglen - 1) / a.seglen;
-  a.ntasks = (long long)B * a.CP * a.nseg;
+  a.ntasks = a.npairs * a.nseg;
   // one strip per wave by default (workgroups dispatched in order keep the window of memory in flight contiguous;
   // persistent waves drift apart and measured slower here); AC_WG_PER_CU_INV > 0 makes the waves persistent
   static const int wgcu = [] { const char* e = getenv("AC_WG_PER_CU_INV"); return e ? atoi(e) : 0; }();   // tuning hook
@@ -1220,9 +1270,11 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, float* x, const float
   const dim3 blk(AC_WAVES * 64);
   if (p->N == Geo<8>::FN) {
     if (C == 2) hipLaunchKernelGGL((k_inv_fast<8, 0, AC_WAVES>), dim3(grid), blk, 0, s, a);
+    else if (C == 1) hipLaunchKernelGGL((k_inv_fast<8, 2, AC_WAVES>), dim3(grid), blk, 0, s, a);
     else hipLaunchKernelGGL((k_inv_fast<8, 1, AC_WAVES>), dim3(grid), blk, 0, s, a);
   } else {
     if (C == 2) hipLaunchKernelGGL((k_inv_fast<16, 0, AC_WAVES>), dim3(grid), blk, 0, s, a);
+    else if (C == 1) hipLaunchKernelGGL((k_inv_fast<16, 2, AC_WAVES>), dim3(grid), blk, 0, s, a);
     else hipLaunchKernelGGL((k_inv_fast<16, 1, AC_WAVES>), dim3(grid), blk, 0, s, a);
   }
   AC_HIP_CHECK(hipGetLastError());
@@ -1239,8 +1291,9 @@ int launch_psy_fast(const ac_psy_plan* p, const float* X, const float* t_in, flo
   a.thr = thr;
   a.psy = psy_params(p, drown);
   a.C = C;
-  a.CP = (C + 1) / 2;
-  a.ntasks = (long long)B * F * a.CP;
+  a.F = F;
+  a.nsig = (long long)B * C;
+  a.ntasks = ((C == 2) ? (long long)B : (a.nsig + 1) / 2) * F;
   unsigned grid;
   int st = grid_for(a.ntasks, AC_WAVES, &grid);
   if (st) return st;
@@ -1248,12 +1301,15 @@ int launch_psy_fast(const ac_psy_plan* p, const float* X, const float* t_in, flo
   const bool want_t = (t_out != nullptr), want_thr = (thr != nullptr);
   if (want_t && !want_thr) {
     if (C == 2) hipLaunchKernelGGL((k_psy_fast<0, true, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
+    else if (C == 1) hipLaunchKernelGGL((k_psy_fast<2, true, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
     else hipLaunchKernelGGL((k_psy_fast<1, true, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
   } else if (!want_t && want_thr) {
     if (C == 2) hipLaunchKernelGGL((k_psy_fast<0, false, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
+    else if (C == 1) hipLaunchKernelGGL((k_psy_fast<2, false, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
     else hipLaunchKernelGGL((k_psy_fast<1, false, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
   } else if (want_t && want_thr) {
     if (C == 2) hipLaunchKernelGGL((k_psy_fast<0, true, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
+    else if (C == 1) hipLaunchKernelGGL((k_psy_fast<2, true, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
     else hipLaunchKernelGGL((k_psy_fast<1, true, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
   }
   AC_HIP_CHECK(hipGetLastError());
