@@ -1235,7 +1235,9 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const float* 
     grid = persistent_grid(p->cus, wgcu, a.nframes, nw);
   }
   if (p->N == Geo<8>::FN) launch_fwd_R<8>(a, psy != nullptr, C, grid, s);
+#ifndef AC_NO_R16
   else launch_fwd_R<16>(a, false, C, grid, s);
+#endif
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }
@@ -1273,9 +1275,11 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, float* x, const float
     else if (C == 1) hipLaunchKernelGGL((k_inv_fast<8, 2, AC_WAVES>), dim3(grid), blk, 0, s, a);
     else hipLaunchKernelGGL((k_inv_fast<8, 1, AC_WAVES>), dim3(grid), blk, 0, s, a);
   } else {
+#ifndef AC_NO_R16
     if (C == 2) hipLaunchKernelGGL((k_inv_fast<16, 0, AC_WAVES>), dim3(grid), blk, 0, s, a);
     else if (C == 1) hipLaunchKernelGGL((k_inv_fast<16, 2, AC_WAVES>), dim3(grid), blk, 0, s, a);
     else hipLaunchKernelGGL((k_inv_fast<16, 1, AC_WAVES>), dim3(grid), blk, 0, s, a);
+#endif
   }
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
