@@ -1,5 +1,6 @@
 // C ABI of libaudiocodec_amd.so (see include/audiocodec_amd.h).  gfx950 only.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -314,8 +315,16 @@ int ac_encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const floa
   AC_REQUIRE(X != nullptr && t != nullptr && thr != nullptr && (x != nullptr || K == 0), "NULL tensor pointer");
   DeviceGuard guard(mdct->device);
   hipStream_t s = (hipStream_t)stream;
-  if (mdct->fast && psy->fast && !g_force_generic)
-    return launch_fwd_fast(mdct, psy, x, X, t, thr, drown, nullptr, B, K, K + 1, C, s);
+  if (mdct->fast && psy->fast && !g_force_generic) {
+    static const int fuse2048 = [] { const char* e = getenv("AC_FUSE_2048"); return e ? atoi(e) : 0; }();   // tuning hook
+    if (mdct->N == 1024 || fuse2048)
+      return launch_fwd_fast(mdct, psy, x, X, t, thr, drown, nullptr, B, K, K + 1, C, s);
+    // filters_n = 2048: the fused kernel runs out of registers (59 spilled at 256); two wave-level launches instead,
+    // the second one computing tonality and threshold in one pass over X
+    st = launch_fwd_fast(mdct, nullptr, x, X, nullptr, nullptr, 0.f, nullptr, B, K, K + 1, C, s);
+    if (!st) st = launch_psy_fast(psy, X, nullptr, t, thr, drown, B, K + 1, C, s);
+    return st;
+  }
   // un-fused composition for configurations the fused kernel does not cover
   st = ac_mdct_forward(mdct, x, X, B, K, C, stream);
   if (!st) st = ac_tonality(psy, X, t, B, K + 1, C, stream);

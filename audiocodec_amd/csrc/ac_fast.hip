@@ -36,7 +36,6 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const float* gtab_t;   // LDS-resident table image
 
-constexpr int PSY_FN = 1024;        // filter_bands_n of the wave-level psychoacoustic epilogue
 #ifndef AC_WAVES_PSY
 #define AC_WAVES_PSY 4              // waves per workgroup, fused encode (LDS: three workgroups per CU)
 #endif
@@ -79,17 +78,24 @@ struct Geo {
 template <int R, int CMODE, bool PSY = false>
 constexpr int wpe() { return (R == 8 && CMODE != 1) ? AC_WPE : 2; }
 
-// ---- psy image (32-bit words) in ac_psy_plan::d_fast, copied into LDS once per workgroup -------------------
-constexpr int PL_G = 0;                   // [128]     spreading prototype g
-constexpr int PL_LST = 128;               // [12][64]  gather lists: two 16-bit LDS byte offsets per word
-constexpr int PL_HALF = 12;               // list length / 2
-constexpr int PL_LDS = PL_LST + PL_HALF * 64;    // 896 words = 3584 bytes live in LDS; the rest is held in registers
-constexpr int PL_BAND = PL_LDS;           // [2][64] x 4 words: per-lane (= per Bark band) constants
-//   group 0: edge offsets (lo | hi << 16), wf, wl, quiet        group 1: beta, rho, u0, u1
-constexpr int PL_IDX = PL_BAND + 512;     // [2][64] x 4 words: byte offsets (lo | hi << 16) of the threshold entries
-//   of the two bins of granule 64 i + lane, word i
-constexpr int P_TOTAL = PL_IDX + 512;     // 1920 words in global memory
-constexpr int PSY_LDS = PL_LDS * 4;
+// ---- psy image (32-bit words) in ac_psy_plan::d_fast for filter_bands_n = 128 R and 64 Bark bands; the first PL_LDS
+// words are copied into LDS once per workgroup, the rest is held in registers.  The spectrum passes through the wave's
+// 8 KB intensity image in NH = R / 8 halves of 1024 bins.
+template <int R>
+struct PsyGeo {
+  static constexpr int NH = R / 8;
+  static constexpr int PL_HALF = (R == 8) ? 12 : 16;          // gather-list length / 2 (per half of the spectrum)
+  static constexpr int FN = 128 * R;
+  static constexpr int PL_G = 0;                              // [128]         spreading prototype g
+  static constexpr int PL_LST = 128;                          // [NH][PL_HALF][64]  gather lists: two 16-bit LDS byte offsets per word
+  static constexpr int PL_LDS = PL_LST + NH * PL_HALF * 64;   // R = 8: 896 words = 3584 bytes
+  static constexpr int PL_BAND = PL_LDS;                      // [NH + 1][64] x 4 words: per-lane (= per Bark band) constants
+  //   group h < NH: edge offsets of half h (lo | hi << 16), wf, wl, quiet      group NH: beta, rho, u0, u1
+  static constexpr int PL_IDX = PL_BAND + (NH + 1) * 256;     // [R / 4][64] x 4 words: byte offsets (lo | hi << 16) of the
+  //   threshold entries of the two bins of granule 64 i + lane, word i
+  static constexpr int P_TOTAL = PL_IDX + (R / 4) * 256;
+  static constexpr int PSY_LDS = PL_LDS * 4;
+};
 
 struct C2 {   // one complex value for both channels of the pair
   v2f re, im;
@@ -379,24 +385,31 @@ struct PsyParams {
 };
 
 // per-lane (= per Bark band) constants and the lane's threshold-entry offsets, held in registers
+template <int R>
 struct PsyLane {
-  v4f bc0;   // edge offsets (lo | hi << 16), wf, wl, quiet
-  v4f bc1;   // beta, rho, u0, u1
-  v4f ia, ib;   // byte offsets (lo | hi << 16) of the entries of the two bins of granule 64 i + lane, i = 0..7
+  v4f bc0[R / 8];   // per half: edge offsets (lo | hi << 16), wf, wl, quiet
+  v4f bc1;          // beta, rho, u0, u1
+  v4f idx[R / 4];   // byte offsets (lo | hi << 16) of the entries of the two bins of granule 64 i + lane, word i
 };
 // wave_base = byte offset of the wave's buffer inside the workgroup's LDS object: the packed 16-bit offsets become
 // absolute, so unpacking one costs a single and / shift inside the loop
-__device__ __forceinline__ PsyLane load_psy_lane(const uint32_t* __restrict__ tab, int lane, uint32_t wave_base) {
-  PsyLane c;
-  c.bc0 = reinterpret_cast<const v4f*>(tab + PL_BAND)[lane];
-  c.bc1 = reinterpret_cast<const v4f*>(tab + PL_BAND)[64 + lane];
-  c.ia = reinterpret_cast<const v4f*>(tab + PL_IDX)[lane];
-  c.ib = reinterpret_cast<const v4f*>(tab + PL_IDX)[64 + lane];
+template <int R>
+__device__ __forceinline__ PsyLane<R> load_psy_lane(const uint32_t* __restrict__ tab, int lane, uint32_t wave_base) {
+  using P = PsyGeo<R>;
+  PsyLane<R> c;
   const uint32_t both = wave_base * 0x10001u;
   auto rebase = [both](float f) { return __uint_as_float(__float_as_uint(f) + both); };
-  c.bc0.x = rebase(c.bc0.x);
-  c.ia = v4f{rebase(c.ia.x), rebase(c.ia.y), rebase(c.ia.z), rebase(c.ia.w)};
-  c.ib = v4f{rebase(c.ib.x), rebase(c.ib.y), rebase(c.ib.z), rebase(c.ib.w)};
+#pragma unroll
+  for (int h = 0; h < P::NH; ++h) {
+    c.bc0[h] = reinterpret_cast<const v4f*>(tab + P::PL_BAND)[h * 64 + lane];
+    c.bc0[h].x = rebase(c.bc0[h].x);
+  }
+  c.bc1 = reinterpret_cast<const v4f*>(tab + P::PL_BAND)[P::NH * 64 + lane];
+#pragma unroll
+  for (int i = 0; i < R / 4; ++i) {
+    const v4f w = reinterpret_cast<const v4f*>(tab + P::PL_IDX)[i * 64 + lane];
+    c.idx[i] = v4f{rebase(w.x), rebase(w.y), rebase(w.z), rebase(w.w)};
+  }
   return c;
 }
 
@@ -408,76 +421,81 @@ __device__ __forceinline__ uint32_t in_loop(uint32_t w) {
 
 // buf = the wave's LDS region (WAVE_LDS_PSY bytes), pimg = the workgroup's copy of the psy image
 // lds0 = base of the workgroup's LDS object (the absolute offsets of PsyLane count from it)
-template <bool WANT_T, bool WANT_THR>
-__device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* lds0, char* buf, const uint32_t* pimg,
-                                          const PsyLane& pc, const PsyParams& pp, int lane, v2f& t, v4f (&thr)[8]) {
-  if (WANT_THR) wave_sync();
-  v2f slog = {0.f, 0.f}, ssq = {0.f, 0.f};
-  {
-    const int lsw = lane ^ ((lane >> 4) & 3);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const v4f I = xq[i] * xq[i];
-      // intensities in natural order: granule q = (I[2q], I[2q+1]) x (c0, c1) at byte 16 (q ^ ((q >> 4) & 3))
-      if (WANT_THR) *reinterpret_cast<v4f*>(buf + 16 * lsw + 1024 * i) = I;
-      if (WANT_T) {
-        const v2f ie = v2f{I.x, I.y}, io = v2f{I.z, I.w};
-        ssq += ie + io;
-        // ln max(eps, a) + ln max(eps, b) = ln(max(eps, a) max(eps, b)): one v_log per two bins; the product stays
-        // in the normal float range for |X| < 1e9 (>= 1e-28)
-        slog += log2v(maxv(ie, kEps) * maxv(io, kEps));
-      }
-    }
-  }
+template <int R, bool WANT_T, bool WANT_THR>
+__device__ __forceinline__ void psy_stage(const v4f (&xq)[R], char* lds0, char* buf, const uint32_t* pimg,
+                                          const PsyLane<R>& pc, const PsyParams& pp, int lane, v2f& t, v4f (&thr)[R]) {
+  using P = PsyGeo<R>;
   if (WANT_T) {
+    v2f slog = {0.f, 0.f}, ssq = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const v4f I = xq[i] * xq[i];
+      const v2f ie = v2f{I.x, I.y}, io = v2f{I.z, I.w};
+      ssq += ie + io;
+      // ln max(eps, a) + ln max(eps, b) = ln(max(eps, a) max(eps, b)): one v_log per two bins; the product stays
+      // in the normal float range for |X| < 1e9 (>= 1e-28)
+      slog += log2v(maxv(ie, kEps) * maxv(io, kEps));
+    }
     slog.x = wave_sum(slog.x);
     slog.y = wave_sum(slog.y);
     ssq.x = wave_sum(ssq.x);
     ssq.y = wave_sum(ssq.y);
-    const v2f am = ssq * (1.0f / PSY_FN) + kEps;
+    const v2f am = ssq * (1.0f / P::FN) + kEps;
     // sfm = 10 log10(gm / am) with gm = exp(mean ln I)  ==  10 log10(2) (mean log2 I - log2 am)
-    const v2f sfm = 3.0102999566398120f * (slog * (1.0f / PSY_FN) - log2v(am));
+    const v2f sfm = 3.0102999566398120f * (slog * (1.0f / P::FN) - log2v(am));
     const v2f tt = sfm * (-1.0f / 60.0f);
     t = v2f{fminf(tt.x, 1.0f), fminf(tt.y, 1.0f)};
   }
   if (!WANT_THR) return;
 
-  wave_sync();
-  // sums over aligned chunks of 8 bins (4 granules): lane c owns chunks c and c + 64
-  {
-    const int x = (lane >> 2) & 3;
-    const char* cb = buf + 64 * lane;
-    const int o0 = 16 * x, o1 = 16 * (1 ^ x), o2 = 16 * (2 ^ x), o3 = 16 * (3 ^ x);
+  // P_j = sum_f I_f W[f, j]  (:312-313): lane = Bark band; the two edge bins carry weights wf / wl, the interior
+  // (weight 1) is gathered as single bins + 8-bin chunk sums through a host-built list of LDS offsets.  The spectrum
+  // goes through the 8 KB image in halves of 1024 bins; an edge or list entry outside the half points at the zero slot.
+  v2f P0 = {0.f, 0.f}, P1 = {0.f, 0.f};
 #pragma unroll
-    for (int i2 = 0; i2 < 2; ++i2) {
-      const char* c2 = cb + 4096 * i2;
-      const v4f g0 = *reinterpret_cast<const v4f*>(c2 + o0), g1 = *reinterpret_cast<const v4f*>(c2 + o1),
-                g2 = *reinterpret_cast<const v4f*>(c2 + o2), g3 = *reinterpret_cast<const v4f*>(c2 + o3);
-      const v4f s = (g0 + g1) + (g2 + g3);
-      *reinterpret_cast<v2f*>(buf + S8_OFF + 8 * lane + 512 * i2) = v2f{s.x + s.z, s.y + s.w};
+  for (int h = 0; h < P::NH; ++h) {
+    wave_sync();
+    {
+      // intensities in natural order: granule q = (I[2q], I[2q+1]) x (c0, c1) at byte 16 (q ^ ((q >> 4) & 3))
+      const int lsw = lane ^ ((lane >> 4) & 3);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<v4f*>(buf + 16 * lsw + 1024 * i) = xq[8 * h + i] * xq[8 * h + i];
+    }
+    wave_sync();
+    // sums over aligned chunks of 8 bins (4 granules): lane c owns chunks c and c + 64
+    {
+      const int x = (lane >> 2) & 3;
+      const char* cb = buf + 64 * lane;
+      const int o0 = 16 * x, o1 = 16 * (1 ^ x), o2 = 16 * (2 ^ x), o3 = 16 * (3 ^ x);
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) {
+        const char* c2 = cb + 4096 * i2;
+        const v4f g0 = *reinterpret_cast<const v4f*>(c2 + o0), g1 = *reinterpret_cast<const v4f*>(c2 + o1),
+                  g2 = *reinterpret_cast<const v4f*>(c2 + o2), g3 = *reinterpret_cast<const v4f*>(c2 + o3);
+        const v4f s = (g0 + g1) + (g2 + g3);
+        *reinterpret_cast<v2f*>(buf + S8_OFF + 8 * lane + 512 * i2) = v2f{s.x + s.z, s.y + s.w};
+      }
+    }
+    wave_sync();
+    const v4f bc0 = pc.bc0[h];
+    const uint32_t edge = in_loop(__float_as_uint(bc0.x));
+    P0 += *reinterpret_cast<const v2f*>(lds0 + (edge & 0xffffu)) * bc0.y;
+    P1 += *reinterpret_cast<const v2f*>(lds0 + (edge >> 16)) * bc0.z;
+#pragma unroll
+    for (int hlf = 0; hlf < P::PL_HALF; ++hlf) {
+      const uint32_t w = pimg[P::PL_LST + (h * P::PL_HALF + hlf) * 64 + lane];
+      P0 += *reinterpret_cast<const v2f*>(buf + (w & 0xffffu));
+      P1 += *reinterpret_cast<const v2f*>(buf + (w >> 16));
     }
   }
-  wave_sync();
-  // P_j = sum_f I_f W[f, j]  (:312-313): lane = Bark band; the two edge bins carry weights wf / wl, the interior
-  // (weight 1) is gathered as single bins + 8-bin chunk sums through a host-built list of LDS offsets
-  const v4f bc0 = pc.bc0;
-  const uint32_t edge = in_loop(__float_as_uint(bc0.x));
-  v2f P0 = *reinterpret_cast<const v2f*>(lds0 + (edge & 0xffffu)) * bc0.y;
-  v2f P1 = *reinterpret_cast<const v2f*>(lds0 + (edge >> 16)) * bc0.z;
-#pragma unroll
-  for (int hlf = 0; hlf < PL_HALF; ++hlf) {
-    const uint32_t w = pimg[PL_LST + hlf * 64 + lane];
-    P0 += *reinterpret_cast<const v2f*>(buf + (w & 0xffffu));
-    P1 += *reinterpret_cast<const v2f*>(buf + (w >> 16));
-  }
-  const v2f P = P0 + P1;
-  const v2f Q = exp2v(pp.alpha * log2v(maxv(P, kEps)));   // max(eps, P)^alpha  (:206)
+  const v2f Pj = P0 + P1;
+  const v2f Q = exp2v(pp.alpha * log2v(maxv(Pj, kEps)));   // max(eps, P)^alpha  (:206)
   wave_sync();
   *reinterpret_cast<v2f*>(buf + 8 * lane) = Q;
   wave_sync();
   // sum_i Q_i S[i, j], S[i, j] = g[64 - i + j]  (:205-207 with the offset factor pulled out of the sum)
   v2f acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
-  const float* gp = reinterpret_cast<const float*>(pimg + PL_G) + 64 + lane;
+  const float* gp = reinterpret_cast<const float*>(pimg + P::PL_G) + 64 + lane;
 #pragma unroll 8
   for (int i = 0; i < 64; i += 2) {
     const v4f qq = *reinterpret_cast<const v4f*>(buf + 8 * i);   // Q_i, Q_{i+1} (broadcast read)
@@ -489,13 +507,10 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* lds0, char* 
   const v2f offset = (1.0f - pp.drown) * (t * bc1.x + 9.0f * t + 5.5f);                        // (:185-191)
   const v2f fac = exp2v(offset * (-pp.alpha * 0.33219280948873623f));                          // 10^(-alpha O / 10)
   const v2f T = exp2v(pp.inv_alpha * log2v(maxv(fac * acc, kEps)));                             // (:208)
-  const v2f G = maxv(T, bc0.w);                                                                 // (:144)
+  const v2f G = maxv(T, pc.bc0[0].w);                                                           // (:144)
   v2f Gn;
-  {
-    // G of band j + 1 (lane + 1): wave_shr:1 would shift the wrong way; row_shl within rows + fix-up is no shorter
-    Gn.x = __shfl_down(G.x, 1, 64);
-    Gn.y = __shfl_down(G.y, 1, 64);
-  }
+  Gn.x = __shfl_down(G.x, 1, 64);   // G of band j + 1
+  Gn.y = __shfl_down(G.y, 1, 64);
   // thr of the bins of band j: interior bins sqrt(max(eps, G_j rho_j)); the bin shared with band j+1
   // sqrt(max(eps, G_j u0 + G_{j+1} u1))  (:330-331) -- one value per entry, not per bin
   const v2f A0 = maxv(G * bc1.y, kEps), A1 = maxv(G * bc1.z + Gn * bc1.w, kEps);
@@ -504,22 +519,19 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[8], char* lds0, char* 
   *reinterpret_cast<v4f*>(buf + 16 * lane) = v4f{__builtin_amdgcn_sqrtf(A0.x), __builtin_amdgcn_sqrtf(A0.y),
                                                  __builtin_amdgcn_sqrtf(A1.x), __builtin_amdgcn_sqrtf(A1.y)};   // entry e at byte 8 e
   wave_sync();
-  {
-    const v4f ia = pc.ia, ib = pc.ib;
-    const uint32_t iw[8] = {__float_as_uint(ia.x), __float_as_uint(ia.y), __float_as_uint(ia.z), __float_as_uint(ia.w),
-                            __float_as_uint(ib.x), __float_as_uint(ib.y), __float_as_uint(ib.z), __float_as_uint(ib.w)};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const uint32_t w = in_loop(iw[i]);
-      const v2f a0 = *reinterpret_cast<const v2f*>(lds0 + (w & 0xffffu));
-      const v2f a1 = *reinterpret_cast<const v2f*>(lds0 + (w >> 16));
-      thr[i] = v4f{a0.x, a0.y, a1.x, a1.y};
-    }
+  for (int i = 0; i < R; ++i) {
+    const v4f ww = pc.idx[i >> 2];
+    const float wf = (i & 3) == 0 ? ww.x : (i & 3) == 1 ? ww.y : (i & 3) == 2 ? ww.z : ww.w;
+    const uint32_t w = in_loop(__float_as_uint(wf));
+    const v2f a0 = *reinterpret_cast<const v2f*>(lds0 + (w & 0xffffu));
+    const v2f a1 = *reinterpret_cast<const v2f*>(lds0 + (w >> 16));
+    thr[i] = v4f{a0.x, a0.y, a1.x, a1.y};
   }
 }
 
 // copies the table image (and the psy image) into the workgroup's LDS behind the wave buffers; every thread takes part
-template <int NW, int WSTRIDE, int TABF>
+template <int NW, int WSTRIDE, int TABF, int PSYW>
 __device__ __forceinline__ void load_tables(char* lds, const float* __restrict__ image, const uint32_t* psy_tab) {
   if (image) {
     v4f* dst = reinterpret_cast<v4f*>(lds + NW * WSTRIDE);
@@ -529,7 +541,7 @@ __device__ __forceinline__ void load_tables(char* lds, const float* __restrict__
   if (psy_tab) {
     uint4* pd = reinterpret_cast<uint4*>(lds + NW * WSTRIDE + (image ? TABF * 4 : 0));
     const uint4* ps = reinterpret_cast<const uint4*>(psy_tab);
-    for (int i = threadIdx.x; i < PL_LDS / 4; i += NW * 64) pd[i] = ps[i];
+    for (int i = threadIdx.x; i < PSYW / 4; i += NW * 64) pd[i] = ps[i];
   }
   __syncthreads();
 }
@@ -566,20 +578,19 @@ struct FwdArgs {
 template <int R, int CMODE, bool PSY, int NW>
 __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY>())) void k_fwd_fast(FwdArgs a) {
   using G = Geo<R>;
-  static_assert(!PSY || R == 8, "the fused epilogue serves filter_bands_n = 1024");
   // one LDS object: [NW wave buffers | table image | psy image]
   constexpr int WSTRIDE = PSY ? WAVE_LDS_PSY : WAVE_LDS;
-  __shared__ __attribute__((aligned(16))) char lds[NW * WSTRIDE + G::TAB_LDS + (PSY ? PSY_LDS : 0)];
+  __shared__ __attribute__((aligned(16))) char lds[NW * WSTRIDE + G::TAB_LDS + (PSY ? PsyGeo<R>::PSY_LDS : 0)];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  load_tables<NW, WSTRIDE, G::I_LDS>(lds, a.tab, PSY ? a.psy.tab : nullptr);
+  load_tables<NW, WSTRIDE, G::I_LDS, PsyGeo<R>::PL_LDS>(lds, a.tab, PSY ? a.psy.tab : nullptr);
   char* buf = lds + wave * WSTRIDE;
   gtab_t tab = reinterpret_cast<const float*>(lds + NW * WSTRIDE);
   const uint32_t* pimg = reinterpret_cast<const uint32_t*>(lds + NW * WSTRIDE + G::TAB_LDS);
   if (PSY) *reinterpret_cast<v2f*>(buf + ZERO_OFF) = v2f{0.f, 0.f};   // the gather lists' padding slot
   v2f p1[R];
   load_p1<R>(a.tab, lane, p1);
-  PsyLane pc;
-  if (PSY) pc = load_psy_lane(a.psy.tab, lane, (uint32_t)(wave * WSTRIDE));
+  PsyLane<R> pc;
+  if (PSY) pc = load_psy_lane<R>(a.psy.tab, lane, (uint32_t)(wave * WSTRIDE));
   int g = blockIdx.x;
   if (a.xcd) g = (g & 7) * (gridDim.x >> 3) + (g >> 3);
   const int C = a.C;
@@ -732,9 +743,9 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY>())) void k_fwd_fast(Fw
     --left;
     if constexpr (PSY) {
       v2f tt;
-      v4f th[8];
-      psy_stage<true, true>(row, lds, buf, pimg, pc, a.psy, lane, tt, th);
-      store_row<CMODE>(a.thr + o0, a.thr + o1, C, pq.has1, lane, th);
+      v4f th[R];
+      psy_stage<R, true, true>(row, lds, buf, pimg, pc, a.psy, lane, tt, th);
+      store_row<CMODE, R>(a.thr + o0, a.thr + o1, C, pq.has1, lane, th);
       if (lane == 0) {
         a.t[t0] = tt.x;
         if (pq.has1) a.t[t1] = tt.y;
@@ -796,7 +807,7 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_inv_fast(InvArgs
   constexpr int FH = G::FH;
   __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS + G::TAB_LDS];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  load_tables<NW, WAVE_LDS, G::I_LDS>(lds, a.tab + G::I_TOTAL, nullptr);
+  load_tables<NW, WAVE_LDS, G::I_LDS, 0>(lds, a.tab + G::I_TOTAL, nullptr);
   char* buf = lds + wave * WAVE_LDS;
   gtab_t tab = reinterpret_cast<const float*>(lds + NW * WAVE_LDS);
   v2f p1[R];
@@ -907,12 +918,13 @@ struct PsyArgs {
   long long ntasks;   // npairs * F
 };
 
-template <int CMODE, bool WANT_T, bool WANT_THR, int NW>
-__global__ __launch_bounds__(NW * 64, AC_WPE) void k_psy_fast(PsyArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS_PSY + PSY_LDS];
+template <int R, int CMODE, bool WANT_T, bool WANT_THR, int NW>
+__global__ __launch_bounds__(NW * 64, (R == 8 ? AC_WPE : 2)) void k_psy_fast(PsyArgs a) {
+  using P = PsyGeo<R>;
+  __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS_PSY + P::PSY_LDS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t* pimg = reinterpret_cast<const uint32_t*>(lds + NW * WAVE_LDS_PSY);
-  if (WANT_THR) load_tables<NW, WAVE_LDS_PSY, 0>(lds, nullptr, a.psy.tab);
+  if (WANT_THR) load_tables<NW, WAVE_LDS_PSY, 0, P::PL_LDS>(lds, nullptr, a.psy.tab);
   const long long task = (long long)blockIdx.x * NW + wave;
   if (task >= a.ntasks) return;
   char* buf = lds + wave * WAVE_LDS_PSY;
@@ -921,24 +933,24 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_psy_fast(PsyArgs a) {
   const int C = a.C;
   const Pair pq = make_pair<CMODE>(task / a.F, C, a.nsig);
   const bool has1 = pq.has1;
-  const size_t blk = (size_t)PSY_FN * C;
+  const size_t blk = (size_t)P::FN * C;
   const size_t o0 = row_off(pq.b0, a.F, f, blk, pq.c0), o1 = row_off(pq.b1, a.F, f, blk, pq.c1);
   const size_t t0 = ((size_t)pq.b0 * a.F + (size_t)f) * C + pq.c0, t1 = ((size_t)pq.b1 * a.F + (size_t)f) * C + pq.c1;
-  v4f row[8], th[8];
-  load_row<CMODE>(a.X + o0, a.X + o1, C, has1, lane, row);
+  v4f row[R], th[R];
+  load_row<CMODE, false, R>(a.X + o0, a.X + o1, C, has1, lane, row);
   v2f tt = {0.f, 0.f};
   if (!WANT_T) {
     tt.x = a.t_in[t0];
     tt.y = has1 ? a.t_in[t1] : 0.f;
   }
-  PsyLane pc;
-  if (WANT_THR) pc = load_psy_lane(a.psy.tab, lane, (uint32_t)(wave * WAVE_LDS_PSY));
-  psy_stage<WANT_T, WANT_THR>(row, lds, buf, pimg, pc, a.psy, lane, tt, th);
+  PsyLane<R> pc;
+  if (WANT_THR) pc = load_psy_lane<R>(a.psy.tab, lane, (uint32_t)(wave * WAVE_LDS_PSY));
+  psy_stage<R, WANT_T, WANT_THR>(row, lds, buf, pimg, pc, a.psy, lane, tt, th);
   if (WANT_T && lane == 0) {
     a.t_out[t0] = tt.x;
     if (has1) a.t_out[t1] = tt.y;
   }
-  if (WANT_THR) store_row<CMODE>(a.thr + o0, a.thr + o1, C, has1, lane, th);
+  if (WANT_THR) store_row<CMODE, R>(a.thr + o0, a.thr + o1, C, has1, lane, th);
 }
 
 // synthesis strips: short, so that the strips in flight cover a nearly contiguous window of memory (HBM rewards that
@@ -1051,18 +1063,22 @@ int fast_mdct_plan_init(ac_mdct_plan* p) {
   return AC_OK;
 }
 
-// The fused epilogue needs: N = 1024, 64 Bark bands (lane = band), every band a contiguous bin range whose
-// interior weights are exactly 1, every bin overlapping at most two (adjacent) bands, and a per-band constant
-// W_inv on the bins that belong to one band only.
-static bool build_psy_fast(const ac_psy_plan* p, std::vector<uint32_t>* out) {
+// The wave-level epilogue needs: N = 128 R (1024 or 2048), 64 Bark bands (lane = band), every band a contiguous bin
+// range whose interior weights are exactly 1, every bin overlapping at most two (adjacent) bands, a per-band constant
+// W_inv on the bins that belong to one band only, and per-half gather lists of at most 24 entries.
+template <int R>
+static bool build_psy_fast_R(const ac_psy_plan* p, std::vector<uint32_t>* out) {
+  using P = PsyGeo<R>;
   const PsyTables& t = p->host;
   const int N = t.N, M = t.M;
-  if (N != PSY_FN || M != 64) return false;
+  if (N != P::FN || M != 64) return false;
   auto Wf = [&](int f, int j) { return (float)t.W[(size_t)f * M + j]; };
   auto Vf = [&](int j, int f) { return (float)t.W_inv[(size_t)j * N + f]; };
-  std::vector<uint32_t> w(P_TOTAL, 0u);
+  std::vector<uint32_t> w(P::P_TOTAL, 0u);
   auto putf = [&](int idx, float v) { uint32_t u; memcpy(&u, &v, 4); w[idx] = u; };
-  auto band = [](int group, int j, int word) { return PL_BAND + 4 * (group * 64 + j) + word; };
+  auto band = [](int group, int j, int word) { return P::PL_BAND + 4 * (group * 64 + j) + word; };
+  // LDS byte offset of I[f] in the wave buffer while half f / 1024 is staged (granule swizzle of psy_stage)
+  auto addrI = [](int f) { const int q = (f & 1023) >> 1; return (uint32_t)(16 * (q ^ ((q >> 4) & 3)) + 8 * (f & 1)); };
   for (int j = 0; j < M; ++j) {
     int f0 = -1, f1 = -1;
     for (int f = 0; f < N; ++f)
@@ -1075,27 +1091,32 @@ static bool build_psy_fast(const ac_psy_plan* p, std::vector<uint32_t>* out) {
       if (Wf(f, j) == 0.f) return false;
       if (f > f0 && f < f1 && Wf(f, j) != 1.0f) return false;
     }
-    // LDS byte offset of I[f] in the wave buffer (granule swizzle of psy_stage)
-    auto addrI = [](int f) { const int q = f >> 1; return (uint32_t)(16 * (q ^ ((q >> 4) & 3)) + 8 * (f & 1)); };
-    w[band(0, j, 0)] = addrI(f0) | (addrI(f1) << 16);
-    putf(band(0, j, 1), Wf(f0, j));
-    putf(band(0, j, 2), (f1 > f0) ? Wf(f1, j) : 0.f);
-    putf(band(0, j, 3), (float)t.quiet[j]);
-    putf(band(1, j, 0), t.beta[j]);
-    // interior bins f0+1 .. f1-1 (weight 1): single bins up to an 8-aligned boundary, whole chunks, single bins
-    std::vector<uint32_t> lst;
-    for (int f = f0 + 1; f <= f1 - 1;) {
-      if ((f & 7) == 0 && f + 7 <= f1 - 1) {
-        lst.push_back((uint32_t)(S8_OFF + 8 * (f >> 3)));
-        f += 8;
-      } else {
-        lst.push_back(addrI(f));
-        f += 1;
+    for (int h = 0; h < P::NH; ++h) {
+      const int lo = 1024 * h, hi = lo + 1023;   // bins of this half
+      const bool has0 = f0 >= lo && f0 <= hi, has1 = f1 > f0 && f1 >= lo && f1 <= hi;
+      w[band(h, j, 0)] = (has0 ? addrI(f0) : (uint32_t)ZERO_OFF) | ((has1 ? addrI(f1) : (uint32_t)ZERO_OFF) << 16);
+      putf(band(h, j, 1), has0 ? Wf(f0, j) : 0.f);
+      putf(band(h, j, 2), has1 ? Wf(f1, j) : 0.f);
+      putf(band(h, j, 3), (float)t.quiet[j]);
+      // interior bins f0+1 .. f1-1 (weight 1) inside this half: single bins up to an 8-aligned boundary, whole
+      // chunks, single bins
+      std::vector<uint32_t> lst;
+      const int a = std::max(f0 + 1, lo), b = std::min(f1 - 1, hi);
+      for (int f = a; f <= b;) {
+        if ((f & 7) == 0 && f + 7 <= b) {
+          lst.push_back((uint32_t)(S8_OFF + 8 * ((f & 1023) >> 3)));
+          f += 8;
+        } else {
+          lst.push_back(addrI(f));
+          f += 1;
+        }
       }
+      if ((int)lst.size() > 2 * P::PL_HALF) return false;
+      lst.resize(2 * P::PL_HALF, (uint32_t)ZERO_OFF);
+      for (int hlf = 0; hlf < P::PL_HALF; ++hlf)
+        w[P::PL_LST + (h * P::PL_HALF + hlf) * 64 + j] = lst[2 * hlf] | (lst[2 * hlf + 1] << 16);
     }
-    if ((int)lst.size() > 2 * PL_HALF) return false;
-    lst.resize(2 * PL_HALF, (uint32_t)ZERO_OFF);
-    for (int hlf = 0; hlf < PL_HALF; ++hlf) w[PL_LST + hlf * 64 + j] = lst[2 * hlf] | (lst[2 * hlf + 1] << 16);
+    putf(band(P::NH, j, 0), t.beta[j]);
   }
   // bins -> entries; nnz pattern of W and W_inv is identical (same overlap)
   std::vector<int> entry(N, -1);
@@ -1127,20 +1148,26 @@ static bool build_psy_fast(const ac_psy_plan* p, std::vector<uint32_t>* out) {
     }
   }
   for (int j = 0; j < M; ++j) {
-    putf(band(1, j, 1), rho[j]);
-    putf(band(1, j, 2), u0[j]);
-    putf(band(1, j, 3), u1[j]);
+    putf(band(P::NH, j, 1), rho[j]);
+    putf(band(P::NH, j, 2), u0[j]);
+    putf(band(P::NH, j, 3), u1[j]);
   }
   // threshold entry e lives at byte 8 e of the wave buffer; word i of lane l = offsets of bins 2q, 2q+1, q = 64 i + l
   for (int l = 0; l < 64; ++l)
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < R; ++i) {
       const int q = 64 * i + l;
       const uint32_t e0 = 8u * (uint32_t)entry[2 * q], e1 = 8u * (uint32_t)entry[2 * q + 1];
-      w[PL_IDX + 4 * ((i >> 2) * 64 + l) + (i & 3)] = e0 | (e1 << 16);
+      w[P::PL_IDX + 4 * ((i >> 2) * 64 + l) + (i & 3)] = e0 | (e1 << 16);
     }
-  for (int i = 0; i < 128; ++i) putf(PL_G + i, (float)t.g[i]);
+  for (int i = 0; i < 128; ++i) putf(P::PL_G + i, (float)t.g[i]);
   if (out) *out = w;
   return true;
+}
+
+static bool build_psy_fast(const ac_psy_plan* p, std::vector<uint32_t>* out) {
+  if (p->host.N == PsyGeo<8>::FN) return build_psy_fast_R<8>(p, out);
+  if (p->host.N == PsyGeo<16>::FN) return build_psy_fast_R<16>(p, out);
+  return false;
 }
 
 bool fast_psy_supported(const ac_psy_plan* p) { return build_psy_fast(p, nullptr); }
@@ -1178,14 +1205,12 @@ static unsigned persistent_grid(int cus, int wg_per_cu, long long ntasks, int nw
 
 template <int R>
 static void launch_fwd_R(const FwdArgs& a, bool psy, int C, unsigned grid, hipStream_t s) {
-  if constexpr (R == 8) {
-    if (psy) {
-      const dim3 blk(AC_WAVES_PSY * 64);
-      if (C == 2) hipLaunchKernelGGL((k_fwd_fast<8, 0, true, AC_WAVES_PSY>), dim3(grid), blk, 0, s, a);
-      else if (C == 1) hipLaunchKernelGGL((k_fwd_fast<8, 2, true, AC_WAVES_PSY>), dim3(grid), blk, 0, s, a);
-      else hipLaunchKernelGGL((k_fwd_fast<8, 1, true, AC_WAVES_PSY>), dim3(grid), blk, 0, s, a);
-      return;
-    }
+  if (psy) {
+    const dim3 blk(AC_WAVES_PSY * 64);
+    if (C == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY>), dim3(grid), blk, 0, s, a);
+    else if (C == 1) hipLaunchKernelGGL((k_fwd_fast<R, 2, true, AC_WAVES_PSY>), dim3(grid), blk, 0, s, a);
+    else hipLaunchKernelGGL((k_fwd_fast<R, 1, true, AC_WAVES_PSY>), dim3(grid), blk, 0, s, a);
+    return;
   }
   const dim3 blk(AC_WAVES * 64);
   if (C == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
@@ -1236,7 +1261,7 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const float* 
   }
   if (p->N == Geo<8>::FN) launch_fwd_R<8>(a, psy != nullptr, C, grid, s);
 #ifndef AC_NO_R16
-  else launch_fwd_R<16>(a, false, C, grid, s);
+  else launch_fwd_R<16>(a, psy != nullptr, C, grid, s);
 #endif
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
@@ -1285,6 +1310,14 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, float* x, const float
   return AC_OK;
 }
 
+template <int R, int CMODE>
+static void launch_psy_R(const PsyArgs& a, bool want_t, bool want_thr, unsigned grid, hipStream_t s) {
+  const dim3 blk(AC_WAVES * 64);
+  if (want_t && !want_thr) hipLaunchKernelGGL((k_psy_fast<R, CMODE, true, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
+  else if (!want_t && want_thr) hipLaunchKernelGGL((k_psy_fast<R, CMODE, false, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
+  else if (want_t && want_thr) hipLaunchKernelGGL((k_psy_fast<R, CMODE, true, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
+}
+
 int launch_psy_fast(const ac_psy_plan* p, const float* X, const float* t_in, float* t_out, float* thr, float drown,
                     int B, int F, int C, hipStream_t s) {
   if (B <= 0 || C <= 0 || F <= 0) return AC_OK;
@@ -1301,20 +1334,18 @@ int launch_psy_fast(const ac_psy_plan* p, const float* X, const float* t_in, flo
   unsigned grid;
   int st = grid_for(a.ntasks, AC_WAVES, &grid);
   if (st) return st;
-  const dim3 blk(AC_WAVES * 64);
   const bool want_t = (t_out != nullptr), want_thr = (thr != nullptr);
-  if (want_t && !want_thr) {
-    if (C == 2) hipLaunchKernelGGL((k_psy_fast<0, true, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
-    else if (C == 1) hipLaunchKernelGGL((k_psy_fast<2, true, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
-    else hipLaunchKernelGGL((k_psy_fast<1, true, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
-  } else if (!want_t && want_thr) {
-    if (C == 2) hipLaunchKernelGGL((k_psy_fast<0, false, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
-    else if (C == 1) hipLaunchKernelGGL((k_psy_fast<2, false, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
-    else hipLaunchKernelGGL((k_psy_fast<1, false, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
-  } else if (want_t && want_thr) {
-    if (C == 2) hipLaunchKernelGGL((k_psy_fast<0, true, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
-    else if (C == 1) hipLaunchKernelGGL((k_psy_fast<2, true, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
-    else hipLaunchKernelGGL((k_psy_fast<1, true, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
+  const int cmode = (C == 2) ? 0 : (C == 1) ? 2 : 1;
+  if (p->N == PsyGeo<8>::FN) {
+    if (cmode == 0) launch_psy_R<8, 0>(a, want_t, want_thr, grid, s);
+    else if (cmode == 2) launch_psy_R<8, 2>(a, want_t, want_thr, grid, s);
+    else launch_psy_R<8, 1>(a, want_t, want_thr, grid, s);
+  } else {
+#ifndef AC_NO_R16
+    if (cmode == 0) launch_psy_R<16, 0>(a, want_t, want_thr, grid, s);
+    else if (cmode == 2) launch_psy_R<16, 2>(a, want_t, want_thr, grid, s);
+    else launch_psy_R<16, 1>(a, want_t, want_thr, grid, s);
+#endif
   }
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;

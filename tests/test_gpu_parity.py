@@ -208,9 +208,9 @@ def test_psy_random_vs_oracle(path, sr, N, M, B, F, C):
         assert rel_elem(thr, o.global_masking_threshold(X.astype(np.float64), to, drown)) <= TOL
 
 
-@pytest.mark.parametrize("B,K,C", [(3, 5, 2), (2, 4, 1), (1, 3, 3), (2, 37, 2)])
-def test_encode_fused_equals_unfused_and_oracle(path, B, K, C):
-    N = 1024
+@pytest.mark.parametrize("B,K,C,N", [(3, 5, 2, 1024), (2, 4, 1, 1024), (1, 3, 3, 1024), (2, 37, 2, 1024), (3, 4, 1, 1024),
+                                     (2, 5, 2, 2048), (3, 3, 1, 2048), (1, 4, 3, 2048)])
+def test_encode_fused_equals_unfused_and_oracle(path, B, K, C, N):
     rng = np.random.default_rng(11 + B)
     x = rng.uniform(-1, 1, (B, K * N, C)).astype(np.float32)
     x[0, : 2 * N, 0] *= 1e-3
@@ -314,7 +314,9 @@ def test_fast_path_selection():
     assert not audiocodec_amd.MDCTransformer(2048, "rect").is_fast()
     assert not audiocodec_amd.MDCTransformer(512).is_fast()
     assert audiocodec_amd.PsychoacousticModel(48000, 1024, 64).is_fast()
-    assert not audiocodec_amd.PsychoacousticModel(48000, 2048, 64).is_fast()
+    assert audiocodec_amd.PsychoacousticModel(48000, 2048, 64).is_fast()
+    assert not audiocodec_amd.PsychoacousticModel(48000, 512, 64).is_fast()
+    assert not audiocodec_amd.PsychoacousticModel(48000, 1024, 32).is_fast()
 
 
 @pytest.mark.parametrize("wt", ["rect", None])
