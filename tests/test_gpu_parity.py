@@ -380,3 +380,23 @@ def test_autograd_of_the_filter_bank(path, N, wt):
         mr = audiocodec_amd.MDCTransformer(64, window_type="rect")
         xr = torch.rand(1, 128, 1, device="cuda", requires_grad=True)
         mr.transform(xr).sum().backward()
+
+
+def test_tensors_beyond_4_gib():
+    """Offsets are 64-bit: a batch whose tensors exceed 4 GiB gives, clip for clip, the bits of a small batch."""
+    N, B, K, C = 1024, 1200, 468, 2                       # x: 4.6 GB, X / thr: 4.6 GB each
+    free, _ = torch.cuda.mem_get_info()
+    if free < 24 * 2 ** 30:
+        pytest.skip("needs 24 GiB of free HBM")
+    g = torch.Generator(device="cuda").manual_seed(99)
+    x = torch.rand(B, K * N, C, device="cuda", generator=g) * 2 - 1
+    assert x.numel() * 4 > 2 ** 32
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    X, t, thr = codec.encode(x)
+    for b in (0, 599, 1199):
+        Xb, tb, thrb = codec.encode(x[b:b + 1].contiguous())
+        assert torch.equal(Xb, X[b:b + 1]) and torch.equal(tb, t[b:b + 1]) and torch.equal(thrb, thr[b:b + 1])
+    del t, thr
+    xh = codec.decode(X)
+    assert float((xh[-1:, N:-N] - x[-1:]).abs().max()) <= LSB
+    assert torch.equal(codec.decode(X[1199:].contiguous()), xh[1199:])
