@@ -115,6 +115,13 @@ __device__ __forceinline__ C2 cmul(const C2& x, const v2f w) {
   r.im = x.re * w.y + x.im * w.x;
   return r;
 }
+// (re, -im) of x * w: the sign rides on the operand modifiers of the multiply-add instead of a separate negation
+__device__ __forceinline__ C2 cmul_negim(const C2& x, const v2f w) {
+  C2 r;
+  r.re = x.re * w.x - x.im * w.y;
+  r.im = (-x.re) * w.y - x.im * w.x;
+  return r;
+}
 __device__ __forceinline__ C2 cadd(const C2& a, const C2& b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ C2 csub(const C2& a, const C2& b) { return {a.re - b.re, a.im - b.im}; }
 __device__ __forceinline__ C2 mul_mi(const C2& a) { return {a.im, -a.re}; }   // a * (-i)
@@ -722,9 +729,9 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY>())) void k_fwd_fast(Fw
       v2f xe[R], xo_in[R], xo[R];
 #pragma unroll
       for (int j = 0; j < R; ++j) {
-        const C2 r = cmul(z[j], reinterpret_cast<const v2f*>(tab + G::I_POST)[j * 64 + lane]);
+        const C2 r = cmul_negim(z[j], reinterpret_cast<const v2f*>(tab + G::I_POST)[j * 64 + lane]);
         xe[j] = r.re;
-        xo_in[j] = -r.im;
+        xo_in[j] = r.im;
       }
       rev_exchange<R - 1, R>(buf, lane, xo_in, xo);
 #pragma unroll
@@ -789,13 +796,13 @@ __device__ __forceinline__ void idct_frame(const v4f (&frm)[R], char* buf, gtab_
   fft_wave<R>(z, buf, tab, p1, lane);
 #pragma unroll
   for (int j = 0; j < R; ++j) {
-    const C2 r = cmul(z[j], reinterpret_cast<const v2f*>(tab + G::I_POST)[j * 64 + lane]);
+    const C2 r = cmul_negim(z[j], reinterpret_cast<const v2f*>(tab + G::I_POST)[j * 64 + lane]);
     // u[2k] = Re, u[N-1-2k] = -Im; k < N/4 (j < R/2): u[2k] belongs to this block, u[N-1-2k] to the next
     if (j < R / 2) {
       now[j] = r.re;
-      nxt[j] = -r.im;
+      nxt[j] = r.im;
     } else {
-      now[j] = -r.im;
+      now[j] = r.im;
       nxt[j] = r.re;
     }
   }
