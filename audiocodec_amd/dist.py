@@ -49,7 +49,7 @@ def reduce_scalars(values, op="sum", device=None):
     """All-reduce a short list of Python floats (float64 on the wire).  Also serves as a barrier."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return [float(v) for v in values]
-    if device is None:
+    if device is None or dist.get_backend() != "nccl":
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
     ops = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}

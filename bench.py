@@ -97,10 +97,13 @@ def main():
     cpu = None
     if world == 1 and args.gpus == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()          # before this process initialises the GPU
-    rank, world, local_rank = acd.init_process_group("nccl" if args.gpus > 1 else None)
+    # RCCL ("nccl") carries the barrier and the scalar reductions; AC_BENCH_BACKEND=gloo rehearses the multi-rank path
+    # on a box with fewer GPUs than ranks (ranks then share devices)
+    backend = os.environ.get("AC_BENCH_BACKEND", "nccl")
+    rank, world, local_rank = acd.init_process_group(backend if args.gpus > 1 else None)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", (local_rank % torch.cuda.device_count()) if world > 1 else 0)
     torch.cuda.set_device(dev)
 
     B, K, C = args.clips, args.blocks, 2
