@@ -192,7 +192,9 @@ def test_tonality_like_reference(path):
 
 
 @pytest.mark.parametrize("sr,N,M,B,F,C", [(48000, 1024, 64, 3, 4, 2), (48000, 1024, 64, 2, 3, 1), (48000, 1024, 64, 1, 2, 3),
-                                          (44100, 256, 48, 2, 5, 2), (32768, 64, 64, 2, 3, 2), (48000, 2048, 64, 1, 2, 2)])
+                                          (44100, 256, 48, 2, 5, 2), (32768, 64, 64, 2, 3, 2), (48000, 2048, 64, 1, 2, 2),
+                                          (44100, 1024, 64, 2, 3, 2), (16000, 1024, 64, 1, 3, 1), (8000, 1024, 64, 1, 2, 2),
+                                          (96000, 2048, 64, 2, 2, 2), (22050, 2048, 64, 1, 3, 3), (48000, 2048, 64, 3, 2, 1)])
 def test_psy_random_vs_oracle(path, sr, N, M, B, F, C):
     rng = np.random.default_rng(F * 100 + C)
     env = np.logspace(-5, 0, N).reshape(1, 1, N, 1)
