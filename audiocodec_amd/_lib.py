@@ -37,6 +37,9 @@ PROTOTYPES = {
     "ac_mdct_inverse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ac_tonality": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ac_mask_threshold": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ac_tonality_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ac_mask_threshold_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int,
+                                           c_int, c_int, c_void_p]),
     "ac_encode_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int,
                                 c_int, c_void_p]),
     "ac_stream_create": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),

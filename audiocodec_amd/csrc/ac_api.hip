@@ -198,9 +198,11 @@ int ac_psy_plan_create(int N, int M, double sample_rate, double alpha, int devic
   p->sample_rate = sample_rate;
   p->alpha = alpha;
   psy_tables(N, M, sample_rate, alpha, p->host);
-  SparseRows wb, wi;
+  SparseRows wb, wi, wf, vb;
   w_by_band(p->host, wb);
   winv_by_bin(p->host, wi);
+  w_by_bin(p->host, wf);
+  winv_by_band(p->host, vb);
   p->wb_max = wb.max_row;
   p->wi_max = wi.max_row;
   std::vector<float> S(p->host.S.size()), quiet(M);
@@ -212,6 +214,12 @@ int ac_psy_plan_create(int N, int M, double sample_rate, double alpha, int devic
   if (!st) st = upload(wi.ptr, &p->d_wi_ptr);
   if (!st) st = upload(wi.idx, &p->d_wi_idx);
   if (!st) st = upload(wi.val, &p->d_wi_val);
+  if (!st) st = upload(wf.ptr, &p->d_wf_ptr);
+  if (!st) st = upload(wf.idx, &p->d_wf_idx);
+  if (!st) st = upload(wf.val, &p->d_wf_val);
+  if (!st) st = upload(vb.ptr, &p->d_vb_ptr);
+  if (!st) st = upload(vb.idx, &p->d_vb_idx);
+  if (!st) st = upload(vb.val, &p->d_vb_val);
   if (!st) st = upload(S, &p->d_S);
   if (!st) st = upload(quiet, &p->d_quiet);
   if (!st) st = upload(p->host.beta, &p->d_beta);
@@ -236,6 +244,12 @@ int ac_psy_plan_destroy(ac_psy_plan* p) {
   (void)hipFree(p->d_wi_ptr);
   (void)hipFree(p->d_wi_idx);
   (void)hipFree(p->d_wi_val);
+  (void)hipFree(p->d_wf_ptr);
+  (void)hipFree(p->d_wf_idx);
+  (void)hipFree(p->d_wf_val);
+  (void)hipFree(p->d_vb_ptr);
+  (void)hipFree(p->d_vb_idx);
+  (void)hipFree(p->d_vb_val);
   (void)hipFree(p->d_S);
   (void)hipFree(p->d_quiet);
   (void)hipFree(p->d_beta);
@@ -302,6 +316,29 @@ int ac_mask_threshold(const ac_psy_plan* p, const float* X, const float* t, floa
   hipStream_t s = (hipStream_t)stream;
   if (p->fast && !g_force_generic) return launch_psy_fast(p, X, t, nullptr, thr, drown, B, F, C, s);
   return launch_threshold_generic(p, X, t, drown, thr, B, F, C, s);
+}
+
+int ac_tonality_backward(const ac_psy_plan* p, const float* X, const float* grad_t, float* grad_X, int accumulate, int B,
+                         int F, int C, void* stream) {
+  AC_REQUIRE(p != nullptr, "plan is NULL");
+  int st = check_dims(B, F, C);
+  if (st) return st;
+  if (B == 0 || C == 0 || F == 0) return AC_OK;
+  AC_REQUIRE(X != nullptr && grad_t != nullptr && grad_X != nullptr, "NULL tensor pointer");
+  DeviceGuard guard(p->device);
+  return launch_tonality_bwd_generic(p, X, grad_t, grad_X, accumulate, B, F, C, (hipStream_t)stream);
+}
+
+int ac_mask_threshold_backward(const ac_psy_plan* p, const float* X, const float* t, float drown, const float* grad_thr,
+                               float* grad_X, float* grad_t, int B, int F, int C, void* stream) {
+  AC_REQUIRE(p != nullptr, "plan is NULL");
+  int st = check_dims(B, F, C);
+  if (st) return st;
+  if (B == 0 || C == 0 || F == 0) return AC_OK;
+  AC_REQUIRE(X != nullptr && t != nullptr && grad_thr != nullptr && grad_X != nullptr && grad_t != nullptr,
+             "NULL tensor pointer");
+  DeviceGuard guard(p->device);
+  return launch_threshold_bwd_generic(p, X, t, drown, grad_thr, grad_X, grad_t, B, F, C, (hipStream_t)stream);
 }
 
 int ac_encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr,

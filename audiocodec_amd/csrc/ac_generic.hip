@@ -217,6 +217,123 @@ __global__ __launch_bounds__(kThreads) void k_threshold_generic(
 }
 
 // ------------------------------------------------------------------------------------------------
+// backward passes of the masking model (adjoints of the two kernels above); one workgroup per (b, frame, c)
+// ------------------------------------------------------------------------------------------------
+// t = min(c' [mean_f ln max(eps, I_f) - ln(mean_f I_f + eps)], 1), c' = (10 / ln 10) / (-60), I_f = X_f^2:
+// d t / d X_f = c' (1/N) ([I_f > eps] / I_f - 1 / (mean I + eps)) 2 X_f   where the clamp is inactive
+__global__ __launch_bounds__(kThreads) void k_tonality_bwd_generic(const float* __restrict__ X,
+                                                                   const float* __restrict__ gt,
+                                                                   float* __restrict__ gX, int accumulate, int C,
+                                                                   int N) {
+  __shared__ float red[kThreads / 64];
+  const long long wg = blockIdx.x;   // (b*F + f)*C + c
+  const int c = (int)(wg % C);
+  const long long bf = wg / C;
+  const float* Xi = X + (size_t)bf * N * C + c;
+  float* gi = gX + (size_t)bf * N * C + c;
+  float slog = 0.f, ssq = 0.f;
+  for (int k = threadIdx.x; k < N; k += kThreads) {
+    const float a = Xi[(size_t)k * C];
+    slog += logf(fmaxf(kEps, a * a));
+    ssq += a * a;
+  }
+  slog = block_sum(slog, red);
+  ssq = block_sum(ssq, red);
+  const float am = ssq / (float)N + kEps;
+  const float cc = (10.f / 2.302585092994046f) / -60.f;
+  const float tt = cc * (slog / (float)N - logf(am));
+  const float g = (tt < 1.f) ? gt[wg] * cc / (float)N : 0.f;
+  for (int k = threadIdx.x; k < N; k += kThreads) {
+    const float a = Xi[(size_t)k * C];
+    const float I = a * a;
+    const float d = g * ((I > kEps ? 1.f / I : 0.f) - 1.f / am) * 2.f * a;
+    gi[(size_t)k * C] = accumulate ? gi[(size_t)k * C] + d : d;
+  }
+}
+
+// thr_f = sqrt(max(eps, E_f)), E_f = sum_j G_j Winv[j,f], G_j = max(T_j, quiet_j), T_j = max(eps, Y_j)^(1/alpha),
+// Y_j = fac_j A_j, A_j = sum_i Q_i S[i,j], Q_i = max(eps, P_i)^alpha, P_i = sum_f X_f^2 W[f,i],
+// fac_j = 10^(-alpha O_j / 10), O_j = (1 - drown)(t beta_j + 9 t + 5.5).  The adjoint walks the chain backwards;
+// every max() passes the gradient to its active branch.
+__global__ __launch_bounds__(kThreads) void k_threshold_bwd_generic(
+    const float* __restrict__ X, const float* __restrict__ t, const float* __restrict__ gthr, float* __restrict__ gX,
+    float* __restrict__ gt, float drown, float alpha,
+    const int32_t* __restrict__ wb_ptr, const int32_t* __restrict__ wb_idx, const float* __restrict__ wb_val,
+    const int32_t* __restrict__ wi_ptr, const int32_t* __restrict__ wi_idx, const float* __restrict__ wi_val,
+    const int32_t* __restrict__ wf_ptr, const int32_t* __restrict__ wf_idx, const float* __restrict__ wf_val,
+    const int32_t* __restrict__ vb_ptr, const int32_t* __restrict__ vb_idx, const float* __restrict__ vb_val,
+    const float* __restrict__ S, const float* __restrict__ quiet, const float* __restrict__ beta, int C, int N,
+    int M) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float red[kThreads / 64];
+  float* xs = smem;        // [N] X
+  float* gE = xs + N;      // [N] d L / d E
+  float* P = gE + N;       // [M]
+  float* Q = P + M;        // [M]
+  float* A = Q + M;        // [M]
+  float* G = A + M;        // [M]
+  float* gA = G + M;       // [M]
+  float* gP = gA + M;      // [M]
+  const long long wg = blockIdx.x;
+  const int c = (int)(wg % C);
+  const long long bf = wg / C;
+  const float* Xi = X + (size_t)bf * N * C + c;
+  const float* gi = gthr + (size_t)bf * N * C + c;
+  for (int k = threadIdx.x; k < N; k += kThreads) xs[k] = Xi[(size_t)k * C];
+  __syncthreads();
+  for (int j = threadIdx.x; j < M; j += kThreads) {
+    float p = 0.f;
+    for (int e = wb_ptr[j]; e < wb_ptr[j + 1]; ++e) p += xs[wb_idx[e]] * xs[wb_idx[e]] * wb_val[e];
+    P[j] = p;
+    Q[j] = powf(fmaxf(kEps, p), alpha);
+  }
+  __syncthreads();
+  const float tt = t[wg];
+  for (int j = threadIdx.x; j < M; j += kThreads) {
+    float acc = 0.f;
+    for (int i = 0; i < M; ++i) acc += Q[i] * S[(size_t)i * M + j];
+    const float fac = powf(10.f, -alpha * (1.f - drown) * (tt * beta[j] + 9.f * tt + 5.5f) / 10.f);
+    A[j] = acc;
+    G[j] = fmaxf(powf(fmaxf(kEps, fac * acc), 1.f / alpha), quiet[j]);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < N; k += kThreads) {
+    float E = 0.f;
+    for (int e = wi_ptr[k]; e < wi_ptr[k + 1]; ++e) E += G[wi_idx[e]] * wi_val[e];
+    gE[k] = (E > kEps) ? gi[(size_t)k * C] * 0.5f / sqrtf(E) : 0.f;
+  }
+  __syncthreads();
+  float gt_part = 0.f;
+  for (int j = threadIdx.x; j < M; j += kThreads) {
+    float gG = 0.f;
+    for (int e = vb_ptr[j]; e < vb_ptr[j + 1]; ++e) gG += gE[vb_idx[e]] * vb_val[e];
+    const float fac = powf(10.f, -alpha * (1.f - drown) * (tt * beta[j] + 9.f * tt + 5.5f) / 10.f);
+    const float Y = fac * A[j];
+    const float T = powf(fmaxf(kEps, Y), 1.f / alpha);
+    const float gT = (T > quiet[j]) ? gG : 0.f;
+    const float gY = (Y > kEps) ? gT * T / (alpha * Y) : 0.f;
+    gA[j] = gY * fac;
+    // d fac / d t = fac (-alpha ln 10 / 10) (1 - drown) (beta_j + 9)
+    gt_part += gY * A[j] * fac * (-alpha * 0.2302585092994046f) * (1.f - drown) * (beta[j] + 9.f);
+  }
+  gt_part = block_sum(gt_part, red);
+  if (threadIdx.x == 0) gt[wg] = gt_part;
+  __syncthreads();
+  for (int i = threadIdx.x; i < M; i += kThreads) {
+    float gQ = 0.f;
+    for (int j = 0; j < M; ++j) gQ += S[(size_t)i * M + j] * gA[j];
+    gP[i] = (P[i] > kEps) ? gQ * alpha * Q[i] / P[i] : 0.f;
+  }
+  __syncthreads();
+  float* go = gX + (size_t)bf * N * C + c;
+  for (int k = threadIdx.x; k < N; k += kThreads) {
+    float gI = 0.f;
+    for (int e = wf_ptr[k]; e < wf_ptr[k + 1]; ++e) gI += gP[wf_idx[e]] * wf_val[e];
+    go[(size_t)k * C] = 2.f * xs[k] * gI;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // element-wise utilities
 // ------------------------------------------------------------------------------------------------
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -337,6 +454,31 @@ int launch_threshold_generic(const ac_psy_plan* p, const float* X, const float* 
   hipLaunchKernelGGL(k_threshold_generic, dim3((unsigned)nwg), dim3(kThreads), lds, s, X, t, thr, drown,
                      (float)p->alpha, p->d_wb_ptr, p->d_wb_idx, p->d_wb_val, p->d_wi_ptr, p->d_wi_idx, p->d_wi_val,
                      p->d_S, p->d_quiet, p->d_beta, C, p->N, p->M);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+int launch_tonality_bwd_generic(const ac_psy_plan* p, const float* X, const float* gt, float* gX, int accumulate, int B,
+                                int F, int C, hipStream_t s) {
+  const long long nwg = (long long)B * F * C;
+  const int st = check_grid(nwg);
+  if (st) return st < 0 ? st : AC_OK;
+  hipLaunchKernelGGL(k_tonality_bwd_generic, dim3((unsigned)nwg), dim3(kThreads), 0, s, X, gt, gX, accumulate, C, p->N);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+int launch_threshold_bwd_generic(const ac_psy_plan* p, const float* X, const float* t, float drown, const float* gthr,
+                                 float* gX, float* gt, int B, int F, int C, hipStream_t s) {
+  const long long nwg = (long long)B * F * C;
+  const int st = check_grid(nwg);
+  if (st) return st < 0 ? st : AC_OK;
+  const size_t lds = (2 * (size_t)p->N + 6 * (size_t)p->M) * sizeof(float);
+  AC_REQUIRE(lds <= 64 * 1024, "filter_bands_n = %d / bark_bands_n = %d too large for the backward kernel", p->N, p->M);
+  hipLaunchKernelGGL(k_threshold_bwd_generic, dim3((unsigned)nwg), dim3(kThreads), lds, s, X, t, gthr, gX, gt, drown,
+                     (float)p->alpha, p->d_wb_ptr, p->d_wb_idx, p->d_wb_val, p->d_wi_ptr, p->d_wi_idx, p->d_wi_val,
+                     p->d_wf_ptr, p->d_wf_idx, p->d_wf_val, p->d_vb_ptr, p->d_vb_idx, p->d_vb_val, p->d_S, p->d_quiet,
+                     p->d_beta, C, p->N, p->M);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }

@@ -68,6 +68,9 @@ struct ac_psy_plan {
   ac::PsyTables host;
   int32_t* d_wb_ptr = nullptr; int32_t* d_wb_idx = nullptr; float* d_wb_val = nullptr; int wb_max = 0;
   int32_t* d_wi_ptr = nullptr; int32_t* d_wi_idx = nullptr; float* d_wi_val = nullptr; int wi_max = 0;
+  // transposed walks for the backward pass: W by bin, W_inv by band
+  int32_t* d_wf_ptr = nullptr; int32_t* d_wf_idx = nullptr; float* d_wf_val = nullptr;
+  int32_t* d_vb_ptr = nullptr; int32_t* d_vb_idx = nullptr; float* d_vb_val = nullptr;
   float* d_S = nullptr;        // [M, M]
   float* d_quiet = nullptr;    // [M]
   float* d_beta = nullptr;     // [M]
@@ -109,6 +112,10 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, float* x, const float
 int launch_psy_fast(const ac_psy_plan* p, const float* X, const float* t_in, float* t_out, float* thr, float drown,
                     int B, int F, int C, hipStream_t s);
 
+int launch_tonality_bwd_generic(const ac_psy_plan* p, const float* X, const float* gt, float* gX, int accumulate, int B,
+                                int F, int C, hipStream_t s);
+int launch_threshold_bwd_generic(const ac_psy_plan* p, const float* X, const float* t, float drown, const float* gthr,
+                                 float* gX, float* gt, int B, int F, int C, hipStream_t s);
 int launch_db(const float* a, float* out, size_t n, int norm, hipStream_t s);
 int launch_add_noise(const float* X, const float* thr, float* out, size_t n, uint64_t seed, hipStream_t s);
 

@@ -163,4 +163,40 @@ void winv_by_bin(const PsyTables& t, SparseRows& out) {
   }
 }
 
+void w_by_bin(const PsyTables& t, SparseRows& out) {
+  out.ptr.assign(t.N + 1, 0);
+  out.idx.clear();
+  out.val.clear();
+  out.max_row = 0;
+  for (int f = 0; f < t.N; ++f) {
+    for (int j = 0; j < t.M; ++j) {
+      const float v = (float)t.W[(size_t)f * t.M + j];
+      if (v != 0.f) {
+        out.idx.push_back(j);
+        out.val.push_back(v);
+      }
+    }
+    out.ptr[f + 1] = (int32_t)out.idx.size();
+    out.max_row = std::max(out.max_row, out.ptr[f + 1] - out.ptr[f]);
+  }
+}
+
+void winv_by_band(const PsyTables& t, SparseRows& out) {
+  out.ptr.assign(t.M + 1, 0);
+  out.idx.clear();
+  out.val.clear();
+  out.max_row = 0;
+  for (int j = 0; j < t.M; ++j) {
+    for (int f = 0; f < t.N; ++f) {
+      const float v = (float)t.W_inv[(size_t)j * t.N + f];
+      if (v != 0.f) {
+        out.idx.push_back(f);
+        out.val.push_back(v);
+      }
+    }
+    out.ptr[j + 1] = (int32_t)out.idx.size();
+    out.max_row = std::max(out.max_row, out.ptr[j + 1] - out.ptr[j]);
+  }
+}
+
 }  // namespace ac

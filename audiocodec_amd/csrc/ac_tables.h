@@ -41,5 +41,9 @@ struct SparseRows {           // CSR: row r has entries ptr[r] .. ptr[r+1]-1
 void w_by_band(const PsyTables& t, SparseRows& out);
 // W_inv as "by bin" lists (rows = bin f, entries = (band j, W_inv[j,f]))
 void winv_by_bin(const PsyTables& t, SparseRows& out);
+// the transposed walks used by the backward pass: W "by bin" (rows = bin f, entries = (band j, W[f,j])) and
+// W_inv "by band" (rows = band j, entries = (bin f, W_inv[j,f]))
+void w_by_bin(const PsyTables& t, SparseRows& out);
+void winv_by_band(const PsyTables& t, SparseRows& out);
 
 }  // namespace ac

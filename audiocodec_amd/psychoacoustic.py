@@ -16,6 +16,38 @@ import torch
 from . import _host, _lib
 
 
+class _TonalityFn(torch.autograd.Function):
+    """Differentiable ``tonality`` (the reference is differentiated by TensorFlow inside a training graph,
+    ``psychoacoustic.py:311``); the backward pass is the explicit adjoint kernel ``ac_tonality_backward``."""
+
+    @staticmethod
+    def forward(ctx, X, model):
+        ctx.model = model
+        ctx.save_for_backward(X)
+        return model._tonality(X)
+
+    @staticmethod
+    def backward(ctx, gt):
+        (X,) = ctx.saved_tensors
+        return ctx.model._tonality_backward(X, gt.contiguous()), None
+
+
+class _ThresholdFn(torch.autograd.Function):
+    """Differentiable ``global_masking_threshold`` w.r.t. the amplitudes and the tonality (``ac_mask_threshold_backward``)."""
+
+    @staticmethod
+    def forward(ctx, X, t, model, drown):
+        ctx.model, ctx.drown = model, drown
+        ctx.save_for_backward(X, t)
+        return model._threshold(X, t, drown)
+
+    @staticmethod
+    def backward(ctx, gthr):
+        X, t = ctx.saved_tensors
+        gX, gt = ctx.model._threshold_backward(X, t, ctx.drown, gthr.contiguous())
+        return gX, gt, None, None
+
+
 class PsychoacousticModel:
     def __init__(self, sample_rate, filter_bands_n=1024, bark_bands_n=64, alpha=0.6,
                  compute_dtype=torch.float32, precompute_dtype=torch.float64):
@@ -102,6 +134,11 @@ class PsychoacousticModel:
 
     def tonality(self, mdct_amplitudes):
         """``tonality`` (``psychoacoustic.py:102-120``): [B, K, N, C] -> [B, K, 1, C] in [0, 1]."""
+        if isinstance(mdct_amplitudes, torch.Tensor) and mdct_amplitudes.requires_grad and torch.is_grad_enabled():
+            return _TonalityFn.apply(mdct_amplitudes, self)
+        return self._tonality(mdct_amplitudes)
+
+    def _tonality(self, mdct_amplitudes):
         X = self._check_spectrum(mdct_amplitudes)
         B, F, N, C = X.shape
         t = torch.empty((B, F, 1, C), dtype=X.dtype, device=X.device)
@@ -110,8 +147,35 @@ class PsychoacousticModel:
                                              _host.stream_ptr(X.device)))
         return t
 
+    def _tonality_backward(self, X, gt):
+        X = self._check_spectrum(X)
+        B, F, N, C = X.shape
+        gX = torch.empty_like(X)
+        with torch.cuda.device(X.device):
+            _lib.check(self._lib.ac_tonality_backward(self._plans.get(X.device), _host.ptr(X), _host.ptr(gt),
+                                                      _host.ptr(gX), 0, B, F, C, _host.stream_ptr(X.device)))
+        return gX
+
     def global_masking_threshold(self, mdct_amplitudes, tonality_per_block, drown=0.0):
         """``global_masking_threshold`` (``psychoacoustic.py:122-148``): -> [B, K, N, C], strictly positive."""
+        needs_grad = any(isinstance(v, torch.Tensor) and v.requires_grad for v in (mdct_amplitudes, tonality_per_block))
+        if needs_grad and torch.is_grad_enabled():
+            return _ThresholdFn.apply(mdct_amplitudes, tonality_per_block, self, float(drown))
+        return self._threshold(mdct_amplitudes, tonality_per_block, drown)
+
+    def _threshold_backward(self, X, t, drown, gthr):
+        X = self._check_spectrum(X)
+        B, F, N, C = X.shape
+        t = t.contiguous()
+        gX = torch.empty_like(X)
+        gt = torch.empty_like(t)
+        with torch.cuda.device(X.device):
+            _lib.check(self._lib.ac_mask_threshold_backward(self._plans.get(X.device), _host.ptr(X), _host.ptr(t),
+                                                            float(drown), _host.ptr(gthr), _host.ptr(gX), _host.ptr(gt),
+                                                            B, F, C, _host.stream_ptr(X.device)))
+        return gX, gt
+
+    def _threshold(self, mdct_amplitudes, tonality_per_block, drown=0.0):
         X = self._check_spectrum(mdct_amplitudes)
         B, F, N, C = X.shape
         t = _host.check_device_tensor(tonality_per_block, "tonality_per_block", self.compute_dtype, 4)

@@ -109,6 +109,17 @@ int ac_tonality(const ac_psy_plan* plan, const float* X, float* t, int B, int F,
 int ac_mask_threshold(const ac_psy_plan* plan, const float* X, const float* t, float drown, float* thr,
                       int B, int F, int C, void* stream);
 
+/* Backward passes of the masking model (the reference is differentiated by TensorFlow when it is used inside a
+ * training graph -- see the gradient remark at psychoacoustic.py:311; here the adjoints are explicit kernels).
+ * ac_tonality_backward: grad_t [B,F,1,C] -> grad_X [B,F,N,C] (d tonality / d X, psychoacoustic.py:102-120);
+ *   accumulate != 0 adds into grad_X instead of overwriting it.
+ * ac_mask_threshold_backward: grad_thr [B,F,N,C] -> grad_X [B,F,N,C] and grad_t [B,F,1,C]
+ *   (d threshold / d X and d threshold / d tonality, psychoacoustic.py:122-148 with 169-210, 301-331). */
+int ac_tonality_backward(const ac_psy_plan* plan, const float* X, const float* grad_t, float* grad_X, int accumulate,
+                         int B, int F, int C, void* stream);
+int ac_mask_threshold_backward(const ac_psy_plan* plan, const float* X, const float* t, float drown,
+                               const float* grad_thr, float* grad_X, float* grad_t, int B, int F, int C, void* stream);
+
 /* Fused encode = transform -> tonality -> global_masking_threshold in one pass over the PCM
  * (the composition of tests/test_psychoacoustic.py:38-41 + psychoacoustic.py:130-131).
  * x [B,K*N,C] -> X [B,K+1,N,C], t [B,K+1,1,C], thr [B,K+1,N,C].  mdct N must equal psy N. */
