@@ -42,6 +42,10 @@ PROTOTYPES = {
                                            c_int, c_int, c_void_p]),
     "ac_encode_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int,
                                 c_int, c_void_p]),
+    "ac_mdct_forward_pcm16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ac_mdct_inverse_pcm16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ac_encode_fused_pcm16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
+                                      c_int, c_int, c_void_p]),
     "ac_stream_create": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
     "ac_stream_reset": (c_int, [c_void_p, c_void_p]),
     "ac_stream_destroy": (c_int, [c_void_p]),

@@ -31,16 +31,20 @@ class AudioCodec:
         self._lib = _lib.load()
 
     def encode(self, x, drown=0.0):
-        """x [B, K*N, C] -> (X [B,K+1,N,C], tonality [B,K+1,1,C], threshold [B,K+1,N,C])."""
-        x = _host.check_device_tensor(x, "x", self.compute_dtype, 3)
+        """x [B, K*N, C] -> (X [B,K+1,N,C], tonality [B,K+1,1,C], threshold [B,K+1,N,C]).
+
+        ``x`` is float PCM in [-1, 1] (the reference's convention) or ``torch.int16`` PCM (extension: x = pcm / 32768
+        is applied inside the kernel's loads, half the PCM bytes)."""
+        pcm16 = isinstance(x, torch.Tensor) and x.dtype == torch.int16
+        x = _host.check_device_tensor(x, "x", torch.int16 if pcm16 else self.compute_dtype, 3)
         B, S, C = x.shape
         N = self.filters_n
         if S % N != 0:
             raise ValueError("samples_n (%d) is not a multiple of filters_n (%d)" % (S, N))
         K = S // N
-        X = torch.empty((B, K + 1, N, C), dtype=x.dtype, device=x.device)
-        t = torch.empty((B, K + 1, 1, C), dtype=x.dtype, device=x.device)
-        thr = torch.empty((B, K + 1, N, C), dtype=x.dtype, device=x.device)
+        X = torch.empty((B, K + 1, N, C), dtype=self.compute_dtype, device=x.device)
+        t = torch.empty((B, K + 1, 1, C), dtype=self.compute_dtype, device=x.device)
+        thr = torch.empty((B, K + 1, N, C), dtype=self.compute_dtype, device=x.device)
         self.encode_into(x, X, t, thr, drown)
         return X, t, thr
 
@@ -48,20 +52,29 @@ class AudioCodec:
         """Same as :meth:`encode` into caller-owned output tensors (no allocation in the timed path)."""
         B, S, C = x.shape
         K = S // self.filters_n
+        fn = self._lib.ac_encode_fused_pcm16 if x.dtype == torch.int16 else self._lib.ac_encode_fused
         with torch.cuda.device(x.device):
-            _lib.check(self._lib.ac_encode_fused(self.mdct._plan(x.device), self.psy._plan(x.device), _host.ptr(x),
-                                                 _host.ptr(X), _host.ptr(t), _host.ptr(thr), float(drown), B, K, C,
-                                                 _host.stream_ptr(x.device)))
+            _lib.check(fn(self.mdct._plan(x.device), self.psy._plan(x.device), _host.ptr(x), _host.ptr(X), _host.ptr(t),
+                          _host.ptr(thr), float(drown), B, K, C, _host.stream_ptr(x.device)))
 
-    def decode(self, X):
-        """X [B, K', N, C] -> x [B, (K'+1)*N, C]."""
-        return self.mdct.inverse_transform(X)
+    def decode(self, X, pcm16=False):
+        """X [B, K', N, C] -> x [B, (K'+1)*N, C]; ``pcm16=True`` returns ``torch.int16`` PCM
+        (clamp(round(32768 x)) applied inside the kernel's stores)."""
+        if not pcm16:
+            return self.mdct.inverse_transform(X)
+        X = _host.check_device_tensor(X, "X", self.compute_dtype, 4)
+        B, Kp, N, C = X.shape
+        if N != self.filters_n:
+            raise ValueError("axis 2 of X (%d) != filters_n (%d)" % (N, self.filters_n))
+        x = torch.empty((B, (Kp + 1) * N, C), dtype=torch.int16, device=X.device)
+        self.decode_into(X, x)
+        return x
 
     def decode_into(self, X, x):
         B, Kp, N, C = X.shape
+        fn = self._lib.ac_mdct_inverse_pcm16 if x.dtype == torch.int16 else self._lib.ac_mdct_inverse
         with torch.cuda.device(X.device):
-            _lib.check(self._lib.ac_mdct_inverse(self.mdct._plan(X.device), _host.ptr(X), _host.ptr(x), B, Kp, C,
-                                                 _host.stream_ptr(X.device)))
+            _lib.check(fn(self.mdct._plan(X.device), _host.ptr(X), _host.ptr(x), B, Kp, C, _host.stream_ptr(X.device)))
 
 
 class StreamingMDCT:

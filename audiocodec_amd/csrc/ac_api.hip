@@ -268,7 +268,7 @@ static int check_dims(int B, int K, int C) {
   return AC_OK;
 }
 
-int ac_mdct_forward(const ac_mdct_plan* p, const float* x, float* X, int B, int K, int C, void* stream) {
+static int mdct_forward(const ac_mdct_plan* p, const void* x, bool pcm16, float* X, int B, int K, int C, void* stream) {
   AC_REQUIRE(p != nullptr, "plan is NULL");
   int st = check_dims(B, K, C);
   if (st) return st;
@@ -277,11 +277,15 @@ int ac_mdct_forward(const ac_mdct_plan* p, const float* x, float* X, int B, int 
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
   if (p->fast && !g_force_generic)
-    return launch_fwd_fast(p, nullptr, x, X, nullptr, nullptr, 0.f, nullptr, B, K, K + 1, C, s);
-  return launch_fwd_generic(p, x, X, nullptr, B, K, K + 1, C, s);
+    return launch_fwd_fast(p, nullptr, x, pcm16, X, nullptr, nullptr, 0.f, nullptr, B, K, K + 1, C, s);
+  if (pcm16) {
+    set_error("16-bit PCM is served by the wave-level kernels only (filters_n 1024 or 2048, 'vorbis' or 'sine' window)");
+    return AC_EUNSUPPORTED;
+  }
+  return launch_fwd_generic(p, static_cast<const float*>(x), X, nullptr, B, K, K + 1, C, s);
 }
 
-int ac_mdct_inverse(const ac_mdct_plan* p, const float* X, float* x, int B, int Kp, int C, void* stream) {
+static int mdct_inverse(const ac_mdct_plan* p, const float* X, void* x, bool pcm16, int B, int Kp, int C, void* stream) {
   AC_REQUIRE(p != nullptr, "plan is NULL");
   int st = check_dims(B, Kp, C);
   if (st) return st;
@@ -289,8 +293,25 @@ int ac_mdct_inverse(const ac_mdct_plan* p, const float* X, float* x, int B, int 
   AC_REQUIRE(x != nullptr && (X != nullptr || Kp == 0), "NULL tensor pointer");
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
-  if (p->fast && !g_force_generic) return launch_inv_fast(p, X, x, nullptr, nullptr, B, Kp, Kp + 1, C, s);
-  return launch_inv_generic(p, X, x, nullptr, nullptr, B, Kp, Kp + 1, C, s);
+  if (p->fast && !g_force_generic) return launch_inv_fast(p, X, x, pcm16, nullptr, nullptr, B, Kp, Kp + 1, C, s);
+  if (pcm16) {
+    set_error("16-bit PCM is served by the wave-level kernels only (filters_n 1024 or 2048, 'vorbis' or 'sine' window)");
+    return AC_EUNSUPPORTED;
+  }
+  return launch_inv_generic(p, X, static_cast<float*>(x), nullptr, nullptr, B, Kp, Kp + 1, C, s);
+}
+
+int ac_mdct_forward(const ac_mdct_plan* p, const float* x, float* X, int B, int K, int C, void* stream) {
+  return mdct_forward(p, x, false, X, B, K, C, stream);
+}
+int ac_mdct_forward_pcm16(const ac_mdct_plan* p, const int16_t* x, float* X, int B, int K, int C, void* stream) {
+  return mdct_forward(p, x, true, X, B, K, C, stream);
+}
+int ac_mdct_inverse(const ac_mdct_plan* p, const float* X, float* x, int B, int Kp, int C, void* stream) {
+  return mdct_inverse(p, X, x, false, B, Kp, C, stream);
+}
+int ac_mdct_inverse_pcm16(const ac_mdct_plan* p, const float* X, int16_t* x, int B, int Kp, int C, void* stream) {
+  return mdct_inverse(p, X, x, true, B, Kp, C, stream);
 }
 
 int ac_tonality(const ac_psy_plan* p, const float* X, float* t, int B, int F, int C, void* stream) {
@@ -341,8 +362,8 @@ int ac_mask_threshold_backward(const ac_psy_plan* p, const float* X, const float
   return launch_threshold_bwd_generic(p, X, t, drown, grad_thr, grad_X, grad_t, B, F, C, (hipStream_t)stream);
 }
 
-int ac_encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr,
-                    float drown, int B, int K, int C, void* stream) {
+static int encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const void* x, bool pcm16, float* X, float* t,
+                        float* thr, float drown, int B, int K, int C, void* stream) {
   AC_REQUIRE(mdct != nullptr && psy != nullptr, "plan is NULL");
   AC_REQUIRE(mdct->N == psy->N, "mdct filters_n (%d) != psychoacoustic filter_bands_n (%d)", mdct->N, psy->N);
   AC_REQUIRE(mdct->device == psy->device, "plans live on different devices");
@@ -355,18 +376,27 @@ int ac_encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const floa
   if (mdct->fast && psy->fast && !g_force_generic) {
     static const int fuse2048 = [] { const char* e = getenv("AC_FUSE_2048"); return e ? atoi(e) : 0; }();   // tuning hook
     if (mdct->N == 1024 || fuse2048)
-      return launch_fwd_fast(mdct, psy, x, X, t, thr, drown, nullptr, B, K, K + 1, C, s);
+      return launch_fwd_fast(mdct, psy, x, pcm16, X, t, thr, drown, nullptr, B, K, K + 1, C, s);
     // filters_n = 2048: the fused kernel runs out of registers (59 spilled at 256); two wave-level launches instead,
     // the second one computing tonality and threshold in one pass over X
-    st = launch_fwd_fast(mdct, nullptr, x, X, nullptr, nullptr, 0.f, nullptr, B, K, K + 1, C, s);
+    st = launch_fwd_fast(mdct, nullptr, x, pcm16, X, nullptr, nullptr, 0.f, nullptr, B, K, K + 1, C, s);
     if (!st) st = launch_psy_fast(psy, X, nullptr, t, thr, drown, B, K + 1, C, s);
     return st;
   }
   // un-fused composition for configurations the fused kernel does not cover
-  st = ac_mdct_forward(mdct, x, X, B, K, C, stream);
+  st = mdct_forward(mdct, x, pcm16, X, B, K, C, stream);
   if (!st) st = ac_tonality(psy, X, t, B, K + 1, C, stream);
   if (!st) st = ac_mask_threshold(psy, X, t, drown, thr, B, K + 1, C, stream);
   return st;
+}
+
+int ac_encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr,
+                    float drown, int B, int K, int C, void* stream) {
+  return encode_fused(mdct, psy, x, false, X, t, thr, drown, B, K, C, stream);
+}
+int ac_encode_fused_pcm16(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const int16_t* x, float* X, float* t,
+                          float* thr, float drown, int B, int K, int C, void* stream) {
+  return encode_fused(mdct, psy, x, true, X, t, thr, drown, B, K, C, stream);
 }
 
 // ---- streaming ---------------------------------------------------------------------------------------
@@ -432,7 +462,7 @@ int ac_stream_forward(ac_stream* s, const float* x_chunk, float* X, int k, void*
   hipStream_t hs = (hipStream_t)stream;
   int st;
   if (p->fast && !g_force_generic)
-    st = launch_fwd_fast(p, nullptr, x_chunk, X, nullptr, nullptr, 0.f, s->d_prev_block, s->B, k, k, s->C, hs);
+    st = launch_fwd_fast(p, nullptr, x_chunk, false, X, nullptr, nullptr, 0.f, s->d_prev_block, s->B, k, k, s->C, hs);
   else
     st = launch_fwd_generic(p, x_chunk, X, s->d_prev_block, s->B, k, k, s->C, hs);
   if (st) return st;
@@ -453,7 +483,7 @@ int ac_stream_inverse(ac_stream* s, const float* X_chunk, float* x, int k, void*
   hipStream_t hs = (hipStream_t)stream;
   int st;
   if (p->fast && !g_force_generic)
-    st = launch_inv_fast(p, X_chunk, x, s->d_tail, s->d_tail_tmp, s->B, k, k, s->C, hs);
+    st = launch_inv_fast(p, X_chunk, x, false, s->d_tail, s->d_tail_tmp, s->B, k, k, s->C, hs);
   else
     st = launch_inv_generic(p, X_chunk, x, s->d_tail, s->d_tail_tmp, s->B, k, k, s->C, hs);
   if (st) return st;

@@ -358,6 +358,62 @@ __device__ __forceinline__ void store_row(float* __restrict__ r0, float* __restr
   }
 }
 
+// ---- the same rows as 16-bit PCM (x = pcm / 32768; pcm = clamp(round(32768 x))) ------------------------------
+typedef short s4 __attribute__((ext_vector_type(4)));
+typedef short s2 __attribute__((ext_vector_type(2)));
+constexpr float kPcmScale = 1.0f / 32768.0f;
+__device__ __forceinline__ short to_pcm16(float v) {
+  return (short)__float2int_rn(fminf(fmaxf(v * 32768.0f, -32768.0f), 32767.0f));
+}
+
+template <int CMODE, int R>
+__device__ __forceinline__ void load_row_pcm16(const int16_t* __restrict__ r0, const int16_t* __restrict__ r1, int C,
+                                               bool has1, int lane, v4f (&v)[R]) {
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int q = 64 * i + lane;
+    if (CMODE == 0) {
+      const s4 p = reinterpret_cast<const s4*>(r0)[q];
+      v[i] = v4f{(float)p.x, (float)p.y, (float)p.z, (float)p.w} * kPcmScale;
+    } else if (CMODE == 2) {
+      const s2 u = reinterpret_cast<const s2*>(r0)[q];
+      const s2 w = has1 ? reinterpret_cast<const s2*>(r1)[q] : s2{0, 0};
+      v[i] = v4f{(float)u.x, (float)w.x, (float)u.y, (float)w.y} * kPcmScale;
+    } else {
+      const size_t step = (size_t)(128 * i) * C;
+      const int off = 2 * lane * C;
+      v[i].x = (float)r0[step + off] * kPcmScale;
+      v[i].z = (float)r0[step + off + C] * kPcmScale;
+      v[i].y = has1 ? (float)r1[step + off] * kPcmScale : 0.f;
+      v[i].w = has1 ? (float)r1[step + off + C] * kPcmScale : 0.f;
+    }
+  }
+}
+
+template <int CMODE, int R>
+__device__ __forceinline__ void store_row_pcm16(int16_t* __restrict__ r0, int16_t* __restrict__ r1, int C, bool has1,
+                                                int lane, const v4f (&v)[R]) {
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int q = 64 * i + lane;
+    if (CMODE == 0) {
+      reinterpret_cast<s4*>(r0)[q] = s4{to_pcm16(v[i].x), to_pcm16(v[i].y), to_pcm16(v[i].z), to_pcm16(v[i].w)};
+    } else if (CMODE == 2) {
+      reinterpret_cast<s2*>(r0)[q] = s2{to_pcm16(v[i].x), to_pcm16(v[i].z)};
+      if (has1) reinterpret_cast<s2*>(r1)[q] = s2{to_pcm16(v[i].y), to_pcm16(v[i].w)};
+    } else {
+      const size_t step = (size_t)(128 * i) * C;
+      const int off = 2 * lane * C;
+      r0[step + off] = to_pcm16(v[i].x);
+      r0[step + off + C] = to_pcm16(v[i].z);
+      if (has1) {
+        r1[step + off] = to_pcm16(v[i].y);
+        r1[step + off + C] = to_pcm16(v[i].w);
+      }
+    }
+  }
+}
+
 // wave-wide sum, result uniform (scalar register): xor butterflies inside each row of 16 lanes, then the two
 // row broadcasts of the DPP unit; no LDS traffic
 template <int CTRL, int ROW_MASK>
@@ -557,7 +613,7 @@ __device__ __forceinline__ void load_tables(char* lds, const float* __restrict__
 // analysis (+ fused epilogue)
 // ------------------------------------------------------------------------------------------------------
 struct FwdArgs {
-  const float* x;            // [B, Kin*N, C]
+  const void* x;             // [B, Kin*N, C] float32, or int16 PCM for the PCM16 kernels
   float* X;                  // [B, F, N, C]
   float* t;                  // [B, F, 1, C]   (PSY)
   float* thr;                // [B, F, N, C]   (PSY)
@@ -582,7 +638,7 @@ struct FwdArgs {
 // register (r + 4) & 7) and the odd sample of granule 767 - e (lane 63 - lane, register (3 - r) & 7).
 // With (A, B) = COEF[e]:  carried part (block n-1) = B xe + A xo;  current part (block n) = B xo - A xe (r < 4),
 // A xe - B xo (r >= 4)   (Princen-Bradley windows make the 2x2 fold blocks rotations).
-template <int R, int CMODE, bool PSY, int NW>
+template <int R, int CMODE, bool PSY, int NW, bool PCM16 = false>
 __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY>())) void k_fwd_fast(FwdArgs a) {
   using G = Geo<R>;
   // one LDS object: [NW wave buffers | table image | psy image]
@@ -611,15 +667,16 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY>())) void k_fwd_fast(Fw
   long long pair = f0 / a.F;
   int n = (int)(f0 % a.F);
   const long long npairs = a.npairs;
-  const float* __restrict__ xin = a.x;
-  const float* __restrict__ xstate = a.prev_block;
+  using pcm_t = typename std::conditional<PCM16, int16_t, float>::type;
+  const pcm_t* __restrict__ xin = static_cast<const pcm_t*>(a.x);
+  const pcm_t* __restrict__ xstate = PCM16 ? nullptr : reinterpret_cast<const pcm_t*>(a.prev_block);
 
   // loads block fn (WHICH 0) or block fn-1 (WHICH 1) of frame (pr, fn) in natural order.  A missing block (before the
   // first / after the last) is loaded from a neighbouring, valid address and zeroed when it is consumed (returns false),
   // so that the loads stay unconditional and nothing waits for them at the point of issue.
   auto issue_loads = [&](auto which, long long pr, int fn, v4f (&dst)[R]) -> bool {
     const Pair q = make_pair<CMODE>(pr, C, a.nsig);
-    const float *s0, *s1;
+    const pcm_t *s0, *s1;
     bool ok;
     if (decltype(which)::value == 0) {
       ok = fn < a.Kin;
@@ -638,10 +695,11 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY>())) void k_fwd_fast(Fw
       }
     }
     if (a.Kin == 0 && !(decltype(which)::value == 1 && fn == 0 && xstate)) {   // no PCM at all: any mapped address
-      s0 = s1 = a.X;
+      s0 = s1 = reinterpret_cast<const pcm_t*>(a.X);
       ok = false;
     }
-    load_row<CMODE, ((AC_NT_LOAD >> decltype(which)::value) & 1) != 0, R>(s0, s1, C, q.has1, lane, dst);
+    if constexpr (PCM16) load_row_pcm16<CMODE, R>(s0, s1, C, q.has1, lane, dst);
+    else load_row<CMODE, ((AC_NT_LOAD >> decltype(which)::value) & 1) != 0, R>(s0, s1, C, q.has1, lane, dst);
     return ok;
   };
   constexpr std::integral_constant<int, 0> kCur{};
@@ -766,7 +824,7 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY>())) void k_fwd_fast(Fw
 // ------------------------------------------------------------------------------------------------------
 struct InvArgs {
   const float* X;          // [B, Kp, N, C]
-  float* x;                // [B, nblk*N, C]
+  void* x;                 // [B, nblk*N, C] float32, or int16 PCM for the PCM16 kernels
   const float* tail_in;    // [B, C, N/2] or null
   float* tail_out;         // [B, C, N/2] or null
   const float* tab;
@@ -808,7 +866,7 @@ __device__ __forceinline__ void idct_frame(const v4f (&frm)[R], char* buf, gtab_
   }
 }
 
-template <int R, int CMODE, int NW>
+template <int R, int CMODE, int NW, bool PCM16 = false>
 __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_inv_fast(InvArgs a) {
   using G = Geo<R>;
   constexpr int FH = G::FH;
@@ -895,8 +953,9 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_inv_fast(InvArgs
 #pragma unroll
         for (int i = 0; i < R; ++i) row[i] = v4f{xe[i].x, xe[i].y, xo[i].x, xo[i].y};
       }
-      store_row<CMODE, R>(a.x + row_off(pq.b0, a.nblk, n, blk, pq.c0), a.x + row_off(pq.b1, a.nblk, n, blk, pq.c1), C, has1,
-                          lane, row);
+      const size_t o0 = row_off(pq.b0, a.nblk, n, blk, pq.c0), o1 = row_off(pq.b1, a.nblk, n, blk, pq.c1);
+      if constexpr (PCM16) store_row_pcm16<CMODE, R>(static_cast<int16_t*>(a.x) + o0, static_cast<int16_t*>(a.x) + o1, C, has1, lane, row);
+      else store_row<CMODE, R>(static_cast<float*>(a.x) + o0, static_cast<float*>(a.x) + o1, C, has1, lane, row);
     }
 
     if (a.tail_out && n1 == a.nblk) {
@@ -1210,23 +1269,23 @@ static unsigned persistent_grid(int cus, int wg_per_cu, long long ntasks, int nw
   return (unsigned)g;
 }
 
-template <int R>
+template <int R, bool PCM16>
 static void launch_fwd_R(const FwdArgs& a, bool psy, int C, unsigned grid, hipStream_t s) {
   if (psy) {
     const dim3 blk(AC_WAVES_PSY * 64);
-    if (C == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY>), dim3(grid), blk, 0, s, a);
-    else if (C == 1) hipLaunchKernelGGL((k_fwd_fast<R, 2, true, AC_WAVES_PSY>), dim3(grid), blk, 0, s, a);
-    else hipLaunchKernelGGL((k_fwd_fast<R, 1, true, AC_WAVES_PSY>), dim3(grid), blk, 0, s, a);
+    if (C == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, PCM16>), dim3(grid), blk, 0, s, a);
+    else if (C == 1) hipLaunchKernelGGL((k_fwd_fast<R, 2, true, AC_WAVES_PSY, PCM16>), dim3(grid), blk, 0, s, a);
+    else hipLaunchKernelGGL((k_fwd_fast<R, 1, true, AC_WAVES_PSY, PCM16>), dim3(grid), blk, 0, s, a);
     return;
   }
   const dim3 blk(AC_WAVES * 64);
-  if (C == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
-  else if (C == 1) hipLaunchKernelGGL((k_fwd_fast<R, 2, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
-  else hipLaunchKernelGGL((k_fwd_fast<R, 1, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
+  if (C == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, false, AC_WAVES, PCM16>), dim3(grid), blk, 0, s, a);
+  else if (C == 1) hipLaunchKernelGGL((k_fwd_fast<R, 2, false, AC_WAVES, PCM16>), dim3(grid), blk, 0, s, a);
+  else hipLaunchKernelGGL((k_fwd_fast<R, 1, false, AC_WAVES, PCM16>), dim3(grid), blk, 0, s, a);
 }
 
-int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr,
-                    float drown, const float* prev_block, int B, int Kin, int F, int C, hipStream_t s) {
+int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x, bool pcm16, float* X, float* t,
+                    float* thr, float drown, const float* prev_block, int B, int Kin, int F, int C, hipStream_t s) {
   if (B <= 0 || C <= 0 || F <= 0) return AC_OK;
   FwdArgs a;
   a.x = x;
@@ -1266,16 +1325,28 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const float* 
   } else {
     grid = persistent_grid(p->cus, wgcu, a.nframes, nw);
   }
-  if (p->N == Geo<8>::FN) launch_fwd_R<8>(a, psy != nullptr, C, grid, s);
+  if (p->N == Geo<8>::FN) {
+    if (pcm16) launch_fwd_R<8, true>(a, psy != nullptr, C, grid, s);
+    else launch_fwd_R<8, false>(a, psy != nullptr, C, grid, s);
+  }
 #ifndef AC_NO_R16
-  else launch_fwd_R<16>(a, psy != nullptr, C, grid, s);
+  else if (pcm16) launch_fwd_R<16, true>(a, psy != nullptr, C, grid, s);
+  else launch_fwd_R<16, false>(a, psy != nullptr, C, grid, s);
 #endif
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }
 
-int launch_inv_fast(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out, int B,
-                    int Kp, int nblk, int C, hipStream_t s) {
+template <int R, bool PCM16>
+static void launch_inv_R(const InvArgs& a, int C, unsigned grid, hipStream_t s) {
+  const dim3 blk(AC_WAVES * 64);
+  if (C == 2) hipLaunchKernelGGL((k_inv_fast<R, 0, AC_WAVES, PCM16>), dim3(grid), blk, 0, s, a);
+  else if (C == 1) hipLaunchKernelGGL((k_inv_fast<R, 2, AC_WAVES, PCM16>), dim3(grid), blk, 0, s, a);
+  else hipLaunchKernelGGL((k_inv_fast<R, 1, AC_WAVES, PCM16>), dim3(grid), blk, 0, s, a);
+}
+
+int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, bool pcm16, const float* tail_in, float* tail_out,
+                    int B, int Kp, int nblk, int C, hipStream_t s) {
   if (B <= 0 || C <= 0 || nblk <= 0) return AC_OK;
   InvArgs a;
   a.X = X;
@@ -1301,18 +1372,14 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, float* x, const float
     return AC_EINVAL;
   }
   const unsigned grid = wgcu > 0 ? persistent_grid(p->cus, wgcu, a.ntasks, AC_WAVES) : (unsigned)need;
-  const dim3 blk(AC_WAVES * 64);
   if (p->N == Geo<8>::FN) {
-    if (C == 2) hipLaunchKernelGGL((k_inv_fast<8, 0, AC_WAVES>), dim3(grid), blk, 0, s, a);
-    else if (C == 1) hipLaunchKernelGGL((k_inv_fast<8, 2, AC_WAVES>), dim3(grid), blk, 0, s, a);
-    else hipLaunchKernelGGL((k_inv_fast<8, 1, AC_WAVES>), dim3(grid), blk, 0, s, a);
-  } else {
-#ifndef AC_NO_R16
-    if (C == 2) hipLaunchKernelGGL((k_inv_fast<16, 0, AC_WAVES>), dim3(grid), blk, 0, s, a);
-    else if (C == 1) hipLaunchKernelGGL((k_inv_fast<16, 2, AC_WAVES>), dim3(grid), blk, 0, s, a);
-    else hipLaunchKernelGGL((k_inv_fast<16, 1, AC_WAVES>), dim3(grid), blk, 0, s, a);
-#endif
+    if (pcm16) launch_inv_R<8, true>(a, C, grid, s);
+    else launch_inv_R<8, false>(a, C, grid, s);
   }
+#ifndef AC_NO_R16
+  else if (pcm16) launch_inv_R<16, true>(a, C, grid, s);
+  else launch_inv_R<16, false>(a, C, grid, s);
+#endif
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }

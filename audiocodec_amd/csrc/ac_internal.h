@@ -105,10 +105,11 @@ bool fast_psy_supported(const ac_psy_plan* p);
 int fast_mdct_plan_init(ac_mdct_plan* p);
 int fast_psy_plan_init(ac_psy_plan* p);
 // psy may be null (plain transform).  X/t/thr as in ac_encode_fused.
-int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr,
-                    float drown, const float* prev_block, int B, int Kin, int F, int C, hipStream_t s);
-int launch_inv_fast(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out, int B,
-                    int Kp, int nblk, int C, hipStream_t s);
+// x: float32 PCM, or int16 PCM when pcm16 (then prev_block / tail state must be null)
+int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x, bool pcm16, float* X, float* t,
+                    float* thr, float drown, const float* prev_block, int B, int Kin, int F, int C, hipStream_t s);
+int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, bool pcm16, const float* tail_in, float* tail_out,
+                    int B, int Kp, int nblk, int C, hipStream_t s);
 int launch_psy_fast(const ac_psy_plan* p, const float* X, const float* t_in, float* t_out, float* thr, float drown,
                     int B, int F, int C, hipStream_t s);
 

@@ -126,6 +126,15 @@ int ac_mask_threshold_backward(const ac_psy_plan* plan, const float* X, const fl
 int ac_encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t,
                     float* thr, float drown, int B, int K, int C, void* stream);
 
+/* 16-bit PCM at the boundary (extension; the reference takes float PCM in [-1, 1] only, mdctransformer.py:104):
+ * x = pcm / 32768 on the way in, pcm = clamp(round(32768 x), -32768, 32767) on the way out, fused into the kernels'
+ * loads / stores, so a frame moves 2 bytes per sample instead of 4.  Served by the wave-level kernels (filters_n 1024
+ * or 2048, 'vorbis' / 'sine' window); AC_EUNSUPPORTED otherwise.  Shapes as the float32 entry points. */
+int ac_mdct_forward_pcm16(const ac_mdct_plan* plan, const int16_t* x, float* X, int B, int K, int C, void* stream);
+int ac_mdct_inverse_pcm16(const ac_mdct_plan* plan, const float* X, int16_t* x, int B, int Kp, int C, void* stream);
+int ac_encode_fused_pcm16(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const int16_t* x, float* X, float* t,
+                          float* thr, float drown, int B, int K, int C, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Streaming overlap-add (chunked transform with device-resident state).
  * Analysis state: the last input block per (b,c) [B,N,C]; synthesis state: the aliased second half of

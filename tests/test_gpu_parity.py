@@ -467,3 +467,22 @@ def test_autograd_of_the_masking_model(sr, N, M, C, drown):
     (_torch_psy_reference(p, Xd2, td2, drown) * w.double()).sum().backward()
     assert float((t2.grad.double() - td2.grad).abs().max()) <= 2e-3 * float(td2.grad.abs().max())
     assert float(torch.linalg.vector_norm(X2.grad.double() - Xd2.grad) / torch.linalg.vector_norm(Xd2.grad)) <= 1e-3
+
+
+@pytest.mark.parametrize("N,C", [(1024, 2), (1024, 1), (2048, 2), (1024, 3)])
+def test_pcm16_at_the_boundary(N, C):
+    """int16 PCM in / out: bit-identical to the float path fed pcm / 32768, and the round trip returns the PCM exactly."""
+    B, K = 3, 5
+    pcm = torch.randint(-32768, 32768, (B, K * N, C), device="cuda", dtype=torch.int16)
+    pcm[0, :7, 0] = torch.tensor([-32768, 32767, 0, 1, -1, 12345, -12345], dtype=torch.int16)
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    X, t, thr = codec.encode(pcm)
+    Xf, tf, thrf = codec.encode(pcm.float() / 32768.0)
+    assert X.dtype == torch.float32 and torch.equal(X, Xf) and torch.equal(t, tf) and torch.equal(thr, thrf)
+    out = codec.decode(X, pcm16=True)
+    assert out.dtype == torch.int16 and tuple(out.shape) == (B, (K + 2) * N, C)
+    assert torch.equal(out[:, N:-N], pcm)
+    ref = torch.clamp(torch.round(codec.decode(X) * 32768.0), -32768, 32767).to(torch.int16)
+    assert torch.equal(out, ref)
+    with pytest.raises(_lib.AudioCodecError):      # the generic kernels do not take 16-bit PCM
+        audiocodec_amd.AudioCodec(48000, 256).encode(pcm[:, : 4 * 256])

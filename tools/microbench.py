@@ -33,6 +33,11 @@ rows = [
     ("torch fill X (0R:1W)", lambda: thr.fill_(1.0), 4 * N),
     ("torch sum X (1R:0W)", lambda: X.sum(), 4 * N),
 ]
+if codec.mdct.is_fast():
+    pcm = (x * 32767).to(torch.int16)
+    pcm_out = torch.empty((B, (K + 2) * N, C), device=dev, dtype=torch.int16)
+    rows += [("encode_fused pcm16", lambda: codec.encode_into(pcm, X, t, thr), 10 * N + 4),
+             ("inverse pcm16", lambda: codec.decode_into(X, pcm_out), 6 * N)]
 for name, fn, bpf in rows:
     ms = timeit(fn)
     print("%-24s %8.3f ms   %7.0f GB/s (algorithmic %d B/frame)" % (name, ms, bpf * frames / ms / 1e6, bpf))
