@@ -1,23 +1,24 @@
 // Wave-level kernels for filters_n = 1024 and 2048 on gfx950 (MI355X); the description below is for 1024
 // (8 complex FFT points per lane), 2048 runs the same code with 16 (template parameter R).
 //
-// One 64-lane wavefront owns one "strip": a pair of channels of one clip over a run of consecutive
-// frames, and walks it in time.  Both channels ride in the two halves of 64-bit register pairs
-// (v2f = (c0, c1)), so twiddles, window coefficients, addresses and LDS traffic are shared.
+// One 64-lane wavefront transforms one frame of two signals at a time (the two channels of a stereo clip, or two
+// mono signals): both ride in the two halves of 64-bit register pairs (v2f = (s0, s1)), so twiddles, window
+// coefficients, addresses and LDS traffic are shared.
 //
-// Data movement per frame (both channels), q = 64 i + lane being the 16-byte granule (x[2q], x[2q+1]) x (c0, c1)
-// that lane `lane` loads / stores with one coalesced 16-byte access per i:
-//   * FFT element e = lane + 64 r needs the even sample of granule q = e + 256 (same lane, another register) and
-//     the odd sample of granule 767 - e (lane 63 - lane): only the odd halves cross lanes, through one
-//     lane-reversal exchange in LDS (8 ds_write_b64 + 8 ds_read_b64);
-//   * window fold with two coefficients per element (Princen-Bradley windows: the 2x2 fold blocks are
-//     rotations), the half that aliases into the NEXT frame carried in registers;
+// Data movement per frame, q = 64 i + lane being the 16-byte granule (x[2q], x[2q+1]) x (s0, s1) that lane `lane`
+// loads / stores with one coalesced 16-byte access per i:
+//   * analysis loads blocks n-1 and n of the PCM.  FFT element e = lane + 64 r needs, from each block, the even sample
+//     of granule e + 256 (same lane, another register) and the odd sample of granule 767 - e (lane 63 - lane): only
+//     the odd halves cross lanes, through one lane-reversal exchange in LDS (ds_write_b64 / ds_read_b64);
+//   * window fold with two coefficients per element (Princen-Bradley windows: the 2x2 fold blocks are rotations);
 //   * pre-twiddle -> 512-point complex FFT as three in-register radix-8 passes with two padded, conflict-free LDS
 //     exchanges whose addresses are one per-lane base + an immediate -> post-twiddle; the output bin of
 //     (lane, register k2) is lane + 64 k2, so the even coefficients X[2k] are already where the store wants
 //     them and only the odd ones (X[N-1-2k]) take the lane-reversal exchange again;
 //   * coalesced 16-byte stores of X; the psychoacoustic epilogue (tonality, Bark sums, spreading, threshold)
-//     runs on the frame in registers before the next block.
+//     runs on the frame in registers;
+//   * synthesis carries the aliased half of a frame's DCT-IV in registers along a short strip of output blocks.
+// Frames are dealt to waves in order, so the chip works on one contiguous window of every tensor.
 //
 // Index maps and their bank behaviour are emulated lane by lane in tools/emulate_wave_fft.py.
 // Reference formulas: mdctransformer.py:62-153 (closed forms in SURVEY.md App. A), psychoacoustic.py:102-210,301-331.
@@ -629,10 +630,11 @@ struct FwdArgs {
 };
 
 // Analysis is frame-independent: frame n of a channel pair needs blocks n-1 and n of the PCM, and a wave that loads
-// both needs nothing from its neighbours.  Waves are persistent and deal the frames out in order -- wave w of W takes
-// frames w, w + W, w + 2W, ... -- so at any moment the chip reads one contiguous window of the PCM and writes one
-// contiguous window of each output tensor, which is what HBM rewards (tools/ubench_strips.hip: 10-15 % over per-wave
-// strips); block n-1 is the block the neighbouring wave loads as its block n, so the second read is an L2 hit.
+// both needs nothing from its neighbours.  Frames are dealt out in order -- workgroup g owns frames [g NW T, (g+1) NW T)
+// and its wave w takes g NW T + w + NW t (or, with T = 0, persistent waves take w, w + W, ...) -- so at any moment the
+// chip reads one contiguous window of the PCM and writes one contiguous window of each output tensor, which is what HBM
+// rewards (tools/ubench_strips.hip: 10-15 % over per-wave strips); block n-1 is the block the neighbouring wave loads as
+// its block n, so the second read is an L2 hit.
 //
 // Element e = lane + 64 r of the FFT input takes, from each block, the even sample of granule e + 256 (this lane,
 // register (r + 4) & 7) and the odd sample of granule 767 - e (lane 63 - lane, register (3 - r) & 7).
