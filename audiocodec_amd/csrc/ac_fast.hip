@@ -881,25 +881,60 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_inv_fast(InvArgs
   load_p1<R>(a.tab + G::I_TOTAL, lane, p1);
   const int C = a.C;
   const size_t blk = (size_t)G::FN * C;
-  // Synthesis carries the aliased half of the previous frame's DCT-IV, so a wave walks a short strip of consecutive
-  // output blocks (the first one costs an extra DCT-IV of the frame before the strip).  One strip per wave by default
-  // (workgroups dispatched in order keep the window of memory in flight contiguous); the loop serves persistent grids.
-  const long long stride = (long long)gridDim.x * NW;
-  for (long long task = (long long)blockIdx.x * NW + wave; task < a.ntasks; task += stride) {
-    const int sgm = (int)(task % a.nseg);
-    const Pair pq = make_pair<CMODE>(task / a.nseg, C, a.nsig);
-    const bool has1 = pq.has1;
-    const int n0 = sgm * a.seglen;
-    const int n1 = min(a.nblk, n0 + a.seglen);
-    const float* X0 = a.X + row_off(pq.b0, a.Kp, 0, blk, pq.c0);   // frame 0 of the two signals
-    const float* X1 = a.X + row_off(pq.b1, a.Kp, 0, blk, pq.c1);
-    const size_t ts0 = ((size_t)pq.b0 * C + pq.c0) * FH, ts1 = ((size_t)pq.b1 * C + pq.c1) * FH;   // stream state rows
-    constexpr bool NT = (AC_NT_LOAD & 4) != 0;
+  // Synthesis block n overlap-adds the DCT-IV of frames n and n-1, so a wave walks a short strip of consecutive output
+  // blocks with the aliased half of the last frame carried in registers.  The waves of a workgroup own consecutive
+  // strips: the first block of a strip is finished last, when the neighbouring wave hands over the aliased half of
+  // its last frame through LDS -- only the first wave of a workgroup pays an extra DCT-IV (of the frame before its
+  // strip).  Workgroups are dispatched in order, which keeps the window of memory in flight contiguous.
+  constexpr bool COOP = (R == 8);   // hand-over between waves (the 2048-filter kernel has no registers to spare)
+  const long long task_raw = (long long)blockIdx.x * NW + wave;
+  const bool valid = task_raw < a.ntasks;
+  const long long task = valid ? task_raw : a.ntasks - 1;   // idle waves of the last workgroup only join the barriers
+  const int sgm = (int)(task % a.nseg);
+  const Pair pq = make_pair<CMODE>(task / a.nseg, C, a.nsig);
+  const bool has1 = pq.has1;
+  const int n0 = sgm * a.seglen;
+  const int n1 = min(a.nblk, n0 + a.seglen);
+  const float* X0 = a.X + row_off(pq.b0, a.Kp, 0, blk, pq.c0);   // frame 0 of the two signals
+  const float* X1 = a.X + row_off(pq.b1, a.Kp, 0, blk, pq.c1);
+  const size_t ts0 = ((size_t)pq.b0 * C + pq.c0) * FH, ts1 = ((size_t)pq.b1 * C + pq.c1) * FH;   // stream state rows
+  constexpr bool NT = (AC_NT_LOAD & 4) != 0;
+  constexpr bool AHEAD = (R == 8);   // the next frame in flight while the current one is transformed
+  const bool left = valid && n0 >= 1;              // block n0 needs the aliased half of frame n0-1 ...
+  const bool deferred = COOP && left && wave > 0;  // ... which the previous wave (strip sgm-1 of the same signals) hands over
 
-    constexpr bool AHEAD = (R == 8);   // the next frame in flight while the current one is transformed
-    v2f carry[R];
+  // block n from the current frame's half (now) and the previous frame's aliased half (cin):
+  // with (a, b) = COEF[k]: o1 = a now + b cin -> out[j], o2 = b now - a cin -> out[N-1-j]  
+  // k < N/4: j = N/2-1 - 2k (odd: granule N/4-1-k, lane 63 - lane), N-1-j = N/2 + 2k (even: granule N/4+k, this lane)
+  // else     j = 2k - N/2 (even: granule k - N/4, this lane),       N-1-j = 3N/2-1 - 2k (odd: granule 3N/4-1-k)
+  auto emit = [&](int n, const v2f (&now)[R], const v2f (&cin)[R]) {
+    v4f row[R];
+    v2f xe[R], xo_in[R], xo[R];
+#pragma unroll
+    for (int j2 = 0; j2 < R; ++j2) {
+      const v2f ab = reinterpret_cast<const v2f*>(tab + G::I_COEF)[j2 * 64 + lane];
+      const v2f o1 = ab.x * now[j2] + ab.y * cin[j2];
+      const v2f o2 = ab.y * now[j2] - ab.x * cin[j2];
+      xe[(j2 + R / 2) & (R - 1)] = (j2 < R / 2) ? o2 : o1;
+      xo_in[j2] = (j2 < R / 2) ? o1 : o2;
+    }
+    rev_exchange<R / 2 - 1, R>(buf, lane, xo_in, xo);
+#pragma unroll
+    for (int i = 0; i < R; ++i) row[i] = v4f{xe[i].x, xe[i].y, xo[i].x, xo[i].y};
+    const size_t o0 = row_off(pq.b0, a.nblk, n, blk, pq.c0), o1 = row_off(pq.b1, a.nblk, n, blk, pq.c1);
+    if constexpr (PCM16) store_row_pcm16<CMODE, R>(static_cast<int16_t*>(a.x) + o0, static_cast<int16_t*>(a.x) + o1, C, has1, lane, row);
+    else store_row<CMODE, R>(static_cast<float*>(a.x) + o0, static_cast<float*>(a.x) + o1, C, has1, lane, row);
+  };
+
+  v2f carry[R], now0[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    carry[r] = v2f{0.f, 0.f};
+    now0[r] = v2f{0.f, 0.f};
+  }
+  if (valid) {
     v4f ahead[R];
-    if (n0 >= 1) {
+    if (left && !deferred) {
       // aliased half of frame n0-1 (always an existing frame: n0-1 < Kp)
       v4f row[R];
       load_row<CMODE, NT, R>(X0 + (size_t)(n0 - 1) * blk, X1 + (size_t)(n0 - 1) * blk, C, has1, lane, row);
@@ -908,7 +943,7 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_inv_fast(InvArgs
       idct_frame<R>(row, buf, tab, p1, lane, dummy, carry);
     } else {
       if (AHEAD && n0 < a.Kp) load_row<CMODE, NT, R>(X0 + (size_t)n0 * blk, X1 + (size_t)n0 * blk, C, has1, lane, ahead);
-      if (a.tail_in) {
+      if (!left && a.tail_in) {
 #pragma unroll
         for (int j2 = 0; j2 < R; ++j2) {
           const int k = lane + 64 * j2;
@@ -916,9 +951,6 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_inv_fast(InvArgs
           carry[j2].x = a.tail_in[ts0 + j];
           carry[j2].y = has1 ? a.tail_in[ts1 + j] : 0.f;
         }
-      } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r) carry[r] = v2f{0.f, 0.f};
       }
     }
 
@@ -936,28 +968,14 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_inv_fast(InvArgs
           nxt[r] = v2f{0.f, 0.f};
         }
       }
-      v4f row[R];
-      {
-        // with (a, b) = COEF[k]: o1 = a now + b carry -> out[j], o2 = b now - a carry -> out[N-1-j]  
-        // k < N/4: j = N/2-1 - 2k (odd: granule N/4-1-k, lane 63 - lane), N-1-j = N/2 + 2k (even: granule N/4+k, this lane)
-        // else     j = 2k - N/2 (even: granule k - N/4, this lane),       N-1-j = 3N/2-1 - 2k (odd: granule 3N/4-1-k)
-        v2f xe[R], xo_in[R], xo[R];
+      if (deferred && n == n0) {
 #pragma unroll
-        for (int j2 = 0; j2 < R; ++j2) {
-          const v2f ab = reinterpret_cast<const v2f*>(tab + G::I_COEF)[j2 * 64 + lane];
-          const v2f o1 = ab.x * now[j2] + ab.y * carry[j2];
-          const v2f o2 = ab.y * now[j2] - ab.x * carry[j2];
-          xe[(j2 + R / 2) & (R - 1)] = (j2 < R / 2) ? o2 : o1;
-          xo_in[j2] = (j2 < R / 2) ? o1 : o2;
-          carry[j2] = nxt[j2];
-        }
-        rev_exchange<R / 2 - 1, R>(buf, lane, xo_in, xo);
-#pragma unroll
-        for (int i = 0; i < R; ++i) row[i] = v4f{xe[i].x, xe[i].y, xo[i].x, xo[i].y};
+        for (int r = 0; r < R; ++r) now0[r] = now[r];   // finished after the hand-over
+      } else {
+        emit(n, now, carry);
       }
-      const size_t o0 = row_off(pq.b0, a.nblk, n, blk, pq.c0), o1 = row_off(pq.b1, a.nblk, n, blk, pq.c1);
-      if constexpr (PCM16) store_row_pcm16<CMODE, R>(static_cast<int16_t*>(a.x) + o0, static_cast<int16_t*>(a.x) + o1, C, has1, lane, row);
-      else store_row<CMODE, R>(static_cast<float*>(a.x) + o0, static_cast<float*>(a.x) + o1, C, has1, lane, row);
+#pragma unroll
+      for (int r = 0; r < R; ++r) carry[r] = nxt[r];
     }
 
     if (a.tail_out && n1 == a.nblk) {
@@ -969,7 +987,24 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_inv_fast(InvArgs
         if (has1) a.tail_out[ts1 + j] = carry[j2].y;
       }
     }
-  }   // strips of this wave
+  }
+
+  if (COOP) {
+    // hand the aliased half of the strip's last frame to the wave that owns the next strip
+    wave_sync();
+    if (valid) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) *reinterpret_cast<v2f*>(buf + 8 * lane + 512 * r) = carry[r];
+    }
+    __syncthreads();
+    v2f cin[R];
+    if (deferred) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) cin[r] = *reinterpret_cast<const v2f*>(buf - WAVE_LDS + 8 * lane + 512 * r);
+    }
+    __syncthreads();   // every hand-over has been read: the buffers may be reused for the last exchange
+    if (deferred) emit(n0, now0, cin);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1021,12 +1056,13 @@ __global__ __launch_bounds__(NW * 64, (R == 8 ? AC_WPE : 2)) void k_psy_fast(Psy
   if (WANT_THR) store_row<CMODE, R>(a.thr + o0, a.thr + o1, C, has1, lane, th);
 }
 
-// synthesis strips: short, so that the strips in flight cover a nearly contiguous window of memory (HBM rewards that
-// more than the extra DCT-IV per strip costs: measured 0.38 ms at 4 blocks against 0.42 ms at 15, B = 256, K = 468)
+// synthesis strips: short, so that the strips in flight cover a nearly contiguous window of memory (HBM rewards that:
+// 0.42 ms at 15 blocks per strip, 0.38 ms at 4 with an extra DCT-IV per strip, 0.355-0.365 ms at 3 with the hand-over
+// between the waves of a workgroup; B = 256, K = 468)
 int pick_seglen(long long pairs, int frames) {
   static const int fixed = [] {
     const char* e = getenv("AC_SEGLEN");   // tuning hook
-    return e ? atoi(e) : 4;
+    return e ? atoi(e) : 3;
   }();
   int s = fixed;
   if (s > frames) s = frames;
@@ -1365,15 +1401,13 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, bool pcm16, 
   a.seglen = pick_seglen(a.npairs, nblk);
   a.nseg = (nblk + a.seglen - 1) / a.seglen;
   a.ntasks = a.npairs * a.nseg;
-  // one strip per wave by default (workgroups dispatched in order keep the window of memory in flight contiguous;
-  // persistent waves drift apart and measured slower here); AC_WG_PER_CU_INV > 0 makes the waves persistent
-  static const int wgcu = [] { const char* e = getenv("AC_WG_PER_CU_INV"); return e ? atoi(e) : 0; }();   // tuning hook
+  // one strip per wave, workgroups dispatched in order (persistent waves drift apart and measured slower here)
   const long long need = (a.ntasks + AC_WAVES - 1) / AC_WAVES;
   if (need > 2147483647ll) {
     set_error("problem too large for one launch (%lld workgroups)", need);
     return AC_EINVAL;
   }
-  const unsigned grid = wgcu > 0 ? persistent_grid(p->cus, wgcu, a.ntasks, AC_WAVES) : (unsigned)need;
+  const unsigned grid = (unsigned)need;
   if (p->N == Geo<8>::FN) {
     if (pcm16) launch_inv_R<8, true>(a, C, grid, s);
     else launch_inv_R<8, false>(a, C, grid, s);
