@@ -160,7 +160,7 @@ def main():
                                    "(%.1f s), fused MDCT+tonality+masking encode then IMDCT decode" % (B, K, K * N / 48000.0),
                        "clips_per_gpu": B, "channels": C, "blocks": K, "filters_n": N, "sample_rate": 48000,
                        "sharding": "clips split across ranks, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_fwd_fast<8,0,true,4> (fused encode)",
+            "roofline": {"bound": "hbm", "kernel": "k_fwd_fast<8,0,true,4,false> (fused encode)",
                          "achieved": enc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": enc_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_frame": ENC_BYTES, "frames_per_launch": frames_rank,
                          "avg_launch_ms": enc_ms},
