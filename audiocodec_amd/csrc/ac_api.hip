@@ -347,6 +347,9 @@ int ac_tonality_backward(const ac_psy_plan* p, const float* X, const float* grad
   if (B == 0 || C == 0 || F == 0) return AC_OK;
   AC_REQUIRE(X != nullptr && grad_t != nullptr && grad_X != nullptr, "NULL tensor pointer");
   DeviceGuard guard(p->device);
+  if (p->fast && !g_force_generic)
+    return launch_psy_bwd_fast(p, X, nullptr, 0.f, nullptr, grad_t, grad_X, nullptr, accumulate, B, F, C,
+                               (hipStream_t)stream);
   return launch_tonality_bwd_generic(p, X, grad_t, grad_X, accumulate, B, F, C, (hipStream_t)stream);
 }
 
@@ -359,6 +362,8 @@ int ac_mask_threshold_backward(const ac_psy_plan* p, const float* X, const float
   AC_REQUIRE(X != nullptr && t != nullptr && grad_thr != nullptr && grad_X != nullptr && grad_t != nullptr,
              "NULL tensor pointer");
   DeviceGuard guard(p->device);
+  if (p->fast && !g_force_generic)
+    return launch_psy_bwd_fast(p, X, t, drown, grad_thr, nullptr, grad_X, grad_t, 0, B, F, C, (hipStream_t)stream);
   return launch_threshold_bwd_generic(p, X, t, drown, grad_thr, grad_X, grad_t, B, F, C, (hipStream_t)stream);
 }
 

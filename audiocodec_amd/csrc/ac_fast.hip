@@ -1056,6 +1056,245 @@ __global__ __launch_bounds__(NW * 64, (R == 8 ? AC_WPE : 2)) void k_psy_fast(Psy
   if (WANT_THR) store_row<CMODE, R>(a.thr + o0, a.thr + o1, C, has1, lane, th);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// backward passes of the masking model at wave level (the adjoints of psy_stage): one wave per (frame, signal pair)
+// ------------------------------------------------------------------------------------------------------
+struct PsyBwdArgs {
+  const float* X;
+  const float* t;        // tonality used by the forward pass (threshold backward)
+  const float* g_thr;    // [B,F,N,C] (threshold backward)
+  const float* g_t;      // [B,F,1,C] (tonality backward)
+  float* g_X;            // [B,F,N,C]
+  float* g_t_out;        // [B,F,1,C] (threshold backward)
+  PsyParams psy;
+  int C, F, accumulate;
+  long long nsig, ntasks;
+};
+
+// sums of an image of N per-bin values over the bins of each Bark band (lane = band), through the same chunk sums,
+// edge offsets and gather lists as the forward Bark mapping: returns w_first v[f0] + w_last v[f1] + sum over the
+// interior bins, the two edge weights given per lane.
+template <int R>
+__device__ __forceinline__ v2f band_sums(const v4f (&v)[R], char* lds0, char* buf, const uint32_t* pimg,
+                                         const PsyLane<R>& pc, v2f w_first, v2f w_last, v2f w_inner, int lane) {
+  using P = PsyGeo<R>;
+  v2f e0 = {0.f, 0.f}, e1 = {0.f, 0.f}, in0 = {0.f, 0.f}, in1 = {0.f, 0.f};
+#pragma unroll
+  for (int h = 0; h < P::NH; ++h) {
+    wave_sync();
+    {
+      const int lsw = lane ^ ((lane >> 4) & 3);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<v4f*>(buf + 16 * lsw + 1024 * i) = v[8 * h + i];
+    }
+    wave_sync();
+    {
+      const int x = (lane >> 2) & 3;
+      const char* cb = buf + 64 * lane;
+      const int o0 = 16 * x, o1 = 16 * (1 ^ x), o2 = 16 * (2 ^ x), o3 = 16 * (3 ^ x);
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) {
+        const char* c2 = cb + 4096 * i2;
+        const v4f g0 = *reinterpret_cast<const v4f*>(c2 + o0), g1 = *reinterpret_cast<const v4f*>(c2 + o1),
+                  g2 = *reinterpret_cast<const v4f*>(c2 + o2), g3 = *reinterpret_cast<const v4f*>(c2 + o3);
+        const v4f s = (g0 + g1) + (g2 + g3);
+        *reinterpret_cast<v2f*>(buf + S8_OFF + 8 * lane + 512 * i2) = v2f{s.x + s.z, s.y + s.w};
+      }
+    }
+    wave_sync();
+    const uint32_t edge = in_loop(__float_as_uint(pc.bc0[h].x));
+    e0 += *reinterpret_cast<const v2f*>(lds0 + (edge & 0xffffu));   // zero slot when the edge bin is in another half
+    e1 += *reinterpret_cast<const v2f*>(lds0 + (edge >> 16));
+#pragma unroll
+    for (int hlf = 0; hlf < P::PL_HALF; ++hlf) {
+      const uint32_t w = pimg[P::PL_LST + (h * P::PL_HALF + hlf) * 64 + lane];
+      in0 += *reinterpret_cast<const v2f*>(buf + (w & 0xffffu));
+      in1 += *reinterpret_cast<const v2f*>(buf + (w >> 16));
+    }
+  }
+  return w_first * e0 + w_last * e1 + w_inner * (in0 + in1);
+}
+
+// per-bin values from two per-band entry values (entry 2j: bins of band j alone, entry 2j+1: the bin shared by bands j
+// and j+1), gathered through the lane's entry offsets: out[i] = (entry(2q), entry(2q+1)) for granule q = 64 i + lane
+template <int R>
+__device__ __forceinline__ void entry_gather(v2f own, v2f shared, char* lds0, char* buf, const PsyLane<R>& pc, int lane,
+                                             v4f (&out)[R]) {
+  wave_sync();
+  *reinterpret_cast<v4f*>(buf + 16 * lane) = v4f{own.x, own.y, shared.x, shared.y};   // entry e at byte 8 e
+  wave_sync();
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const v4f ww = pc.idx[i >> 2];
+    const float wf = (i & 3) == 0 ? ww.x : (i & 3) == 1 ? ww.y : (i & 3) == 2 ? ww.z : ww.w;
+    const uint32_t w = in_loop(__float_as_uint(wf));
+    const v2f a0 = *reinterpret_cast<const v2f*>(lds0 + (w & 0xffffu));
+    const v2f a1 = *reinterpret_cast<const v2f*>(lds0 + (w >> 16));
+    out[i] = v4f{a0.x, a0.y, a1.x, a1.y};
+  }
+}
+
+// band x band product with the Toeplitz spreading matrix: FORWARD: out_j = sum_i v_i S[i, j] = sum_i v_i g[64 - i + j];
+// otherwise the transposed product out_i = sum_j S[i, j] v_j = sum_j v_j g[64 - i + j]  (lane = the output index)
+template <bool FORWARD>
+__device__ __forceinline__ v2f spread(v2f v, char* buf, const uint32_t* pimg_g, int lane) {
+  wave_sync();
+  *reinterpret_cast<v2f*>(buf + 8 * lane) = v;
+  wave_sync();
+  v2f acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+  const float* gp = reinterpret_cast<const float*>(pimg_g) + 64 + (FORWARD ? lane : -lane);
+#pragma unroll 8
+  for (int i = 0; i < 64; i += 2) {
+    const v4f qq = *reinterpret_cast<const v4f*>(buf + 8 * i);   // v_i, v_{i+1} (broadcast read)
+    acc0 += v2f{qq.x, qq.y} * (FORWARD ? gp[-i] : gp[i]);
+    acc1 += v2f{qq.z, qq.w} * (FORWARD ? gp[-i - 1] : gp[i + 1]);
+  }
+  return acc0 + acc1;
+}
+
+// d thr / d X and d thr / d t  (the chain of k_threshold_bwd_generic in ac_generic.hip, psychoacoustic.py:122-148 with
+// 169-210, 301-331), and d t / d X (psychoacoustic.py:102-120) when TONALITY
+template <int R, int CMODE, bool TONALITY, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_psy_bwd_fast(PsyBwdArgs a) {
+  using P = PsyGeo<R>;
+  __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS_PSY + P::PSY_LDS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t* pimg = reinterpret_cast<const uint32_t*>(lds + NW * WAVE_LDS_PSY);
+  if (!TONALITY) load_tables<NW, WAVE_LDS_PSY, 0, P::PL_LDS>(lds, nullptr, a.psy.tab);
+  const long long task = (long long)blockIdx.x * NW + wave;
+  if (task >= a.ntasks) return;
+  char* buf = lds + wave * WAVE_LDS_PSY;
+  const int f = (int)(task % a.F);
+  const int C = a.C;
+  const Pair pq = make_pair<CMODE>(task / a.F, C, a.nsig);
+  const bool has1 = pq.has1;
+  const size_t blk = (size_t)P::FN * C;
+  const size_t o0 = row_off(pq.b0, a.F, f, blk, pq.c0), o1 = row_off(pq.b1, a.F, f, blk, pq.c1);
+  const size_t t0 = ((size_t)pq.b0 * a.F + (size_t)f) * C + pq.c0, t1 = ((size_t)pq.b1 * a.F + (size_t)f) * C + pq.c1;
+  v4f x[R];
+  load_row<CMODE, false, R>(a.X + o0, a.X + o1, C, has1, lane, x);
+
+  if (TONALITY) {
+    // t = min(c' [mean ln max(eps, I) - ln(mean I + eps)], 1), c' = (10 / ln 10) / (-60):
+    // d t / d X_f = c' / N ([I_f > eps] / I_f - 1 / (mean I + eps)) 2 X_f   where the clamp is inactive
+    v2f slog = {0.f, 0.f}, ssq = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const v4f I = x[i] * x[i];
+      const v2f ie = v2f{I.x, I.y}, io = v2f{I.z, I.w};
+      ssq += ie + io;
+      slog += log2v(maxv(ie, kEps) * maxv(io, kEps));
+    }
+    slog.x = wave_sum(slog.x);
+    slog.y = wave_sum(slog.y);
+    ssq.x = wave_sum(ssq.x);
+    ssq.y = wave_sum(ssq.y);
+    const v2f am = ssq * (1.0f / P::FN) + kEps;
+    const v2f tt = (3.0102999566398120f / -60.0f) * (slog * (1.0f / P::FN) - log2v(am));
+    const float cc = (10.0f / 2.302585092994046f) / -60.0f;
+    v2f g = v2f{a.g_t[t0], has1 ? a.g_t[t1] : 0.f} * (cc / P::FN);
+    g.x = tt.x < 1.0f ? g.x : 0.f;
+    g.y = tt.y < 1.0f ? g.y : 0.f;
+    const v2f inv_am = v2f{1.0f / am.x, 1.0f / am.y};
+    v4f gx[R];
+    if (a.accumulate) load_row<CMODE, false, R>(a.g_X + o0, a.g_X + o1, C, has1, lane, gx);
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const v4f I = x[i] * x[i];
+      v4f r;
+      r.x = (I.x > kEps ? 1.0f / I.x : 0.f) - inv_am.x;
+      r.y = (I.y > kEps ? 1.0f / I.y : 0.f) - inv_am.y;
+      r.z = (I.z > kEps ? 1.0f / I.z : 0.f) - inv_am.x;
+      r.w = (I.w > kEps ? 1.0f / I.w : 0.f) - inv_am.y;
+      const v4f d = r * v4f{g.x, g.y, g.x, g.y} * 2.0f * x[i];
+      gx[i] = a.accumulate ? gx[i] + d : d;
+    }
+    store_row<CMODE, R>(a.g_X + o0, a.g_X + o1, C, has1, lane, gx);
+    return;
+  } else {
+    *reinterpret_cast<v2f*>(buf + ZERO_OFF) = v2f{0.f, 0.f};
+    const PsyLane<R> pc = load_psy_lane<R>(a.psy.tab, lane, (uint32_t)(wave * WAVE_LDS_PSY));
+    const PsyParams& pp = a.psy;
+    const v2f t = v2f{a.t[t0], has1 ? a.t[t1] : 0.f};
+    // true edge weights of the forward Bark mapping (only one half carries each)
+    float wfirst = 0.f, wlast = 0.f;
+#pragma unroll
+    for (int h = 0; h < P::NH; ++h) {
+      wfirst += pc.bc0[h].y;
+      wlast += pc.bc0[h].z;
+    }
+    const float quiet = pc.bc0[0].w, beta = pc.bc1.x, rho = pc.bc1.y, u0 = pc.bc1.z, u1 = pc.bc1.w;
+    // ---- forward recompute: P, Q, A, fac, Y, T, G per band (lane) ----
+    v4f I[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) I[i] = x[i] * x[i];
+    const v2f one = {1.f, 1.f};
+    const v2f Pj = band_sums<R>(I, lds, buf, pimg, pc, one * wfirst, one * wlast, one, lane);
+    const v2f Q = exp2v(pp.alpha * log2v(maxv(Pj, kEps)));
+    const v2f A = spread<true>(Q, buf, pimg + P::PL_G, lane);
+    const v2f dOdt = one * ((1.0f - pp.drown) * (beta + 9.0f));
+    const v2f offset = (1.0f - pp.drown) * (t * beta + 9.0f * t + 5.5f);
+    const v2f fac = exp2v(offset * (-pp.alpha * 0.33219280948873623f));
+    const v2f Y = fac * A;
+    const v2f T = exp2v(pp.inv_alpha * log2v(maxv(Y, kEps)));
+    const v2f G = maxv(T, quiet);
+    v2f Gn;
+    Gn.x = __shfl_down(G.x, 1, 64);
+    Gn.y = __shfl_down(G.y, 1, 64);
+    // ---- E per entry, thr and d L / d E per bin ----
+    const v2f E0 = G * rho, E1 = G * u0 + Gn * u1;
+    v4f Eb[R];
+    entry_gather<R>(E0, E1, lds, buf, pc, lane, Eb);
+    v4f gE[R];
+    {
+      v4f g[R];
+      load_row<CMODE, false, R>(a.g_thr + o0, a.g_thr + o1, C, has1, lane, g);
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        gE[i].x = Eb[i].x > kEps ? 0.5f * g[i].x * __builtin_amdgcn_rsqf(Eb[i].x) : 0.f;
+        gE[i].y = Eb[i].y > kEps ? 0.5f * g[i].y * __builtin_amdgcn_rsqf(Eb[i].y) : 0.f;
+        gE[i].z = Eb[i].z > kEps ? 0.5f * g[i].z * __builtin_amdgcn_rsqf(Eb[i].z) : 0.f;
+        gE[i].w = Eb[i].w > kEps ? 0.5f * g[i].w * __builtin_amdgcn_rsqf(Eb[i].w) : 0.f;
+      }
+    }
+    // ---- d L / d G_j = sum_f gE_f Winv[j, f]: first bin u1 of the band below when shared, last bin u0 when shared ----
+    const float u1_below = __shfl_up(u1, 1, 64);
+    const float bw_first = (lane > 0 && u1_below != 0.f) ? u1_below : rho;
+    const float bw_last = (u0 != 0.f) ? u0 : rho;
+    const v2f gG = band_sums<R>(gE, lds, buf, pimg, pc, one * bw_first, one * bw_last, one * rho, lane);
+    v2f gT, gY;
+    gT.x = T.x > quiet ? gG.x : 0.f;
+    gT.y = T.y > quiet ? gG.y : 0.f;
+    gY.x = Y.x > kEps ? gT.x * T.x / (pp.alpha * Y.x) : 0.f;
+    gY.y = Y.y > kEps ? gT.y * T.y / (pp.alpha * Y.y) : 0.f;
+    const v2f gA = gY * fac;
+    // d fac / d t = fac (-alpha ln 10 / 10) d O / d t
+    v2f gt = gY * A * fac * (-pp.alpha * 0.2302585092994046f) * dOdt;
+    gt.x = wave_sum(gt.x);
+    gt.y = wave_sum(gt.y);
+    if (lane == 0) {
+      a.g_t_out[t0] = gt.x;
+      if (has1) a.g_t_out[t1] = gt.y;
+    }
+    // ---- d L / d Q_i = sum_j S[i, j] gA_j, d L / d P_i ----
+    const v2f gQ = spread<false>(gA, buf, pimg + P::PL_G, lane);
+    v2f gP;
+    gP.x = Pj.x > kEps ? gQ.x * pp.alpha * Q.x / Pj.x : 0.f;
+    gP.y = Pj.y > kEps ? gQ.y * pp.alpha * Q.y / Pj.y : 0.f;
+    // ---- d L / d I_f = sum_i W[f, i] gP_i: bins of one band gP_i, the shared bin wl_i gP_i + wf_{i+1} gP_{i+1} ----
+    v2f gPn;
+    gPn.x = __shfl_down(gP.x, 1, 64);
+    gPn.y = __shfl_down(gP.y, 1, 64);
+    const float wfirst_above = __shfl_down(wfirst, 1, 64);
+    const v2f B1 = gP * wlast + gPn * wfirst_above;
+    v4f gI[R];
+    entry_gather<R>(gP, B1, lds, buf, pc, lane, gI);
+#pragma unroll
+    for (int i = 0; i < R; ++i) gI[i] = 2.0f * x[i] * gI[i];
+    store_row<CMODE, R>(a.g_X + o0, a.g_X + o1, C, has1, lane, gI);
+  }
+}
+
 // synthesis strips: short, so that the strips in flight cover a nearly contiguous window of memory (HBM rewards that:
 // 0.42 ms at 15 blocks per strip, 0.38 ms at 4 with an extra DCT-IV per strip, 0.355-0.365 ms at 3 with the hand-over
 // between the waves of a workgroup; B = 256, K = 468)
@@ -1455,6 +1694,51 @@ int launch_psy_fast(const ac_psy_plan* p, const float* X, const float* t_in, flo
     if (cmode == 0) launch_psy_R<16, 0>(a, want_t, want_thr, grid, s);
     else if (cmode == 2) launch_psy_R<16, 2>(a, want_t, want_thr, grid, s);
     else launch_psy_R<16, 1>(a, want_t, want_thr, grid, s);
+#endif
+  }
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+template <int R, int CMODE>
+static void launch_psy_bwd_R(const PsyBwdArgs& a, bool tonality, unsigned grid, hipStream_t s) {
+  const dim3 blk(AC_WAVES * 64);
+  if (tonality) hipLaunchKernelGGL((k_psy_bwd_fast<R, CMODE, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
+  else hipLaunchKernelGGL((k_psy_bwd_fast<R, CMODE, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
+}
+
+// tonality backward when g_thr is null (g_t -> g_X, optionally accumulated), else threshold backward
+int launch_psy_bwd_fast(const ac_psy_plan* p, const float* X, const float* t, float drown, const float* g_thr,
+                        const float* g_t, float* g_X, float* g_t_out, int accumulate, int B, int F, int C,
+                        hipStream_t s) {
+  if (B <= 0 || C <= 0 || F <= 0) return AC_OK;
+  PsyBwdArgs a;
+  a.X = X;
+  a.t = t;
+  a.g_thr = g_thr;
+  a.g_t = g_t;
+  a.g_X = g_X;
+  a.g_t_out = g_t_out;
+  a.psy = psy_params(p, drown);
+  a.C = C;
+  a.F = F;
+  a.accumulate = accumulate;
+  a.nsig = (long long)B * C;
+  a.ntasks = ((C == 2) ? (long long)B : (a.nsig + 1) / 2) * F;
+  unsigned grid;
+  int st = grid_for(a.ntasks, AC_WAVES, &grid);
+  if (st) return st;
+  const bool tonality = (g_thr == nullptr);
+  const int cmode = (C == 2) ? 0 : (C == 1) ? 2 : 1;
+  if (p->N == PsyGeo<8>::FN) {
+    if (cmode == 0) launch_psy_bwd_R<8, 0>(a, tonality, grid, s);
+    else if (cmode == 2) launch_psy_bwd_R<8, 2>(a, tonality, grid, s);
+    else launch_psy_bwd_R<8, 1>(a, tonality, grid, s);
+  } else {
+#ifndef AC_NO_R16
+    if (cmode == 0) launch_psy_bwd_R<16, 0>(a, tonality, grid, s);
+    else if (cmode == 2) launch_psy_bwd_R<16, 2>(a, tonality, grid, s);
+    else launch_psy_bwd_R<16, 1>(a, tonality, grid, s);
 #endif
   }
   AC_HIP_CHECK(hipGetLastError());

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kThreads) void k_threshold_bwd_generic(
     const int32_t* __restrict__ wf_ptr, const int32_t* __restrict__ wf_idx, const float* __restrict__ wf_val,
     const int32_t* __restrict__ vb_ptr, const int32_t* __restrict__ vb_idx, const float* __restrict__ vb_val,
     const float* __restrict__ S, const float* __restrict__ quiet, const float* __restrict__ beta, int C, int N,
-    int M) {
+    int M, int s_in_lds) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ float red[kThreads / 64];
   float* xs = smem;        // [N] X
@@ -274,24 +274,45 @@ __global__ __launch_bounds__(kThreads) void k_threshold_bwd_generic(
   float* G = A + M;        // [M]
   float* gA = G + M;       // [M]
   float* gP = gA + M;      // [M]
+  float* part = gP + M;    // [4][M] partial sums of the band x band products
+  float* Ss = part + 4 * M;   // [M][M] spreading matrix (when it fits)
   const long long wg = blockIdx.x;
   const int c = (int)(wg % C);
   const long long bf = wg / C;
   const float* Xi = X + (size_t)bf * N * C + c;
   const float* gi = gthr + (size_t)bf * N * C + c;
   for (int k = threadIdx.x; k < N; k += kThreads) xs[k] = Xi[(size_t)k * C];
+  if (s_in_lds)
+    for (int k = threadIdx.x; k < M * M; k += kThreads) Ss[k] = S[k];
+  const float* Sm = s_in_lds ? Ss : S;
+  __syncthreads();
+  // the band loops run on four groups of 64 threads: group q takes every fourth term, partial sums meet in LDS
+  const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
+  for (int j0 = 0; j0 < M; j0 += 64) {
+    const int j = j0 + l;
+    float p = 0.f;
+    if (j < M)
+      for (int e = wb_ptr[j] + q; e < wb_ptr[j + 1]; e += 4) p += xs[wb_idx[e]] * xs[wb_idx[e]] * wb_val[e];
+    if (j < M) part[q * M + j] = p;
+  }
   __syncthreads();
   for (int j = threadIdx.x; j < M; j += kThreads) {
-    float p = 0.f;
-    for (int e = wb_ptr[j]; e < wb_ptr[j + 1]; ++e) p += xs[wb_idx[e]] * xs[wb_idx[e]] * wb_val[e];
+    const float p = (part[j] + part[M + j]) + (part[2 * M + j] + part[3 * M + j]);
     P[j] = p;
     Q[j] = powf(fmaxf(kEps, p), alpha);
   }
   __syncthreads();
+  for (int j0 = 0; j0 < M; j0 += 64) {
+    const int j = j0 + l;
+    float acc = 0.f;
+    if (j < M)
+      for (int i = q; i < M; i += 4) acc += Q[i] * Sm[(size_t)i * M + j];
+    if (j < M) part[q * M + j] = acc;
+  }
+  __syncthreads();
   const float tt = t[wg];
   for (int j = threadIdx.x; j < M; j += kThreads) {
-    float acc = 0.f;
-    for (int i = 0; i < M; ++i) acc += Q[i] * S[(size_t)i * M + j];
+    const float acc = (part[j] + part[M + j]) + (part[2 * M + j] + part[3 * M + j]);
     const float fac = powf(10.f, -alpha * (1.f - drown) * (tt * beta[j] + 9.f * tt + 5.5f) / 10.f);
     A[j] = acc;
     G[j] = fmaxf(powf(fmaxf(kEps, fac * acc), 1.f / alpha), quiet[j]);
@@ -303,10 +324,17 @@ __global__ __launch_bounds__(kThreads) void k_threshold_bwd_generic(
     gE[k] = (E > kEps) ? gi[(size_t)k * C] * 0.5f / sqrtf(E) : 0.f;
   }
   __syncthreads();
+  for (int j0 = 0; j0 < M; j0 += 64) {
+    const int j = j0 + l;
+    float gG = 0.f;
+    if (j < M)
+      for (int e = vb_ptr[j] + q; e < vb_ptr[j + 1]; e += 4) gG += gE[vb_idx[e]] * vb_val[e];
+    if (j < M) part[q * M + j] = gG;
+  }
+  __syncthreads();
   float gt_part = 0.f;
   for (int j = threadIdx.x; j < M; j += kThreads) {
-    float gG = 0.f;
-    for (int e = vb_ptr[j]; e < vb_ptr[j + 1]; ++e) gG += gE[vb_idx[e]] * vb_val[e];
+    const float gG = (part[j] + part[M + j]) + (part[2 * M + j] + part[3 * M + j]);
     const float fac = powf(10.f, -alpha * (1.f - drown) * (tt * beta[j] + 9.f * tt + 5.5f) / 10.f);
     const float Y = fac * A[j];
     const float T = powf(fmaxf(kEps, Y), 1.f / alpha);
@@ -316,12 +344,18 @@ __global__ __launch_bounds__(kThreads) void k_threshold_bwd_generic(
     // d fac / d t = fac (-alpha ln 10 / 10) (1 - drown) (beta_j + 9)
     gt_part += gY * A[j] * fac * (-alpha * 0.2302585092994046f) * (1.f - drown) * (beta[j] + 9.f);
   }
-  gt_part = block_sum(gt_part, red);
+  gt_part = block_sum(gt_part, red);   // (contains the barriers that publish gA)
   if (threadIdx.x == 0) gt[wg] = gt_part;
+  for (int i0 = 0; i0 < M; i0 += 64) {
+    const int i = i0 + l;
+    float gQ = 0.f;
+    if (i < M)
+      for (int j = q; j < M; j += 4) gQ += Sm[(size_t)i * M + j] * gA[j];
+    if (i < M) part[q * M + i] = gQ;
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < M; i += kThreads) {
-    float gQ = 0.f;
-    for (int j = 0; j < M; ++j) gQ += S[(size_t)i * M + j] * gA[j];
+    const float gQ = (part[i] + part[M + i]) + (part[2 * M + i] + part[3 * M + i]);
     gP[i] = (P[i] > kEps) ? gQ * alpha * Q[i] / P[i] : 0.f;
   }
   __syncthreads();
@@ -473,12 +507,15 @@ int launch_threshold_bwd_generic(const ac_psy_plan* p, const float* X, const flo
   const long long nwg = (long long)B * F * C;
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
-  const size_t lds = (2 * (size_t)p->N + 6 * (size_t)p->M) * sizeof(float);
+  size_t lds = (2 * (size_t)p->N + 10 * (size_t)p->M) * sizeof(float);
   AC_REQUIRE(lds <= 64 * 1024, "filter_bands_n = %d / bark_bands_n = %d too large for the backward kernel", p->N, p->M);
+  const size_t with_s = lds + (size_t)p->M * p->M * sizeof(float);
+  const int s_in_lds = with_s <= 64 * 1024;
+  if (s_in_lds) lds = with_s;
   hipLaunchKernelGGL(k_threshold_bwd_generic, dim3((unsigned)nwg), dim3(kThreads), lds, s, X, t, gthr, gX, gt, drown,
                      (float)p->alpha, p->d_wb_ptr, p->d_wb_idx, p->d_wb_val, p->d_wi_ptr, p->d_wi_idx, p->d_wi_val,
                      p->d_wf_ptr, p->d_wf_idx, p->d_wf_val, p->d_vb_ptr, p->d_vb_idx, p->d_vb_val, p->d_S, p->d_quiet,
-                     p->d_beta, C, p->N, p->M);
+                     p->d_beta, C, p->N, p->M, s_in_lds);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }

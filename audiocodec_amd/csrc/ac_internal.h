@@ -117,6 +117,10 @@ int launch_tonality_bwd_generic(const ac_psy_plan* p, const float* X, const floa
                                 int F, int C, hipStream_t s);
 int launch_threshold_bwd_generic(const ac_psy_plan* p, const float* X, const float* t, float drown, const float* gthr,
                                  float* gX, float* gt, int B, int F, int C, hipStream_t s);
+// wave-level backward: tonality backward when g_thr is null, else threshold backward
+int launch_psy_bwd_fast(const ac_psy_plan* p, const float* X, const float* t, float drown, const float* g_thr,
+                        const float* g_t, float* g_X, float* g_t_out, int accumulate, int B, int F, int C,
+                        hipStream_t s);
 int launch_db(const float* a, float* out, size_t n, int norm, hipStream_t s);
 int launch_add_noise(const float* X, const float* thr, float* out, size_t n, uint64_t seed, hipStream_t s);
 

@@ -435,7 +435,7 @@ def _torch_tonality_reference(X):
 
 
 @pytest.mark.parametrize("sr,N,M,C,drown", [(48000, 1024, 64, 2, 0.0), (44100, 256, 48, 1, 0.3), (48000, 2048, 64, 3, 0.0)])
-def test_autograd_of_the_masking_model(sr, N, M, C, drown):
+def test_autograd_of_the_masking_model(path, sr, N, M, C, drown):
     """tonality and global_masking_threshold are differentiable: explicit adjoint kernels against torch.autograd on
     a float64 torch restatement of the same formulas."""
     B, F = 2, 3
