@@ -132,6 +132,140 @@ __global__ __launch_bounds__(kThreads) void k_inv_generic(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// Middle tier: any power-of-two filters_n from 16 to 4096 that the wave-level kernels do not serve (and any window,
+// the rectangular one included).  Same O(N) fold / unfold as above, the DCT-IV as an N/2-point complex FFT in LDS
+// (radix-2 Stockham, fp32), one workgroup per (signal, frame / block).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 cis_neg(const float* __restrict__ ctab, int idx, int N) {
+  // exp(-i pi idx / (4 N)), 0 <= idx < 8 N, from ctab[i] = cos(pi i / (4 N)):  sin(x) = cos(x - pi/2)
+  const int s = idx - 2 * N;
+  return make_float2(ctab[idx], -ctab[s < 0 ? -s : s]);
+}
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// v[N] (LDS) -> y[k] = sum_m v[m] cos(pi/N (m + 1/2)(k + 1/2)) written back into v; A, B: N/2 complex each (LDS)
+__device__ void dct4_lds(float* v, float2* A, float2* B, const float* __restrict__ ctab, int N) {
+  const int H = N >> 1;
+  for (int n = threadIdx.x; n < H; n += kThreads)
+    A[n] = cmulf(make_float2(v[2 * n], v[N - 1 - 2 * n]), cis_neg(ctab, 4 * n + 1, N));   // exp(-i pi (n + 1/4) / N)
+  __syncthreads();
+  float2* src = A;
+  float2* dst = B;
+  for (int L = 1; L < H; L <<= 1) {
+    const int m = H / (2 * L);
+    const int tw = 4 * N / L;   // exp(-2 pi i q / (2 L)) = exp(-i pi (4 N q / L) / (4 N))
+    for (int j = threadIdx.x; j < H / 2; j += kThreads) {
+      const int p = j / L, q = j - p * L;
+      const float2 c0 = src[q + L * p];
+      const float2 c1 = cmulf(src[q + L * (p + m)], cis_neg(ctab, tw * q, N));
+      dst[q + 2 * L * p] = make_float2(c0.x + c1.x, c0.y + c1.y);
+      dst[q + 2 * L * p + L] = make_float2(c0.x - c1.x, c0.y - c1.y);
+    }
+    __syncthreads();
+    float2* t = src;
+    src = dst;
+    dst = t;
+  }
+  for (int k = threadIdx.x; k < H; k += kThreads) {
+    const float2 r = cmulf(src[k], cis_neg(ctab, 4 * k, N));   // exp(-i pi k / N)
+    v[2 * k] = r.x;
+    v[N - 1 - 2 * k] = -r.y;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kThreads) void k_fwd_lds(const float* __restrict__ x, float* __restrict__ X,
+                                                      const float* __restrict__ prev_block,
+                                                      const float* __restrict__ coef,
+                                                      const float* __restrict__ ctab, int Kin, int F, int C, int N) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* v = smem;                                        // [N]
+  float2* A = reinterpret_cast<float2*>(smem + N);        // [N/2]
+  float2* Bf = reinterpret_cast<float2*>(smem + 2 * N);   // [N/2]
+  const int h = N >> 1;
+  const long long wg = blockIdx.x;
+  const int n = (int)(wg % F);
+  const long long sig = wg / F;
+  const int c = (int)(sig % C);
+  const long long b = sig / C;
+  const float* a1 = coef;
+  const float* a2 = coef + h;
+  const float* a3 = coef + 2 * h;
+  const float* a4 = coef + 3 * h;
+  const bool has_cur = n < Kin;
+  const float* xc = x + ((size_t)b * Kin + (size_t)n) * N * C + c;
+  const float* xp = nullptr;
+  if (n >= 1) xp = x + ((size_t)b * Kin + (size_t)(n - 1)) * N * C + c;
+  else if (prev_block) xp = prev_block + (size_t)b * N * C + c;
+  for (int j = threadIdx.x; j < h; j += kThreads) {
+    float vc = 0.f, vp = 0.f;
+    if (has_cur) vc = a1[j] * xc[(size_t)j * C] + a2[j] * xc[(size_t)(N - 1 - j) * C];
+    if (xp) vp = a3[j] * xp[(size_t)(h - 1 - j) * C] + a4[j] * xp[(size_t)(h + j) * C];
+    v[h + j] = vc;
+    v[j] = vp;
+  }
+  __syncthreads();
+  dct4_lds(v, A, Bf, ctab, N);
+  const float scale = (float)(1.0 / ((double)N * 1.4142135623730951));   // 1/sqrt(4N) * sqrt(2/N)
+  float* Xo = X + (((size_t)b * F + (size_t)n) * N) * C + c;
+  for (int k = threadIdx.x; k < N; k += kThreads) Xo[(size_t)k * C] = v[k] * scale;
+}
+
+// one workgroup per (signal, output block n); block n = nblk only writes the new stream state
+__global__ __launch_bounds__(kThreads) void k_inv_lds(const float* __restrict__ X, float* __restrict__ x,
+                                                      const float* __restrict__ tail_in, float* __restrict__ tail_out,
+                                                      const float* __restrict__ coef, const float* __restrict__ ctab,
+                                                      int Kp, int nblk, int nwg_per_sig, int C, int N) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* v = smem;                                        // [N]
+  float2* A = reinterpret_cast<float2*>(smem + N);        // [N/2]
+  float2* Bf = reinterpret_cast<float2*>(smem + 2 * N);   // [N/2]
+  float* un = smem + 3 * N;                               // [N/2]  u_n[h-1-j]
+  const int h = N >> 1;
+  const long long wg = blockIdx.x;
+  const int n = (int)(wg % nwg_per_sig);
+  const long long sig = wg / nwg_per_sig;
+  const int c = (int)(sig % C);
+  const long long b = sig / C;
+  const float* s1 = coef + 4 * h;
+  const float* s2 = coef + 5 * h;
+  const float* s3 = coef + 6 * h;
+  const float* s4 = coef + 7 * h;
+  const bool has_n = n < Kp && n < nblk;   // the virtual state block (n == nblk) has no current frame
+  const bool has_m = n >= 1;
+  const float scale = 2.0f * 1.4142135623730951f;   // sqrt(4N) * sqrt(2/N)
+  if (has_n) {
+    for (int k = threadIdx.x; k < N; k += kThreads) v[k] = X[(((size_t)b * Kp + (size_t)n) * N + k) * C + c];
+    __syncthreads();
+    dct4_lds(v, A, Bf, ctab, N);
+    for (int j = threadIdx.x; j < h; j += kThreads) un[j] = v[h - 1 - j] * scale;
+  } else {
+    for (int j = threadIdx.x; j < h; j += kThreads) un[j] = 0.f;
+  }
+  __syncthreads();
+  if (has_m) {
+    for (int k = threadIdx.x; k < N; k += kThreads) v[k] = X[(((size_t)b * Kp + (size_t)(n - 1)) * N + k) * C + c];
+    __syncthreads();
+    dct4_lds(v, A, Bf, ctab, N);
+  }
+  for (int j = threadIdx.x; j < h; j += kThreads) {
+    const float a = un[j];
+    float bb = 0.f;
+    if (has_m) bb = v[h + j] * scale;                     // u_{n-1}[h+j]
+    else if (tail_in) bb = tail_in[((size_t)b * C + c) * h + j];
+    if (n < nblk) {
+      float* xo = x + (((size_t)b * nblk + (size_t)n) * N) * C + c;
+      xo[(size_t)j * C] = s1[j] * a + s2[j] * bb;
+      xo[(size_t)(N - 1 - j) * C] = s3[j] * a + s4[j] * bb;
+    } else if (tail_out) {
+      tail_out[((size_t)b * C + c) * h + j] = bb;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // tonality (psychoacoustic.py:102-120), one workgroup per (b, frame, c)
 // ------------------------------------------------------------------------------------------------
 __device__ inline float block_sum(float v, float* red) {
@@ -432,6 +566,9 @@ __global__ __launch_bounds__(256) void k_add_noise(const float* __restrict__ X, 
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+// power of two from 16 to 4096: the LDS-FFT middle tier applies
+static bool lds_fft_ok(int N) { return N >= 16 && N <= 4096 && (N & (N - 1)) == 0; }
+
 static int check_grid(long long n) {
   if (n <= 0) return 1;
   if (n > 2147483647ll) {
@@ -446,6 +583,12 @@ int launch_fwd_generic(const ac_mdct_plan* p, const float* x, float* X, const fl
   const long long nwg = (long long)B * C * F;
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
+  if (lds_fft_ok(p->N) && !g_force_generic) {
+    hipLaunchKernelGGL(k_fwd_lds, dim3((unsigned)nwg), dim3(kThreads), 3 * (size_t)p->N * sizeof(float), s, x, X,
+                       prev_block, p->d_coef, p->d_ctab, Kin, F, C, p->N);
+    AC_HIP_CHECK(hipGetLastError());
+    return AC_OK;
+  }
   const size_t lds = (size_t)p->N * sizeof(float);
   AC_REQUIRE(lds <= 64 * 1024, "filters_n = %d too large for the generic kernel", p->N);
   hipLaunchKernelGGL(k_fwd_generic, dim3((unsigned)nwg), dim3(kThreads), lds, s, x, X, prev_block, p->d_coef,
@@ -460,6 +603,12 @@ int launch_inv_generic(const ac_mdct_plan* p, const float* X, float* x, const fl
   const long long nwg = (long long)B * C * per_sig;
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
+  if (lds_fft_ok(p->N) && !g_force_generic) {
+    hipLaunchKernelGGL(k_inv_lds, dim3((unsigned)nwg), dim3(kThreads), (3 * (size_t)p->N + p->N / 2) * sizeof(float), s,
+                       X, x, tail_in, tail_out, p->d_coef, p->d_ctab, Kp, nblk, per_sig, C, p->N);
+    AC_HIP_CHECK(hipGetLastError());
+    return AC_OK;
+  }
   const size_t lds = 2 * (size_t)p->N * sizeof(float);
   AC_REQUIRE(lds <= 64 * 1024, "filters_n = %d too large for the generic kernel", p->N);
   hipLaunchKernelGGL(k_inv_generic, dim3((unsigned)nwg), dim3(kThreads), lds, s, X, x, tail_in, tail_out,
