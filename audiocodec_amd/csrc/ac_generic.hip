@@ -213,55 +213,63 @@ __global__ __launch_bounds__(kThreads) void k_fwd_lds(const float* __restrict__ 
   for (int k = threadIdx.x; k < N; k += kThreads) Xo[(size_t)k * C] = v[k] * scale;
 }
 
-// one workgroup per (signal, output block n); block n = nblk only writes the new stream state
+// one workgroup per (signal, strip of `seg` output blocks): the aliased half of the previous frame's DCT-IV stays in
+// LDS along the strip, so a strip of T blocks costs T + 1 transforms; the block index nblk (one past the last) only
+// writes the new stream state
 __global__ __launch_bounds__(kThreads) void k_inv_lds(const float* __restrict__ X, float* __restrict__ x,
                                                       const float* __restrict__ tail_in, float* __restrict__ tail_out,
                                                       const float* __restrict__ coef, const float* __restrict__ ctab,
-                                                      int Kp, int nblk, int nwg_per_sig, int C, int N) {
+                                                      int Kp, int nblk, int seg, int nseg, int C, int N) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* v = smem;                                        // [N]
   float2* A = reinterpret_cast<float2*>(smem + N);        // [N/2]
   float2* Bf = reinterpret_cast<float2*>(smem + 2 * N);   // [N/2]
-  float* un = smem + 3 * N;                               // [N/2]  u_n[h-1-j]
+  float* um = smem + 3 * N;                               // [N/2]  u_{n-1}[h + j]
   const int h = N >> 1;
   const long long wg = blockIdx.x;
-  const int n = (int)(wg % nwg_per_sig);
-  const long long sig = wg / nwg_per_sig;
+  const int sgm = (int)(wg % nseg);
+  const long long sig = wg / nseg;
   const int c = (int)(sig % C);
   const long long b = sig / C;
   const float* s1 = coef + 4 * h;
   const float* s2 = coef + 5 * h;
   const float* s3 = coef + 6 * h;
   const float* s4 = coef + 7 * h;
-  const bool has_n = n < Kp && n < nblk;   // the virtual state block (n == nblk) has no current frame
-  const bool has_m = n >= 1;
   const float scale = 2.0f * 1.4142135623730951f;   // sqrt(4N) * sqrt(2/N)
-  if (has_n) {
-    for (int k = threadIdx.x; k < N; k += kThreads) v[k] = X[(((size_t)b * Kp + (size_t)n) * N + k) * C + c];
+  const int nlast = nblk + (tail_out ? 1 : 0);      // blocks incl. the virtual state block
+  const int n0 = sgm * seg;
+  const int n1 = min(nlast, n0 + seg);
+  // aliased half before the strip: frame n0 - 1, the stream state, or zero
+  if (n0 >= 1) {
+    for (int k = threadIdx.x; k < N; k += kThreads) v[k] = X[(((size_t)b * Kp + (size_t)(n0 - 1)) * N + k) * C + c];
     __syncthreads();
     dct4_lds(v, A, Bf, ctab, N);
-    for (int j = threadIdx.x; j < h; j += kThreads) un[j] = v[h - 1 - j] * scale;
+    for (int j = threadIdx.x; j < h; j += kThreads) um[j] = v[h + j] * scale;
   } else {
-    for (int j = threadIdx.x; j < h; j += kThreads) un[j] = 0.f;
+    for (int j = threadIdx.x; j < h; j += kThreads) um[j] = tail_in ? tail_in[((size_t)b * C + c) * h + j] : 0.f;
   }
   __syncthreads();
-  if (has_m) {
-    for (int k = threadIdx.x; k < N; k += kThreads) v[k] = X[(((size_t)b * Kp + (size_t)(n - 1)) * N + k) * C + c];
-    __syncthreads();
-    dct4_lds(v, A, Bf, ctab, N);
-  }
-  for (int j = threadIdx.x; j < h; j += kThreads) {
-    const float a = un[j];
-    float bb = 0.f;
-    if (has_m) bb = v[h + j] * scale;                     // u_{n-1}[h+j]
-    else if (tail_in) bb = tail_in[((size_t)b * C + c) * h + j];
-    if (n < nblk) {
-      float* xo = x + (((size_t)b * nblk + (size_t)n) * N) * C + c;
-      xo[(size_t)j * C] = s1[j] * a + s2[j] * bb;
-      xo[(size_t)(N - 1 - j) * C] = s3[j] * a + s4[j] * bb;
-    } else if (tail_out) {
-      tail_out[((size_t)b * C + c) * h + j] = bb;
+  for (int n = n0; n < n1; ++n) {
+    const bool has_n = n < Kp && n < nblk;   // the virtual state block (n == nblk) has no current frame
+    if (has_n) {
+      for (int k = threadIdx.x; k < N; k += kThreads) v[k] = X[(((size_t)b * Kp + (size_t)n) * N + k) * C + c];
+      __syncthreads();
+      dct4_lds(v, A, Bf, ctab, N);
     }
+    for (int j = threadIdx.x; j < h; j += kThreads) {
+      const float a = has_n ? v[h - 1 - j] * scale : 0.f;   // u_n[h-1-j]
+      const float bb = um[j];                               // u_{n-1}[h+j]
+      if (n < nblk) {
+        float* xo = x + (((size_t)b * nblk + (size_t)n) * N) * C + c;
+        xo[(size_t)j * C] = s1[j] * a + s2[j] * bb;
+        xo[(size_t)(N - 1 - j) * C] = s3[j] * a + s4[j] * bb;
+      } else if (tail_out) {
+        tail_out[((size_t)b * C + c) * h + j] = bb;
+      }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < h; j += kThreads) um[j] = has_n ? v[h + j] * scale : 0.f;
+    __syncthreads();
   }
 }
 
@@ -604,8 +612,11 @@ int launch_inv_generic(const ac_mdct_plan* p, const float* X, float* x, const fl
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
   if (lds_fft_ok(p->N) && !g_force_generic) {
-    hipLaunchKernelGGL(k_inv_lds, dim3((unsigned)nwg), dim3(kThreads), (3 * (size_t)p->N + p->N / 2) * sizeof(float), s,
-                       X, x, tail_in, tail_out, p->d_coef, p->d_ctab, Kp, nblk, per_sig, C, p->N);
+    const int seg = 8;
+    const int nseg = (per_sig + seg - 1) / seg;
+    const long long nwg2 = (long long)B * C * nseg;
+    hipLaunchKernelGGL(k_inv_lds, dim3((unsigned)nwg2), dim3(kThreads), (3 * (size_t)p->N + p->N / 2) * sizeof(float), s,
+                       X, x, tail_in, tail_out, p->d_coef, p->d_ctab, Kp, nblk, seg, nseg, C, p->N);
     AC_HIP_CHECK(hipGetLastError());
     return AC_OK;
   }
