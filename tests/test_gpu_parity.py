@@ -93,7 +93,8 @@ def test_shape_like_reference(path):
 
 @pytest.mark.parametrize("B,K,C,N", [(3, 5, 2, 1024), (2, 3, 1, 1024), (2, 4, 3, 1024), (1, 1, 2, 1024),
                                      (5, 7, 2, 256), (2, 2, 5, 64), (1, 3, 2, 2048), (2, 37, 2, 1024),
-                                     (3, 9, 2, 2048), (2, 5, 1, 2048), (1, 6, 3, 2048)])
+                                     (3, 9, 2, 2048), (2, 5, 1, 2048), (1, 6, 3, 2048), (2, 3, 4, 1024), (1, 2, 5, 1024),
+                                     (3, 4, 1, 1024), (2, 3, 2, 512), (1, 5, 1, 4096), (2, 2, 3, 32)])
 def test_mdct_random_vs_oracle(path, B, K, C, N):
     rng = np.random.default_rng(B * 1000 + K * 10 + C)
     x = rng.uniform(-1, 1, (B, K * N, C)).astype(np.float32)
