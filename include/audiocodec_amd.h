@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AC_VERSION 100 /* 0.1.0 */
+#define AC_VERSION 110 /* 0.1.1: backward passes, 16-bit PCM entry points */
 
 enum {
   AC_OK = 0,
@@ -84,7 +84,8 @@ int ac_mdct_plan_destroy(ac_mdct_plan* plan);
 int ac_psy_plan_create(int N, int M, double sample_rate, double alpha, int device, ac_psy_plan** out);
 int ac_psy_plan_destroy(ac_psy_plan* plan);
 
-/* 1 when the plan runs the wave-level FFT kernels, 0 when it runs the generic O(N^2) kernels. */
+/* 1 when the plan runs the wave-level kernels (filters_n 1024 / 2048, Princen-Bradley window; 64 Bark bands), 0 when it
+ * runs the LDS-FFT middle tier (power-of-two filters_n from 16 to 4096) or the generic O(N^2) kernels. */
 int ac_mdct_plan_is_fast(const ac_mdct_plan* plan);
 int ac_psy_plan_is_fast(const ac_psy_plan* plan);
 
@@ -154,7 +155,7 @@ int ac_stream_inverse(ac_stream* s, const float* X_chunk, float* x, int k, void*
  * ---------------------------------------------------------------------------------------- */
 /* amplitude_to_dB (norm = 0) / amplitude_to_dB_norm (norm = 1) on n floats. */
 int ac_amplitude_to_db(const float* a, float* out, size_t n, int norm, void* stream);
-/* add_noise: out = X + thr * Normal(0, 1/6), counter-based generator keyed by (seed, element index). */
+/* add_noise: out = X + thr * Normal(0, 1/6), counter-based generator keyed by (seed, element-pair index). */
 int ac_add_noise(const float* X, const float* thr, float* out, size_t n, uint64_t seed, void* stream);
 
 #ifdef __cplusplus
