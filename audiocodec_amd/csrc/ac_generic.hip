@@ -136,60 +136,88 @@ __global__ __launch_bounds__(kThreads) void k_inv_generic(const float* __restric
 // the rectangular one included).  Same O(N) fold / unfold as above, the DCT-IV as an N/2-point complex FFT in LDS
 // (radix-2 Stockham, fp32), one workgroup per (signal, frame / block).
 // ------------------------------------------------------------------------------------------------
+// Two channels of a clip ride side by side (c0, c0 + 1; the last one alone when C is odd): every value is a float2
+// over the pair, a complex value a cpair.
 __device__ __forceinline__ float2 cis_neg(const float* __restrict__ ctab, int idx, int N) {
   // exp(-i pi idx / (4 N)), 0 <= idx < 8 N, from ctab[i] = cos(pi i / (4 N)):  sin(x) = cos(x - pi/2)
   const int s = idx - 2 * N;
   return make_float2(ctab[idx], -ctab[s < 0 ? -s : s]);
 }
-__device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
-  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+struct cpair {
+  float2 re, im;   // (c0, c1)
+};
+__device__ __forceinline__ cpair cmulw(cpair a, float2 w) {
+  cpair r;
+  r.re = make_float2(a.re.x * w.x - a.im.x * w.y, a.re.y * w.x - a.im.y * w.y);
+  r.im = make_float2(a.re.x * w.y + a.im.x * w.x, a.re.y * w.y + a.im.y * w.x);
+  return r;
+}
+__device__ __forceinline__ float2 ld2(const float* p, int C, bool has1) {   // the pair's two samples at one index
+  return make_float2(p[0], has1 ? p[1] : 0.f);
+}
+__device__ __forceinline__ void st2(float* p, float2 v, bool has1) {
+  p[0] = v.x;
+  if (has1) p[1] = v.y;
 }
 
-// v[N] (LDS) -> y[k] = sum_m v[m] cos(pi/N (m + 1/2)(k + 1/2)) written back into v; A, B: N/2 complex each (LDS)
-__device__ void dct4_lds(float* v, float2* A, float2* B, const float* __restrict__ ctab, int N) {
+// v[N] (LDS, float2 per entry) -> y[k] = sum_m v[m] cos(pi/N (m + 1/2)(k + 1/2)) written back into v;
+// A, B: N/2 cpairs each (LDS)
+__device__ void dct4_lds(float2* v, cpair* A, cpair* B, const float* __restrict__ ctab, int N) {
   const int H = N >> 1;
-  for (int n = threadIdx.x; n < H; n += kThreads)
-    A[n] = cmulf(make_float2(v[2 * n], v[N - 1 - 2 * n]), cis_neg(ctab, 4 * n + 1, N));   // exp(-i pi (n + 1/4) / N)
+  for (int n = threadIdx.x; n < H; n += kThreads) {
+    cpair t;
+    t.re = v[2 * n];
+    t.im = v[N - 1 - 2 * n];
+    A[n] = cmulw(t, cis_neg(ctab, 4 * n + 1, N));   // exp(-i pi (n + 1/4) / N)
+  }
   __syncthreads();
-  float2* src = A;
-  float2* dst = B;
+  cpair* src = A;
+  cpair* dst = B;
   for (int L = 1; L < H; L <<= 1) {
     const int m = H / (2 * L);
     const int tw = 4 * N / L;   // exp(-2 pi i q / (2 L)) = exp(-i pi (4 N q / L) / (4 N))
     for (int j = threadIdx.x; j < H / 2; j += kThreads) {
       const int p = j / L, q = j - p * L;
-      const float2 c0 = src[q + L * p];
-      const float2 c1 = cmulf(src[q + L * (p + m)], cis_neg(ctab, tw * q, N));
-      dst[q + 2 * L * p] = make_float2(c0.x + c1.x, c0.y + c1.y);
-      dst[q + 2 * L * p + L] = make_float2(c0.x - c1.x, c0.y - c1.y);
+      const cpair c0 = src[q + L * p];
+      const cpair c1 = cmulw(src[q + L * (p + m)], cis_neg(ctab, tw * q, N));
+      cpair s, d;
+      s.re = make_float2(c0.re.x + c1.re.x, c0.re.y + c1.re.y);
+      s.im = make_float2(c0.im.x + c1.im.x, c0.im.y + c1.im.y);
+      d.re = make_float2(c0.re.x - c1.re.x, c0.re.y - c1.re.y);
+      d.im = make_float2(c0.im.x - c1.im.x, c0.im.y - c1.im.y);
+      dst[q + 2 * L * p] = s;
+      dst[q + 2 * L * p + L] = d;
     }
     __syncthreads();
-    float2* t = src;
+    cpair* t = src;
     src = dst;
     dst = t;
   }
   for (int k = threadIdx.x; k < H; k += kThreads) {
-    const float2 r = cmulf(src[k], cis_neg(ctab, 4 * k, N));   // exp(-i pi k / N)
-    v[2 * k] = r.x;
-    v[N - 1 - 2 * k] = -r.y;
+    const cpair r = cmulw(src[k], cis_neg(ctab, 4 * k, N));   // exp(-i pi k / N)
+    v[2 * k] = r.re;
+    v[N - 1 - 2 * k] = make_float2(-r.im.x, -r.im.y);
   }
   __syncthreads();
 }
 
+// one workgroup per (clip, channel pair, frame)
 __global__ __launch_bounds__(kThreads) void k_fwd_lds(const float* __restrict__ x, float* __restrict__ X,
                                                       const float* __restrict__ prev_block,
                                                       const float* __restrict__ coef,
-                                                      const float* __restrict__ ctab, int Kin, int F, int C, int N) {
+                                                      const float* __restrict__ ctab, int Kin, int F, int C, int CP,
+                                                      int N) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* v = smem;                                        // [N]
-  float2* A = reinterpret_cast<float2*>(smem + N);        // [N/2]
-  float2* Bf = reinterpret_cast<float2*>(smem + 2 * N);   // [N/2]
+  float2* v = reinterpret_cast<float2*>(smem);             // [N]
+  cpair* A = reinterpret_cast<cpair*>(smem + 2 * N);       // [N/2]
+  cpair* Bf = reinterpret_cast<cpair*>(smem + 4 * N);      // [N/2]
   const int h = N >> 1;
   const long long wg = blockIdx.x;
   const int n = (int)(wg % F);
   const long long sig = wg / F;
-  const int c = (int)(sig % C);
-  const long long b = sig / C;
+  const int c = 2 * (int)(sig % CP);
+  const bool has1 = c + 1 < C;
+  const long long b = sig / CP;
   const float* a1 = coef;
   const float* a2 = coef + h;
   const float* a3 = coef + 2 * h;
@@ -200,9 +228,15 @@ __global__ __launch_bounds__(kThreads) void k_fwd_lds(const float* __restrict__ 
   if (n >= 1) xp = x + ((size_t)b * Kin + (size_t)(n - 1)) * N * C + c;
   else if (prev_block) xp = prev_block + (size_t)b * N * C + c;
   for (int j = threadIdx.x; j < h; j += kThreads) {
-    float vc = 0.f, vp = 0.f;
-    if (has_cur) vc = a1[j] * xc[(size_t)j * C] + a2[j] * xc[(size_t)(N - 1 - j) * C];
-    if (xp) vp = a3[j] * xp[(size_t)(h - 1 - j) * C] + a4[j] * xp[(size_t)(h + j) * C];
+    float2 vc = make_float2(0.f, 0.f), vp = make_float2(0.f, 0.f);
+    if (has_cur) {
+      const float2 p = ld2(xc + (size_t)j * C, C, has1), q = ld2(xc + (size_t)(N - 1 - j) * C, C, has1);
+      vc = make_float2(a1[j] * p.x + a2[j] * q.x, a1[j] * p.y + a2[j] * q.y);
+    }
+    if (xp) {
+      const float2 p = ld2(xp + (size_t)(h - 1 - j) * C, C, has1), q = ld2(xp + (size_t)(h + j) * C, C, has1);
+      vp = make_float2(a3[j] * p.x + a4[j] * q.x, a3[j] * p.y + a4[j] * q.y);
+    }
     v[h + j] = vc;
     v[j] = vp;
   }
@@ -210,27 +244,29 @@ __global__ __launch_bounds__(kThreads) void k_fwd_lds(const float* __restrict__ 
   dct4_lds(v, A, Bf, ctab, N);
   const float scale = (float)(1.0 / ((double)N * 1.4142135623730951));   // 1/sqrt(4N) * sqrt(2/N)
   float* Xo = X + (((size_t)b * F + (size_t)n) * N) * C + c;
-  for (int k = threadIdx.x; k < N; k += kThreads) Xo[(size_t)k * C] = v[k] * scale;
+  for (int k = threadIdx.x; k < N; k += kThreads)
+    st2(Xo + (size_t)k * C, make_float2(v[k].x * scale, v[k].y * scale), has1);
 }
 
-// one workgroup per (signal, strip of `seg` output blocks): the aliased half of the previous frame's DCT-IV stays in
-// LDS along the strip, so a strip of T blocks costs T + 1 transforms; the block index nblk (one past the last) only
-// writes the new stream state
+// one workgroup per (clip, channel pair, strip of `seg` output blocks): the aliased half of the previous frame's DCT-IV
+// stays in LDS along the strip, so a strip of T blocks costs T + 1 transforms; the block index nblk (one past the
+// last) only writes the new stream state
 __global__ __launch_bounds__(kThreads) void k_inv_lds(const float* __restrict__ X, float* __restrict__ x,
                                                       const float* __restrict__ tail_in, float* __restrict__ tail_out,
                                                       const float* __restrict__ coef, const float* __restrict__ ctab,
-                                                      int Kp, int nblk, int seg, int nseg, int C, int N) {
+                                                      int Kp, int nblk, int seg, int nseg, int C, int CP, int N) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* v = smem;                                        // [N]
-  float2* A = reinterpret_cast<float2*>(smem + N);        // [N/2]
-  float2* Bf = reinterpret_cast<float2*>(smem + 2 * N);   // [N/2]
-  float* um = smem + 3 * N;                               // [N/2]  u_{n-1}[h + j]
+  float2* v = reinterpret_cast<float2*>(smem);             // [N]
+  cpair* A = reinterpret_cast<cpair*>(smem + 2 * N);       // [N/2]
+  cpair* Bf = reinterpret_cast<cpair*>(smem + 4 * N);      // [N/2]
+  float2* um = reinterpret_cast<float2*>(smem + 6 * N);    // [N/2]  u_{n-1}[h + j]
   const int h = N >> 1;
   const long long wg = blockIdx.x;
   const int sgm = (int)(wg % nseg);
   const long long sig = wg / nseg;
-  const int c = (int)(sig % C);
-  const long long b = sig / C;
+  const int c = 2 * (int)(sig % CP);
+  const bool has1 = c + 1 < C;
+  const long long b = sig / CP;
   const float* s1 = coef + 4 * h;
   const float* s2 = coef + 5 * h;
   const float* s3 = coef + 6 * h;
@@ -239,36 +275,43 @@ __global__ __launch_bounds__(kThreads) void k_inv_lds(const float* __restrict__ 
   const int nlast = nblk + (tail_out ? 1 : 0);      // blocks incl. the virtual state block
   const int n0 = sgm * seg;
   const int n1 = min(nlast, n0 + seg);
+  const size_t ts = ((size_t)b * C + c) * h;        // stream state rows of the pair: ts, ts + h
   // aliased half before the strip: frame n0 - 1, the stream state, or zero
   if (n0 >= 1) {
-    for (int k = threadIdx.x; k < N; k += kThreads) v[k] = X[(((size_t)b * Kp + (size_t)(n0 - 1)) * N + k) * C + c];
+    const float* Xi = X + (((size_t)b * Kp + (size_t)(n0 - 1)) * N) * C + c;
+    for (int k = threadIdx.x; k < N; k += kThreads) v[k] = ld2(Xi + (size_t)k * C, C, has1);
     __syncthreads();
     dct4_lds(v, A, Bf, ctab, N);
-    for (int j = threadIdx.x; j < h; j += kThreads) um[j] = v[h + j] * scale;
+    for (int j = threadIdx.x; j < h; j += kThreads) um[j] = make_float2(v[h + j].x * scale, v[h + j].y * scale);
   } else {
-    for (int j = threadIdx.x; j < h; j += kThreads) um[j] = tail_in ? tail_in[((size_t)b * C + c) * h + j] : 0.f;
+    for (int j = threadIdx.x; j < h; j += kThreads)
+      um[j] = tail_in ? make_float2(tail_in[ts + j], has1 ? tail_in[ts + h + j] : 0.f) : make_float2(0.f, 0.f);
   }
   __syncthreads();
   for (int n = n0; n < n1; ++n) {
     const bool has_n = n < Kp && n < nblk;   // the virtual state block (n == nblk) has no current frame
     if (has_n) {
-      for (int k = threadIdx.x; k < N; k += kThreads) v[k] = X[(((size_t)b * Kp + (size_t)n) * N + k) * C + c];
+      const float* Xi = X + (((size_t)b * Kp + (size_t)n) * N) * C + c;
+      for (int k = threadIdx.x; k < N; k += kThreads) v[k] = ld2(Xi + (size_t)k * C, C, has1);
       __syncthreads();
       dct4_lds(v, A, Bf, ctab, N);
     }
     for (int j = threadIdx.x; j < h; j += kThreads) {
-      const float a = has_n ? v[h - 1 - j] * scale : 0.f;   // u_n[h-1-j]
-      const float bb = um[j];                               // u_{n-1}[h+j]
+      float2 a = make_float2(0.f, 0.f);
+      if (has_n) a = make_float2(v[h - 1 - j].x * scale, v[h - 1 - j].y * scale);   // u_n[h-1-j]
+      const float2 bb = um[j];                                                      // u_{n-1}[h+j]
       if (n < nblk) {
         float* xo = x + (((size_t)b * nblk + (size_t)n) * N) * C + c;
-        xo[(size_t)j * C] = s1[j] * a + s2[j] * bb;
-        xo[(size_t)(N - 1 - j) * C] = s3[j] * a + s4[j] * bb;
+        st2(xo + (size_t)j * C, make_float2(s1[j] * a.x + s2[j] * bb.x, s1[j] * a.y + s2[j] * bb.y), has1);
+        st2(xo + (size_t)(N - 1 - j) * C, make_float2(s3[j] * a.x + s4[j] * bb.x, s3[j] * a.y + s4[j] * bb.y), has1);
       } else if (tail_out) {
-        tail_out[((size_t)b * C + c) * h + j] = bb;
+        tail_out[ts + j] = bb.x;
+        if (has1) tail_out[ts + h + j] = bb.y;
       }
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < h; j += kThreads) um[j] = has_n ? v[h + j] * scale : 0.f;
+    for (int j = threadIdx.x; j < h; j += kThreads)
+      um[j] = has_n ? make_float2(v[h + j].x * scale, v[h + j].y * scale) : make_float2(0.f, 0.f);
     __syncthreads();
   }
 }
@@ -574,8 +617,16 @@ __global__ __launch_bounds__(256) void k_add_noise(const float* __restrict__ X, 
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-// power of two from 16 to 4096: the LDS-FFT middle tier applies
+// power of two from 16 to 4096 (7 N floats of LDS <= 112 KB of the CU's 160 KB): the LDS-FFT middle tier applies
 static bool lds_fft_ok(int N) { return N >= 16 && N <= 4096 && (N & (N - 1)) == 0; }
+// dynamic LDS beyond the default 64 KB cap must be requested once per kernel (and per device)
+template <typename K>
+static int allow_lds(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return AC_OK;
+  AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)bytes));
+  return AC_OK;
+}
 
 static int check_grid(long long n) {
   if (n <= 0) return 1;
@@ -592,8 +643,11 @@ int launch_fwd_generic(const ac_mdct_plan* p, const float* x, float* X, const fl
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
   if (lds_fft_ok(p->N) && !g_force_generic) {
-    hipLaunchKernelGGL(k_fwd_lds, dim3((unsigned)nwg), dim3(kThreads), 3 * (size_t)p->N * sizeof(float), s, x, X,
-                       prev_block, p->d_coef, p->d_ctab, Kin, F, C, p->N);
+    const int CP = (C + 1) / 2;
+    const int st2 = allow_lds(k_fwd_lds, 6 * (size_t)p->N * sizeof(float));
+    if (st2) return st2;
+    hipLaunchKernelGGL(k_fwd_lds, dim3((unsigned)((long long)B * CP * F)), dim3(kThreads),
+                       6 * (size_t)p->N * sizeof(float), s, x, X, prev_block, p->d_coef, p->d_ctab, Kin, F, C, CP, p->N);
     AC_HIP_CHECK(hipGetLastError());
     return AC_OK;
   }
@@ -612,11 +666,13 @@ int launch_inv_generic(const ac_mdct_plan* p, const float* X, float* x, const fl
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
   if (lds_fft_ok(p->N) && !g_force_generic) {
-    const int seg = 8;
+    const int seg = 8, CP = (C + 1) / 2;
     const int nseg = (per_sig + seg - 1) / seg;
-    const long long nwg2 = (long long)B * C * nseg;
-    hipLaunchKernelGGL(k_inv_lds, dim3((unsigned)nwg2), dim3(kThreads), (3 * (size_t)p->N + p->N / 2) * sizeof(float), s,
-                       X, x, tail_in, tail_out, p->d_coef, p->d_ctab, Kp, nblk, seg, nseg, C, p->N);
+    const long long nwg2 = (long long)B * CP * nseg;
+    const int st2 = allow_lds(k_inv_lds, 7 * (size_t)p->N * sizeof(float));
+    if (st2) return st2;
+    hipLaunchKernelGGL(k_inv_lds, dim3((unsigned)nwg2), dim3(kThreads), 7 * (size_t)p->N * sizeof(float), s, X, x,
+                       tail_in, tail_out, p->d_coef, p->d_ctab, Kp, nblk, seg, nseg, C, CP, p->N);
     AC_HIP_CHECK(hipGetLastError());
     return AC_OK;
   }
