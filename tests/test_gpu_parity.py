@@ -487,3 +487,42 @@ def test_pcm16_at_the_boundary(N, C):
     assert torch.equal(out, ref)
     with pytest.raises(_lib.AudioCodecError):      # the generic kernels do not take 16-bit PCM
         audiocodec_amd.AudioCodec(48000, 256).encode(pcm[:, : 4 * 256])
+
+
+def test_plan_and_stream_lifecycle():
+    """Plans and streams own device memory: creating and dropping them repeatedly returns it (no leak), and a model
+    shared by two host threads on two HIP streams gives the single-threaded bits."""
+    import gc
+    import threading
+    torch.cuda.synchronize()
+    x = torch.rand(2, 4 * 1024, 2, device="cuda") * 2 - 1
+    ref = audiocodec_amd.AudioCodec(48000, 1024).encode(x)
+    gc.collect()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(50):
+        c = audiocodec_amd.AudioCodec(48000, 1024)
+        X, t, thr = c.encode(x)
+        st = audiocodec_amd.StreamingMDCT(c.mdct, 2, 2)
+        st.transform_chunk(x[:, :1024])
+        st.close()
+        del c, st
+    gc.collect()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 * 2 ** 20, "device memory not returned: %d bytes" % (free0 - free1)
+    assert torch.equal(X, ref[0]) and torch.equal(thr, ref[2])
+    codec = audiocodec_amd.AudioCodec(48000, 1024)
+    outs = [None, None]
+
+    def work(i):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            for _ in range(5):
+                outs[i] = codec.encode(x)
+        s.synchronize()
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t_.start() for t_ in th]
+    [t_.join() for t_ in th]
+    for o in outs:
+        assert torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]) and torch.equal(o[2], ref[2])
