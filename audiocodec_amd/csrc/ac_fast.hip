@@ -77,7 +77,7 @@ struct Geo {
 // waves per SIMD the register allocator must leave room for: the strided any-channel-count variants (CMODE 1) and the
 // 2048-filter kernels get the larger budget
 template <int R, int CMODE, bool PSY = false>
-constexpr int wpe() { return (R == 8 && CMODE != 1) ? AC_WPE : 2; }
+constexpr int wpe() { return (R == 8 && (CMODE == 0 || (CMODE == 2 && !PSY))) ? AC_WPE : 2; }
 
 // ---- psy image (32-bit words) in ac_psy_plan::d_fast for filter_bands_n = 128 R and 64 Bark bands; the first PL_LDS
 // words are copied into LDS once per workgroup, the rest is held in registers.  The spectrum passes through the wave's
@@ -309,24 +309,43 @@ __device__ __forceinline__ size_t row_off(long long b, long long rows_per_clip, 
 template <int CMODE, bool NT = false, int R = 8>
 __device__ __forceinline__ void load_row(const float* __restrict__ r0, const float* __restrict__ r1, int C, bool has1,
                                          int lane, v4f (&v)[R]) {
+  if (CMODE == 0) {
 #pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int q = 64 * i + lane;
-    if (CMODE == 0) {
+    for (int i = 0; i < R; ++i) {
+      const int q = 64 * i + lane;
       if (NT) v[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(r0) + q);
       else v[i] = reinterpret_cast<const v4f*>(r0)[q];
-    } else if (CMODE == 2) {
-      const v2f u = reinterpret_cast<const v2f*>(r0)[q];
-      const v2f w = has1 ? reinterpret_cast<const v2f*>(r1)[q] : v2f{0.f, 0.f};
-      v[i] = v4f{u.x, w.x, u.y, w.y};
-    } else {
-      // uniform base per register + two 32-bit lane offsets shared by all registers (keeps the addresses out of VGPRs)
+    }
+  } else if (CMODE == 2) {
+    // one wave-uniform branch for the second signal (only the last pair of an odd signal count lacks it)
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const v2f u = reinterpret_cast<const v2f*>(r0)[64 * i + lane];
+      v[i] = v4f{u.x, 0.f, u.y, 0.f};
+    }
+    if (has1) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const v2f w = reinterpret_cast<const v2f*>(r1)[64 * i + lane];
+        v[i].y = w.x;
+        v[i].w = w.y;
+      }
+    }
+  } else {
+    // uniform base per register + two 32-bit lane offsets shared by all registers (keeps the addresses out of VGPRs)
+    const int off = 2 * lane * C;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
       const size_t step = (size_t)(128 * i) * C;
-      const int off = 2 * lane * C;
-      v[i].x = r0[step + off];
-      v[i].z = r0[step + off + C];
-      v[i].y = has1 ? r1[step + off] : 0.f;
-      v[i].w = has1 ? r1[step + off + C] : 0.f;
+      v[i] = v4f{r0[step + off], 0.f, r0[step + off + C], 0.f};
+    }
+    if (has1) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const size_t step = (size_t)(128 * i) * C;
+        v[i].y = r1[step + off];
+        v[i].w = r1[step + off + C];
+      }
     }
   }
 }
@@ -334,24 +353,35 @@ __device__ __forceinline__ void load_row(const float* __restrict__ r0, const flo
 template <int CMODE, int R = 8>
 __device__ __forceinline__ void store_row(float* __restrict__ r0, float* __restrict__ r1, int C, bool has1, int lane,
                                           const v4f (&v)[R]) {
+  if (CMODE == 0) {
 #pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int q = 64 * i + lane;
-    if (CMODE == 0) {
+    for (int i = 0; i < R; ++i) {
+      const int q = 64 * i + lane;
 #if AC_NT_STORE
       __builtin_nontemporal_store(v[i], reinterpret_cast<v4f*>(r0) + q);
 #else
       reinterpret_cast<v4f*>(r0)[q] = v[i];
 #endif
-    } else if (CMODE == 2) {
-      reinterpret_cast<v2f*>(r0)[q] = v2f{v[i].x, v[i].z};
-      if (has1) reinterpret_cast<v2f*>(r1)[q] = v2f{v[i].y, v[i].w};
-    } else {
+    }
+  } else if (CMODE == 2) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) reinterpret_cast<v2f*>(r0)[64 * i + lane] = v2f{v[i].x, v[i].z};
+    if (has1) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) reinterpret_cast<v2f*>(r1)[64 * i + lane] = v2f{v[i].y, v[i].w};
+    }
+  } else {
+    const int off = 2 * lane * C;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
       const size_t step = (size_t)(128 * i) * C;
-      const int off = 2 * lane * C;
       r0[step + off] = v[i].x;
       r0[step + off + C] = v[i].z;
-      if (has1) {
+    }
+    if (has1) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const size_t step = (size_t)(128 * i) * C;
         r1[step + off] = v[i].y;
         r1[step + off + C] = v[i].w;
       }
@@ -370,23 +400,40 @@ __device__ __forceinline__ short to_pcm16(float v) {
 template <int CMODE, int R>
 __device__ __forceinline__ void load_row_pcm16(const int16_t* __restrict__ r0, const int16_t* __restrict__ r1, int C,
                                                bool has1, int lane, v4f (&v)[R]) {
+  if (CMODE == 0) {
 #pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int q = 64 * i + lane;
-    if (CMODE == 0) {
-      const s4 p = reinterpret_cast<const s4*>(r0)[q];
+    for (int i = 0; i < R; ++i) {
+      const s4 p = reinterpret_cast<const s4*>(r0)[64 * i + lane];
       v[i] = v4f{(float)p.x, (float)p.y, (float)p.z, (float)p.w} * kPcmScale;
-    } else if (CMODE == 2) {
-      const s2 u = reinterpret_cast<const s2*>(r0)[q];
-      const s2 w = has1 ? reinterpret_cast<const s2*>(r1)[q] : s2{0, 0};
-      v[i] = v4f{(float)u.x, (float)w.x, (float)u.y, (float)w.y} * kPcmScale;
-    } else {
+    }
+  } else if (CMODE == 2) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const s2 u = reinterpret_cast<const s2*>(r0)[64 * i + lane];
+      v[i] = v4f{(float)u.x * kPcmScale, 0.f, (float)u.y * kPcmScale, 0.f};
+    }
+    if (has1) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const s2 w = reinterpret_cast<const s2*>(r1)[64 * i + lane];
+        v[i].y = (float)w.x * kPcmScale;
+        v[i].w = (float)w.y * kPcmScale;
+      }
+    }
+  } else {
+    const int off = 2 * lane * C;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
       const size_t step = (size_t)(128 * i) * C;
-      const int off = 2 * lane * C;
-      v[i].x = (float)r0[step + off] * kPcmScale;
-      v[i].z = (float)r0[step + off + C] * kPcmScale;
-      v[i].y = has1 ? (float)r1[step + off] * kPcmScale : 0.f;
-      v[i].w = has1 ? (float)r1[step + off + C] * kPcmScale : 0.f;
+      v[i] = v4f{(float)r0[step + off] * kPcmScale, 0.f, (float)r0[step + off + C] * kPcmScale, 0.f};
+    }
+    if (has1) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const size_t step = (size_t)(128 * i) * C;
+        v[i].y = (float)r1[step + off] * kPcmScale;
+        v[i].w = (float)r1[step + off + C] * kPcmScale;
+      }
     }
   }
 }
@@ -394,20 +441,29 @@ __device__ __forceinline__ void load_row_pcm16(const int16_t* __restrict__ r0, c
 template <int CMODE, int R>
 __device__ __forceinline__ void store_row_pcm16(int16_t* __restrict__ r0, int16_t* __restrict__ r1, int C, bool has1,
                                                 int lane, const v4f (&v)[R]) {
+  if (CMODE == 0) {
 #pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int q = 64 * i + lane;
-    if (CMODE == 0) {
-      reinterpret_cast<s4*>(r0)[q] = s4{to_pcm16(v[i].x), to_pcm16(v[i].y), to_pcm16(v[i].z), to_pcm16(v[i].w)};
-    } else if (CMODE == 2) {
-      reinterpret_cast<s2*>(r0)[q] = s2{to_pcm16(v[i].x), to_pcm16(v[i].z)};
-      if (has1) reinterpret_cast<s2*>(r1)[q] = s2{to_pcm16(v[i].y), to_pcm16(v[i].w)};
-    } else {
+    for (int i = 0; i < R; ++i)
+      reinterpret_cast<s4*>(r0)[64 * i + lane] = s4{to_pcm16(v[i].x), to_pcm16(v[i].y), to_pcm16(v[i].z), to_pcm16(v[i].w)};
+  } else if (CMODE == 2) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) reinterpret_cast<s2*>(r0)[64 * i + lane] = s2{to_pcm16(v[i].x), to_pcm16(v[i].z)};
+    if (has1) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) reinterpret_cast<s2*>(r1)[64 * i + lane] = s2{to_pcm16(v[i].y), to_pcm16(v[i].w)};
+    }
+  } else {
+    const int off = 2 * lane * C;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
       const size_t step = (size_t)(128 * i) * C;
-      const int off = 2 * lane * C;
       r0[step + off] = to_pcm16(v[i].x);
       r0[step + off + C] = to_pcm16(v[i].z);
-      if (has1) {
+    }
+    if (has1) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const size_t step = (size_t)(128 * i) * C;
         r1[step + off] = to_pcm16(v[i].y);
         r1[step + off + C] = to_pcm16(v[i].w);
       }

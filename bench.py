@@ -140,8 +140,9 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     elapsed_max, = acd.reduce_scalars([elapsed], "max", device=dev)   # also the closing barrier
-    enc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    dec_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    enc_all = [e[0].elapsed_time(e[1]) for e in ev]
+    dec_all = [e[1].elapsed_time(e[2]) for e in ev]
+    enc_ms, dec_ms = float(np.mean(enc_all)), float(np.mean(dec_all))
 
     frames_rank = B * C * K
     frames_total = frames_rank * world * args.steps
@@ -165,6 +166,8 @@ def main():
                          "traffic": traffic, "bytes_per_frame": ENC_BYTES, "frames_per_launch": frames_rank,
                          "avg_launch_ms": enc_ms},
             "kernels": {"encode_ms": enc_ms, "encode_GBs": enc_gbs, "decode_ms": dec_ms, "decode_GBs": dec_gbs,
+                        "encode_ms_median": float(np.median(enc_all)), "encode_ms_min": float(np.min(enc_all)),
+                        "decode_ms_median": float(np.median(dec_all)), "decode_ms_min": float(np.min(dec_all)),
                         "step_frac_of_hbm_peak": (ENC_BYTES + DEC_BYTES) * (value / world) / (HBM_PEAK_GBS * 1e9)},
             "round_trip_max_abs_err": err,
         }
