@@ -69,9 +69,12 @@ struct Geo {
   static constexpr int I_P2 = I_PRE + 128 * R;      // [8][8]  float2  W64^(e0 k1)
   static constexpr int I_POST = I_P2 + 128;         // [R][64] float2  exp(-i pi k / N) * (1/(N sqrt 2) | 2 sqrt 2), k = lane + 64 j
   static constexpr int I_COEF = I_POST + 128 * R;   // [R][64] float2  fold (A, B)(e) | unfold (a, b)(k)
-  static constexpr int I_LDS = I_COEF + 128 * R;    // floats that live in LDS (R = 8: 12 800 bytes)
-  static constexpr int I_P1 = I_LDS;                // [R][64] float2  W_{64R}^(lane k0): held in registers
+  static constexpr int I_P1 = I_COEF + 128 * R;     // [R][64] float2  W_{64R}^(lane k0), pass-1 twiddles
   static constexpr int I_TOTAL = I_P1 + 128 * R;    // floats per image in global memory
+  // R = 8 holds the seven pass-1 twiddles of a lane in registers (LDS is the scarcer resource: 3 workgroups per CU);
+  // R = 16 reads its fifteen from LDS (registers are: 64 for the frame alone)
+  static constexpr bool P1_IN_REGS = (R == 8);
+  static constexpr int I_LDS = P1_IN_REGS ? I_P1 : I_TOTAL;   // floats that live in LDS (R = 8: 12 800 bytes)
   static constexpr int TAB_LDS = I_LDS * 4;
 };
 // waves per SIMD the register allocator must leave room for: the strided any-channel-count variants (CMODE 1) and the
@@ -200,7 +203,8 @@ __device__ __forceinline__ void fft_wave(C2 (&z)[R], char* buf, gtab_t tab, cons
   const int a = lane >> 3, m0 = lane & 7;
   dft_regs(z);
 #pragma unroll
-  for (int k = 1; k < R; ++k) z[k] = cmul(z[k], p1[k]);
+  for (int k = 1; k < R; ++k)
+    z[k] = cmul(z[k], Geo<R>::P1_IN_REGS ? p1[k] : reinterpret_cast<const v2f*>(tab + Geo<R>::I_P1)[k * 64 + lane]);
 #pragma unroll
   for (int beta = 0; beta < NB; ++beta) {
     C2 y[8];
@@ -252,7 +256,8 @@ template <int R>
 __device__ __forceinline__ void load_p1(const float* __restrict__ image, int lane, v2f (&p1)[R]) {
   p1[0] = v2f{1.f, 0.f};
 #pragma unroll
-  for (int k = 1; k < R; ++k) p1[k] = reinterpret_cast<const v2f*>(image + Geo<R>::I_P1)[k * 64 + lane];
+  for (int k = 1; k < R; ++k)
+    p1[k] = Geo<R>::P1_IN_REGS ? reinterpret_cast<const v2f*>(image + Geo<R>::I_P1)[k * 64 + lane] : v2f{0.f, 0.f};
 }
 
 // lane-reversal exchange of R (c0, c1) pairs: afterwards out[i] = in[(OFS - i) mod R] of lane 63 - lane
