@@ -930,7 +930,7 @@ __device__ __forceinline__ void idct_frame(const v4f (&frm)[R], char* buf, gtab_
 }
 
 template <int R, int CMODE, int NW, bool PCM16 = false>
-__global__ __launch_bounds__(NW * 64, (wpe<R, CMODE>())) void k_inv_fast(InvArgs a) {
+__global__ __launch_bounds__(NW * 64, (PCM16 ? 2 : wpe<R, CMODE>())) void k_inv_fast(InvArgs a) {
   using G = Geo<R>;
   constexpr int FH = G::FH;
   __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS + G::TAB_LDS];
