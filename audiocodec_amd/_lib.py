@@ -75,6 +75,8 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
+        if not os.path.exists(LIB_PATH) and not os.environ.get("AUDIOCODEC_AMD_LIB"):
+            _build_in_tree()
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 "%s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
@@ -88,6 +90,18 @@ def load():
             raise ImportError("libaudiocodec_amd too old: %d" % lib.ac_version())
         _lib = lib
     return _lib
+
+
+def _build_in_tree():
+    """The library is built in-tree by ``__graft_entry__.build()`` / ``make -C audiocodec_amd/csrc``; when it is missing
+    (a fresh checkout) try that once -- hipcc cross-compiles for gfx950 without a GPU.  Failure is not hidden: load()
+    raises ImportError afterwards."""
+    import subprocess
+    try:
+        subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, timeout=1800)
+    except Exception:
+        pass
 
 
 def check(status):
