@@ -161,10 +161,11 @@ __device__ __forceinline__ void st2(float* p, float2 v, bool has1) {
 }
 
 // v[N] (LDS, float2 per entry) -> y[k] = sum_m v[m] cos(pi/N (m + 1/2)(k + 1/2)) written back into v;
-// A, B: N/2 cpairs each (LDS)
-__device__ void dct4_lds(float2* v, cpair* A, cpair* B, const float* __restrict__ ctab, int N) {
+// A, B: N/2 cpairs each (LDS).  Executed by a group of nt threads (tid = index inside the group); every group of the
+// workgroup runs it at the same time on its own buffers (the barriers are workgroup-wide).
+__device__ void dct4_lds(float2* v, cpair* A, cpair* B, const float* __restrict__ ctab, int N, int tid, int nt) {
   const int H = N >> 1;
-  for (int n = threadIdx.x; n < H; n += kThreads) {
+  for (int n = tid; n < H; n += nt) {
     cpair t;
     t.re = v[2 * n];
     t.im = v[N - 1 - 2 * n];
@@ -176,7 +177,7 @@ __device__ void dct4_lds(float2* v, cpair* A, cpair* B, const float* __restrict_
   for (int L = 1; L < H; L <<= 1) {
     const int m = H / (2 * L);
     const int tw = 4 * N / L;   // exp(-2 pi i q / (2 L)) = exp(-i pi (4 N q / L) / (4 N))
-    for (int j = threadIdx.x; j < H / 2; j += kThreads) {
+    for (int j = tid; j < H / 2; j += nt) {
       const int p = j / L, q = j - p * L;
       const cpair c0 = src[q + L * p];
       const cpair c1 = cmulw(src[q + L * (p + m)], cis_neg(ctab, tw * q, N));
@@ -193,7 +194,7 @@ __device__ void dct4_lds(float2* v, cpair* A, cpair* B, const float* __restrict_
     src = dst;
     dst = t;
   }
-  for (int k = threadIdx.x; k < H; k += kThreads) {
+  for (int k = tid; k < H; k += nt) {
     const cpair r = cmulw(src[k], cis_neg(ctab, 4 * k, N));   // exp(-i pi k / N)
     v[2 * k] = r.re;
     v[N - 1 - 2 * k] = make_float2(-r.im.x, -r.im.y);
@@ -201,18 +202,28 @@ __device__ void dct4_lds(float2* v, cpair* A, cpair* B, const float* __restrict_
   __syncthreads();
 }
 
-// one workgroup per (clip, channel pair, frame)
+// threads per group: enough for the N/4 butterflies of a stage, at least one wave; a workgroup holds kThreads / nt groups
+static inline __host__ __device__ int lds_group_threads(int N) {
+  const int want = N / 4;
+  return want >= kThreads ? kThreads : (want < 64 ? 64 : want);
+}
+
+// one group per (clip, channel pair, frame)
 __global__ __launch_bounds__(kThreads) void k_fwd_lds(const float* __restrict__ x, float* __restrict__ X,
                                                       const float* __restrict__ prev_block,
                                                       const float* __restrict__ coef,
                                                       const float* __restrict__ ctab, int Kin, int F, int C, int CP,
-                                                      int N) {
+                                                      int N, long long ntasks) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float2* v = reinterpret_cast<float2*>(smem);             // [N]
-  cpair* A = reinterpret_cast<cpair*>(smem + 2 * N);       // [N/2]
-  cpair* Bf = reinterpret_cast<cpair*>(smem + 4 * N);      // [N/2]
+  const int nt = lds_group_threads(N), grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
+  float* base = smem + (size_t)grp * 6 * N;
+  float2* v = reinterpret_cast<float2*>(base);             // [N]
+  cpair* A = reinterpret_cast<cpair*>(base + 2 * N);       // [N/2]
+  cpair* Bf = reinterpret_cast<cpair*>(base + 4 * N);      // [N/2]
   const int h = N >> 1;
-  const long long wg = blockIdx.x;
+  const long long task_raw = (long long)blockIdx.x * (kThreads / nt) + grp;
+  const bool valid = task_raw < ntasks;
+  const long long wg = valid ? task_raw : ntasks - 1;      // idle groups of the last workgroup only join the barriers
   const int n = (int)(wg % F);
   const long long sig = wg / F;
   const int c = 2 * (int)(sig % CP);
@@ -227,7 +238,7 @@ __global__ __launch_bounds__(kThreads) void k_fwd_lds(const float* __restrict__ 
   const float* xp = nullptr;
   if (n >= 1) xp = x + ((size_t)b * Kin + (size_t)(n - 1)) * N * C + c;
   else if (prev_block) xp = prev_block + (size_t)b * N * C + c;
-  for (int j = threadIdx.x; j < h; j += kThreads) {
+  for (int j = tid; j < h; j += nt) {
     float2 vc = make_float2(0.f, 0.f), vp = make_float2(0.f, 0.f);
     if (has_cur) {
       const float2 p = ld2(xc + (size_t)j * C, C, has1), q = ld2(xc + (size_t)(N - 1 - j) * C, C, has1);
@@ -241,27 +252,32 @@ __global__ __launch_bounds__(kThreads) void k_fwd_lds(const float* __restrict__ 
     v[j] = vp;
   }
   __syncthreads();
-  dct4_lds(v, A, Bf, ctab, N);
+  dct4_lds(v, A, Bf, ctab, N, tid, nt);
+  if (!valid) return;
   const float scale = (float)(1.0 / ((double)N * 1.4142135623730951));   // 1/sqrt(4N) * sqrt(2/N)
   float* Xo = X + (((size_t)b * F + (size_t)n) * N) * C + c;
-  for (int k = threadIdx.x; k < N; k += kThreads)
-    st2(Xo + (size_t)k * C, make_float2(v[k].x * scale, v[k].y * scale), has1);
+  for (int k = tid; k < N; k += nt) st2(Xo + (size_t)k * C, make_float2(v[k].x * scale, v[k].y * scale), has1);
 }
 
-// one workgroup per (clip, channel pair, strip of `seg` output blocks): the aliased half of the previous frame's DCT-IV
+// one group per (clip, channel pair, strip of `seg` output blocks): the aliased half of the previous frame's DCT-IV
 // stays in LDS along the strip, so a strip of T blocks costs T + 1 transforms; the block index nblk (one past the
-// last) only writes the new stream state
+// last) only writes the new stream state.  Every group runs the same number of transforms (barriers are workgroup-wide).
 __global__ __launch_bounds__(kThreads) void k_inv_lds(const float* __restrict__ X, float* __restrict__ x,
                                                       const float* __restrict__ tail_in, float* __restrict__ tail_out,
                                                       const float* __restrict__ coef, const float* __restrict__ ctab,
-                                                      int Kp, int nblk, int seg, int nseg, int C, int CP, int N) {
+                                                      int Kp, int nblk, int seg, int nseg, int C, int CP, int N,
+                                                      long long ntasks) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float2* v = reinterpret_cast<float2*>(smem);             // [N]
-  cpair* A = reinterpret_cast<cpair*>(smem + 2 * N);       // [N/2]
-  cpair* Bf = reinterpret_cast<cpair*>(smem + 4 * N);      // [N/2]
-  float2* um = reinterpret_cast<float2*>(smem + 6 * N);    // [N/2]  u_{n-1}[h + j]
+  const int nt = lds_group_threads(N), grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
+  float* base = smem + (size_t)grp * 7 * N;
+  float2* v = reinterpret_cast<float2*>(base);             // [N]
+  cpair* A = reinterpret_cast<cpair*>(base + 2 * N);       // [N/2]
+  cpair* Bf = reinterpret_cast<cpair*>(base + 4 * N);      // [N/2]
+  float2* um = reinterpret_cast<float2*>(base + 6 * N);    // [N/2]  u_{n-1}[h + j]
   const int h = N >> 1;
-  const long long wg = blockIdx.x;
+  const long long task_raw = (long long)blockIdx.x * (kThreads / nt) + grp;
+  const bool valid = task_raw < ntasks;
+  const long long wg = valid ? task_raw : ntasks - 1;
   const int sgm = (int)(wg % nseg);
   const long long sig = wg / nseg;
   const int c = 2 * (int)(sig % CP);
@@ -274,44 +290,46 @@ __global__ __launch_bounds__(kThreads) void k_inv_lds(const float* __restrict__ 
   const float scale = 2.0f * 1.4142135623730951f;   // sqrt(4N) * sqrt(2/N)
   const int nlast = nblk + (tail_out ? 1 : 0);      // blocks incl. the virtual state block
   const int n0 = sgm * seg;
-  const int n1 = min(nlast, n0 + seg);
   const size_t ts = ((size_t)b * C + c) * h;        // stream state rows of the pair: ts, ts + h
   // aliased half before the strip: frame n0 - 1, the stream state, or zero
-  if (n0 >= 1) {
-    const float* Xi = X + (((size_t)b * Kp + (size_t)(n0 - 1)) * N) * C + c;
-    for (int k = threadIdx.x; k < N; k += kThreads) v[k] = ld2(Xi + (size_t)k * C, C, has1);
+  {
+    const bool halo = n0 >= 1;
+    const float* Xi = X + (((size_t)b * Kp + (size_t)(halo ? n0 - 1 : 0)) * N) * C + c;
+    for (int k = tid; k < N; k += nt) v[k] = halo ? ld2(Xi + (size_t)k * C, C, has1) : make_float2(0.f, 0.f);
     __syncthreads();
-    dct4_lds(v, A, Bf, ctab, N);
-    for (int j = threadIdx.x; j < h; j += kThreads) um[j] = make_float2(v[h + j].x * scale, v[h + j].y * scale);
-  } else {
-    for (int j = threadIdx.x; j < h; j += kThreads)
-      um[j] = tail_in ? make_float2(tail_in[ts + j], has1 ? tail_in[ts + h + j] : 0.f) : make_float2(0.f, 0.f);
-  }
-  __syncthreads();
-  for (int n = n0; n < n1; ++n) {
-    const bool has_n = n < Kp && n < nblk;   // the virtual state block (n == nblk) has no current frame
-    if (has_n) {
-      const float* Xi = X + (((size_t)b * Kp + (size_t)n) * N) * C + c;
-      for (int k = threadIdx.x; k < N; k += kThreads) v[k] = ld2(Xi + (size_t)k * C, C, has1);
-      __syncthreads();
-      dct4_lds(v, A, Bf, ctab, N);
+    dct4_lds(v, A, Bf, ctab, N, tid, nt);
+    for (int j = tid; j < h; j += nt) {
+      if (halo) um[j] = make_float2(v[h + j].x * scale, v[h + j].y * scale);
+      else um[j] = tail_in ? make_float2(tail_in[ts + j], has1 ? tail_in[ts + h + j] : 0.f) : make_float2(0.f, 0.f);
     }
-    for (int j = threadIdx.x; j < h; j += kThreads) {
-      float2 a = make_float2(0.f, 0.f);
-      if (has_n) a = make_float2(v[h - 1 - j].x * scale, v[h - 1 - j].y * scale);   // u_n[h-1-j]
-      const float2 bb = um[j];                                                      // u_{n-1}[h+j]
-      if (n < nblk) {
-        float* xo = x + (((size_t)b * nblk + (size_t)n) * N) * C + c;
-        st2(xo + (size_t)j * C, make_float2(s1[j] * a.x + s2[j] * bb.x, s1[j] * a.y + s2[j] * bb.y), has1);
-        st2(xo + (size_t)(N - 1 - j) * C, make_float2(s3[j] * a.x + s4[j] * bb.x, s3[j] * a.y + s4[j] * bb.y), has1);
-      } else if (tail_out) {
-        tail_out[ts + j] = bb.x;
-        if (has1) tail_out[ts + h + j] = bb.y;
+    __syncthreads();
+  }
+  for (int t = 0; t < seg; ++t) {
+    const int n = n0 + t;
+    const bool live = valid && n < nlast;    // this group still has a block to write
+    const bool has_n = n < Kp && n < nblk;   // the virtual state block (n == nblk) has no current frame
+    {
+      const float* Xi = X + (((size_t)b * Kp + (size_t)(has_n ? n : 0)) * N) * C + c;
+      for (int k = tid; k < N; k += nt) v[k] = has_n ? ld2(Xi + (size_t)k * C, C, has1) : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    dct4_lds(v, A, Bf, ctab, N, tid, nt);
+    if (live) {
+      for (int j = tid; j < h; j += nt) {
+        const float2 a = make_float2(v[h - 1 - j].x * scale, v[h - 1 - j].y * scale);   // u_n[h-1-j]
+        const float2 bb = um[j];                                                        // u_{n-1}[h+j]
+        if (n < nblk) {
+          float* xo = x + (((size_t)b * nblk + (size_t)n) * N) * C + c;
+          st2(xo + (size_t)j * C, make_float2(s1[j] * a.x + s2[j] * bb.x, s1[j] * a.y + s2[j] * bb.y), has1);
+          st2(xo + (size_t)(N - 1 - j) * C, make_float2(s3[j] * a.x + s4[j] * bb.x, s3[j] * a.y + s4[j] * bb.y), has1);
+        } else if (tail_out) {
+          tail_out[ts + j] = bb.x;
+          if (has1) tail_out[ts + h + j] = bb.y;
+        }
       }
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < h; j += kThreads)
-      um[j] = has_n ? make_float2(v[h + j].x * scale, v[h + j].y * scale) : make_float2(0.f, 0.f);
+    for (int j = tid; j < h; j += nt) um[j] = make_float2(v[h + j].x * scale, v[h + j].y * scale);
     __syncthreads();
   }
 }
@@ -643,11 +661,13 @@ int launch_fwd_generic(const ac_mdct_plan* p, const float* x, float* X, const fl
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
   if (lds_fft_ok(p->N) && !g_force_generic) {
-    const int CP = (C + 1) / 2;
-    const int st2 = allow_lds(k_fwd_lds, 6 * (size_t)p->N * sizeof(float));
+    const int CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
+    const long long ntasks = (long long)B * CP * F;
+    const size_t lds2 = (size_t)gpw * 6 * p->N * sizeof(float);
+    const int st2 = allow_lds(k_fwd_lds, lds2);
     if (st2) return st2;
-    hipLaunchKernelGGL(k_fwd_lds, dim3((unsigned)((long long)B * CP * F)), dim3(kThreads),
-                       6 * (size_t)p->N * sizeof(float), s, x, X, prev_block, p->d_coef, p->d_ctab, Kin, F, C, CP, p->N);
+    hipLaunchKernelGGL(k_fwd_lds, dim3((unsigned)((ntasks + gpw - 1) / gpw)), dim3(kThreads), lds2, s, x, X, prev_block,
+                       p->d_coef, p->d_ctab, Kin, F, C, CP, p->N, ntasks);
     AC_HIP_CHECK(hipGetLastError());
     return AC_OK;
   }
@@ -666,13 +686,14 @@ int launch_inv_generic(const ac_mdct_plan* p, const float* X, float* x, const fl
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
   if (lds_fft_ok(p->N) && !g_force_generic) {
-    const int seg = 8, CP = (C + 1) / 2;
+    const int seg = 8, CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const int nseg = (per_sig + seg - 1) / seg;
-    const long long nwg2 = (long long)B * CP * nseg;
-    const int st2 = allow_lds(k_inv_lds, 7 * (size_t)p->N * sizeof(float));
+    const long long ntasks = (long long)B * CP * nseg;
+    const size_t lds2 = (size_t)gpw * 7 * p->N * sizeof(float);
+    const int st2 = allow_lds(k_inv_lds, lds2);
     if (st2) return st2;
-    hipLaunchKernelGGL(k_inv_lds, dim3((unsigned)nwg2), dim3(kThreads), 7 * (size_t)p->N * sizeof(float), s, X, x,
-                       tail_in, tail_out, p->d_coef, p->d_ctab, Kp, nblk, seg, nseg, C, CP, p->N);
+    hipLaunchKernelGGL(k_inv_lds, dim3((unsigned)((ntasks + gpw - 1) / gpw)), dim3(kThreads), lds2, s, X, x, tail_in,
+                       tail_out, p->d_coef, p->d_ctab, Kp, nblk, seg, nseg, C, CP, p->N, ntasks);
     AC_HIP_CHECK(hipGetLastError());
     return AC_OK;
   }
