@@ -153,9 +153,14 @@ __device__ __forceinline__ cpair cmulw(cpair a, float2 w) {
   return r;
 }
 __device__ __forceinline__ float2 ld2(const float* p, int C, bool has1) {   // the pair's two samples at one index
+  if (C == 2) return *reinterpret_cast<const float2*>(p);                     // stereo: one 8-byte access
   return make_float2(p[0], has1 ? p[1] : 0.f);
 }
-__device__ __forceinline__ void st2(float* p, float2 v, bool has1) {
+__device__ __forceinline__ void st2(float* p, float2 v, int C, bool has1) {
+  if (C == 2) {
+    *reinterpret_cast<float2*>(p) = v;
+    return;
+  }
   p[0] = v.x;
   if (has1) p[1] = v.y;
 }
@@ -163,7 +168,8 @@ __device__ __forceinline__ void st2(float* p, float2 v, bool has1) {
 // v[N] (LDS, float2 per entry) -> y[k] = sum_m v[m] cos(pi/N (m + 1/2)(k + 1/2)) written back into v;
 // A, B: N/2 cpairs each (LDS).  Executed by a group of nt threads (tid = index inside the group); every group of the
 // workgroup runs it at the same time on its own buffers (the barriers are workgroup-wide).
-__device__ void dct4_lds(float2* v, cpair* A, cpair* B, const float* __restrict__ ctab, int N, int tid, int nt) {
+__device__ void dct4_lds(float2* v, cpair* A, cpair* B, const float* __restrict__ ctab, const float2* __restrict__ tw,
+                         int N, int tid, int nt) {
   const int H = N >> 1;
   for (int n = tid; n < H; n += nt) {
     cpair t;
@@ -175,12 +181,11 @@ __device__ void dct4_lds(float2* v, cpair* A, cpair* B, const float* __restrict_
   cpair* src = A;
   cpair* dst = B;
   for (int L = 1; L < H; L <<= 1) {
-    const int m = H / (2 * L);
-    const int tw = 4 * N / L;   // exp(-2 pi i q / (2 L)) = exp(-i pi (4 N q / L) / (4 N))
+    const int m = H / (2 * L);   // exp(-2 pi i q / (2 L)) = exp(-2 pi i (q m) / H) = tw[q m]
     for (int j = tid; j < H / 2; j += nt) {
       const int p = j / L, q = j - p * L;
       const cpair c0 = src[q + L * p];
-      const cpair c1 = cmulw(src[q + L * (p + m)], cis_neg(ctab, tw * q, N));
+      const cpair c1 = cmulw(src[q + L * (p + m)], tw[q * m]);
       cpair s, d;
       s.re = make_float2(c0.re.x + c1.re.x, c0.re.y + c1.re.y);
       s.im = make_float2(c0.im.x + c1.im.x, c0.im.y + c1.im.y);
@@ -202,6 +207,12 @@ __device__ void dct4_lds(float2* v, cpair* A, cpair* B, const float* __restrict_
   __syncthreads();
 }
 
+// the FFT's twiddles exp(-2 pi i k / (N/2)), k < N/4, once per workgroup into LDS (every thread takes part; the caller
+// synchronises before the first use)
+__device__ __forceinline__ void fill_twiddles(float2* tw, const float* __restrict__ ctab, int N) {
+  for (int k = threadIdx.x; k < N / 4; k += kThreads) tw[k] = cis_neg(ctab, 16 * k, N);   // exp(-i pi (16 k) / (4 N))
+}
+
 // threads per group: enough for the N/4 butterflies of a stage, at least one wave; a workgroup holds kThreads / nt groups
 static inline __host__ __device__ int lds_group_threads(int N) {
   const int want = N / 4;
@@ -216,6 +227,8 @@ __global__ __launch_bounds__(kThreads) void k_fwd_lds(const float* __restrict__ 
                                                       int N, long long ntasks) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int nt = lds_group_threads(N), grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
+  float2* tw = reinterpret_cast<float2*>(smem + (size_t)(kThreads / nt) * 6 * N);   // [N/4] behind the groups' buffers
+  fill_twiddles(tw, ctab, N);
   float* base = smem + (size_t)grp * 6 * N;
   float2* v = reinterpret_cast<float2*>(base);             // [N]
   cpair* A = reinterpret_cast<cpair*>(base + 2 * N);       // [N/2]
@@ -252,11 +265,11 @@ __global__ __launch_bounds__(kThreads) void k_fwd_lds(const float* __restrict__ 
     v[j] = vp;
   }
   __syncthreads();
-  dct4_lds(v, A, Bf, ctab, N, tid, nt);
+  dct4_lds(v, A, Bf, ctab, tw, N, tid, nt);
   if (!valid) return;
   const float scale = (float)(1.0 / ((double)N * 1.4142135623730951));   // 1/sqrt(4N) * sqrt(2/N)
   float* Xo = X + (((size_t)b * F + (size_t)n) * N) * C + c;
-  for (int k = tid; k < N; k += nt) st2(Xo + (size_t)k * C, make_float2(v[k].x * scale, v[k].y * scale), has1);
+  for (int k = tid; k < N; k += nt) st2(Xo + (size_t)k * C, make_float2(v[k].x * scale, v[k].y * scale), C, has1);
 }
 
 // one group per (clip, channel pair, strip of `seg` output blocks): the aliased half of the previous frame's DCT-IV
@@ -269,6 +282,8 @@ __global__ __launch_bounds__(kThreads) void k_inv_lds(const float* __restrict__ 
                                                       long long ntasks) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int nt = lds_group_threads(N), grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
+  float2* tw = reinterpret_cast<float2*>(smem + (size_t)(kThreads / nt) * 7 * N);   // [N/4] behind the groups' buffers
+  fill_twiddles(tw, ctab, N);
   float* base = smem + (size_t)grp * 7 * N;
   float2* v = reinterpret_cast<float2*>(base);             // [N]
   cpair* A = reinterpret_cast<cpair*>(base + 2 * N);       // [N/2]
@@ -297,7 +312,7 @@ __global__ __launch_bounds__(kThreads) void k_inv_lds(const float* __restrict__ 
     const float* Xi = X + (((size_t)b * Kp + (size_t)(halo ? n0 - 1 : 0)) * N) * C + c;
     for (int k = tid; k < N; k += nt) v[k] = halo ? ld2(Xi + (size_t)k * C, C, has1) : make_float2(0.f, 0.f);
     __syncthreads();
-    dct4_lds(v, A, Bf, ctab, N, tid, nt);
+    dct4_lds(v, A, Bf, ctab, tw, N, tid, nt);
     for (int j = tid; j < h; j += nt) {
       if (halo) um[j] = make_float2(v[h + j].x * scale, v[h + j].y * scale);
       else um[j] = tail_in ? make_float2(tail_in[ts + j], has1 ? tail_in[ts + h + j] : 0.f) : make_float2(0.f, 0.f);
@@ -313,15 +328,15 @@ __global__ __launch_bounds__(kThreads) void k_inv_lds(const float* __restrict__ 
       for (int k = tid; k < N; k += nt) v[k] = has_n ? ld2(Xi + (size_t)k * C, C, has1) : make_float2(0.f, 0.f);
     }
     __syncthreads();
-    dct4_lds(v, A, Bf, ctab, N, tid, nt);
+    dct4_lds(v, A, Bf, ctab, tw, N, tid, nt);
     if (live) {
       for (int j = tid; j < h; j += nt) {
         const float2 a = make_float2(v[h - 1 - j].x * scale, v[h - 1 - j].y * scale);   // u_n[h-1-j]
         const float2 bb = um[j];                                                        // u_{n-1}[h+j]
         if (n < nblk) {
           float* xo = x + (((size_t)b * nblk + (size_t)n) * N) * C + c;
-          st2(xo + (size_t)j * C, make_float2(s1[j] * a.x + s2[j] * bb.x, s1[j] * a.y + s2[j] * bb.y), has1);
-          st2(xo + (size_t)(N - 1 - j) * C, make_float2(s3[j] * a.x + s4[j] * bb.x, s3[j] * a.y + s4[j] * bb.y), has1);
+          st2(xo + (size_t)j * C, make_float2(s1[j] * a.x + s2[j] * bb.x, s1[j] * a.y + s2[j] * bb.y), C, has1);
+          st2(xo + (size_t)(N - 1 - j) * C, make_float2(s3[j] * a.x + s4[j] * bb.x, s3[j] * a.y + s4[j] * bb.y), C, has1);
         } else if (tail_out) {
           tail_out[ts + j] = bb.x;
           if (has1) tail_out[ts + h + j] = bb.y;
@@ -663,7 +678,7 @@ int launch_fwd_generic(const ac_mdct_plan* p, const float* x, float* X, const fl
   if (lds_fft_ok(p->N) && !g_force_generic) {
     const int CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const long long ntasks = (long long)B * CP * F;
-    const size_t lds2 = (size_t)gpw * 6 * p->N * sizeof(float);
+    const size_t lds2 = ((size_t)gpw * 6 * p->N + p->N / 2) * sizeof(float);
     const int st2 = allow_lds(k_fwd_lds, lds2);
     if (st2) return st2;
     hipLaunchKernelGGL(k_fwd_lds, dim3((unsigned)((ntasks + gpw - 1) / gpw)), dim3(kThreads), lds2, s, x, X, prev_block,
@@ -689,7 +704,7 @@ int launch_inv_generic(const ac_mdct_plan* p, const float* X, float* x, const fl
     const int seg = 8, CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const int nseg = (per_sig + seg - 1) / seg;
     const long long ntasks = (long long)B * CP * nseg;
-    const size_t lds2 = (size_t)gpw * 7 * p->N * sizeof(float);
+    const size_t lds2 = ((size_t)gpw * 7 * p->N + p->N / 2) * sizeof(float);
     const int st2 = allow_lds(k_inv_lds, lds2);
     if (st2) return st2;
     hipLaunchKernelGGL(k_inv_lds, dim3((unsigned)((ntasks + gpw - 1) / gpw)), dim3(kThreads), lds2, s, X, x, tail_in,
