@@ -20,7 +20,7 @@
 //   * synthesis carries the aliased half of a frame's DCT-IV in registers along a short strip of output blocks.
 // Frames are dealt to waves in order, so the chip works on one contiguous window of every tensor.
 //
-// Index maps and their bank behaviour are emulated lane by lane in tools/emulate_wave_fft.py.
+// Index maps and their bank behaviour are emulated lane by lane in tests/emulate_wave_fft.py.
 // Reference formulas: mdctransformer.py:62-153 (closed forms in SURVEY.md App. A), psychoacoustic.py:102-210,301-331.
 #include <cmath>
 #include <cstdlib>
@@ -195,7 +195,7 @@ __device__ __forceinline__ void dft_regs(C2 (&x)[16]) { dft16(x); }
 //   per half h of the k1 (k1 = (64/R) h + kk): exchange 2: element (k0, kk, e0) at 9 (k0 + R kk) + e0;
 //     lane k0 + R kk reads its 8 consecutive e0;  pass 3 over e0 -> k2;  bin = lane + 64 (h + (R/8) k2).
 // Every exchange address is one per-lane base + an immediate, and every access is bank-conflict-free under the
-// gfx950 lane-group rules (tools/emulate_wave_fft.py emulates the maps for R = 8 and 16).
+// gfx950 lane-group rules (tests/emulate_wave_fft.py emulates the maps for R = 8 and 16).
 template <int R>
 __device__ __forceinline__ void fft_wave(C2 (&z)[R], char* buf, gtab_t tab, const v2f (&p1)[R], int lane) {
   constexpr int NB = R / 8;      // batches of eight 64-point FFTs

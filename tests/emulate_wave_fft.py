@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Lane-level numpy emulation of the wave kernels in audiocodec_amd/csrc/ac_fast.hip (design aid).
+"""Lane-level numpy emulation of the wave kernels in audiocodec_amd/csrc/ac_fast.hip (design aid and CPU test
+infrastructure: tests/test_wave_maps.py runs its checks; it compares against the oracle, so it lives under tests/).
 
 Emulates one 64-lane wavefront holding 8 complex points per lane: fold + pre-twiddle, three radix-8
 passes with the two LDS exchanges, post-twiddle and the natural-order staging, for analysis and
