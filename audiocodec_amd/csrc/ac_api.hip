@@ -179,8 +179,19 @@ int ac_mdct_plan_destroy(ac_mdct_plan* p) {
 }
 
 int ac_psy_plan_create(int N, int M, double sample_rate, double alpha, int device, ac_psy_plan** out) {
+  // AC_SPREAD: tuning hook, the spreading product of plans created without an explicit choice
+  static const int dflt = [] { const char* e = getenv("AC_SPREAD"); const int v = e ? atoi(e) : 0; return v >= 0 && v <= 2 ? v : 0; }();
+  ac_psy_plan* p = nullptr;
+  int st = ac_psy_plan_create_ex(N, M, sample_rate, alpha, device, dflt, &p);
+  if (st == AC_EUNSUPPORTED && dflt != 0) st = ac_psy_plan_create_ex(N, M, sample_rate, alpha, device, 0, &p);
+  if (out) *out = p;
+  return st;
+}
+
+int ac_psy_plan_create_ex(int N, int M, double sample_rate, double alpha, int device, int spreading, ac_psy_plan** out) {
   AC_REQUIRE(out != nullptr, "out is NULL");
   *out = nullptr;
+  AC_REQUIRE(spreading >= AC_SPREAD_F32 && spreading <= AC_SPREAD_BF16X2_MFMA, "spreading = %d is not one of AC_SPREAD_*", spreading);
   AC_REQUIRE(N >= 1 && M >= 1, "filter_bands_n (%d) and bark_bands_n (%d) must be positive", N, M);
   AC_REQUIRE(N <= 8192 && M <= 4096, "filter_bands_n = %d / bark_bands_n = %d not supported", N, M);
   AC_REQUIRE(sample_rate > 0 && alpha > 0, "sample_rate and alpha must be positive");
@@ -227,6 +238,15 @@ int ac_psy_plan_create(int N, int M, double sample_rate, double alpha, int devic
     st = fast_psy_plan_init(p);
     if (!st) p->fast = 1;
   }
+  if (!st && spreading != AC_SPREAD_F32) {
+    if (p->fast) {
+      p->spread = spreading;
+    } else {
+      set_error("the matrix-core spreading product needs the wave-level masking model (filter_bands_n 1024 or 2048, 64 Bark "
+                "bands); got filter_bands_n = %d, bark_bands_n = %d", N, M);
+      st = AC_EUNSUPPORTED;
+    }
+  }
   if (st) {
     ac_psy_plan_destroy(p);
     return st;
@@ -260,6 +280,7 @@ int ac_psy_plan_destroy(ac_psy_plan* p) {
 
 int ac_mdct_plan_is_fast(const ac_mdct_plan* p) { return p ? p->fast : 0; }
 int ac_psy_plan_is_fast(const ac_psy_plan* p) { return p ? p->fast : 0; }
+int ac_psy_plan_spreading(const ac_psy_plan* p) { return p ? p->spread : 0; }
 
 // ---- hot path -------------------------------------------------------------------------------------
 

@@ -56,6 +56,8 @@ constexpr int WAVE_LDS = 9216;      // bytes of LDS per wave: 576 x 16-byte elem
 constexpr int S8_OFF = 8192;        // psycho: 128 chunk sums (8 bins each) behind the 8 KB intensity image
 constexpr int ZERO_OFF = 9216;      // psycho: one zero slot (padding target of the gather lists)
 constexpr int WAVE_LDS_PSY = 9232;
+constexpr int MF_COPY_STRIDE = 320;               // bytes between the four shifted copies of the reversed bf16 prototype
+constexpr int MF_TAB_BYTES = 4 * MF_COPY_STRIDE;  // one table (hi or lo parts)
 constexpr float kEps = 1e-14f;      // _INTENSITY_EPS, psychoacoustic.py:56
 
 // ---- geometry and mdct tables for R complex FFT points per lane: filters_n = 128 R (R = 8: 1024, R = 16: 2048).
@@ -79,8 +81,8 @@ struct Geo {
 };
 // waves per SIMD the register allocator must leave room for: the strided any-channel-count variants (CMODE 1) and the
 // 2048-filter kernels get the larger budget
-template <int R, int CMODE, bool PSY = false>
-constexpr int wpe() { return (R == 8 && (CMODE == 0 || (CMODE == 2 && !PSY))) ? AC_WPE : 2; }
+template <int R, int CMODE, bool PSY = false, int SPREAD = 0>
+constexpr int wpe() { return (R == 8 && SPREAD == 0 && (CMODE == 0 || (CMODE == 2 && !PSY))) ? AC_WPE : 2; }
 
 // ---- psy image (32-bit words) in ac_psy_plan::d_fast for filter_bands_n = 128 R and 64 Bark bands; the first PL_LDS
 // words are copied into LDS once per workgroup, the rest is held in registers.  The spectrum passes through the wave's
@@ -99,7 +101,15 @@ struct PsyGeo {
   //   threshold entries of the two bins of granule 64 i + lane, word i
   static constexpr int P_TOTAL = PL_IDX + (R / 4) * 256;
   static constexpr int PSY_LDS = PL_LDS * 4;
+  // bf16 tiles of the spreading matrix for the MFMA form of the band x band product (spread_mfma): hi table, lo table
+  static constexpr int PL_MF = P_TOTAL;
+  static constexpr int P_TOTAL_MF = PL_MF + 2 * (MF_TAB_BYTES / 4);
 };
+// bytes of LDS the MFMA tiles take behind the psy image (SPREAD 0: f32 VALU product, 1: bf16, 2: split bf16)
+constexpr int mf_lds(int spread) { return spread * MF_TAB_BYTES; }
+
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef __bf16 v2b __attribute__((ext_vector_type(2)));
 
 struct C2 {   // one complex value for both channels of the pair
   v2f re, im;
@@ -544,9 +554,77 @@ __device__ __forceinline__ uint32_t in_loop(uint32_t w) {
   return w;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Band x band product with the Toeplitz spreading matrix on the matrix cores (BASELINE configs[3]):
+//   out_j = sum_i Q_i S[i, j],  S[i, j] = g[64 - i + j]   (psychoacoustic.py:205-207)
+// as 16 (MODE 1) or 32 (MODE 2) v_mfma_f32_4x4x4_16b_bf16.  The instruction's 16 blocks are the 16 column tiles of S
+// (block b = bands 4 b .. 4 b + 3, so D lands with band j in lane j, the layout the epilogue continues in); step s
+// contracts bands 4 s .. 4 s + 3.  The A tile of step s (4 rows x 4 bands) is the same for every block: it sits in the
+// four lanes of block s and cbsz = 4 / abid = s broadcast it.  Rows 0, 1 = the two signals of the pair; MODE 1 leaves
+// rows 2, 3 zero (plain bf16, ~3 significant digits: the tolerance is stated in the tests); MODE 2 splits Q = hi + lo
+// (rows 2, 3 carry the lo parts) and S = hi + lo (a second B table), four partial products in f32 accumulators, ~16
+// mantissa bits -- inside the 1e-4 parity bar.  B tile of step s in lane l: g[64 - 4 s - k + l], k = 0..3 = four
+// consecutive entries of the reversed prototype; four copies of the table, shifted by one entry each, make the read an
+// aligned ds_read_b64 for every lane (copy l & 3; the copies sit 320 bytes apart = on disjoint banks for a half wave).
+// mf = LDS copy of the hi table (MF_TAB_BYTES) followed by the lo table.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {   // v_cvt_pk_bf16_f32 (round to nearest even)
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v2f{a, b}, v2b));
+}
+template <int K>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {   // lane K of every quad to the whole quad
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, K * 0x55, 0xf, 0xf, false);
+}
+template <int S, int MODE>
+struct MfSteps {
+  static __device__ __forceinline__ void run(const v4s a, const char* bhi, v4f& d0, v4f& d1) {
+    MfSteps<S - 1, MODE>::run(a, bhi, d0, d1);
+    const v4s b = *reinterpret_cast<const v4s*>(bhi + 8 * S);
+    if (MODE == 2) {
+      d0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a, b, d0, 4, S, 0);
+      const v4s bl = *reinterpret_cast<const v4s*>(bhi + MF_TAB_BYTES + 8 * S);
+      d1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a, bl, d1, 4, S, 0);
+    } else if (S & 1) {
+      d1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a, b, d1, 4, S, 0);
+    } else {
+      d0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a, b, d0, 4, S, 0);
+    }
+  }
+};
+template <int MODE>
+struct MfSteps<-1, MODE> {
+  static __device__ __forceinline__ void run(const v4s, const char*, v4f&, v4f&) {}
+};
+template <int MODE>
+__device__ __forceinline__ v2f spread_mfma(v2f Q, const char* mf, int lane) {
+  const uint32_t whi = pk_bf16(Q.x, Q.y);
+  // quad-local 4 x 4 transpose of 16-bit values: lane 4 s + i gets row i of bands 4 s .. 4 s + 3.  Every lane
+  // evaluates all broadcasts before the select (a DPP read needs its source lane active)
+  const int i = lane & 3;
+  const bool lo_row = i >= 2;
+  uint32_t c0 = quad_bcast<0>(whi), c1 = quad_bcast<1>(whi), c2 = quad_bcast<2>(whi), c3 = quad_bcast<3>(whi);
+  if (MODE == 2) {
+    const float hx = __uint_as_float(whi << 16), hy = __uint_as_float(whi & 0xffff0000u);
+    const uint32_t wlo = pk_bf16(Q.x - hx, Q.y - hy);
+    const uint32_t l0 = quad_bcast<0>(wlo), l1 = quad_bcast<1>(wlo), l2 = quad_bcast<2>(wlo), l3 = quad_bcast<3>(wlo);
+    c0 = lo_row ? l0 : c0, c1 = lo_row ? l1 : c1, c2 = lo_row ? l2 : c2, c3 = lo_row ? l3 : c3;
+  } else {
+    c0 = lo_row ? 0u : c0, c1 = lo_row ? 0u : c1, c2 = lo_row ? 0u : c2, c3 = lo_row ? 0u : c3;
+  }
+  const uint32_t sel = (i & 1) ? 0x07060302u : 0x05040100u;   // the signal's half of each word
+  const uint2 au = {__builtin_amdgcn_perm(c1, c0, sel), __builtin_amdgcn_perm(c3, c2, sel)};
+  const v4s a = __builtin_bit_cast(v4s, au);
+  // (kept inside the frame loop: hoisted, the 16 / 32 tiles would pin 32 / 64 registers)
+  const uint32_t boff = in_loop((uint32_t)((lane & 3) * MF_COPY_STRIDE + 8 * (16 - (lane >> 2))));
+  v4f d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+  MfSteps<15, MODE>::run(a, mf + boff, d0, d1);
+  const v4f d = d0 + d1;
+  return MODE == 2 ? v2f{d.x + d.z, d.y + d.w} : v2f{d.x, d.y};
+}
+
 // buf = the wave's LDS region (WAVE_LDS_PSY bytes), pimg = the workgroup's copy of the psy image
 // lds0 = base of the workgroup's LDS object (the absolute offsets of PsyLane count from it)
-template <int R, bool WANT_T, bool WANT_THR>
+template <int R, bool WANT_T, bool WANT_THR, int SPREAD = 0>
 __device__ __forceinline__ void psy_stage(const v4f (&xq)[R], char* lds0, char* buf, const uint32_t* pimg,
                                           const PsyLane<R>& pc, const PsyParams& pp, int lane, v2f& t, v4f (&thr)[R]) {
   using P = PsyGeo<R>;
@@ -615,19 +693,24 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[R], char* lds0, char* 
   }
   const v2f Pj = P0 + P1;
   const v2f Q = exp2v(pp.alpha * log2v(maxv(Pj, kEps)));   // max(eps, P)^alpha  (:206)
-  wave_sync();
-  *reinterpret_cast<v2f*>(buf + 8 * lane) = Q;
-  wave_sync();
-  // sum_i Q_i S[i, j], S[i, j] = g[64 - i + j]  (:205-207 with the offset factor pulled out of the sum)
-  v2f acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
-  const float* gp = reinterpret_cast<const float*>(pimg + P::PL_G) + 64 + lane;
+  v2f acc;
+  if (SPREAD == 0) {
+    wave_sync();
+    *reinterpret_cast<v2f*>(buf + 8 * lane) = Q;
+    wave_sync();
+    // sum_i Q_i S[i, j], S[i, j] = g[64 - i + j]  (:205-207 with the offset factor pulled out of the sum)
+    v2f acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+    const float* gp = reinterpret_cast<const float*>(pimg + P::PL_G) + 64 + lane;
 #pragma unroll 8
-  for (int i = 0; i < 64; i += 2) {
-    const v4f qq = *reinterpret_cast<const v4f*>(buf + 8 * i);   // Q_i, Q_{i+1} (broadcast read)
-    acc0 += v2f{qq.x, qq.y} * gp[-i];
-    acc1 += v2f{qq.z, qq.w} * gp[-i - 1];
+    for (int i = 0; i < 64; i += 2) {
+      const v4f qq = *reinterpret_cast<const v4f*>(buf + 8 * i);   // Q_i, Q_{i+1} (broadcast read)
+      acc0 += v2f{qq.x, qq.y} * gp[-i];
+      acc1 += v2f{qq.z, qq.w} * gp[-i - 1];
+    }
+    acc = acc0 + acc1;
+  } else {
+    acc = spread_mfma<SPREAD>(Q, reinterpret_cast<const char*>(pimg) + P::PSY_LDS, lane);
   }
-  const v2f acc = acc0 + acc1;
   const v4f bc1 = pc.bc1;
   const v2f offset = (1.0f - pp.drown) * (t * bc1.x + 9.0f * t + 5.5f);                        // (:185-191)
   const v2f fac = exp2v(offset * (-pp.alpha * 0.33219280948873623f));                          // 10^(-alpha O / 10)
@@ -656,7 +739,7 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[R], char* lds0, char* 
 }
 
 // copies the table image (and the psy image) into the workgroup's LDS behind the wave buffers; every thread takes part
-template <int NW, int WSTRIDE, int TABF, int PSYW>
+template <int NW, int WSTRIDE, int TABF, int PSYW, int PSY_TOTAL = 0, int MFB = 0>
 __device__ __forceinline__ void load_tables(char* lds, const float* __restrict__ image, const uint32_t* psy_tab) {
   if (image) {
     v4f* dst = reinterpret_cast<v4f*>(lds + NW * WSTRIDE);
@@ -667,6 +750,10 @@ __device__ __forceinline__ void load_tables(char* lds, const float* __restrict__
     uint4* pd = reinterpret_cast<uint4*>(lds + NW * WSTRIDE + (image ? TABF * 4 : 0));
     const uint4* ps = reinterpret_cast<const uint4*>(psy_tab);
     for (int i = threadIdx.x; i < PSYW / 4; i += NW * 64) pd[i] = ps[i];
+    if (MFB > 0) {   // the bf16 tiles of spread_mfma, behind the psy image
+      const uint4* ms = reinterpret_cast<const uint4*>(psy_tab + PSY_TOTAL);
+      for (int i = threadIdx.x; i < MFB / 16; i += NW * 64) pd[PSYW / 4 + i] = ms[i];
+    }
   }
   __syncthreads();
 }
@@ -701,14 +788,14 @@ struct FwdArgs {
 // register (r + 4) & 7) and the odd sample of granule 767 - e (lane 63 - lane, register (3 - r) & 7).
 // With (A, B) = COEF[e]:  carried part (block n-1) = B xe + A xo;  current part (block n) = B xo - A xe (r < 4),
 // A xe - B xo (r >= 4)   (Princen-Bradley windows make the 2x2 fold blocks rotations).
-template <int R, int CMODE, bool PSY, int NW, bool PCM16 = false>
-__global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY>())) void k_fwd_fast(FwdArgs a) {
+template <int R, int CMODE, bool PSY, int NW, bool PCM16 = false, int SPREAD = 0>
+__global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY, SPREAD>())) void k_fwd_fast(FwdArgs a) {
   using G = Geo<R>;
-  // one LDS object: [NW wave buffers | table image | psy image]
+  // one LDS object: [NW wave buffers | table image | psy image | bf16 tiles of the spreading matrix (SPREAD > 0)]
   constexpr int WSTRIDE = PSY ? WAVE_LDS_PSY : WAVE_LDS;
-  __shared__ __attribute__((aligned(16))) char lds[NW * WSTRIDE + G::TAB_LDS + (PSY ? PsyGeo<R>::PSY_LDS : 0)];
+  __shared__ __attribute__((aligned(16))) char lds[NW * WSTRIDE + G::TAB_LDS + (PSY ? PsyGeo<R>::PSY_LDS + mf_lds(SPREAD) : 0)];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  load_tables<NW, WSTRIDE, G::I_LDS, PsyGeo<R>::PL_LDS>(lds, a.tab, PSY ? a.psy.tab : nullptr);
+  load_tables<NW, WSTRIDE, G::I_LDS, PsyGeo<R>::PL_LDS, PsyGeo<R>::PL_MF, mf_lds(SPREAD)>(lds, a.tab, PSY ? a.psy.tab : nullptr);
   char* buf = lds + wave * WSTRIDE;
   gtab_t tab = reinterpret_cast<const float*>(lds + NW * WSTRIDE);
   const uint32_t* pimg = reinterpret_cast<const uint32_t*>(lds + NW * WSTRIDE + G::TAB_LDS);
@@ -872,7 +959,7 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY>())) void k_fwd_fast(Fw
     if constexpr (PSY) {
       v2f tt;
       v4f th[R];
-      psy_stage<R, true, true>(row, lds, buf, pimg, pc, a.psy, lane, tt, th);
+      psy_stage<R, true, true, SPREAD>(row, lds, buf, pimg, pc, a.psy, lane, tt, th);
       store_row<CMODE, R>(a.thr + o0, a.thr + o1, C, pq.has1, lane, th);
       if (lane == 0) {
         a.t[t0] = tt.x;
@@ -1082,13 +1169,13 @@ struct PsyArgs {
   long long ntasks;   // npairs * F
 };
 
-template <int R, int CMODE, bool WANT_T, bool WANT_THR, int NW>
+template <int R, int CMODE, bool WANT_T, bool WANT_THR, int NW, int SPREAD = 0>
 __global__ __launch_bounds__(NW * 64, (R == 8 ? AC_WPE : 2)) void k_psy_fast(PsyArgs a) {
   using P = PsyGeo<R>;
-  __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS_PSY + P::PSY_LDS];
+  __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS_PSY + P::PSY_LDS + mf_lds(SPREAD)];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t* pimg = reinterpret_cast<const uint32_t*>(lds + NW * WAVE_LDS_PSY);
-  if (WANT_THR) load_tables<NW, WAVE_LDS_PSY, 0, P::PL_LDS>(lds, nullptr, a.psy.tab);
+  if (WANT_THR) load_tables<NW, WAVE_LDS_PSY, 0, P::PL_LDS, P::PL_MF, mf_lds(SPREAD)>(lds, nullptr, a.psy.tab);
   const long long task = (long long)blockIdx.x * NW + wave;
   if (task >= a.ntasks) return;
   char* buf = lds + wave * WAVE_LDS_PSY;
@@ -1109,7 +1196,7 @@ __global__ __launch_bounds__(NW * 64, (R == 8 ? AC_WPE : 2)) void k_psy_fast(Psy
   }
   PsyLane<R> pc;
   if (WANT_THR) pc = load_psy_lane<R>(a.psy.tab, lane, (uint32_t)(wave * WAVE_LDS_PSY));
-  psy_stage<R, WANT_T, WANT_THR>(row, lds, buf, pimg, pc, a.psy, lane, tt, th);
+  psy_stage<R, WANT_T, WANT_THR, SPREAD>(row, lds, buf, pimg, pc, a.psy, lane, tt, th);
   if (WANT_T && lane == 0) {
     a.t_out[t0] = tt.x;
     if (has1) a.t_out[t1] = tt.y;
@@ -1478,7 +1565,7 @@ static bool build_psy_fast_R(const ac_psy_plan* p, std::vector<uint32_t>* out) {
   if (N != P::FN || M != 64) return false;
   auto Wf = [&](int f, int j) { return (float)t.W[(size_t)f * M + j]; };
   auto Vf = [&](int j, int f) { return (float)t.W_inv[(size_t)j * N + f]; };
-  std::vector<uint32_t> w(P::P_TOTAL, 0u);
+  std::vector<uint32_t> w(P::P_TOTAL_MF, 0u);
   auto putf = [&](int idx, float v) { uint32_t u; memcpy(&u, &v, 4); w[idx] = u; };
   auto band = [](int group, int j, int word) { return P::PL_BAND + 4 * (group * 64 + j) + word; };
   // LDS byte offset of I[f] in the wave buffer while half f / 1024 is staged (granule swizzle of psy_stage)
@@ -1564,6 +1651,21 @@ static bool build_psy_fast_R(const ac_psy_plan* p, std::vector<uint32_t>* out) {
       w[P::PL_IDX + 4 * ((i >> 2) * 64 + l) + (i & 3)] = e0 | (e1 << 16);
     }
   for (int i = 0; i < 128; ++i) putf(P::PL_G + i, (float)t.g[i]);
+  // bf16 tiles for spread_mfma: copy c, entry y = rev[y - c], rev[m] = g[128 - m] (m = 1 .. 127); hi parts, then lo parts
+  {
+    auto bf16_rne = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+    auto bf16_val = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+    uint16_t* tb = reinterpret_cast<uint16_t*>(w.data() + P::PL_MF);
+    for (int c = 0; c < 4; ++c)
+      for (int y = 0; y < 132; ++y) {
+        const int m = y - c;
+        if (m < 1 || m > 127) continue;
+        const float v = (float)t.g[128 - m];
+        const uint16_t hi = bf16_rne(v);
+        tb[(c * MF_COPY_STRIDE) / 2 + y] = hi;
+        tb[(MF_TAB_BYTES + c * MF_COPY_STRIDE) / 2 + y] = bf16_rne(v - bf16_val(hi));
+      }
+  }
   if (out) *out = w;
   return true;
 }
@@ -1608,10 +1710,13 @@ static unsigned persistent_grid(int cus, int wg_per_cu, long long ntasks, int nw
 }
 
 template <int R, bool PCM16>
-static void launch_fwd_R(const FwdArgs& a, bool psy, int C, unsigned grid, hipStream_t s) {
+static void launch_fwd_R(const FwdArgs& a, bool psy, int spread, int C, unsigned grid, hipStream_t s) {
   if (psy) {
     const dim3 blk(AC_WAVES_PSY * 64);
-    if (C == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, PCM16>), dim3(grid), blk, 0, s, a);
+    // the matrix-core forms of the spreading product serve the stereo float32 kernels; the others keep the f32 product
+    if (C == 2 && !PCM16 && spread == 1) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, false, 1>), dim3(grid), blk, 0, s, a);
+    else if (C == 2 && !PCM16 && spread == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, false, 2>), dim3(grid), blk, 0, s, a);
+    else if (C == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, PCM16>), dim3(grid), blk, 0, s, a);
     else if (C == 1) hipLaunchKernelGGL((k_fwd_fast<R, 2, true, AC_WAVES_PSY, PCM16>), dim3(grid), blk, 0, s, a);
     else hipLaunchKernelGGL((k_fwd_fast<R, 1, true, AC_WAVES_PSY, PCM16>), dim3(grid), blk, 0, s, a);
     return;
@@ -1649,6 +1754,7 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x
   static const int tper = [] { const char* e = getenv("AC_FWD_T"); return e ? atoi(e) : 4; }();
   a.xcd = xcd;
   a.T = tper;
+  const int spread = psy ? psy->spread : 0;
   const int nw = psy ? AC_WAVES_PSY : AC_WAVES;
   unsigned grid;
   if (tper > 0) {
@@ -1664,12 +1770,12 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x
     grid = persistent_grid(p->cus, wgcu, a.nframes, nw);
   }
   if (p->N == Geo<8>::FN) {
-    if (pcm16) launch_fwd_R<8, true>(a, psy != nullptr, C, grid, s);
-    else launch_fwd_R<8, false>(a, psy != nullptr, C, grid, s);
+    if (pcm16) launch_fwd_R<8, true>(a, psy != nullptr, spread, C, grid, s);
+    else launch_fwd_R<8, false>(a, psy != nullptr, spread, C, grid, s);
   }
 #ifndef AC_NO_R16
-  else if (pcm16) launch_fwd_R<16, true>(a, psy != nullptr, C, grid, s);
-  else launch_fwd_R<16, false>(a, psy != nullptr, C, grid, s);
+  else if (pcm16) launch_fwd_R<16, true>(a, psy != nullptr, spread, C, grid, s);
+  else launch_fwd_R<16, false>(a, psy != nullptr, spread, C, grid, s);
 #endif
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
@@ -1720,9 +1826,17 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, bool pcm16, 
   return AC_OK;
 }
 
-template <int R, int CMODE>
-static void launch_psy_R(const PsyArgs& a, bool want_t, bool want_thr, unsigned grid, hipStream_t s) {
+template <int R, int CMODE, int SPREAD>
+static void launch_psy_thr(const PsyArgs& a, bool want_t, unsigned grid, hipStream_t s) {
   const dim3 blk(AC_WAVES * 64);
+  if (want_t) hipLaunchKernelGGL((k_psy_fast<R, CMODE, true, true, AC_WAVES, SPREAD>), dim3(grid), blk, 0, s, a);
+  else hipLaunchKernelGGL((k_psy_fast<R, CMODE, false, true, AC_WAVES, SPREAD>), dim3(grid), blk, 0, s, a);
+}
+template <int R, int CMODE>
+static void launch_psy_R(const PsyArgs& a, bool want_t, bool want_thr, int spread, unsigned grid, hipStream_t s) {
+  const dim3 blk(AC_WAVES * 64);
+  if (CMODE == 0 && want_thr && spread == 1) return launch_psy_thr<R, 0, 1>(a, want_t, grid, s);
+  if (CMODE == 0 && want_thr && spread == 2) return launch_psy_thr<R, 0, 2>(a, want_t, grid, s);
   if (want_t && !want_thr) hipLaunchKernelGGL((k_psy_fast<R, CMODE, true, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
   else if (!want_t && want_thr) hipLaunchKernelGGL((k_psy_fast<R, CMODE, false, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
   else if (want_t && want_thr) hipLaunchKernelGGL((k_psy_fast<R, CMODE, true, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
@@ -1747,14 +1861,14 @@ int launch_psy_fast(const ac_psy_plan* p, const float* X, const float* t_in, flo
   const bool want_t = (t_out != nullptr), want_thr = (thr != nullptr);
   const int cmode = (C == 2) ? 0 : (C == 1) ? 2 : 1;
   if (p->N == PsyGeo<8>::FN) {
-    if (cmode == 0) launch_psy_R<8, 0>(a, want_t, want_thr, grid, s);
-    else if (cmode == 2) launch_psy_R<8, 2>(a, want_t, want_thr, grid, s);
-    else launch_psy_R<8, 1>(a, want_t, want_thr, grid, s);
+    if (cmode == 0) launch_psy_R<8, 0>(a, want_t, want_thr, p->spread, grid, s);
+    else if (cmode == 2) launch_psy_R<8, 2>(a, want_t, want_thr, p->spread, grid, s);
+    else launch_psy_R<8, 1>(a, want_t, want_thr, p->spread, grid, s);
   } else {
 #ifndef AC_NO_R16
-    if (cmode == 0) launch_psy_R<16, 0>(a, want_t, want_thr, grid, s);
-    else if (cmode == 2) launch_psy_R<16, 2>(a, want_t, want_thr, grid, s);
-    else launch_psy_R<16, 1>(a, want_t, want_thr, grid, s);
+    if (cmode == 0) launch_psy_R<16, 0>(a, want_t, want_thr, p->spread, grid, s);
+    else if (cmode == 2) launch_psy_R<16, 2>(a, want_t, want_thr, p->spread, grid, s);
+    else launch_psy_R<16, 1>(a, want_t, want_thr, p->spread, grid, s);
 #endif
   }
   AC_HIP_CHECK(hipGetLastError());

@@ -65,6 +65,7 @@ struct ac_psy_plan {
   int N = 0, M = 0, device = 0;
   double sample_rate = 0, alpha = 0;
   int fast = 0;                // 1: the fused wave-level epilogue supports this (N, M, table shape)
+  int spread = 0;              // AC_SPREAD_*: form of the band x band spreading product in the wave-level kernels
   ac::PsyTables host;
   int32_t* d_wb_ptr = nullptr; int32_t* d_wb_idx = nullptr; float* d_wb_val = nullptr; int wb_max = 0;
   int32_t* d_wi_ptr = nullptr; int32_t* d_wi_idx = nullptr; float* d_wi_val = nullptr; int wi_max = 0;

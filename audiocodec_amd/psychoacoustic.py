@@ -49,9 +49,18 @@ class _ThresholdFn(torch.autograd.Function):
 
 
 class PsychoacousticModel:
+    SPREADING = {"f32": 0, "bf16_mfma": 1, "bf16x2_mfma": 2}
+
     def __init__(self, sample_rate, filter_bands_n=1024, bark_bands_n=64, alpha=0.6,
-                 compute_dtype=torch.float32, precompute_dtype=torch.float64):
-        """Same signature as the reference (``psychoacoustic.py:14-15``).
+                 compute_dtype=torch.float32, precompute_dtype=torch.float64, spreading=None):
+        """Same signature as the reference (``psychoacoustic.py:14-15``) plus one extension:
+
+        :param spreading: form of the band x band product with the spreading matrix (``psychoacoustic.py:205-207``) in
+                          the wave-level kernels (include/audiocodec_amd.h, AC_SPREAD_*): ``"f32"`` vector-ALU
+                          multiply-adds, ``"bf16_mfma"`` bfloat16 operands on the matrix cores (thresholds within 5e-3),
+                          ``"bf16x2_mfma"`` split-bfloat16 operands on the matrix cores (thresholds within the 1e-4
+                          parity bar).  None = the library's default (``"f32"`` unless the AC_SPREAD tuning hook says
+                          otherwise).  The matrix-core forms need filter_bands_n 1024 / 2048 and 64 Bark bands
 
         :raises TypeError: when compute_dtype is not float64, float32 or bfloat16 (``:42-43``);
                            of those the HIP path implements float32 (others: NotImplementedError)
@@ -91,8 +100,15 @@ class PsychoacousticModel:
         self.spreading_matrix = torch.from_numpy(S)                             # :69
 
         sr, al, lib = float(sample_rate), float(alpha), self._lib
-        self._plans = _host.PlanCache(self, lambda dev, out: lib.ac_psy_plan_create(N, M, sr, al, dev, out),
-                                      lib.ac_psy_plan_destroy)
+        if spreading is not None and spreading not in self.SPREADING:
+            raise ValueError("spreading must be one of %s" % sorted(self.SPREADING))
+        self.spreading = spreading
+        if spreading is None:
+            create = lambda dev, out: lib.ac_psy_plan_create(N, M, sr, al, dev, out)   # noqa: E731
+        else:
+            mode = self.SPREADING[spreading]
+            create = lambda dev, out: lib.ac_psy_plan_create_ex(N, M, sr, al, dev, mode, out)   # noqa: E731
+        self._plans = _host.PlanCache(self, create, lib.ac_psy_plan_destroy)
 
     def _plan(self, device):
         return self._plans.get(device)
@@ -100,6 +116,12 @@ class PsychoacousticModel:
     def is_fast(self, device=None):
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         return bool(self._lib.ac_psy_plan_is_fast(self._plans.get(dev)))
+
+    def plan_spreading(self, device=None):
+        """The form of the spreading product the plan on ``device`` runs (a key of ``SPREADING``)."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        mode = self._lib.ac_psy_plan_spreading(self._plans.get(dev))
+        return {v: k for k, v in self.SPREADING.items()}[mode]
 
     # ---- element-wise utilities -----------------------------------------------------------------
     def _elementwise_db(self, mdct_amplitude, norm):

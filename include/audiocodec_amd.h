@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AC_VERSION 110 /* 0.1.1: backward passes, 16-bit PCM entry points */
+#define AC_VERSION 120 /* 0.1.2: + matrix-core spreading product (ac_psy_plan_create_ex) */
 
 enum {
   AC_OK = 0,
@@ -83,6 +83,19 @@ int ac_mdct_plan_destroy(ac_mdct_plan* plan);
 /* PsychoacousticModel.__init__ (psychoacoustic.py:14-69). */
 int ac_psy_plan_create(int N, int M, double sample_rate, double alpha, int device, ac_psy_plan** out);
 int ac_psy_plan_destroy(ac_psy_plan* plan);
+
+/* Form of the band x band product with the spreading matrix (psychoacoustic.py:205-207: sum_i max(eps, P_i)^alpha S[i,j])
+ * in the wave-level kernels -- BASELINE configs[3] "Bark spreading cast as band x band MFMA contraction, bf16":
+ *   AC_SPREAD_F32          float32 multiply-adds on the vector ALU (what ac_psy_plan_create builds);
+ *   AC_SPREAD_BF16_MFMA    operands rounded to bfloat16, v_mfma_f32_4x4x4_16b_bf16, float32 accumulation: thresholds
+ *                          within 5e-3 relative of the float32 form (bfloat16 has 8 mantissa bits);
+ *   AC_SPREAD_BF16X2_MFMA  both operands split into bfloat16 hi + lo parts, four partial products on the matrix cores:
+ *                          thresholds within the 1e-4 parity bar.
+ * Served for stereo float32 input by ac_encode_fused and ac_mask_threshold (other channel counts and the 16-bit PCM
+ * entry points keep the float32 product).  AC_EUNSUPPORTED unless the plan runs the wave-level kernels. */
+enum { AC_SPREAD_F32 = 0, AC_SPREAD_BF16_MFMA = 1, AC_SPREAD_BF16X2_MFMA = 2 };
+int ac_psy_plan_create_ex(int N, int M, double sample_rate, double alpha, int device, int spreading, ac_psy_plan** out);
+int ac_psy_plan_spreading(const ac_psy_plan* plan);
 
 /* 1 when the plan runs the wave-level kernels (filters_n 1024 / 2048, Princen-Bradley window; 64 Bark bands), 0 when it
  * runs the LDS-FFT middle tier (power-of-two filters_n from 16 to 4096) or the generic O(N^2) kernels. */

@@ -236,6 +236,70 @@ def test_encode_fused_equals_unfused_and_oracle(path, B, K, C, N):
     assert np.max(np.abs(xh[:, N:-N] - x)) <= LSB
 
 
+# BASELINE configs[3]: Bark spreading cast as a band x band MFMA contraction, bf16.  Tolerances, stated separately from the
+# float32 path's: split-bfloat16 operands (hi + lo parts, four partial products) keep the 1e-4 bar; plain bfloat16
+# operands (8 mantissa bits) are held to 5e-3 on the thresholds.
+SPREAD_TOL = {"f32": TOL, "bf16x2_mfma": TOL, "bf16_mfma": 5e-3}
+
+
+@pytest.mark.parametrize("spreading", ["bf16x2_mfma", "bf16_mfma"])
+@pytest.mark.parametrize("sr,N,B,F", [(48000, 2048, 3, 5), (48000, 1024, 2, 7), (44100, 1024, 1, 3), (96000, 2048, 2, 2)])
+def test_mfma_spreading_vs_oracle(spreading, sr, N, B, F):
+    rng = np.random.default_rng(N + F)
+    env = np.logspace(-5, 0, N).reshape(1, 1, N, 1)
+    X = (rng.uniform(-1, 1, (B, F, N, 2)) * env * rng.uniform(1e-3, 1, (B, F, 1, 2))).astype(np.float32)
+    X[0, 0, :, 0] = 0.0
+    X[0, 1, :, 1] = 0.0
+    X[0, 1, 100, 1] = 0.5                                   # a single tone: the spreading function alone shapes thr
+    p = audiocodec_amd.PsychoacousticModel(sr, filter_bands_n=N, spreading=spreading)
+    assert p.is_fast() and p.plan_spreading() == spreading
+    o = PsychoOracle(sr, N, 64, compute_dtype=np.float64)
+    to = o.tonality(X.astype(np.float64))
+    for drown in (0.0, 0.5, 1.0):
+        thr = host(p.global_masking_threshold(dev(X), dev(to.astype(np.float32)), drown))
+        assert rel_elem(thr, o.global_masking_threshold(X.astype(np.float64), to, drown)) <= SPREAD_TOL[spreading]
+
+
+@pytest.mark.parametrize("spreading", ["bf16x2_mfma", "bf16_mfma"])
+@pytest.mark.parametrize("N,B,K", [(2048, 3, 5), (1024, 2, 37)])
+def test_mfma_spreading_fused_encode(spreading, N, B, K):
+    """config 4 end to end: N = 2048 long-window MDCT + masking with the MFMA contraction, against the oracle and
+    against the float32 form on the same input"""
+    rng = np.random.default_rng(B + K)
+    x = rng.uniform(-1, 1, (B, K * N, 2)).astype(np.float32)
+    x[0, : 2 * N, 0] *= 1e-3
+    codec = audiocodec_amd.AudioCodec(48000, N, spreading=spreading)
+    plain = audiocodec_amd.AudioCodec(48000, N)
+    assert plain.psy.plan_spreading() == "f32"
+    X, t, thr = codec.encode(dev(x), drown=0.2)
+    X0, t0, thr0 = plain.encode(dev(x), drown=0.2)
+    assert torch.equal(X, X0) and torch.equal(t, t0)        # only the spreading product differs
+    tol = SPREAD_TOL[spreading]
+    assert float(((thr - thr0).abs() / thr0).max()) <= tol
+    thru = codec.psy.global_masking_threshold(X, t, 0.2)    # stand-alone kernel, same form of the product
+    assert float(((thr - thru).abs() / thru).max()) <= TOL
+    om, op = MDCTOracle(N, "vorbis", np.float64), PsychoOracle(48000, N, 64, compute_dtype=np.float64)
+    Xo = om.transform(x.astype(np.float64))
+    to = op.tonality(Xo)
+    assert rel_elem(host(thr), op.global_masking_threshold(Xo, to, 0.2)) <= max(2e-4, tol)
+    if spreading == "bf16_mfma":
+        assert float(((thr - thr0).abs() / thr0).max()) > 1e-4   # the bf16 rounding is really there
+
+
+def test_mfma_spreading_scope():
+    """other channel counts and 16-bit PCM keep the float32 product; plans outside the wave-level tier refuse"""
+    N = 1024
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, (2, 3 * N, 3)).astype(np.float32)
+    a = audiocodec_amd.AudioCodec(48000, N, spreading="bf16_mfma").encode(dev(x))
+    b = audiocodec_amd.AudioCodec(48000, N).encode(dev(x))
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    with pytest.raises(RuntimeError, match="wave-level"):
+        audiocodec_amd.PsychoacousticModel(48000, filter_bands_n=512, spreading="bf16x2_mfma").tonality(dev(np.zeros((1, 1, 512, 1), np.float32)))
+    with pytest.raises(ValueError):
+        audiocodec_amd.PsychoacousticModel(48000, spreading="fp8")
+
+
 def test_db_and_noise(golden, path):
     g = golden("db_utils")
     p = audiocodec_amd.PsychoacousticModel(48000)

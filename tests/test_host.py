@@ -31,7 +31,7 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(lib, s), "libaudiocodec_amd.so does not export %s" % s
     assert sorted(_lib.PROTOTYPES) == syms, "ctypes prototypes and header disagree"
-    assert lib.ac_version() == 110
+    assert lib.ac_version() == 120
 
 
 def test_library_contains_gfx950_code_object():
@@ -110,6 +110,11 @@ def test_constructor_validation():
     assert b"even" in lib.ac_last_error()
     with pytest.raises(ValueError):
         _lib.check(lib.ac_mdct_fold_coefficients_host(8, 9, (ctypes.c_double * 32)()))
+    assert lib.ac_psy_plan_create_ex(1024, 64, 48000.0, 0.6, 0, 7, ctypes.byref(out)) == _lib.AC_EINVAL
+    assert b"AC_SPREAD" in lib.ac_last_error()
+    with pytest.raises(ValueError):
+        audiocodec_amd.PsychoacousticModel(48000, spreading="fp8")
+    assert audiocodec_amd.PsychoacousticModel(48000, spreading="bf16x2_mfma").spreading == "bf16x2_mfma"
 
 
 def test_no_cpu_fallback():
