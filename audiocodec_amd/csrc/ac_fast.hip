@@ -56,7 +56,7 @@ constexpr int WAVE_LDS = 9216;      // bytes of LDS per wave: 576 x 16-byte elem
 constexpr int S8_OFF = 8192;        // psycho: 128 chunk sums (8 bins each) behind the 8 KB intensity image
 constexpr int ZERO_OFF = 9216;      // psycho: one zero slot (padding target of the gather lists)
 constexpr int WAVE_LDS_PSY = 9232;
-constexpr int MF_COPY_STRIDE = 320;               // bytes between the four shifted copies of the reversed bf16 prototype
+constexpr int MF_COPY_STRIDE = 288;               // bytes between the four shifted copies of the reversed bf16 prototype
 constexpr int MF_TAB_BYTES = 4 * MF_COPY_STRIDE;  // one table (hi or lo parts)
 constexpr float kEps = 1e-14f;      // _INTENSITY_EPS, psychoacoustic.py:56
 
@@ -565,7 +565,9 @@ __device__ __forceinline__ uint32_t in_loop(uint32_t w) {
 // (rows 2, 3 carry the lo parts) and S = hi + lo (a second B table), four partial products in f32 accumulators, ~16
 // mantissa bits -- inside the 1e-4 parity bar.  B tile of step s in lane l: g[64 - 4 s - k + l], k = 0..3 = four
 // consecutive entries of the reversed prototype; four copies of the table, shifted by one entry each, make the read an
-// aligned ds_read_b64 for every lane (copy l & 3; the copies sit 320 bytes apart = on disjoint banks for a half wave).
+// aligned 8-byte read for every lane (copy l & 3).  The compiler pairs the reads of two steps into ds_read2_b64, which
+// the LDS serves in groups of 16 consecutive lanes over 32 banks: the copies sit 288 bytes = 8 banks (mod 32) apart, so
+// the four copies a group touches (8 dwords each) fall on disjoint banks.
 // mf = LDS copy of the hi table (MF_TAB_BYTES) followed by the lo table.
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {   // v_cvt_pk_bf16_f32 (round to nearest even)
