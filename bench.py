@@ -83,6 +83,65 @@ def measured_traffic():
     return best
 
 
+def other_configs(dev):
+    """BASELINE configs[3] and configs[4] timed beside the headline (rank 0, N = 1 only, outside the timed region; they
+    are parity-test cases first -- tests/test_gpu_parity.py -- and these are their measured rates)."""
+    out = {}
+    # configs[3]: N = 2048 long-window MDCT + masking, Bark spreading as a band x band bf16 MFMA contraction
+    n, B, K, C = 2048, 256, 234, 2
+    x = torch.rand((B, K * n, C), device=dev) * 2 - 1
+    X = torch.empty((B, K + 1, n, C), device=dev)
+    t = torch.empty((B, K + 1, 1, C), device=dev)
+    thr = torch.empty_like(X)
+    ref = torch.empty_like(X)
+    xh = torch.empty((B, (K + 2) * n, C), device=dev)
+
+    def med(fn, reps=7):
+        fn()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return float(np.median(ts))
+
+    rows = {}
+    for mode in ("f32", "bf16x2_mfma", "bf16_mfma"):
+        codec = audiocodec_amd.AudioCodec(48000, n, spreading=mode)
+        codec.encode_into(x, X, t, thr)
+        if mode == "f32":
+            ref.copy_(thr)
+        rows[mode] = {"encode_ms": med(lambda: codec.encode_into(x, X, t, thr)),
+                      "thr_max_rel_dev_vs_f32": float(((thr - ref).abs() / ref).max())}
+    dec = med(lambda: codec.decode_into(X, xh))
+    fr = B * C * K
+    out["configs[3]"] = {"workload": "batch=256 stereo 48 kHz clips, N=2048, K=234 blocks (10 s)", "spreading": rows,
+                         "decode_ms": dec, "bytes_per_frame_encode": 12 * n + 4, "bytes_per_frame_decode": 8 * n,
+                         "frames_per_s_bf16x2_mfma": fr / ((rows["bf16x2_mfma"]["encode_ms"] + dec) * 1e-3),
+                         "encode_GBs_bf16x2_mfma": (12 * n + 4) * fr / (rows["bf16x2_mfma"]["encode_ms"] * 1e-3) / 1e9}
+    del x, X, t, thr, ref, xh
+    # configs[4]: streaming overlap-add, 10 min of stereo in chunks of 256 blocks through the device-resident state
+    m = audiocodec_amd.MDCTransformer(N)
+    Kt, k = 28125, 256
+    xs = torch.rand((1, Kt * N, 2), device=dev) * 2 - 1
+    st = audiocodec_amd.StreamingMDCT(m, 1, 2)
+
+    def stream_pass():
+        st.reset()
+        for p in range(0, Kt, k):
+            Xc = st.transform_chunk(xs[:, p * N:min(Kt, p + k) * N])
+            st.inverse_chunk(Xc)
+
+    ms = med(stream_pass, reps=3)
+    st.close()
+    out["configs[4]"] = {"workload": "1 stereo clip of 10 min (28125 blocks), chunks of 256 blocks, analysis + synthesis per chunk",
+                         "ms_per_10_min": ms, "frames_per_s": 2 * Kt / (ms * 1e-3), "x_real_time": 600.0 / (ms * 1e-3)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,6 +150,7 @@ def main():
     ap.add_argument("--clips", type=int, default=256, help="stereo clips per GPU")
     ap.add_argument("--blocks", type=int, default=468, help="blocks (hops) per clip; 468 = 10 s at 48 kHz")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[3] / configs[4] side measurements")
     args = ap.parse_args()
 
     rank, world, _ = acd.env_rank_world()
@@ -173,6 +233,9 @@ def main():
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if world == 1 and not args.no_other_configs:
+            del x, X, t, thr, xh
+            out["other_configs"] = other_configs(dev)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -2,7 +2,7 @@
 # run bench.py once per library variant (audiocodec_amd/lib/variants/*.so) and print encode/decode ms
 for so in audiocodec_amd/lib/variants/libaudiocodec_amd_*.so; do
   name=$(basename $so .so | sed 's/libaudiocodec_amd_//')
-  AUDIOCODEC_AMD_LIB=$PWD/$so python bench.py --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+  AUDIOCODEC_AMD_LIB=$PWD/$so python bench.py --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "
 import json,sys
 for line in sys.stdin:
     if line.startswith('{'):

@@ -6,7 +6,7 @@ rounds=${ROUNDS:-3}
 tmp=$(mktemp)
 for r in $(seq $rounds); do
   for v in "$@"; do
-    env $var=$v python bench.py --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+    env $var=$v python bench.py --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "
 import json,sys
 for line in sys.stdin:
     if line.startswith('{'):
