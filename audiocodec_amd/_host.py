@@ -29,11 +29,23 @@ def as_torch_dtype(dtype):
     raise TypeError("unsupported dtype %r" % (dtype,))
 
 
+# AC_F32 / AC_F64 / AC_BF16 of include/audiocodec_amd.h
+DTYPE_IDS = {torch.float32: 0, torch.float64: 1, torch.bfloat16: 2}
+
+
 def require_hip_compute_dtype(compute_dtype, who):
-    if compute_dtype != torch.float32:
+    """float32 (wave-level / LDS-FFT / generic kernels), float64 (float64 kernels and constants) and bfloat16
+    (bfloat16 tensors, float32 arithmetic) have HIP kernels; anything else is refused."""
+    if compute_dtype not in DTYPE_IDS:
         raise NotImplementedError(
-            "%s: the HIP kernels compute in float32 only (got compute_dtype=%s); "
+            "%s: the HIP kernels serve compute_dtype float32, float64 and bfloat16 (got %s); "
             "there is no CPU or other-precision fallback" % (who, compute_dtype))
+    return DTYPE_IDS[compute_dtype]
+
+
+def require_float32(compute_dtype, what):
+    if compute_dtype != torch.float32:
+        raise NotImplementedError("%s is implemented for compute_dtype float32 only (got %s)" % (what, compute_dtype))
 
 
 def check_device_tensor(t, name, dtype, ndim):

@@ -27,6 +27,8 @@ PROTOTYPES = {
     "ac_mdct_dense_matrices_host": (c_int, [c_int, c_int, POINTER(c_float), POINTER(c_float)]),
     "ac_psy_tables_host": (c_int, [c_int, c_int, c_double, c_double, POINTER(c_float), POINTER(c_float),
                                    POINTER(c_float), POINTER(c_float), POINTER(c_double)]),
+    "ac_psy_tables_host_f64": (c_int, [c_int, c_int, c_double, c_double, POINTER(c_double), POINTER(c_double),
+                                       POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     "ac_mdct_plan_create": (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
     "ac_mdct_plan_destroy": (c_int, [c_void_p]),
     "ac_psy_plan_create": (c_int, [c_int, c_int, c_double, c_double, c_int, POINTER(c_void_p)]),
@@ -35,6 +37,13 @@ PROTOTYPES = {
     "ac_psy_plan_is_fast": (c_int, [c_void_p]),
     "ac_psy_plan_create_ex": (c_int, [c_int, c_int, c_double, c_double, c_int, c_int, POINTER(c_void_p)]),
     "ac_psy_plan_spreading": (c_int, [c_void_p]),
+    "ac_mdct_forward_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ac_mdct_inverse_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ac_tonality_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ac_mask_threshold_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_int, c_int, c_int, c_int,
+                                        c_void_p]),
+    "ac_amplitude_to_db_typed": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "ac_add_noise_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_uint64, c_int, c_void_p]),
     "ac_mdct_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ac_mdct_inverse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ac_tonality": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

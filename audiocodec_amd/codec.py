@@ -52,6 +52,17 @@ class AudioCodec:
         """Same as :meth:`encode` into caller-owned output tensors (no allocation in the timed path)."""
         B, S, C = x.shape
         K = S // self.filters_n
+        if self.compute_dtype != torch.float32:
+            # float64 / bfloat16: the three typed entry points in sequence (the fused kernel is float32)
+            if x.dtype != self.compute_dtype:
+                raise ValueError("x has dtype %s but compute_dtype is %s" % (x.dtype, self.compute_dtype))
+            lib, dt, st = self._lib, self.mdct._dtype_id, _host.stream_ptr(x.device)
+            with torch.cuda.device(x.device):
+                _lib.check(lib.ac_mdct_forward_typed(self.mdct._plan(x.device), _host.ptr(x), _host.ptr(X), dt, B, K, C, st))
+                _lib.check(lib.ac_tonality_typed(self.psy._plan(x.device), _host.ptr(X), _host.ptr(t), dt, B, K + 1, C, st))
+                _lib.check(lib.ac_mask_threshold_typed(self.psy._plan(x.device), _host.ptr(X), _host.ptr(t), float(drown),
+                                                       _host.ptr(thr), dt, B, K + 1, C, st))
+            return
         fn = self._lib.ac_encode_fused_pcm16 if x.dtype == torch.int16 else self._lib.ac_encode_fused
         with torch.cuda.device(x.device):
             _lib.check(fn(self.mdct._plan(x.device), self.psy._plan(x.device), _host.ptr(x), _host.ptr(X), _host.ptr(t),
@@ -72,6 +83,13 @@ class AudioCodec:
 
     def decode_into(self, X, x):
         B, Kp, N, C = X.shape
+        if self.compute_dtype != torch.float32:
+            if x.dtype != self.compute_dtype:
+                raise ValueError("x has dtype %s but compute_dtype is %s" % (x.dtype, self.compute_dtype))
+            with torch.cuda.device(X.device):
+                _lib.check(self._lib.ac_mdct_inverse_typed(self.mdct._plan(X.device), _host.ptr(X), _host.ptr(x),
+                                                           self.mdct._dtype_id, B, Kp, C, _host.stream_ptr(X.device)))
+            return
         fn = self._lib.ac_mdct_inverse_pcm16 if x.dtype == torch.int16 else self._lib.ac_mdct_inverse
         with torch.cuda.device(X.device):
             _lib.check(fn(self.mdct._plan(X.device), _host.ptr(X), _host.ptr(x), B, Kp, C, _host.stream_ptr(X.device)))
@@ -87,6 +105,7 @@ class StreamingMDCT:
     """
 
     def __init__(self, mdct: MDCTransformer, batches_n, channels_n, device=None):
+        _host.require_float32(mdct.compute_dtype, "streaming overlap-add")
         self.mdct = mdct
         self.B, self.C = int(batches_n), int(channels_n)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)

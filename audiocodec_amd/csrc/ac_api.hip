@@ -124,6 +124,25 @@ int ac_psy_tables_host(int N, int M, double sample_rate, double alpha, float* W,
   return AC_OK;
 }
 
+int ac_psy_tables_host_f64(int N, int M, double sample_rate, double alpha, double* W, double* W_inv, double* S,
+                           double* quiet, double* scalars) {
+  AC_REQUIRE(N >= 1 && M >= 1, "filter_bands_n (%d) and bark_bands_n (%d) must be positive", N, M);
+  AC_REQUIRE(sample_rate > 0 && alpha > 0, "sample_rate and alpha must be positive");
+  PsyTables t;
+  psy_tables(N, M, sample_rate, alpha, t);
+  if (W) std::copy(t.W.begin(), t.W.end(), W);
+  if (W_inv) std::copy(t.W_inv.begin(), t.W_inv.end(), W_inv);
+  if (S) std::copy(t.S.begin(), t.S.end(), S);
+  if (quiet) std::copy(t.quiet.begin(), t.quiet.end(), quiet);
+  if (scalars) {
+    scalars[0] = t.max_frequency;
+    scalars[1] = t.max_bark;
+    scalars[2] = t.bark_band_width;
+    scalars[3] = t.dB_MIN;
+  }
+  return AC_OK;
+}
+
 // ---- plans --------------------------------------------------------------------------------------
 
 int ac_mdct_plan_create(int N, int window, int device, ac_mdct_plan** out) {
@@ -154,8 +173,14 @@ int ac_mdct_plan_create(int N, int window, int device, ac_mdct_plan** out) {
     for (int j = 0; j < h; ++j) coef[(size_t)i * h + j] = (float)(*v[i])[j];
   std::vector<float> ctab(8 * (size_t)N);
   for (size_t i = 0; i < ctab.size(); ++i) ctab[i] = (float)std::cos(3.14159265358979323846 * (double)i / (4.0 * N));
+  std::vector<double> coef64(8 * (size_t)h), ctab64(8 * (size_t)N);
+  for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < h; ++j) coef64[(size_t)i * h + j] = (*v[i])[j];
+  for (size_t i = 0; i < ctab64.size(); ++i) ctab64[i] = std::cos(3.14159265358979323846 * (double)i / (4.0 * N));
   st = upload(coef, &p->d_coef);
   if (!st) st = upload(ctab, &p->d_ctab);
+  if (!st) st = upload(coef64, &p->d_coef64);
+  if (!st) st = upload(ctab64, &p->d_ctab64);
   if (!st && fast_mdct_supported(N, window)) {
     st = fast_mdct_plan_init(p);
     if (!st) p->fast = 1;
@@ -173,6 +198,8 @@ int ac_mdct_plan_destroy(ac_mdct_plan* p) {
   DeviceGuard guard(p->device);
   (void)hipFree(p->d_coef);
   (void)hipFree(p->d_ctab);
+  (void)hipFree(p->d_coef64);
+  (void)hipFree(p->d_ctab64);
   (void)hipFree(p->d_fast);
   delete p;
   return AC_OK;
@@ -234,6 +261,23 @@ int ac_psy_plan_create_ex(int N, int M, double sample_rate, double alpha, int de
   if (!st) st = upload(S, &p->d_S);
   if (!st) st = upload(quiet, &p->d_quiet);
   if (!st) st = upload(p->host.beta, &p->d_beta);
+  {
+    // the same constants in float64 (AC_F64 entry points): W / W_inv entries in CSR order, S, quiet, and the offset
+    // grid linspace(0, max_bark, M) evaluated in float64 (psychoacoustic.py:187-189 with compute_dtype = float64)
+    std::vector<double> wbv(wb.idx.size()), wiv(wi.idx.size()), beta64(M);
+    for (int j = 0; j < M; ++j)
+      for (int e = wb.ptr[j]; e < wb.ptr[j + 1]; ++e) wbv[e] = p->host.W[(size_t)wb.idx[e] * M + j];
+    for (int f = 0; f < N; ++f)
+      for (int e = wi.ptr[f]; e < wi.ptr[f + 1]; ++e) wiv[e] = p->host.W_inv[(size_t)wi.idx[e] * N + f];
+    const double stop = p->host.max_bark, step = (M > 1) ? stop / (double)(M - 1) : 0.0;
+    for (int j = 0; j < M; ++j) beta64[j] = step * (double)j;
+    if (M > 1) beta64[M - 1] = stop;
+    if (!st) st = upload(wbv, &p->d_wb_val64);
+    if (!st) st = upload(wiv, &p->d_wi_val64);
+    if (!st) st = upload(p->host.S, &p->d_S64);
+    if (!st) st = upload(p->host.quiet, &p->d_quiet64);
+    if (!st) st = upload(beta64, &p->d_beta64);
+  }
   if (!st && fast_psy_supported(p)) {
     st = fast_psy_plan_init(p);
     if (!st) p->fast = 1;
@@ -273,6 +317,11 @@ int ac_psy_plan_destroy(ac_psy_plan* p) {
   (void)hipFree(p->d_S);
   (void)hipFree(p->d_quiet);
   (void)hipFree(p->d_beta);
+  (void)hipFree(p->d_wb_val64);
+  (void)hipFree(p->d_wi_val64);
+  (void)hipFree(p->d_S64);
+  (void)hipFree(p->d_quiet64);
+  (void)hipFree(p->d_beta64);
   (void)hipFree(p->d_fast);
   delete p;
   return AC_OK;
@@ -526,6 +575,86 @@ int ac_amplitude_to_db(const float* a, float* out, size_t n, int norm, void* str
 int ac_add_noise(const float* X, const float* thr, float* out, size_t n, uint64_t seed, void* stream) {
   AC_REQUIRE(n == 0 || (X != nullptr && thr != nullptr && out != nullptr), "NULL tensor pointer");
   return launch_add_noise(X, thr, out, n, seed, (hipStream_t)stream);
+}
+
+// ---- compute_dtype variants ---------------------------------------------------------------------
+#define AC_REQUIRE_DTYPE(d) AC_REQUIRE((d) == AC_F32 || (d) == AC_F64 || (d) == AC_BF16, "dtype = %d is not one of AC_F32, AC_F64, AC_BF16", (d))
+
+int ac_mdct_forward_typed(const ac_mdct_plan* p, const void* x, void* X, int dtype, int B, int K, int C, void* stream) {
+  AC_REQUIRE_DTYPE(dtype);
+  if (dtype == AC_F32) return ac_mdct_forward(p, static_cast<const float*>(x), static_cast<float*>(X), B, K, C, stream);
+  AC_REQUIRE(p != nullptr, "plan is NULL");
+  int st = check_dims(B, K, C);
+  if (st) return st;
+  if (B == 0 || C == 0) return AC_OK;
+  AC_REQUIRE(X != nullptr && (x != nullptr || K == 0), "NULL tensor pointer");
+  DeviceGuard guard(p->device);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == AC_F64) return launch_fwd_f64(p, static_cast<const double*>(x), static_cast<double*>(X), B, K, K + 1, C, s);
+  return launch_fwd_bf16(p, static_cast<const bf16_t*>(x), static_cast<bf16_t*>(X), B, K, K + 1, C, s);
+}
+
+int ac_mdct_inverse_typed(const ac_mdct_plan* p, const void* X, void* x, int dtype, int B, int Kp, int C, void* stream) {
+  AC_REQUIRE_DTYPE(dtype);
+  if (dtype == AC_F32) return ac_mdct_inverse(p, static_cast<const float*>(X), static_cast<float*>(x), B, Kp, C, stream);
+  AC_REQUIRE(p != nullptr, "plan is NULL");
+  int st = check_dims(B, Kp, C);
+  if (st) return st;
+  if (B == 0 || C == 0) return AC_OK;
+  AC_REQUIRE(x != nullptr && (X != nullptr || Kp == 0), "NULL tensor pointer");
+  DeviceGuard guard(p->device);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == AC_F64) return launch_inv_f64(p, static_cast<const double*>(X), static_cast<double*>(x), B, Kp, Kp + 1, C, s);
+  return launch_inv_bf16(p, static_cast<const bf16_t*>(X), static_cast<bf16_t*>(x), B, Kp, Kp + 1, C, s);
+}
+
+int ac_tonality_typed(const ac_psy_plan* p, const void* X, void* t, int dtype, int B, int F, int C, void* stream) {
+  AC_REQUIRE_DTYPE(dtype);
+  if (dtype == AC_F32) return ac_tonality(p, static_cast<const float*>(X), static_cast<float*>(t), B, F, C, stream);
+  AC_REQUIRE(p != nullptr, "plan is NULL");
+  int st = check_dims(B, F, C);
+  if (st) return st;
+  if (B == 0 || C == 0 || F == 0) return AC_OK;
+  AC_REQUIRE(X != nullptr && t != nullptr, "NULL tensor pointer");
+  DeviceGuard guard(p->device);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == AC_F64) return launch_tonality_f64(p, static_cast<const double*>(X), static_cast<double*>(t), B, F, C, s);
+  return launch_tonality_bf16(p, static_cast<const bf16_t*>(X), static_cast<bf16_t*>(t), B, F, C, s);
+}
+
+int ac_mask_threshold_typed(const ac_psy_plan* p, const void* X, const void* t, double drown, void* thr, int dtype, int B,
+                            int F, int C, void* stream) {
+  AC_REQUIRE_DTYPE(dtype);
+  if (dtype == AC_F32)
+    return ac_mask_threshold(p, static_cast<const float*>(X), static_cast<const float*>(t), (float)drown,
+                             static_cast<float*>(thr), B, F, C, stream);
+  AC_REQUIRE(p != nullptr, "plan is NULL");
+  int st = check_dims(B, F, C);
+  if (st) return st;
+  if (B == 0 || C == 0 || F == 0) return AC_OK;
+  AC_REQUIRE(X != nullptr && t != nullptr && thr != nullptr, "NULL tensor pointer");
+  DeviceGuard guard(p->device);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == AC_F64)
+    return launch_threshold_f64(p, static_cast<const double*>(X), static_cast<const double*>(t), drown,
+                                static_cast<double*>(thr), B, F, C, s);
+  return launch_threshold_bf16(p, static_cast<const bf16_t*>(X), static_cast<const bf16_t*>(t), (float)drown,
+                               static_cast<bf16_t*>(thr), B, F, C, s);
+}
+
+int ac_amplitude_to_db_typed(const void* a, void* out, size_t n, int norm, int dtype, void* stream) {
+  AC_REQUIRE_DTYPE(dtype);
+  if (dtype == AC_F32) return ac_amplitude_to_db(static_cast<const float*>(a), static_cast<float*>(out), n, norm, stream);
+  AC_REQUIRE(n == 0 || (a != nullptr && out != nullptr), "NULL tensor pointer");
+  return launch_db_typed(a, out, n, norm, dtype, (hipStream_t)stream);
+}
+
+int ac_add_noise_typed(const void* X, const void* thr, void* out, size_t n, uint64_t seed, int dtype, void* stream) {
+  AC_REQUIRE_DTYPE(dtype);
+  if (dtype == AC_F32)
+    return ac_add_noise(static_cast<const float*>(X), static_cast<const float*>(thr), static_cast<float*>(out), n, seed, stream);
+  AC_REQUIRE(n == 0 || (X != nullptr && thr != nullptr && out != nullptr), "NULL tensor pointer");
+  return launch_add_noise_typed(X, thr, out, n, seed, dtype, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -8,38 +8,51 @@ namespace ac {
 static constexpr int kThreads = 256;
 static constexpr float kEps = 1e-14f;   // _INTENSITY_EPS, psychoacoustic.py:56
 
+// ---- compute_dtype variants: the kernels below are templates over the storage type TIO of the
+// tensors -- float (the primary path), double (everything in fp64, constants included: the on-device oracle) and
+// bfloat16 (storage only: arithmetic in float32).  TC = the type of the arithmetic and of the constant tables.
+template <typename TIO> struct Compute { using type = float; };
+template <> struct Compute<double> { using type = double; };
+__device__ __forceinline__ float ldv(const float* p) { return *p; }
+__device__ __forceinline__ double ldv(const double* p) { return *p; }
+__device__ __forceinline__ float ldv(const bf16_t* p) { return (float)*p; }
+__device__ __forceinline__ void stv(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stv(double* p, double v) { *p = v; }
+__device__ __forceinline__ void stv(bf16_t* p, float v) { *p = (bf16_t)v; }   // round to nearest even
+extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
 // ------------------------------------------------------------------------------------------------
 // analysis: fold (mdctransformer.py:118,349-368 in closed form) + DCT-IV (:311-347) + scale (:125)
 // one workgroup per (signal = b*C + c, frame n)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_fwd_generic(const float* __restrict__ x, float* __restrict__ X,
-                                                          const float* __restrict__ prev_block,
-                                                          const float* __restrict__ coef,
-                                                          const float* __restrict__ ctab, int Kin, int F, int C,
+template <typename TIO, typename TC = typename Compute<TIO>::type>
+__global__ __launch_bounds__(kThreads) void k_fwd_generic(const TIO* __restrict__ x, TIO* __restrict__ X,
+                                                          const TIO* __restrict__ prev_block,
+                                                          const TC* __restrict__ coef,
+                                                          const TC* __restrict__ ctab, int Kin, int F, int C,
                                                           int N) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* v = smem;  // [N]
+  TC* v = reinterpret_cast<TC*>(smem_raw);  // [N]
   const int h = N >> 1;
   const long long wg = blockIdx.x;
   const int n = (int)(wg % F);
   const long long sig = wg / F;
   const int c = (int)(sig % C);
   const long long b = sig / C;
-  const float* a1 = coef;
-  const float* a2 = coef + h;
-  const float* a3 = coef + 2 * h;
-  const float* a4 = coef + 3 * h;
+  const TC* a1 = coef;
+  const TC* a2 = coef + h;
+  const TC* a3 = coef + 2 * h;
+  const TC* a4 = coef + 3 * h;
 
   const bool has_cur = n < Kin;
-  const float* xc = x + ((size_t)b * Kin + (size_t)n) * N * C + c;              // block n
-  const float* xp = nullptr;                                                       // block n-1
+  const TIO* xc = x + ((size_t)b * Kin + (size_t)n) * N * C + c;              // block n
+  const TIO* xp = nullptr;                                                     // block n-1
   if (n >= 1) xp = x + ((size_t)b * Kin + (size_t)(n - 1)) * N * C + c;
   else if (prev_block) xp = prev_block + (size_t)b * N * C + c;
 
   for (int j = threadIdx.x; j < h; j += kThreads) {
-    float vc = 0.f, vp = 0.f;
-    if (has_cur) vc = a1[j] * xc[(size_t)j * C] + a2[j] * xc[(size_t)(N - 1 - j) * C];
-    if (xp) vp = a3[j] * xp[(size_t)(h - 1 - j) * C] + a4[j] * xp[(size_t)(h + j) * C];
+    TC vc = 0, vp = 0;
+    if (has_cur) vc = a1[j] * ldv(xc + (size_t)j * C) + a2[j] * ldv(xc + (size_t)(N - 1 - j) * C);
+    if (xp) vp = a3[j] * ldv(xp + (size_t)(h - 1 - j) * C) + a4[j] * ldv(xp + (size_t)(h + j) * C);
     v[h + j] = vc;
     v[j] = vp;
   }
@@ -47,7 +60,7 @@ __global__ __launch_bounds__(kThreads) void k_fwd_generic(const float* __restric
 
   const unsigned mod = 8u * (unsigned)N;
   const double scale = 1.0 / ((double)N * 1.4142135623730951);   // 1/sqrt(4N) * sqrt(2/N)
-  float* Xo = X + (((size_t)b * F + (size_t)n) * N) * C + c;
+  TIO* Xo = X + (((size_t)b * F + (size_t)n) * N) * C + c;
   for (int k = threadIdx.x; k < N; k += kThreads) {
     const unsigned step = (unsigned)((2ull * (2ull * k + 1ull)) % mod);
     unsigned idx = (unsigned)((2ull * k + 1ull) % mod);   // (2m+1)(2k+1) at m = 0
@@ -57,7 +70,7 @@ __global__ __launch_bounds__(kThreads) void k_fwd_generic(const float* __restric
       idx += step;
       if (idx >= mod) idx -= mod;
     }
-    Xo[(size_t)k * C] = (float)(acc * scale);
+    stv(Xo + (size_t)k * C, (TC)(acc * scale));
   }
 }
 
@@ -65,31 +78,31 @@ __global__ __launch_bounds__(kThreads) void k_fwd_generic(const float* __restric
 // synthesis: scale (mdctransformer.py:145) + DCT-IV + unfold/overlap-add (:148 in closed form)
 // one workgroup per (signal, output block n); block n = nblk only writes the new stream state
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_inv_generic(const float* __restrict__ X, float* __restrict__ x,
-                                                          const float* __restrict__ tail_in,
-                                                          float* __restrict__ tail_out,
-                                                          const float* __restrict__ coef,
-                                                          const float* __restrict__ ctab, int Kp, int nblk,
+template <typename TIO, typename TC = typename Compute<TIO>::type>
+__global__ __launch_bounds__(kThreads) void k_inv_generic(const TIO* __restrict__ X, TIO* __restrict__ x,
+                                                          const TC* __restrict__ tail_in,
+                                                          TC* __restrict__ tail_out,
+                                                          const TC* __restrict__ coef,
+                                                          const TC* __restrict__ ctab, int Kp, int nblk,
                                                           int nwg_per_sig, int C, int N) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Xn = smem;       // [N] frame n
-  float* Xm = smem + N;   // [N] frame n-1
+  TC* Xn = reinterpret_cast<TC*>(smem_raw);   // [N] frame n
+  TC* Xm = Xn + N;                            // [N] frame n-1
   const int h = N >> 1;
   const long long wg = blockIdx.x;
   const int n = (int)(wg % nwg_per_sig);
   const long long sig = wg / nwg_per_sig;
   const int c = (int)(sig % C);
   const long long b = sig / C;
-  const float* s1 = coef + 4 * h;
-  const float* s2 = coef + 5 * h;
-  const float* s3 = coef + 6 * h;
-  const float* s4 = coef + 7 * h;
+  const TC* s1 = coef + 4 * h;
+  const TC* s2 = coef + 5 * h;
+  const TC* s3 = coef + 6 * h;
+  const TC* s4 = coef + 7 * h;
 
   const bool has_n = n < Kp && n < nblk;   // the virtual state block (n == nblk) has no current frame
   const bool has_m = n >= 1;
   for (int k = threadIdx.x; k < N; k += kThreads) {
-    Xn[k] = has_n ? X[(((size_t)b * Kp + (size_t)n) * N + k) * C + c] : 0.f;
-    Xm[k] = has_m ? X[(((size_t)b * Kp + (size_t)(n - 1)) * N + k) * C + c] : 0.f;
+    Xn[k] = has_n ? (TC)ldv(X + (((size_t)b * Kp + (size_t)n) * N + k) * C + c) : (TC)0;
+    Xm[k] = has_m ? (TC)ldv(X + (((size_t)b * Kp + (size_t)(n - 1)) * N + k) * C + c) : (TC)0;
   }
   __syncthreads();
 
@@ -122,11 +135,11 @@ __global__ __launch_bounds__(kThreads) void k_inv_generic(const float* __restric
       bb = (double)tail_in[((size_t)b * C + c) * h + j];
     }
     if (n < nblk) {
-      float* xo = x + (((size_t)b * nblk + (size_t)n) * N) * C + c;
-      xo[(size_t)j * C] = (float)((double)s1[j] * a + (double)s2[j] * bb);
-      xo[(size_t)(N - 1 - j) * C] = (float)((double)s3[j] * a + (double)s4[j] * bb);
+      TIO* xo = x + (((size_t)b * nblk + (size_t)n) * N) * C + c;
+      stv(xo + (size_t)j * C, (TC)((double)s1[j] * a + (double)s2[j] * bb));
+      stv(xo + (size_t)(N - 1 - j) * C, (TC)((double)s3[j] * a + (double)s4[j] * bb));
     } else if (tail_out) {
-      tail_out[((size_t)b * C + c) * h + j] = (float)bb;
+      tail_out[((size_t)b * C + c) * h + j] = (TC)bb;
     }
   }
 }
@@ -163,6 +176,24 @@ __device__ __forceinline__ void st2(float* p, float2 v, int C, bool has1) {
   }
   p[0] = v.x;
   if (has1) p[1] = v.y;
+}
+// bfloat16 storage: the stereo pair is one 4-byte access
+typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 ld2(const bf16_t* p, int C, bool has1) {
+  if (C == 2) {
+    const f2v v = __builtin_convertvector(*reinterpret_cast<const bf16x2_t*>(p), f2v);
+    return make_float2(v.x, v.y);
+  }
+  return make_float2((float)p[0], has1 ? (float)p[1] : 0.f);
+}
+__device__ __forceinline__ void st2(bf16_t* p, float2 v, int C, bool has1) {
+  if (C == 2) {
+    *reinterpret_cast<bf16x2_t*>(p) = __builtin_convertvector(f2v{v.x, v.y}, bf16x2_t);
+    return;
+  }
+  p[0] = (bf16_t)v.x;
+  if (has1) p[1] = (bf16_t)v.y;
 }
 
 // v[N] (LDS, float2 per entry) -> y[k] = sum_m v[m] cos(pi/N (m + 1/2)(k + 1/2)) written back into v;
@@ -220,12 +251,13 @@ static inline __host__ __device__ int lds_group_threads(int N) {
 }
 
 // one group per (clip, channel pair, frame)
-__global__ __launch_bounds__(kThreads) void k_fwd_lds(const float* __restrict__ x, float* __restrict__ X,
-                                                      const float* __restrict__ prev_block,
+template <typename TIO>
+__global__ __launch_bounds__(kThreads) void k_fwd_lds(const TIO* __restrict__ x, TIO* __restrict__ X,
+                                                      const TIO* __restrict__ prev_block,
                                                       const float* __restrict__ coef,
                                                       const float* __restrict__ ctab, int Kin, int F, int C, int CP,
                                                       int N, long long ntasks) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* smem = reinterpret_cast<float*>(smem_raw);
   const int nt = lds_group_threads(N), grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
   float2* tw = reinterpret_cast<float2*>(smem + (size_t)(kThreads / nt) * 6 * N);   // [N/4] behind the groups' buffers
   fill_twiddles(tw, ctab, N);
@@ -247,8 +279,8 @@ __global__ __launch_bounds__(kThreads) void k_fwd_lds(const float* __restrict__ 
   const float* a3 = coef + 2 * h;
   const float* a4 = coef + 3 * h;
   const bool has_cur = n < Kin;
-  const float* xc = x + ((size_t)b * Kin + (size_t)n) * N * C + c;
-  const float* xp = nullptr;
+  const TIO* xc = x + ((size_t)b * Kin + (size_t)n) * N * C + c;
+  const TIO* xp = nullptr;
   if (n >= 1) xp = x + ((size_t)b * Kin + (size_t)(n - 1)) * N * C + c;
   else if (prev_block) xp = prev_block + (size_t)b * N * C + c;
   for (int j = tid; j < h; j += nt) {
@@ -268,19 +300,20 @@ __global__ __launch_bounds__(kThreads) void k_fwd_lds(const float* __restrict__ 
   dct4_lds(v, A, Bf, ctab, tw, N, tid, nt);
   if (!valid) return;
   const float scale = (float)(1.0 / ((double)N * 1.4142135623730951));   // 1/sqrt(4N) * sqrt(2/N)
-  float* Xo = X + (((size_t)b * F + (size_t)n) * N) * C + c;
+  TIO* Xo = X + (((size_t)b * F + (size_t)n) * N) * C + c;
   for (int k = tid; k < N; k += nt) st2(Xo + (size_t)k * C, make_float2(v[k].x * scale, v[k].y * scale), C, has1);
 }
 
 // one group per (clip, channel pair, strip of `seg` output blocks): the aliased half of the previous frame's DCT-IV
 // stays in LDS along the strip, so a strip of T blocks costs T + 1 transforms; the block index nblk (one past the
 // last) only writes the new stream state.  Every group runs the same number of transforms (barriers are workgroup-wide).
-__global__ __launch_bounds__(kThreads) void k_inv_lds(const float* __restrict__ X, float* __restrict__ x,
+template <typename TIO>
+__global__ __launch_bounds__(kThreads) void k_inv_lds(const TIO* __restrict__ X, TIO* __restrict__ x,
                                                       const float* __restrict__ tail_in, float* __restrict__ tail_out,
                                                       const float* __restrict__ coef, const float* __restrict__ ctab,
                                                       int Kp, int nblk, int seg, int nseg, int C, int CP, int N,
                                                       long long ntasks) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* smem = reinterpret_cast<float*>(smem_raw);
   const int nt = lds_group_threads(N), grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
   float2* tw = reinterpret_cast<float2*>(smem + (size_t)(kThreads / nt) * 7 * N);   // [N/4] behind the groups' buffers
   fill_twiddles(tw, ctab, N);
@@ -309,7 +342,7 @@ __global__ __launch_bounds__(kThreads) void k_inv_lds(const float* __restrict__ 
   // aliased half before the strip: frame n0 - 1, the stream state, or zero
   {
     const bool halo = n0 >= 1;
-    const float* Xi = X + (((size_t)b * Kp + (size_t)(halo ? n0 - 1 : 0)) * N) * C + c;
+    const TIO* Xi = X + (((size_t)b * Kp + (size_t)(halo ? n0 - 1 : 0)) * N) * C + c;
     for (int k = tid; k < N; k += nt) v[k] = halo ? ld2(Xi + (size_t)k * C, C, has1) : make_float2(0.f, 0.f);
     __syncthreads();
     dct4_lds(v, A, Bf, ctab, tw, N, tid, nt);
@@ -324,7 +357,7 @@ __global__ __launch_bounds__(kThreads) void k_inv_lds(const float* __restrict__ 
     const bool live = valid && n < nlast;    // this group still has a block to write
     const bool has_n = n < Kp && n < nblk;   // the virtual state block (n == nblk) has no current frame
     {
-      const float* Xi = X + (((size_t)b * Kp + (size_t)(has_n ? n : 0)) * N) * C + c;
+      const TIO* Xi = X + (((size_t)b * Kp + (size_t)(has_n ? n : 0)) * N) * C + c;
       for (int k = tid; k < N; k += nt) v[k] = has_n ? ld2(Xi + (size_t)k * C, C, has1) : make_float2(0.f, 0.f);
     }
     __syncthreads();
@@ -334,7 +367,7 @@ __global__ __launch_bounds__(kThreads) void k_inv_lds(const float* __restrict__ 
         const float2 a = make_float2(v[h - 1 - j].x * scale, v[h - 1 - j].y * scale);   // u_n[h-1-j]
         const float2 bb = um[j];                                                        // u_{n-1}[h+j]
         if (n < nblk) {
-          float* xo = x + (((size_t)b * nblk + (size_t)n) * N) * C + c;
+          TIO* xo = x + (((size_t)b * nblk + (size_t)n) * N) * C + c;
           st2(xo + (size_t)j * C, make_float2(s1[j] * a.x + s2[j] * bb.x, s1[j] * a.y + s2[j] * bb.y), C, has1);
           st2(xo + (size_t)(N - 1 - j) * C, make_float2(s3[j] * a.x + s4[j] * bb.x, s3[j] * a.y + s4[j] * bb.y), C, has1);
         } else if (tail_out) {
@@ -352,38 +385,54 @@ __global__ __launch_bounds__(kThreads) void k_inv_lds(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // tonality (psychoacoustic.py:102-120), one workgroup per (b, frame, c)
 // ------------------------------------------------------------------------------------------------
-__device__ inline float block_sum(float v, float* red) {
+template <typename T>
+__device__ inline T block_sum(T v, T* red) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __syncthreads();
   if (lane == 0) red[wave] = v;
   __syncthreads();
-  float s = 0.f;
+  T s = 0;
   for (int w = 0; w < kThreads / 64; ++w) s += red[w];
   return s;
 }
+// the reference's functions in the compute type
+__device__ __forceinline__ float m_log(float x) { return logf(x); }
+__device__ __forceinline__ double m_log(double x) { return log(x); }
+__device__ __forceinline__ float m_exp(float x) { return expf(x); }
+__device__ __forceinline__ double m_exp(double x) { return exp(x); }
+__device__ __forceinline__ float m_pow(float x, float y) { return powf(x, y); }
+__device__ __forceinline__ double m_pow(double x, double y) { return pow(x, y); }
+__device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float m_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double m_max(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float m_min(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double m_min(double a, double b) { return fmin(a, b); }
 
-__global__ __launch_bounds__(kThreads) void k_tonality_generic(const float* __restrict__ X, float* __restrict__ t,
+template <typename TIO, typename TC = typename Compute<TIO>::type>
+__global__ __launch_bounds__(kThreads) void k_tonality_generic(const TIO* __restrict__ X, TIO* __restrict__ t,
                                                                int C, int N) {
-  __shared__ float red[kThreads / 64];
+  __shared__ TC red[kThreads / 64];
+  const TC eps = (TC)1e-14;
   const long long wg = blockIdx.x;   // (b*F + f)*C + c
   const int c = (int)(wg % C);
   const long long bf = wg / C;
-  const float* Xi = X + (size_t)bf * N * C + c;
-  float slog = 0.f, ssq = 0.f;
+  const TIO* Xi = X + (size_t)bf * N * C + c;
+  TC slog = 0, ssq = 0;
   for (int k = threadIdx.x; k < N; k += kThreads) {
-    const float a = Xi[(size_t)k * C];
-    const float I = a * a;
-    slog += logf(fmaxf(kEps, I));
+    const TC a = ldv(Xi + (size_t)k * C);
+    const TC I = a * a;
+    slog += m_log(m_max(eps, I));
     ssq += I;
   }
   slog = block_sum(slog, red);
   ssq = block_sum(ssq, red);
   if (threadIdx.x == 0) {
-    const float gm = expf(slog / (float)N);
-    const float am = ssq / (float)N + kEps;
-    const float sfm = 10.f * logf(gm / am) / 2.302585092994046f;
-    t[wg] = fminf(sfm / -60.f, 1.f);
+    const TC gm = m_exp(slog / (TC)N);
+    const TC am = ssq / (TC)N + eps;
+    const TC sfm = (TC)10 * m_log(gm / am) / (TC)2.302585092994046;
+    stv(t + wg, m_min(sfm / (TC)-60, (TC)1));
   }
 }
 
@@ -391,46 +440,47 @@ __global__ __launch_bounds__(kThreads) void k_tonality_generic(const float* __re
 // global masking threshold (psychoacoustic.py:122-148 with :169-210, :301-331), factorised form
 // one workgroup per (b, frame, c)
 // ------------------------------------------------------------------------------------------------
+template <typename TIO, typename TC = typename Compute<TIO>::type>
 __global__ __launch_bounds__(kThreads) void k_threshold_generic(
-    const float* __restrict__ X, const float* __restrict__ t, float* __restrict__ thr, float drown, float alpha,
-    const int32_t* __restrict__ wb_ptr, const int32_t* __restrict__ wb_idx, const float* __restrict__ wb_val,
-    const int32_t* __restrict__ wi_ptr, const int32_t* __restrict__ wi_idx, const float* __restrict__ wi_val,
-    const float* __restrict__ S, const float* __restrict__ quiet, const float* __restrict__ beta, int C, int N,
+    const TIO* __restrict__ X, const TIO* __restrict__ t, TIO* __restrict__ thr, TC drown, TC alpha,
+    const int32_t* __restrict__ wb_ptr, const int32_t* __restrict__ wb_idx, const TC* __restrict__ wb_val,
+    const int32_t* __restrict__ wi_ptr, const int32_t* __restrict__ wi_idx, const TC* __restrict__ wi_val,
+    const TC* __restrict__ S, const TC* __restrict__ quiet, const TC* __restrict__ beta, int C, int N,
     int M) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* I = smem;       // [N]
-  float* Q = smem + N;   // [M]
-  float* G = Q + M;      // [M]
+  TC* I = reinterpret_cast<TC*>(smem_raw);   // [N]
+  TC* Q = I + N;                             // [M]
+  TC* G = Q + M;                             // [M]
+  const TC eps = (TC)1e-14;
   const long long wg = blockIdx.x;
   const int c = (int)(wg % C);
   const long long bf = wg / C;
-  const float* Xi = X + (size_t)bf * N * C + c;
+  const TIO* Xi = X + (size_t)bf * N * C + c;
   for (int k = threadIdx.x; k < N; k += kThreads) {
-    const float a = Xi[(size_t)k * C];
+    const TC a = ldv(Xi + (size_t)k * C);
     I[k] = a * a;
   }
   __syncthreads();
   for (int j = threadIdx.x; j < M; j += kThreads) {   // _to_bark_intensity (:301-315)
-    float P = 0.f;
+    TC P = 0;
     for (int e = wb_ptr[j]; e < wb_ptr[j + 1]; ++e) P += I[wb_idx[e]] * wb_val[e];
-    Q[j] = powf(fmaxf(kEps, P), alpha);               // (:206)
+    Q[j] = m_pow(m_max(eps, P), alpha);               // (:206)
   }
   __syncthreads();
-  const float tt = t[wg];
+  const TC tt = ldv(t + wg);
   for (int j = threadIdx.x; j < M; j += kThreads) {   // _masking_intensity_in_bark (:169-210)
-    float acc = 0.f;
+    TC acc = 0;
     for (int i = 0; i < M; ++i) acc += Q[i] * S[(size_t)i * M + j];
-    const float offset = (1.f - drown) * (tt * beta[j] + 9.f * tt + 5.5f);     // (:185-191)
-    const float fac = powf(10.f, -alpha * offset / 10.f);                       // (:197)
-    const float T = powf(fmaxf(kEps, fac * acc), 1.f / alpha);                  // (:208)
-    G[j] = fmaxf(T, quiet[j]);                                                  // (:144)
+    const TC offset = ((TC)1 - drown) * (tt * beta[j] + (TC)9 * tt + (TC)5.5);     // (:185-191)
+    const TC fac = m_pow((TC)10, -alpha * offset / (TC)10);                         // (:197)
+    const TC T = m_pow(m_max(eps, fac * acc), (TC)1 / alpha);                       // (:208)
+    G[j] = m_max(T, quiet[j]);                                                      // (:144)
   }
   __syncthreads();
-  float* out = thr + (size_t)bf * N * C + c;
+  TIO* out = thr + (size_t)bf * N * C + c;
   for (int k = threadIdx.x; k < N; k += kThreads) {   // _bark_intensity_to_freq_ampl (:317-331)
-    float acc = 0.f;
+    TC acc = 0;
     for (int e = wi_ptr[k]; e < wi_ptr[k + 1]; ++e) acc += G[wi_idx[e]] * wi_val[e];
-    out[(size_t)k * C] = sqrtf(fmaxf(kEps, acc));
+    stv(out + (size_t)k * C, m_sqrt(m_max(eps, acc)));
   }
 }
 
@@ -647,6 +697,30 @@ __global__ __launch_bounds__(256) void k_add_noise(const float* __restrict__ X, 
   }
 }
 
+// the same two utilities for the other storage types (double: fp64 arithmetic; bfloat16: float32 arithmetic), one
+// element per thread and iteration; the noise stream is the float32 one (same seed, same normals)
+template <typename TIO, typename TC = typename Compute<TIO>::type>
+__global__ __launch_bounds__(256) void k_db_typed(const TIO* __restrict__ a, TIO* __restrict__ out, size_t n, int norm) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const TC v = ldv(a + i);
+    TC dB = (TC)10 * m_log(m_max((TC)1e-14, v * v)) / (TC)2.302585092994046 + (TC)120;
+    if (norm) dB = (dB + (TC)20) / (TC)140;
+    stv(out + i, dB);
+  }
+}
+template <typename TIO, typename TC = typename Compute<TIO>::type>
+__global__ __launch_bounds__(256) void k_add_noise_typed(const TIO* __restrict__ X, const TIO* __restrict__ thr,
+                                                         TIO* __restrict__ out, size_t n, uint64_t seed) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const uint64_t key = mix64(seed);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float g0, g1;
+    normal_pair(key, i >> 1, g0, g1);
+    stv(out + i, (TC)ldv(X + i) + (TC)ldv(thr + i) * ((TC)((i & 1) ? g1 : g0) / (TC)6));
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -679,16 +753,16 @@ int launch_fwd_generic(const ac_mdct_plan* p, const float* x, float* X, const fl
     const int CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const long long ntasks = (long long)B * CP * F;
     const size_t lds2 = ((size_t)gpw * 6 * p->N + p->N / 2) * sizeof(float);
-    const int st2 = allow_lds(k_fwd_lds, lds2);
+    const int st2 = allow_lds(k_fwd_lds<float>, lds2);
     if (st2) return st2;
-    hipLaunchKernelGGL(k_fwd_lds, dim3((unsigned)((ntasks + gpw - 1) / gpw)), dim3(kThreads), lds2, s, x, X, prev_block,
+    hipLaunchKernelGGL(k_fwd_lds<float>, dim3((unsigned)((ntasks + gpw - 1) / gpw)), dim3(kThreads), lds2, s, x, X, prev_block,
                        p->d_coef, p->d_ctab, Kin, F, C, CP, p->N, ntasks);
     AC_HIP_CHECK(hipGetLastError());
     return AC_OK;
   }
   const size_t lds = (size_t)p->N * sizeof(float);
   AC_REQUIRE(lds <= 64 * 1024, "filters_n = %d too large for the generic kernel", p->N);
-  hipLaunchKernelGGL(k_fwd_generic, dim3((unsigned)nwg), dim3(kThreads), lds, s, x, X, prev_block, p->d_coef,
+  hipLaunchKernelGGL((k_fwd_generic<float, float>), dim3((unsigned)nwg), dim3(kThreads), lds, s, x, X, prev_block, p->d_coef,
                      p->d_ctab, Kin, F, C, p->N);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
@@ -705,16 +779,16 @@ int launch_inv_generic(const ac_mdct_plan* p, const float* X, float* x, const fl
     const int nseg = (per_sig + seg - 1) / seg;
     const long long ntasks = (long long)B * CP * nseg;
     const size_t lds2 = ((size_t)gpw * 7 * p->N + p->N / 2) * sizeof(float);
-    const int st2 = allow_lds(k_inv_lds, lds2);
+    const int st2 = allow_lds(k_inv_lds<float>, lds2);
     if (st2) return st2;
-    hipLaunchKernelGGL(k_inv_lds, dim3((unsigned)((ntasks + gpw - 1) / gpw)), dim3(kThreads), lds2, s, X, x, tail_in,
+    hipLaunchKernelGGL(k_inv_lds<float>, dim3((unsigned)((ntasks + gpw - 1) / gpw)), dim3(kThreads), lds2, s, X, x, tail_in,
                        tail_out, p->d_coef, p->d_ctab, Kp, nblk, seg, nseg, C, CP, p->N, ntasks);
     AC_HIP_CHECK(hipGetLastError());
     return AC_OK;
   }
   const size_t lds = 2 * (size_t)p->N * sizeof(float);
   AC_REQUIRE(lds <= 64 * 1024, "filters_n = %d too large for the generic kernel", p->N);
-  hipLaunchKernelGGL(k_inv_generic, dim3((unsigned)nwg), dim3(kThreads), lds, s, X, x, tail_in, tail_out,
+  hipLaunchKernelGGL((k_inv_generic<float, float>), dim3((unsigned)nwg), dim3(kThreads), lds, s, X, x, tail_in, tail_out,
                      p->d_coef, p->d_ctab, Kp, nblk, per_sig, C, p->N);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
@@ -724,7 +798,7 @@ int launch_tonality_generic(const ac_psy_plan* p, const float* X, float* t, int 
   const long long nwg = (long long)B * F * C;
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
-  hipLaunchKernelGGL(k_tonality_generic, dim3((unsigned)nwg), dim3(kThreads), 0, s, X, t, C, p->N);
+  hipLaunchKernelGGL((k_tonality_generic<float, float>), dim3((unsigned)nwg), dim3(kThreads), 0, s, X, t, C, p->N);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }
@@ -737,7 +811,7 @@ int launch_threshold_generic(const ac_psy_plan* p, const float* X, const float* 
   const size_t lds = ((size_t)p->N + 2 * (size_t)p->M) * sizeof(float);
   AC_REQUIRE(lds <= 64 * 1024, "filter_bands_n = %d / bark_bands_n = %d too large for the generic kernel", p->N,
              p->M);
-  hipLaunchKernelGGL(k_threshold_generic, dim3((unsigned)nwg), dim3(kThreads), lds, s, X, t, thr, drown,
+  hipLaunchKernelGGL((k_threshold_generic<float, float>), dim3((unsigned)nwg), dim3(kThreads), lds, s, X, t, thr, drown,
                      (float)p->alpha, p->d_wb_ptr, p->d_wb_idx, p->d_wb_val, p->d_wi_ptr, p->d_wi_idx, p->d_wi_val,
                      p->d_S, p->d_quiet, p->d_beta, C, p->N, p->M);
   AC_HIP_CHECK(hipGetLastError());
@@ -791,6 +865,151 @@ int launch_add_noise(const float* X, const float* thr, float* out, size_t n, uin
   hipLaunchKernelGGL(k_add_noise, dim3(grid), dim3(256), 0, s, X, thr, out, n, n4, seed);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
+}
+
+// ---- compute_dtype variants: double = O(N^2) kernels in fp64 with fp64 tables; bfloat16 = bfloat16 tensors, float32
+// arithmetic, the LDS-FFT middle tier for power-of-two filters_n (O(N^2) kernels otherwise) ----
+int launch_fwd_f64(const ac_mdct_plan* p, const double* x, double* X, int B, int Kin, int F, int C, hipStream_t s) {
+  const long long nwg = (long long)B * C * F;
+  const int st = check_grid(nwg);
+  if (st) return st < 0 ? st : AC_OK;
+  const size_t lds = (size_t)p->N * sizeof(double);
+  AC_REQUIRE(lds <= 64 * 1024, "filters_n = %d too large for the float64 kernel", p->N);
+  hipLaunchKernelGGL((k_fwd_generic<double, double>), dim3((unsigned)nwg), dim3(kThreads), lds, s, x, X,
+                     (const double*)nullptr, p->d_coef64, p->d_ctab64, Kin, F, C, p->N);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+int launch_inv_f64(const ac_mdct_plan* p, const double* X, double* x, int B, int Kp, int nblk, int C, hipStream_t s) {
+  const long long nwg = (long long)B * C * nblk;
+  const int st = check_grid(nwg);
+  if (st) return st < 0 ? st : AC_OK;
+  const size_t lds = 2 * (size_t)p->N * sizeof(double);
+  AC_REQUIRE(lds <= 64 * 1024, "filters_n = %d too large for the float64 kernel", p->N);
+  hipLaunchKernelGGL((k_inv_generic<double, double>), dim3((unsigned)nwg), dim3(kThreads), lds, s, X, x,
+                     (const double*)nullptr, (double*)nullptr, p->d_coef64, p->d_ctab64, Kp, nblk, nblk, C, p->N);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+int launch_fwd_bf16(const ac_mdct_plan* p, const bf16_t* x, bf16_t* X, int B, int Kin, int F, int C, hipStream_t s) {
+  const long long nwg = (long long)B * C * F;
+  const int st = check_grid(nwg);
+  if (st) return st < 0 ? st : AC_OK;
+  if (lds_fft_ok(p->N) && !g_force_generic) {
+    const int CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
+    const long long ntasks = (long long)B * CP * F;
+    const size_t lds2 = ((size_t)gpw * 6 * p->N + p->N / 2) * sizeof(float);
+    const int st2 = allow_lds(k_fwd_lds<bf16_t>, lds2);
+    if (st2) return st2;
+    hipLaunchKernelGGL(k_fwd_lds<bf16_t>, dim3((unsigned)((ntasks + gpw - 1) / gpw)), dim3(kThreads), lds2, s, x, X,
+                       (const bf16_t*)nullptr, p->d_coef, p->d_ctab, Kin, F, C, CP, p->N, ntasks);
+    AC_HIP_CHECK(hipGetLastError());
+    return AC_OK;
+  }
+  const size_t lds = (size_t)p->N * sizeof(float);
+  AC_REQUIRE(lds <= 64 * 1024, "filters_n = %d too large for the generic kernel", p->N);
+  hipLaunchKernelGGL((k_fwd_generic<bf16_t, float>), dim3((unsigned)nwg), dim3(kThreads), lds, s, x, X,
+                     (const bf16_t*)nullptr, p->d_coef, p->d_ctab, Kin, F, C, p->N);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+int launch_inv_bf16(const ac_mdct_plan* p, const bf16_t* X, bf16_t* x, int B, int Kp, int nblk, int C, hipStream_t s) {
+  const long long nwg = (long long)B * C * nblk;
+  const int st = check_grid(nwg);
+  if (st) return st < 0 ? st : AC_OK;
+  if (lds_fft_ok(p->N) && !g_force_generic) {
+    const int seg = 8, CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
+    const int nseg = (nblk + seg - 1) / seg;
+    const long long ntasks = (long long)B * CP * nseg;
+    const size_t lds2 = ((size_t)gpw * 7 * p->N + p->N / 2) * sizeof(float);
+    const int st2 = allow_lds(k_inv_lds<bf16_t>, lds2);
+    if (st2) return st2;
+    hipLaunchKernelGGL(k_inv_lds<bf16_t>, dim3((unsigned)((ntasks + gpw - 1) / gpw)), dim3(kThreads), lds2, s, X, x,
+                       (const float*)nullptr, (float*)nullptr, p->d_coef, p->d_ctab, Kp, nblk, seg, nseg, C, CP, p->N,
+                       ntasks);
+    AC_HIP_CHECK(hipGetLastError());
+    return AC_OK;
+  }
+  const size_t lds = 2 * (size_t)p->N * sizeof(float);
+  AC_REQUIRE(lds <= 64 * 1024, "filters_n = %d too large for the generic kernel", p->N);
+  hipLaunchKernelGGL((k_inv_generic<bf16_t, float>), dim3((unsigned)nwg), dim3(kThreads), lds, s, X, x,
+                     (const float*)nullptr, (float*)nullptr, p->d_coef, p->d_ctab, Kp, nblk, nblk, C, p->N);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+template <typename TIO>
+static int launch_tonality_T(const ac_psy_plan* p, const TIO* X, TIO* t, int B, int F, int C, hipStream_t s) {
+  const long long nwg = (long long)B * F * C;
+  const int st = check_grid(nwg);
+  if (st) return st < 0 ? st : AC_OK;
+  hipLaunchKernelGGL((k_tonality_generic<TIO>), dim3((unsigned)nwg), dim3(kThreads), 0, s, X, t, C, p->N);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+int launch_tonality_f64(const ac_psy_plan* p, const double* X, double* t, int B, int F, int C, hipStream_t s) {
+  return launch_tonality_T<double>(p, X, t, B, F, C, s);
+}
+int launch_tonality_bf16(const ac_psy_plan* p, const bf16_t* X, bf16_t* t, int B, int F, int C, hipStream_t s) {
+  return launch_tonality_T<bf16_t>(p, X, t, B, F, C, s);
+}
+
+int launch_threshold_f64(const ac_psy_plan* p, const double* X, const double* t, double drown, double* thr, int B, int F,
+                         int C, hipStream_t s) {
+  const long long nwg = (long long)B * F * C;
+  const int st = check_grid(nwg);
+  if (st) return st < 0 ? st : AC_OK;
+  const size_t lds = ((size_t)p->N + 2 * (size_t)p->M) * sizeof(double);
+  AC_REQUIRE(lds <= 64 * 1024, "filter_bands_n = %d / bark_bands_n = %d too large for the float64 kernel", p->N, p->M);
+  hipLaunchKernelGGL((k_threshold_generic<double, double>), dim3((unsigned)nwg), dim3(kThreads), lds, s, X, t, thr, drown,
+                     p->alpha, p->d_wb_ptr, p->d_wb_idx, p->d_wb_val64, p->d_wi_ptr, p->d_wi_idx, p->d_wi_val64,
+                     p->d_S64, p->d_quiet64, p->d_beta64, C, p->N, p->M);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+int launch_threshold_bf16(const ac_psy_plan* p, const bf16_t* X, const bf16_t* t, float drown, bf16_t* thr, int B, int F,
+                          int C, hipStream_t s) {
+  const long long nwg = (long long)B * F * C;
+  const int st = check_grid(nwg);
+  if (st) return st < 0 ? st : AC_OK;
+  const size_t lds = ((size_t)p->N + 2 * (size_t)p->M) * sizeof(float);
+  AC_REQUIRE(lds <= 64 * 1024, "filter_bands_n = %d / bark_bands_n = %d too large for the generic kernel", p->N, p->M);
+  hipLaunchKernelGGL((k_threshold_generic<bf16_t, float>), dim3((unsigned)nwg), dim3(kThreads), lds, s, X, t, thr, drown,
+                     (float)p->alpha, p->d_wb_ptr, p->d_wb_idx, p->d_wb_val, p->d_wi_ptr, p->d_wi_idx, p->d_wi_val,
+                     p->d_S, p->d_quiet, p->d_beta, C, p->N, p->M);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+template <typename TIO>
+static int launch_db_T(const TIO* a, TIO* out, size_t n, int norm, hipStream_t s) {
+  if (n == 0) return AC_OK;
+  const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL((k_db_typed<TIO>), dim3(grid), dim3(256), 0, s, a, out, n, norm);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+template <typename TIO>
+static int launch_add_noise_T(const TIO* X, const TIO* thr, TIO* out, size_t n, uint64_t seed, hipStream_t s) {
+  if (n == 0) return AC_OK;
+  const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL((k_add_noise_typed<TIO>), dim3(grid), dim3(256), 0, s, X, thr, out, n, seed);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+int launch_db_typed(const void* a, void* out, size_t n, int norm, int dtype, hipStream_t s) {
+  if (dtype == AC_F64) return launch_db_T(static_cast<const double*>(a), static_cast<double*>(out), n, norm, s);
+  return launch_db_T(static_cast<const bf16_t*>(a), static_cast<bf16_t*>(out), n, norm, s);
+}
+int launch_add_noise_typed(const void* X, const void* thr, void* out, size_t n, uint64_t seed, int dtype, hipStream_t s) {
+  if (dtype == AC_F64)
+    return launch_add_noise_T(static_cast<const double*>(X), static_cast<const double*>(thr), static_cast<double*>(out), n,
+                              seed, s);
+  return launch_add_noise_T(static_cast<const bf16_t*>(X), static_cast<const bf16_t*>(thr), static_cast<bf16_t*>(out), n, seed,
+                            s);
 }
 
 }  // namespace ac

@@ -46,6 +46,8 @@ struct DeviceGuard {
 
 extern int g_force_generic;
 
+typedef __bf16 bf16_t;   // storage type of the AC_BF16 tensors (device code converts with v_cvt_pk_bf16_f32)
+
 }  // namespace ac
 
 // ---- plan objects ---------------------------------------------------------------------------
@@ -56,6 +58,8 @@ struct ac_mdct_plan {
   int fast = 0;                // 1: wave-level FFT kernels available for this N
   float* d_coef = nullptr;     // [8][N/2]  a1 a2 a3 a4 s1 s2 s3 s4
   float* d_ctab = nullptr;     // [8N]      cos(pi i / (4N)), generic kernels
+  double* d_coef64 = nullptr;  // the same two tables in float64 (AC_F64 entry points)
+  double* d_ctab64 = nullptr;
   // fast-path tables (ac_fast.hip): per-FFT-element fold coefficients and twiddles
   float* d_fast = nullptr;
   size_t fast_bytes = 0;
@@ -75,6 +79,9 @@ struct ac_psy_plan {
   float* d_S = nullptr;        // [M, M]
   float* d_quiet = nullptr;    // [M]
   float* d_beta = nullptr;     // [M]
+  // float64 constants (AC_F64 entry points): CSR values, S, quiet, beta = linspace(0, max_bark, M) in float64
+  double* d_wb_val64 = nullptr; double* d_wi_val64 = nullptr;
+  double* d_S64 = nullptr; double* d_quiet64 = nullptr; double* d_beta64 = nullptr;
   // fast-path tables (ac_fast.hip)
   float* d_fast = nullptr;
   size_t fast_bytes = 0;
@@ -122,6 +129,19 @@ int launch_threshold_bwd_generic(const ac_psy_plan* p, const float* X, const flo
 int launch_psy_bwd_fast(const ac_psy_plan* p, const float* X, const float* t, float drown, const float* g_thr,
                         const float* g_t, float* g_X, float* g_t_out, int accumulate, int B, int F, int C,
                         hipStream_t s);
+// compute_dtype variants (ac_generic.hip)
+int launch_fwd_f64(const ac_mdct_plan* p, const double* x, double* X, int B, int Kin, int F, int C, hipStream_t s);
+int launch_inv_f64(const ac_mdct_plan* p, const double* X, double* x, int B, int Kp, int nblk, int C, hipStream_t s);
+int launch_fwd_bf16(const ac_mdct_plan* p, const bf16_t* x, bf16_t* X, int B, int Kin, int F, int C, hipStream_t s);
+int launch_inv_bf16(const ac_mdct_plan* p, const bf16_t* X, bf16_t* x, int B, int Kp, int nblk, int C, hipStream_t s);
+int launch_tonality_f64(const ac_psy_plan* p, const double* X, double* t, int B, int F, int C, hipStream_t s);
+int launch_tonality_bf16(const ac_psy_plan* p, const bf16_t* X, bf16_t* t, int B, int F, int C, hipStream_t s);
+int launch_threshold_f64(const ac_psy_plan* p, const double* X, const double* t, double drown, double* thr, int B, int F,
+                         int C, hipStream_t s);
+int launch_threshold_bf16(const ac_psy_plan* p, const bf16_t* X, const bf16_t* t, float drown, bf16_t* thr, int B, int F,
+                          int C, hipStream_t s);
+int launch_db_typed(const void* a, void* out, size_t n, int norm, int dtype, hipStream_t s);
+int launch_add_noise_typed(const void* X, const void* thr, void* out, size_t n, uint64_t seed, int dtype, hipStream_t s);
 int launch_db(const float* a, float* out, size_t n, int norm, hipStream_t s);
 int launch_add_noise(const float* X, const float* thr, float* out, size_t n, uint64_t seed, hipStream_t s);
 

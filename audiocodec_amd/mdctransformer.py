@@ -60,7 +60,9 @@ class MDCTransformer:
         :param filters_n:        number of filter bands (must be even, ``:26``)
         :param window_type:      'sine', 'vorbis' (default); any other string or None selects the
                                  rectangular window (``:199-211``; the reference crashes on None)
-        :param compute_dtype:    dtype of inputs and outputs; the HIP path supports float32
+        :param compute_dtype:    dtype of inputs and outputs: float32 (the wave-level kernels), float64 (everything in
+                                 float64, constants included: the on-device float64 cross-check) or bfloat16 (bfloat16 tensors,
+                                 float32 arithmetic inside); autograd and streaming are float32 only
         :param precompute_dtype: constants are always pre-computed in float64 on the host (the
                                  reference's default, ``:14,31-35``); other values are rejected
         """
@@ -69,7 +71,7 @@ class MDCTransformer:
         self.window_type = window_type
         self.compute_dtype = _host.as_torch_dtype(compute_dtype)
         self.precompute_dtype = _host.as_torch_dtype(precompute_dtype)
-        _host.require_hip_compute_dtype(self.compute_dtype, "MDCTransformer")
+        self._dtype_id = _host.require_hip_compute_dtype(self.compute_dtype, "MDCTransformer")
         if self.precompute_dtype != torch.float64:
             raise NotImplementedError("constants are pre-computed in float64 only")
         self._window = _lib.window_id(window_type)
@@ -124,6 +126,7 @@ class MDCTransformer:
         :return:  ``[batches_n, blocks_n + 1, filters_n, channels_n]`` amplitudes in ]-1, 1[
         """
         if isinstance(x, torch.Tensor) and x.requires_grad and torch.is_grad_enabled():
+            _host.require_float32(self.compute_dtype, "the backward pass of transform")
             return _TransformFn.apply(x, self)
         return self._transform(x)
 
@@ -141,8 +144,8 @@ class MDCTransformer:
         K = S // N
         X = torch.empty((B, K + 1, N, C), dtype=x.dtype, device=x.device)
         with torch.cuda.device(x.device):
-            _lib.check(self._lib.ac_mdct_forward(self._plans.get(x.device), _host.ptr(x), _host.ptr(X), B, K, C,
-                                                 _host.stream_ptr(x.device)))
+            _lib.check(self._lib.ac_mdct_forward_typed(self._plans.get(x.device), _host.ptr(x), _host.ptr(X),
+                                                       self._dtype_id, B, K, C, _host.stream_ptr(x.device)))
         return X
 
     # ---- synthesis -----------------------------------------------------------------------------------
@@ -153,6 +156,7 @@ class MDCTransformer:
         :return:                ``[batches_n, (blocks_n + 1) * filters_n, channels_n]``
         """
         if isinstance(mdct_amplitudes, torch.Tensor) and mdct_amplitudes.requires_grad and torch.is_grad_enabled():
+            _host.require_float32(self.compute_dtype, "the backward pass of inverse_transform")
             return _InverseFn.apply(mdct_amplitudes, self)
         return self._inverse(mdct_amplitudes)
 
@@ -163,8 +167,8 @@ class MDCTransformer:
             raise ValueError("axis 2 of mdct_amplitudes (%d) != filters_n (%d)" % (N, self.filters_n))
         x = torch.empty((B, (Kp + 1) * N, C), dtype=X.dtype, device=X.device)
         with torch.cuda.device(X.device):
-            _lib.check(self._lib.ac_mdct_inverse(self._plans.get(X.device), _host.ptr(X), _host.ptr(x), B, Kp, C,
-                                                 _host.stream_ptr(X.device)))
+            _lib.check(self._lib.ac_mdct_inverse_typed(self._plans.get(X.device), _host.ptr(X), _host.ptr(x),
+                                                       self._dtype_id, B, Kp, C, _host.stream_ptr(X.device)))
         return x
 
     # native handle for the fused / streaming entry points

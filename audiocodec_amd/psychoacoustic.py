@@ -62,8 +62,10 @@ class PsychoacousticModel:
                           parity bar).  None = the library's default (``"f32"`` unless the AC_SPREAD tuning hook says
                           otherwise).  The matrix-core forms need filter_bands_n 1024 / 2048 and 64 Bark bands
 
-        :raises TypeError: when compute_dtype is not float64, float32 or bfloat16 (``:42-43``);
-                           of those the HIP path implements float32 (others: NotImplementedError)
+        :raises TypeError: when compute_dtype is not float64, float32 or bfloat16 (``:42-43``).  float32 runs the
+                           wave-level kernels; float64 runs float64 kernels on float64 constants (the on-device
+                           cross-check); bfloat16 means bfloat16 tensors with float32 arithmetic inside.  Autograd is
+                           float32 only
         """
         self.alpha = alpha
         self.sample_rate = sample_rate
@@ -73,19 +75,23 @@ class PsychoacousticModel:
         if compute_dtype not in (torch.float64, torch.float32, torch.bfloat16):
             raise TypeError("compute_dtype of PsychoacousticModel should be float64, float32 or bfloat16")
         self.compute_dtype = compute_dtype
-        _host.require_hip_compute_dtype(compute_dtype, "PsychoacousticModel")
+        self._dtype_id = _host.require_hip_compute_dtype(compute_dtype, "PsychoacousticModel")
         if _host.as_torch_dtype(precompute_dtype) != torch.float64:
             raise NotImplementedError("constants are pre-computed in float64 only")
         self._lib = _lib.load()
 
         N, M = self.filter_bands_n, self.bark_bands_n
-        W = np.empty((N, M), dtype=np.float32)
-        W_inv = np.empty((M, N), dtype=np.float32)
-        S = np.empty((M, M), dtype=np.float32)
-        quiet = np.empty((M,), dtype=np.float32)
+        # constants in the compute dtype, as the reference holds them (float64: unrounded; bfloat16: float32 here, the
+        # kernels' arithmetic type)
+        np_t, c_t = (np.float64, ctypes.c_double) if compute_dtype == torch.float64 else (np.float32, ctypes.c_float)
+        W = np.empty((N, M), dtype=np_t)
+        W_inv = np.empty((M, N), dtype=np_t)
+        S = np.empty((M, M), dtype=np_t)
+        quiet = np.empty((M,), dtype=np_t)
         scalars = np.empty((4,), dtype=np.float64)
-        fp = ctypes.POINTER(ctypes.c_float)
-        _lib.check(self._lib.ac_psy_tables_host(
+        fp = ctypes.POINTER(c_t)
+        tables = self._lib.ac_psy_tables_host_f64 if compute_dtype == torch.float64 else self._lib.ac_psy_tables_host
+        _lib.check(tables(
             N, M, float(sample_rate), float(alpha), W.ctypes.data_as(fp), W_inv.ctypes.data_as(fp),
             S.ctypes.data_as(fp), quiet.ctypes.data_as(fp), scalars.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
         self._dB_MAX = torch.tensor(120.0, dtype=compute_dtype)                 # :52
@@ -135,8 +141,8 @@ class PsychoacousticModel:
         a = a.contiguous()
         out = torch.empty_like(a)
         with torch.cuda.device(a.device):
-            _lib.check(self._lib.ac_amplitude_to_db(_host.ptr(a), _host.ptr(out), a.numel(), int(norm),
-                                                    _host.stream_ptr(a.device)))
+            _lib.check(self._lib.ac_amplitude_to_db_typed(_host.ptr(a), _host.ptr(out), a.numel(), int(norm),
+                                                          self._dtype_id, _host.stream_ptr(a.device)))
         return out
 
     def amplitude_to_dB(self, mdct_amplitude):
@@ -157,6 +163,7 @@ class PsychoacousticModel:
     def tonality(self, mdct_amplitudes):
         """``tonality`` (``psychoacoustic.py:102-120``): [B, K, N, C] -> [B, K, 1, C] in [0, 1]."""
         if isinstance(mdct_amplitudes, torch.Tensor) and mdct_amplitudes.requires_grad and torch.is_grad_enabled():
+            _host.require_float32(self.compute_dtype, "the backward pass of tonality")
             return _TonalityFn.apply(mdct_amplitudes, self)
         return self._tonality(mdct_amplitudes)
 
@@ -165,8 +172,8 @@ class PsychoacousticModel:
         B, F, N, C = X.shape
         t = torch.empty((B, F, 1, C), dtype=X.dtype, device=X.device)
         with torch.cuda.device(X.device):
-            _lib.check(self._lib.ac_tonality(self._plans.get(X.device), _host.ptr(X), _host.ptr(t), B, F, C,
-                                             _host.stream_ptr(X.device)))
+            _lib.check(self._lib.ac_tonality_typed(self._plans.get(X.device), _host.ptr(X), _host.ptr(t),
+                                                   self._dtype_id, B, F, C, _host.stream_ptr(X.device)))
         return t
 
     def _tonality_backward(self, X, gt):
@@ -182,6 +189,7 @@ class PsychoacousticModel:
         """``global_masking_threshold`` (``psychoacoustic.py:122-148``): -> [B, K, N, C], strictly positive."""
         needs_grad = any(isinstance(v, torch.Tensor) and v.requires_grad for v in (mdct_amplitudes, tonality_per_block))
         if needs_grad and torch.is_grad_enabled():
+            _host.require_float32(self.compute_dtype, "the backward pass of global_masking_threshold")
             return _ThresholdFn.apply(mdct_amplitudes, tonality_per_block, self, float(drown))
         return self._threshold(mdct_amplitudes, tonality_per_block, drown)
 
@@ -207,9 +215,9 @@ class PsychoacousticModel:
             raise ValueError("mdct_amplitudes and tonality_per_block live on different devices")
         thr = torch.empty_like(X)
         with torch.cuda.device(X.device):
-            _lib.check(self._lib.ac_mask_threshold(self._plans.get(X.device), _host.ptr(X), _host.ptr(t),
-                                                   float(drown), _host.ptr(thr), B, F, C,
-                                                   _host.stream_ptr(X.device)))
+            _lib.check(self._lib.ac_mask_threshold_typed(self._plans.get(X.device), _host.ptr(X), _host.ptr(t),
+                                                         float(drown), _host.ptr(thr), self._dtype_id, B, F, C,
+                                                         _host.stream_ptr(X.device)))
         return thr
 
     def add_noise(self, mdct_amplitudes, masking_threshold, seed=None):
@@ -226,8 +234,9 @@ class PsychoacousticModel:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         out = torch.empty_like(X)
         with torch.cuda.device(X.device):
-            _lib.check(self._lib.ac_add_noise(_host.ptr(X), _host.ptr(thr), _host.ptr(out), X.numel(),
-                                              int(seed) & (2 ** 64 - 1), _host.stream_ptr(X.device)))
+            _lib.check(self._lib.ac_add_noise_typed(_host.ptr(X), _host.ptr(thr), _host.ptr(out), X.numel(),
+                                                    int(seed) & (2 ** 64 - 1), self._dtype_id,
+                                                    _host.stream_ptr(X.device)))
         return out
 
     # ---- Bark scale (host precompute helpers, psychoacoustic.py:333-339) ------------------------------

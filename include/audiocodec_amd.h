@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AC_VERSION 120 /* 0.1.2: + matrix-core spreading product (ac_psy_plan_create_ex) */
+#define AC_VERSION 130 /* 0.1.3: + matrix-core spreading product, compute_dtype variants (*_typed) */
 
 enum {
   AC_OK = 0,
@@ -71,6 +71,9 @@ int ac_mdct_dense_matrices_host(int N, int window, float* H, float* H_inv);
  * scalars[4] = {max_frequency, max_bark, bark_band_width, dB_MIN} as double. */
 int ac_psy_tables_host(int N, int M, double sample_rate, double alpha,
                        float* W, float* W_inv, float* S, float* quiet, double* scalars);
+/* the same constants unrounded, as PsychoacousticModel holds them with compute_dtype = float64 */
+int ac_psy_tables_host_f64(int N, int M, double sample_rate, double alpha,
+                           double* W, double* W_inv, double* S, double* quiet, double* scalars);
 
 /* ------------------------------------------------------------------------------------------
  * Plans (own the device copies of the constant tables).
@@ -170,6 +173,27 @@ int ac_stream_inverse(ac_stream* s, const float* X_chunk, float* x, int k, void*
 int ac_amplitude_to_db(const float* a, float* out, size_t n, int norm, void* stream);
 /* add_noise: out = X + thr * Normal(0, 1/6), counter-based generator keyed by (seed, element-pair index). */
 int ac_add_noise(const float* X, const float* thr, float* out, size_t n, uint64_t seed, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * compute_dtype variants (mdctransformer.py:13-14,22-23; psychoacoustic.py:14-15,30,42-43: the reference accepts
+ * float64 / float32 / bfloat16 and requires the inputs to be of that type).  Same shapes and layouts as the float32
+ * entry points; `dtype` names the element type of every tensor argument:
+ *   AC_F32   the float32 entry points above (wave-level / LDS-FFT / generic kernels);
+ *   AC_F64   float64 tensors, float64 arithmetic and float64 constants throughout (O(N^2) DCT-IV, any even
+ *            filters_n): the on-device oracle the tests hold the float32 kernels against at full size;
+ *   AC_BF16  bfloat16 tensors (half the bytes of float32), float32 arithmetic inside: the LDS-FFT kernels for
+ *            power-of-two filters_n from 16 to 4096, the O(N^2) kernels otherwise; results carry bfloat16's output
+ *            rounding (2^-9 relative) -- more accurate than the reference's all-bfloat16 op sequence.
+ * No streaming state and no backward passes for AC_F64 / AC_BF16.
+ * ---------------------------------------------------------------------------------------- */
+enum { AC_F32 = 0, AC_F64 = 1, AC_BF16 = 2 };
+int ac_mdct_forward_typed(const ac_mdct_plan* plan, const void* x, void* X, int dtype, int B, int K, int C, void* stream);
+int ac_mdct_inverse_typed(const ac_mdct_plan* plan, const void* X, void* x, int dtype, int B, int Kp, int C, void* stream);
+int ac_tonality_typed(const ac_psy_plan* plan, const void* X, void* t, int dtype, int B, int F, int C, void* stream);
+int ac_mask_threshold_typed(const ac_psy_plan* plan, const void* X, const void* t, double drown, void* thr, int dtype,
+                            int B, int F, int C, void* stream);
+int ac_amplitude_to_db_typed(const void* a, void* out, size_t n, int norm, int dtype, void* stream);
+int ac_add_noise_typed(const void* X, const void* thr, void* out, size_t n, uint64_t seed, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -590,3 +590,146 @@ def test_plan_and_stream_lifecycle():
     [t_.join() for t_ in th]
     for o in outs:
         assert torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]) and torch.equal(o[2], ref[2])
+
+
+# ---- compute_dtype variants ------------------------------------------------------------
+
+def _bf16_round(a):
+    """float64 array -> the values a torch.bfloat16 tensor holds (round to nearest even)"""
+    return torch.from_numpy(np.asarray(a, np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
+
+
+@pytest.mark.parametrize("N,wt,C", [(1024, "vorbis", 2), (64, "sine", 1), (12, "vorbis", 3), (16, "rect", 2), (2048, "vorbis", 1)])
+def test_float64_filter_bank_vs_oracle(N, wt, C):
+    """compute_dtype = float64: float64 tensors, arithmetic and constants -- agrees with the oracle to rounding"""
+    rng = np.random.default_rng(N + C)
+    x = rng.uniform(-1, 1, (2, 4 * N, C))
+    m = audiocodec_amd.MDCTransformer(N, window_type=wt, compute_dtype=torch.float64)
+    o = MDCTOracle(N, wt, np.float64)
+    X = m.transform(dev(x))
+    assert X.dtype == torch.float64
+    Xo = o.transform(x)
+    assert rel_peak(host(X), Xo) <= 1e-12
+    xh = host(m.inverse_transform(X))
+    assert np.max(np.abs(xh - o.inverse_transform(Xo))) <= 1e-12
+    if wt != "rect":
+        assert np.max(np.abs(xh[:, N:-N] - x)) <= 1e-12
+    with pytest.raises(ValueError):
+        m.transform(dev(x.astype(np.float32)))              # no implicit cast, as in the reference
+    with pytest.raises(NotImplementedError):
+        m.transform(dev(x).requires_grad_())
+
+
+@pytest.mark.parametrize("sr,N,M,C", [(48000, 1024, 64, 2), (44100, 256, 48, 1), (48000, 2048, 64, 3)])
+def test_float64_masking_model_vs_oracle(sr, N, M, C):
+    rng = np.random.default_rng(N + M)
+    env = np.logspace(-5, 0, N).reshape(1, 1, N, 1)
+    X = rng.uniform(-1, 1, (2, 3, N, C)) * env * rng.uniform(1e-3, 1, (2, 3, 1, C))
+    X[0, 0, :, 0] = 0.0
+    p = audiocodec_amd.PsychoacousticModel(sr, filter_bands_n=N, bark_bands_n=M, compute_dtype=torch.float64)
+    o = PsychoOracle(sr, N, M, compute_dtype=np.float64)
+    np.testing.assert_allclose(p.W.numpy(), o.W, rtol=1e-11, atol=1e-14)   # libm vs numpy in the Bark edges
+    t = p.tonality(dev(X))
+    to = o.tonality(X)
+    assert t.dtype == torch.float64 and np.max(np.abs(host(t) - to)) <= 1e-12
+    for drown in (0.0, 0.4):
+        thr = host(p.global_masking_threshold(dev(X), t, drown))
+        assert rel_elem(thr, o.global_masking_threshold(X, to, drown)) <= 1e-10
+    a = dev(rng.uniform(-1, 1, 1000))
+    np.testing.assert_allclose(host(p.amplitude_to_dB(a)), np.maximum(10 * np.log10(np.maximum(1e-14, host(a) ** 2)) + 120, -20), atol=1e-10)
+    assert float(p.amplitude_to_dB_norm(a).min()) >= 0.0
+    thr_t = dev(np.full(X.shape, 0.3))
+    y64 = p.add_noise(dev(X), thr_t, seed=9)
+    p32 = audiocodec_amd.PsychoacousticModel(sr, filter_bands_n=N, bark_bands_n=M)
+    y32 = p32.add_noise(dev(X.astype(np.float32)), thr_t.float(), seed=9)
+    assert float((y64 - y32.double()).abs().max()) <= 1e-6     # the same normals for the same seed
+
+
+def test_float32_kernels_vs_float64_kernels_at_full_size():
+    """BASELINE configs[1] at its full size, element by element on the device: the wave-level float32 kernels against the
+    float64 kernels on the same input (the float64 kernels are themselves held to the oracle at 1e-12 above)."""
+    N, B, K, C = 1024, 256, 468, 2
+    g = torch.Generator(device="cuda").manual_seed(77)
+    x = torch.rand(B, K * N, C, device="cuda", generator=g) * 2 - 1
+    c32 = audiocodec_amd.AudioCodec(48000, N)
+    X, t, thr = c32.encode(x)
+    xh = c32.decode(X)
+    assert float((xh[:, N:-N] - x).abs().max()) <= LSB
+    del xh
+    m64 = audiocodec_amd.MDCTransformer(N, compute_dtype=torch.float64)
+    p64 = audiocodec_amd.PsychoacousticModel(48000, N, compute_dtype=torch.float64)
+    step = 32                                                # clips per float64 pass (memory: 2 x 8 bytes per sample)
+    worst_X = worst_l2 = worst_t = worst_thr = 0.0
+    for b in range(0, B, step):
+        X64 = m64.transform(x[b:b + step].double())
+        d = (X[b:b + step].double() - X64)
+        peak = X64.abs().amax(dim=2, keepdim=True).clamp_min(1e-30)
+        worst_X = max(worst_X, float((d.abs().amax(dim=2, keepdim=True) / peak).max()))
+        worst_l2 = max(worst_l2, float(d.norm() / X64.norm()))
+        t64 = p64.tonality(X64)
+        worst_t = max(worst_t, float((t[b:b + step].double() - t64).abs().max()))
+        thr64 = p64.global_masking_threshold(X64, t64)
+        worst_thr = max(worst_thr, float(((thr[b:b + step].double() - thr64).abs() / thr64).max()))
+        del X64, d, t64, thr64
+    assert worst_X <= TOL and worst_l2 <= TOL, (worst_X, worst_l2)
+    assert worst_t <= 2e-5, worst_t
+    assert worst_thr <= 2e-4, worst_thr                       # threshold of the float32 X and t (two rounding sources)
+
+
+@pytest.mark.parametrize("N,wt,C", [(1024, "vorbis", 2), (256, "sine", 1), (12, "vorbis", 3), (2048, "vorbis", 2), (64, "rect", 3)])
+def test_bfloat16_filter_bank(N, wt, C):
+    """compute_dtype = bfloat16: bfloat16 tensors, float32 arithmetic.  Tolerance: the output rounding of bfloat16
+    (2^-9 of each value) on top of the float32 kernels' own error -- 4e-3 of the frame's peak."""
+    rng = np.random.default_rng(N)
+    x = _bf16_round(rng.uniform(-1, 1, (2, 5 * N, C)))
+    m = audiocodec_amd.MDCTransformer(N, window_type=wt, compute_dtype=torch.bfloat16)
+    o = MDCTOracle(N, wt, np.float64)
+    X = m.transform(dev(x).to(torch.bfloat16))
+    assert X.dtype == torch.bfloat16
+    Xo = o.transform(x)
+    assert rel_peak(host(X.double()), Xo) <= 4e-3
+    xh = host(m.inverse_transform(X).double())
+    ref = o.inverse_transform(host(X.double()))              # the oracle on the very coefficients the kernel read
+    assert np.max(np.abs(xh - ref)) <= 4e-3 * max(1.0, np.max(np.abs(ref)))
+    if wt != "rect":
+        assert np.max(np.abs(xh[:, N:-N] - x)) <= 2e-2       # round trip through bfloat16 coefficients
+
+
+@pytest.mark.parametrize("sr,N,M,C", [(48000, 1024, 64, 2), (44100, 256, 48, 3), (48000, 2048, 64, 1)])
+def test_bfloat16_masking_model(sr, N, M, C):
+    rng = np.random.default_rng(M + C)
+    env = np.logspace(-4, 0, N).reshape(1, 1, N, 1)
+    X = _bf16_round(rng.uniform(-1, 1, (2, 3, N, C)) * env * rng.uniform(1e-2, 1, (2, 3, 1, C)))
+    p = audiocodec_amd.PsychoacousticModel(sr, filter_bands_n=N, bark_bands_n=M, compute_dtype=torch.bfloat16)
+    o = PsychoOracle(sr, N, M, compute_dtype=np.float64)
+    Xd = dev(X).to(torch.bfloat16)
+    t = p.tonality(Xd)
+    assert t.dtype == torch.bfloat16
+    assert np.max(np.abs(host(t.double()) - o.tonality(X))) <= 4e-3     # 2^-9 of a value in [0, 1]
+    tb = host(t.double())
+    thr = host(p.global_masking_threshold(Xd, t, 0.1).double())
+    assert rel_elem(thr, o.global_masking_threshold(X, tb, 0.1)) <= 6e-3
+    dB = p.amplitude_to_dB(Xd)
+    ref = np.maximum(10 * np.log10(np.maximum(1e-14, X ** 2)) + 120, -20)
+    assert dB.dtype == torch.bfloat16 and np.max(np.abs(host(dB.double()) - ref)) <= 0.5   # 2^-9 of values up to 120
+    y = p.add_noise(Xd, torch.full_like(Xd, 0.25), seed=3)
+    assert y.dtype == torch.bfloat16 and abs(float((y.double() - Xd.double()).std()) - 0.25 / 6) < 2e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.bfloat16])
+def test_codec_in_other_compute_dtypes(dtype):
+    N = 256
+    x = (torch.rand(2, 6 * N, 2, device="cuda") * 2 - 1).to(dtype)
+    codec = audiocodec_amd.AudioCodec(48000, N, compute_dtype=dtype)
+    X, t, thr = codec.encode(x, drown=0.3)
+    assert X.dtype == t.dtype == thr.dtype == dtype
+    Xu = codec.mdct.transform(x)
+    assert torch.equal(X, Xu) and torch.equal(t, codec.psy.tonality(Xu))
+    assert torch.equal(thr, codec.psy.global_masking_threshold(Xu, t, 0.3))
+    xh = codec.decode(X)
+    assert xh.dtype == dtype
+    assert float((xh[:, N:-N] - x).double().abs().max()) <= (1e-12 if dtype == torch.float64 else 2e-2)
+    with pytest.raises(NotImplementedError):
+        audiocodec_amd.StreamingMDCT(codec.mdct, 2, 2)
+    with pytest.raises(NotImplementedError):
+        codec.psy.tonality(X.clone().requires_grad_())

@@ -31,7 +31,7 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(lib, s), "libaudiocodec_amd.so does not export %s" % s
     assert sorted(_lib.PROTOTYPES) == syms, "ctypes prototypes and header disagree"
-    assert lib.ac_version() == 120
+    assert lib.ac_version() == 130
 
 
 def test_library_contains_gfx950_code_object():
@@ -100,7 +100,11 @@ def test_constructor_validation():
     with pytest.raises(TypeError):
         audiocodec_amd.PsychoacousticModel(48000, compute_dtype=torch.float16)
     with pytest.raises(NotImplementedError):
-        audiocodec_amd.PsychoacousticModel(48000, compute_dtype=torch.float64)
+        audiocodec_amd.MDCTransformer(8, compute_dtype=torch.float16)
+    p64 = audiocodec_amd.PsychoacousticModel(48000, compute_dtype=torch.float64)
+    assert p64.W.dtype == torch.float64 and p64._dB_MAX.dtype == torch.float64
+    assert float((p64.W.float() - audiocodec_amd.PsychoacousticModel(48000).W).abs().max()) < 1e-7
+    assert audiocodec_amd.PsychoacousticModel(48000, compute_dtype="bfloat16").W.dtype == torch.float32
     assert audiocodec_amd.MDCTransformer(8, window_type=None)._window == 2
     assert audiocodec_amd.MDCTransformer(8, window_type="SINE")._window == 1
     assert audiocodec_amd.MDCTransformer(8, window_type="hann")._window == 2
@@ -110,6 +114,8 @@ def test_constructor_validation():
     assert b"even" in lib.ac_last_error()
     with pytest.raises(ValueError):
         _lib.check(lib.ac_mdct_fold_coefficients_host(8, 9, (ctypes.c_double * 32)()))
+    assert lib.ac_mdct_forward_typed(None, None, None, 9, 1, 1, 1, None) == _lib.AC_EINVAL
+    assert b"AC_F32" in lib.ac_last_error()
     assert lib.ac_psy_plan_create_ex(1024, 64, 48000.0, 0.6, 0, 7, ctypes.byref(out)) == _lib.AC_EINVAL
     assert b"AC_SPREAD" in lib.ac_last_error()
     with pytest.raises(ValueError):
