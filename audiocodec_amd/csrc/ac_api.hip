@@ -449,9 +449,10 @@ static int encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const 
   DeviceGuard guard(mdct->device);
   hipStream_t s = (hipStream_t)stream;
   if (mdct->fast && psy->fast && !g_force_generic) {
-    // one fused launch, except mono at filters_n = 2048 where the fused kernel spills registers (7 at the 256 budget):
-    // there two wave-level launches, the second computing tonality and threshold in one pass over X
-    if (!(mdct->N == 2048 && C == 1))
+    // one fused launch, except at filters_n = 2048 for mono input and for 16-bit PCM with 3 or more channels, where the
+    // fused kernel would spill registers (7 / 4 at the 256 budget): there two wave-level launches, the second computing
+    // tonality and threshold in one pass over X
+    if (!(mdct->N == 2048 && (C == 1 || (pcm16 && C > 2))))
       return launch_fwd_fast(mdct, psy, x, pcm16, X, t, thr, drown, nullptr, B, K, K + 1, C, s);
     st = launch_fwd_fast(mdct, nullptr, x, pcm16, X, nullptr, nullptr, 0.f, nullptr, B, K, K + 1, C, s);
     if (!st) st = launch_psy_fast(psy, X, nullptr, t, thr, drown, B, K + 1, C, s);

@@ -1719,8 +1719,12 @@ static void launch_fwd_R(const FwdArgs& a, bool psy, int spread, int C, unsigned
     if (C == 2 && !PCM16 && spread == 1) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, false, 1>), dim3(grid), blk, 0, s, a);
     else if (C == 2 && !PCM16 && spread == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, false, 2>), dim3(grid), blk, 0, s, a);
     else if (C == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, PCM16>), dim3(grid), blk, 0, s, a);
-    else if (C == 1) hipLaunchKernelGGL((k_fwd_fast<R, 2, true, AC_WAVES_PSY, PCM16>), dim3(grid), blk, 0, s, a);
-    else hipLaunchKernelGGL((k_fwd_fast<R, 1, true, AC_WAVES_PSY, PCM16>), dim3(grid), blk, 0, s, a);
+    else if (C == 1) {
+      // (R = 16: the caller runs transform and masking model as two launches, see encode_fused in ac_api.hip)
+      if constexpr (R == 8) hipLaunchKernelGGL((k_fwd_fast<R, 2, true, AC_WAVES_PSY, PCM16>), dim3(grid), blk, 0, s, a);
+    } else {
+      if constexpr (R == 8 || !PCM16) hipLaunchKernelGGL((k_fwd_fast<R, 1, true, AC_WAVES_PSY, PCM16>), dim3(grid), blk, 0, s, a);
+    }
     return;
   }
   const dim3 blk(AC_WAVES * 64);

@@ -534,7 +534,7 @@ def test_autograd_of_the_masking_model(path, sr, N, M, C, drown):
     assert float(torch.linalg.vector_norm(X2.grad.double() - Xd2.grad) / torch.linalg.vector_norm(Xd2.grad)) <= 1e-3
 
 
-@pytest.mark.parametrize("N,C", [(1024, 2), (1024, 1), (2048, 2), (1024, 3)])
+@pytest.mark.parametrize("N,C", [(1024, 2), (1024, 1), (2048, 2), (1024, 3), (2048, 1), (2048, 3)])
 def test_pcm16_at_the_boundary(N, C):
     """int16 PCM in / out: bit-identical to the float path fed pcm / 32768, and the round trip returns the PCM exactly."""
     B, K = 3, 5
