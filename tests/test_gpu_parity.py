@@ -733,3 +733,42 @@ def test_codec_in_other_compute_dtypes(dtype):
         audiocodec_amd.StreamingMDCT(codec.mdct, 2, 2)
     with pytest.raises(NotImplementedError):
         codec.psy.tonality(X.clone().requires_grad_())
+
+
+def test_fuzz_wave_kernels_against_the_generic_kernels():
+    """seeded random shapes (ragged batch / block / channel counts, both wave-level sizes, both Princen-Bradley windows):
+    every entry point on the wave-level kernels against the O(N^2) kernels on the same device tensors"""
+    rng = np.random.default_rng(2024)
+    lib = _lib.load()
+    for case in range(36):
+        N = int(rng.choice([1024, 2048]))
+        wt = str(rng.choice(["vorbis", "sine"]))
+        B, K, C = int(rng.integers(1, 6)), int(rng.integers(0, 8)), int(rng.integers(1, 6))
+        drown = float(rng.choice([0.0, 0.25, 1.0]))
+        x = torch.from_numpy(rng.uniform(-1, 1, (B, K * N, C)).astype(np.float32)).cuda()
+        if K > 1:
+            x[0, N:2 * N] *= 1e-4                               # a quiet block
+        codec = audiocodec_amd.AudioCodec(48000, N, window_type=wt)
+        assert codec.mdct.is_fast() and codec.psy.is_fast()
+        lib.ac_set_force_generic(0)
+        X, t, thr = codec.encode(x, drown=drown)
+        Xs = codec.mdct.transform(x)
+        ts = codec.psy.tonality(X)
+        thrs = codec.psy.global_masking_threshold(X, t, drown)
+        xh = codec.decode(X)
+        lib.ac_set_force_generic(1)
+        try:
+            Xg, tg, thrg = codec.encode(x, drown=drown)
+            xg = codec.decode(X)
+        finally:
+            lib.ac_set_force_generic(0)
+        tag = "case %d: N=%d %s B=%d K=%d C=%d" % (case, N, wt, B, K, C)
+        assert tuple(X.shape) == (B, K + 1, N, C) and tuple(xh.shape) == (B, (K + 2) * N, C), tag
+        peak = Xg.abs().amax(dim=2, keepdim=True).clamp_min(1e-20)
+        assert float(((X - Xg).abs() / peak).max()) <= TOL, tag
+        assert float(((Xs - Xg).abs() / peak).max()) <= TOL, tag
+        assert float((t - tg).abs().max()) <= 2e-5 and float((ts - tg).abs().max()) <= 2e-5, tag
+        assert float(((thr - thrg).abs() / thrg).max()) <= 2e-4 and float(((thrs - thrg).abs() / thrg).max()) <= 2e-4, tag
+        assert float((xh - xg).abs().max()) <= 2e-6, tag
+        if K > 0:
+            assert float((xh[:, N:-N] - x).abs().max()) <= LSB, tag
