@@ -42,6 +42,8 @@ PROTOTYPES = {
     "ac_tonality_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ac_mask_threshold_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_int, c_int, c_int, c_int,
                                         c_void_p]),
+    "ac_encode_fused_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_int,
+                                      c_int, c_int, c_void_p]),
     "ac_amplitude_to_db_typed": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "ac_add_noise_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_uint64, c_int, c_void_p]),
     "ac_mdct_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -53,15 +53,13 @@ class AudioCodec:
         B, S, C = x.shape
         K = S // self.filters_n
         if self.compute_dtype != torch.float32:
-            # float64 / bfloat16: the three typed entry points in sequence (the fused kernel is float32)
+            # float64: the three typed entry points in sequence; bfloat16: the fused wave-level kernel where it applies
             if x.dtype != self.compute_dtype:
                 raise ValueError("x has dtype %s but compute_dtype is %s" % (x.dtype, self.compute_dtype))
-            lib, dt, st = self._lib, self.mdct._dtype_id, _host.stream_ptr(x.device)
             with torch.cuda.device(x.device):
-                _lib.check(lib.ac_mdct_forward_typed(self.mdct._plan(x.device), _host.ptr(x), _host.ptr(X), dt, B, K, C, st))
-                _lib.check(lib.ac_tonality_typed(self.psy._plan(x.device), _host.ptr(X), _host.ptr(t), dt, B, K + 1, C, st))
-                _lib.check(lib.ac_mask_threshold_typed(self.psy._plan(x.device), _host.ptr(X), _host.ptr(t), float(drown),
-                                                       _host.ptr(thr), dt, B, K + 1, C, st))
+                _lib.check(self._lib.ac_encode_fused_typed(
+                    self.mdct._plan(x.device), self.psy._plan(x.device), _host.ptr(x), _host.ptr(X), _host.ptr(t),
+                    _host.ptr(thr), float(drown), self.mdct._dtype_id, B, K, C, _host.stream_ptr(x.device)))
             return
         fn = self._lib.ac_encode_fused_pcm16 if x.dtype == torch.int16 else self._lib.ac_encode_fused
         with torch.cuda.device(x.device):

@@ -592,6 +592,8 @@ int ac_mdct_forward_typed(const ac_mdct_plan* p, const void* x, void* X, int dty
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == AC_F64) return launch_fwd_f64(p, static_cast<const double*>(x), static_cast<double*>(X), B, K, K + 1, C, s);
+  if (p->fast && !g_force_generic && C <= 2)   // bfloat16 on the wave-level kernels (stereo / mono)
+    return launch_fwd_fast(p, nullptr, x, 2, static_cast<float*>(X), nullptr, nullptr, 0.f, nullptr, B, K, K + 1, C, s);
   return launch_fwd_bf16(p, static_cast<const bf16_t*>(x), static_cast<bf16_t*>(X), B, K, K + 1, C, s);
 }
 
@@ -606,6 +608,8 @@ int ac_mdct_inverse_typed(const ac_mdct_plan* p, const void* X, void* x, int dty
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == AC_F64) return launch_inv_f64(p, static_cast<const double*>(X), static_cast<double*>(x), B, Kp, Kp + 1, C, s);
+  if (p->fast && !g_force_generic && C <= 2)
+    return launch_inv_fast(p, static_cast<const float*>(X), x, 2, nullptr, nullptr, B, Kp, Kp + 1, C, s);
   return launch_inv_bf16(p, static_cast<const bf16_t*>(X), static_cast<bf16_t*>(x), B, Kp, Kp + 1, C, s);
 }
 
@@ -620,6 +624,8 @@ int ac_tonality_typed(const ac_psy_plan* p, const void* X, void* t, int dtype, i
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == AC_F64) return launch_tonality_f64(p, static_cast<const double*>(X), static_cast<double*>(t), B, F, C, s);
+  if (p->fast && !g_force_generic && C <= 2)
+    return launch_psy_fast(p, static_cast<const float*>(X), nullptr, static_cast<float*>(t), nullptr, 0.f, B, F, C, s, 2);
   return launch_tonality_bf16(p, static_cast<const bf16_t*>(X), static_cast<bf16_t*>(t), B, F, C, s);
 }
 
@@ -639,8 +645,37 @@ int ac_mask_threshold_typed(const ac_psy_plan* p, const void* X, const void* t, 
   if (dtype == AC_F64)
     return launch_threshold_f64(p, static_cast<const double*>(X), static_cast<const double*>(t), drown,
                                 static_cast<double*>(thr), B, F, C, s);
+  if (p->fast && !g_force_generic && C <= 2)
+    return launch_psy_fast(p, static_cast<const float*>(X), static_cast<const float*>(t), nullptr, static_cast<float*>(thr),
+                           (float)drown, B, F, C, s, 2);
   return launch_threshold_bf16(p, static_cast<const bf16_t*>(X), static_cast<const bf16_t*>(t), (float)drown,
                                static_cast<bf16_t*>(thr), B, F, C, s);
+}
+
+int ac_encode_fused_typed(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const void* x, void* X, void* t, void* thr,
+                          double drown, int dtype, int B, int K, int C, void* stream) {
+  AC_REQUIRE_DTYPE(dtype);
+  if (dtype == AC_F32)
+    return ac_encode_fused(mdct, psy, static_cast<const float*>(x), static_cast<float*>(X), static_cast<float*>(t),
+                           static_cast<float*>(thr), (float)drown, B, K, C, stream);
+  AC_REQUIRE(mdct != nullptr && psy != nullptr, "plan is NULL");
+  AC_REQUIRE(mdct->N == psy->N, "mdct filters_n (%d) != psychoacoustic filter_bands_n (%d)", mdct->N, psy->N);
+  AC_REQUIRE(mdct->device == psy->device, "plans live on different devices");
+  int st = check_dims(B, K, C);
+  if (st) return st;
+  if (B == 0 || C == 0) return AC_OK;
+  AC_REQUIRE(X != nullptr && t != nullptr && thr != nullptr && (x != nullptr || K == 0), "NULL tensor pointer");
+  // bfloat16 tensors, stereo / mono, both plans wave-level: one fused launch (mono at filters_n = 2048 excepted, as in
+  // encode_fused); otherwise the three typed entry points in sequence
+  if (dtype == AC_BF16 && mdct->fast && psy->fast && !g_force_generic && C <= 2 && !(mdct->N == 2048 && C == 1)) {
+    DeviceGuard guard(mdct->device);
+    return launch_fwd_fast(mdct, psy, x, 2, static_cast<float*>(X), static_cast<float*>(t), static_cast<float*>(thr),
+                           (float)drown, nullptr, B, K, K + 1, C, (hipStream_t)stream);
+  }
+  st = ac_mdct_forward_typed(mdct, x, X, dtype, B, K, C, stream);
+  if (!st) st = ac_tonality_typed(psy, X, t, dtype, B, K + 1, C, stream);
+  if (!st) st = ac_mask_threshold_typed(psy, X, t, drown, thr, dtype, B, K + 1, C, stream);
+  return st;
 }
 
 int ac_amplitude_to_db_typed(const void* a, void* out, size_t n, int norm, int dtype, void* stream) {

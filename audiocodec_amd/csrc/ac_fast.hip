@@ -404,35 +404,45 @@ __device__ __forceinline__ void store_row(float* __restrict__ r0, float* __restr
   }
 }
 
-// ---- the same rows as 16-bit PCM (x = pcm / 32768; pcm = clamp(round(32768 x))) ------------------------------
+// ---- the same rows in 2-byte storage: 16-bit PCM (x = pcm / 32768; pcm = clamp(round(32768 x))) or bfloat16 ----------
 typedef short s4 __attribute__((ext_vector_type(4)));
 typedef short s2 __attribute__((ext_vector_type(2)));
 constexpr float kPcmScale = 1.0f / 32768.0f;
 __device__ __forceinline__ short to_pcm16(float v) {
   return (short)__float2int_rn(fminf(fmaxf(v * 32768.0f, -32768.0f), 32767.0f));
 }
+struct Pcm16Fmt {
+  static __device__ __forceinline__ float dec(short h) { return (float)h * kPcmScale; }
+  static __device__ __forceinline__ s2 enc2(float a, float b) { return s2{to_pcm16(a), to_pcm16(b)}; }
+};
+struct Bf16Fmt {   // storage = the upper half of the float32 pattern; stores round to nearest even (v_cvt_pk_bf16_f32)
+  static __device__ __forceinline__ float dec(short h) { return __uint_as_float((uint32_t)(uint16_t)h << 16); }
+  static __device__ __forceinline__ s2 enc2(float a, float b) {
+    return __builtin_bit_cast(s2, __builtin_convertvector(v2f{a, b}, v2b));
+  }
+};
 
-template <int CMODE, int R>
-__device__ __forceinline__ void load_row_pcm16(const int16_t* __restrict__ r0, const int16_t* __restrict__ r1, int C,
-                                               bool has1, int lane, v4f (&v)[R]) {
+template <typename FMT, int CMODE, int R>
+__device__ __forceinline__ void load_row_h(const int16_t* __restrict__ r0, const int16_t* __restrict__ r1, int C,
+                                           bool has1, int lane, v4f (&v)[R]) {
   if (CMODE == 0) {
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       const s4 p = reinterpret_cast<const s4*>(r0)[64 * i + lane];
-      v[i] = v4f{(float)p.x, (float)p.y, (float)p.z, (float)p.w} * kPcmScale;
+      v[i] = v4f{FMT::dec(p.x), FMT::dec(p.y), FMT::dec(p.z), FMT::dec(p.w)};
     }
   } else if (CMODE == 2) {
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       const s2 u = reinterpret_cast<const s2*>(r0)[64 * i + lane];
-      v[i] = v4f{(float)u.x * kPcmScale, 0.f, (float)u.y * kPcmScale, 0.f};
+      v[i] = v4f{FMT::dec(u.x), 0.f, FMT::dec(u.y), 0.f};
     }
     if (has1) {
 #pragma unroll
       for (int i = 0; i < R; ++i) {
         const s2 w = reinterpret_cast<const s2*>(r1)[64 * i + lane];
-        v[i].y = (float)w.x * kPcmScale;
-        v[i].w = (float)w.y * kPcmScale;
+        v[i].y = FMT::dec(w.x);
+        v[i].w = FMT::dec(w.y);
       }
     }
   } else {
@@ -440,51 +450,58 @@ __device__ __forceinline__ void load_row_pcm16(const int16_t* __restrict__ r0, c
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       const size_t step = (size_t)(128 * i) * C;
-      v[i] = v4f{(float)r0[step + off] * kPcmScale, 0.f, (float)r0[step + off + C] * kPcmScale, 0.f};
+      v[i] = v4f{FMT::dec(r0[step + off]), 0.f, FMT::dec(r0[step + off + C]), 0.f};
     }
     if (has1) {
 #pragma unroll
       for (int i = 0; i < R; ++i) {
         const size_t step = (size_t)(128 * i) * C;
-        v[i].y = (float)r1[step + off] * kPcmScale;
-        v[i].w = (float)r1[step + off + C] * kPcmScale;
+        v[i].y = FMT::dec(r1[step + off]);
+        v[i].w = FMT::dec(r1[step + off + C]);
       }
     }
   }
 }
 
-template <int CMODE, int R>
-__device__ __forceinline__ void store_row_pcm16(int16_t* __restrict__ r0, int16_t* __restrict__ r1, int C, bool has1,
-                                                int lane, const v4f (&v)[R]) {
+template <typename FMT, int CMODE, int R>
+__device__ __forceinline__ void store_row_h(int16_t* __restrict__ r0, int16_t* __restrict__ r1, int C, bool has1,
+                                            int lane, const v4f (&v)[R]) {
   if (CMODE == 0) {
 #pragma unroll
-    for (int i = 0; i < R; ++i)
-      reinterpret_cast<s4*>(r0)[64 * i + lane] = s4{to_pcm16(v[i].x), to_pcm16(v[i].y), to_pcm16(v[i].z), to_pcm16(v[i].w)};
+    for (int i = 0; i < R; ++i) {
+      const s2 lo = FMT::enc2(v[i].x, v[i].y), hi = FMT::enc2(v[i].z, v[i].w);
+      reinterpret_cast<s4*>(r0)[64 * i + lane] = s4{lo.x, lo.y, hi.x, hi.y};
+    }
   } else if (CMODE == 2) {
 #pragma unroll
-    for (int i = 0; i < R; ++i) reinterpret_cast<s2*>(r0)[64 * i + lane] = s2{to_pcm16(v[i].x), to_pcm16(v[i].z)};
+    for (int i = 0; i < R; ++i) reinterpret_cast<s2*>(r0)[64 * i + lane] = FMT::enc2(v[i].x, v[i].z);
     if (has1) {
 #pragma unroll
-      for (int i = 0; i < R; ++i) reinterpret_cast<s2*>(r1)[64 * i + lane] = s2{to_pcm16(v[i].y), to_pcm16(v[i].w)};
+      for (int i = 0; i < R; ++i) reinterpret_cast<s2*>(r1)[64 * i + lane] = FMT::enc2(v[i].y, v[i].w);
     }
   } else {
     const int off = 2 * lane * C;
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       const size_t step = (size_t)(128 * i) * C;
-      r0[step + off] = to_pcm16(v[i].x);
-      r0[step + off + C] = to_pcm16(v[i].z);
+      const s2 e = FMT::enc2(v[i].x, v[i].z);
+      r0[step + off] = e.x;
+      r0[step + off + C] = e.y;
     }
     if (has1) {
 #pragma unroll
       for (int i = 0; i < R; ++i) {
         const size_t step = (size_t)(128 * i) * C;
-        r1[step + off] = to_pcm16(v[i].y);
-        r1[step + off + C] = to_pcm16(v[i].w);
+        const s2 e = FMT::enc2(v[i].y, v[i].w);
+        r1[step + off] = e.x;
+        r1[step + off + C] = e.y;
       }
     }
   }
 }
+// IOF: 0 = float32 tensors; 1 = 16-bit PCM on the PCM side (spectra float32); 2 = bfloat16 tensors throughout
+template <int IOF> struct RowFmt { using type = Pcm16Fmt; };
+template <> struct RowFmt<2> { using type = Bf16Fmt; };
 
 // wave-wide sum, result uniform (scalar register): xor butterflies inside each row of 16 lanes, then the two
 // row broadcasts of the DPP unit; no LDS traffic
@@ -626,7 +643,7 @@ __device__ __forceinline__ v2f spread_mfma(v2f Q, const char* mf, int lane) {
 
 // buf = the wave's LDS region (WAVE_LDS_PSY bytes), pimg = the workgroup's copy of the psy image
 // lds0 = base of the workgroup's LDS object (the absolute offsets of PsyLane count from it)
-template <int R, bool WANT_T, bool WANT_THR, int SPREAD = 0>
+template <int R, bool WANT_T, bool WANT_THR, int SPREAD = 0, bool T_BF16 = false>
 __device__ __forceinline__ void psy_stage(const v4f (&xq)[R], char* lds0, char* buf, const uint32_t* pimg,
                                           const PsyLane<R>& pc, const PsyParams& pp, int lane, v2f& t, v4f (&thr)[R]) {
   using P = PsyGeo<R>;
@@ -650,6 +667,10 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[R], char* lds0, char* 
     const v2f sfm = 3.0102999566398120f * (slog * (1.0f / P::FN) - log2v(am));
     const v2f tt = sfm * (-1.0f / 60.0f);
     t = v2f{fminf(tt.x, 1.0f), fminf(tt.y, 1.0f)};
+    if (T_BF16) {   // bfloat16 tensors: the threshold is computed from the tonality the caller gets
+      const s2 e = Bf16Fmt::enc2(t.x, t.y);
+      t = v2f{Bf16Fmt::dec(e.x), Bf16Fmt::dec(e.y)};
+    }
   }
   if (!WANT_THR) return;
 
@@ -790,7 +811,7 @@ struct FwdArgs {
 // register (r + 4) & 7) and the odd sample of granule 767 - e (lane 63 - lane, register (3 - r) & 7).
 // With (A, B) = COEF[e]:  carried part (block n-1) = B xe + A xo;  current part (block n) = B xo - A xe (r < 4),
 // A xe - B xo (r >= 4)   (Princen-Bradley windows make the 2x2 fold blocks rotations).
-template <int R, int CMODE, bool PSY, int NW, bool PCM16 = false, int SPREAD = 0>
+template <int R, int CMODE, bool PSY, int NW, int IOF = 0, int SPREAD = 0>
 __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY, SPREAD>())) void k_fwd_fast(FwdArgs a) {
   using G = Geo<R>;
   // one LDS object: [NW wave buffers | table image | psy image | bf16 tiles of the spreading matrix (SPREAD > 0)]
@@ -819,9 +840,9 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY, SPREAD>())) void k_fwd
   long long pair = f0 / a.F;
   int n = (int)(f0 % a.F);
   const long long npairs = a.npairs;
-  using pcm_t = typename std::conditional<PCM16, int16_t, float>::type;
+  using pcm_t = typename std::conditional<IOF != 0, int16_t, float>::type;
   const pcm_t* __restrict__ xin = static_cast<const pcm_t*>(a.x);
-  const pcm_t* __restrict__ xstate = PCM16 ? nullptr : reinterpret_cast<const pcm_t*>(a.prev_block);
+  const pcm_t* __restrict__ xstate = IOF != 0 ? nullptr : reinterpret_cast<const pcm_t*>(a.prev_block);
 
   // loads block fn (WHICH 0) or block fn-1 (WHICH 1) of frame (pr, fn) in natural order.  A missing block (before the
   // first / after the last) is loaded from a neighbouring, valid address and zeroed when it is consumed (returns false),
@@ -850,7 +871,7 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY, SPREAD>())) void k_fwd
       s0 = s1 = reinterpret_cast<const pcm_t*>(a.X);
       ok = false;
     }
-    if constexpr (PCM16) load_row_pcm16<CMODE, R>(s0, s1, C, q.has1, lane, dst);
+    if constexpr (IOF != 0) load_row_h<typename RowFmt<IOF>::type, CMODE, R>(s0, s1, C, q.has1, lane, dst);
     else load_row<CMODE, ((AC_NT_LOAD >> decltype(which)::value) & 1) != 0, R>(s0, s1, C, q.has1, lane, dst);
     return ok;
   };
@@ -949,7 +970,12 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY, SPREAD>())) void k_fwd
     }
     const size_t o0 = row_off(pq.b0, a.F, n, blk, pq.c0), o1 = row_off(pq.b1, a.F, n, blk, pq.c1);
     const size_t t0 = ((size_t)pq.b0 * a.F + (size_t)n) * C + pq.c0, t1 = ((size_t)pq.b1 * a.F + (size_t)n) * C + pq.c1;
-    store_row<CMODE, R>(a.X + o0, a.X + o1, C, pq.has1, lane, row);
+    if constexpr (IOF == 2) {
+      int16_t* Xh = reinterpret_cast<int16_t*>(a.X);
+      store_row_h<Bf16Fmt, CMODE, R>(Xh + o0, Xh + o1, C, pq.has1, lane, row);
+    } else {
+      store_row<CMODE, R>(a.X + o0, a.X + o1, C, pq.has1, lane, row);
+    }
     // next frame of this wave
     pair += dpair;
     n += dn;
@@ -961,11 +987,30 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY, SPREAD>())) void k_fwd
     if constexpr (PSY) {
       v2f tt;
       v4f th[R];
-      psy_stage<R, true, true, SPREAD>(row, lds, buf, pimg, pc, a.psy, lane, tt, th);
-      store_row<CMODE, R>(a.thr + o0, a.thr + o1, C, pq.has1, lane, th);
-      if (lane == 0) {
-        a.t[t0] = tt.x;
-        if (pq.has1) a.t[t1] = tt.y;
+      if constexpr (IOF == 2) {
+        // the masking model sees the spectrum the caller gets: the bfloat16-rounded coefficients
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          const s2 lo = Bf16Fmt::enc2(row[i].x, row[i].y), hi = Bf16Fmt::enc2(row[i].z, row[i].w);
+          row[i] = v4f{Bf16Fmt::dec(lo.x), Bf16Fmt::dec(lo.y), Bf16Fmt::dec(hi.x), Bf16Fmt::dec(hi.y)};
+        }
+      }
+      psy_stage<R, true, true, SPREAD, IOF == 2>(row, lds, buf, pimg, pc, a.psy, lane, tt, th);
+      if constexpr (IOF == 2) {
+        int16_t* th_h = reinterpret_cast<int16_t*>(a.thr);
+        int16_t* t_h = reinterpret_cast<int16_t*>(a.t);
+        store_row_h<Bf16Fmt, CMODE, R>(th_h + o0, th_h + o1, C, pq.has1, lane, th);
+        if (lane == 0) {
+          const s2 e = Bf16Fmt::enc2(tt.x, tt.y);
+          t_h[t0] = e.x;
+          if (pq.has1) t_h[t1] = e.y;
+        }
+      } else {
+        store_row<CMODE, R>(a.thr + o0, a.thr + o1, C, pq.has1, lane, th);
+        if (lane == 0) {
+          a.t[t0] = tt.x;
+          if (pq.has1) a.t[t1] = tt.y;
+        }
       }
     }
   }
@@ -1018,8 +1063,8 @@ __device__ __forceinline__ void idct_frame(const v4f (&frm)[R], char* buf, gtab_
   }
 }
 
-template <int R, int CMODE, int NW, bool PCM16 = false>
-__global__ __launch_bounds__(NW * 64, (PCM16 ? 2 : wpe<R, CMODE>())) void k_inv_fast(InvArgs a) {
+template <int R, int CMODE, int NW, int IOF = 0>
+__global__ __launch_bounds__(NW * 64, (IOF != 0 ? 2 : wpe<R, CMODE>())) void k_inv_fast(InvArgs a) {
   using G = Geo<R>;
   constexpr int FH = G::FH;
   __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS + G::TAB_LDS];
@@ -1045,10 +1090,14 @@ __global__ __launch_bounds__(NW * 64, (PCM16 ? 2 : wpe<R, CMODE>())) void k_inv_
   const bool has1 = pq.has1;
   const int n0 = sgm * a.seglen;
   const int n1 = min(a.nblk, n0 + a.seglen);
-  const float* X0 = a.X + row_off(pq.b0, a.Kp, 0, blk, pq.c0);   // frame 0 of the two signals
-  const float* X1 = a.X + row_off(pq.b1, a.Kp, 0, blk, pq.c1);
+  using spec_t = typename std::conditional<IOF == 2, int16_t, float>::type;   // storage of the spectrum
+  const spec_t* X0 = reinterpret_cast<const spec_t*>(a.X) + row_off(pq.b0, a.Kp, 0, blk, pq.c0);   // frame 0 of the two signals
+  const spec_t* X1 = reinterpret_cast<const spec_t*>(a.X) + row_off(pq.b1, a.Kp, 0, blk, pq.c1);
+  auto load_frame = [&](const spec_t* r0, const spec_t* r1, v4f (&dst)[R]) {
+    if constexpr (IOF == 2) load_row_h<Bf16Fmt, CMODE, R>(r0, r1, C, has1, lane, dst);
+    else load_row<CMODE, (AC_NT_LOAD & 4) != 0, R>(r0, r1, C, has1, lane, dst);
+  };
   const size_t ts0 = ((size_t)pq.b0 * C + pq.c0) * FH, ts1 = ((size_t)pq.b1 * C + pq.c1) * FH;   // stream state rows
-  constexpr bool NT = (AC_NT_LOAD & 4) != 0;
   constexpr bool AHEAD = (R == 8);   // the next frame in flight while the current one is transformed
   const bool left = valid && n0 >= 1;              // block n0 needs the aliased half of frame n0-1 ...
   const bool deferred = COOP && left && wave > 0;  // ... which the previous wave (strip sgm-1 of the same signals) hands over
@@ -1072,7 +1121,8 @@ __global__ __launch_bounds__(NW * 64, (PCM16 ? 2 : wpe<R, CMODE>())) void k_inv_
 #pragma unroll
     for (int i = 0; i < R; ++i) row[i] = v4f{xe[i].x, xe[i].y, xo[i].x, xo[i].y};
     const size_t o0 = row_off(pq.b0, a.nblk, n, blk, pq.c0), o1 = row_off(pq.b1, a.nblk, n, blk, pq.c1);
-    if constexpr (PCM16) store_row_pcm16<CMODE, R>(static_cast<int16_t*>(a.x) + o0, static_cast<int16_t*>(a.x) + o1, C, has1, lane, row);
+    if constexpr (IOF != 0)
+      store_row_h<typename RowFmt<IOF>::type, CMODE, R>(static_cast<int16_t*>(a.x) + o0, static_cast<int16_t*>(a.x) + o1, C, has1, lane, row);
     else store_row<CMODE, R>(static_cast<float*>(a.x) + o0, static_cast<float*>(a.x) + o1, C, has1, lane, row);
   };
 
@@ -1087,12 +1137,12 @@ __global__ __launch_bounds__(NW * 64, (PCM16 ? 2 : wpe<R, CMODE>())) void k_inv_
     if (left && !deferred) {
       // aliased half of frame n0-1 (always an existing frame: n0-1 < Kp)
       v4f row[R];
-      load_row<CMODE, NT, R>(X0 + (size_t)(n0 - 1) * blk, X1 + (size_t)(n0 - 1) * blk, C, has1, lane, row);
-      if (AHEAD && n0 < a.Kp) load_row<CMODE, NT, R>(X0 + (size_t)n0 * blk, X1 + (size_t)n0 * blk, C, has1, lane, ahead);
+      load_frame(X0 + (size_t)(n0 - 1) * blk, X1 + (size_t)(n0 - 1) * blk, row);
+      if (AHEAD && n0 < a.Kp) load_frame(X0 + (size_t)n0 * blk, X1 + (size_t)n0 * blk, ahead);
       v2f dummy[R];
       idct_frame<R>(row, buf, tab, p1, lane, dummy, carry);
     } else {
-      if (AHEAD && n0 < a.Kp) load_row<CMODE, NT, R>(X0 + (size_t)n0 * blk, X1 + (size_t)n0 * blk, C, has1, lane, ahead);
+      if (AHEAD && n0 < a.Kp) load_frame(X0 + (size_t)n0 * blk, X1 + (size_t)n0 * blk, ahead);
       if (!left && a.tail_in) {
 #pragma unroll
         for (int j2 = 0; j2 < R; ++j2) {
@@ -1107,10 +1157,10 @@ __global__ __launch_bounds__(NW * 64, (PCM16 ? 2 : wpe<R, CMODE>())) void k_inv_
     for (int n = n0; n < n1; ++n) {
       v2f now[R], nxt[R];
       if (n < a.Kp) {
-        if (!AHEAD) load_row<CMODE, NT, R>(X0 + (size_t)n * blk, X1 + (size_t)n * blk, C, has1, lane, ahead);
+        if (!AHEAD) load_frame(X0 + (size_t)n * blk, X1 + (size_t)n * blk, ahead);
         idct_frame<R>(ahead, buf, tab, p1, lane, now, nxt);
         if (AHEAD && n + 1 < n1 && n + 1 < a.Kp)
-          load_row<CMODE, NT, R>(X0 + (size_t)(n + 1) * blk, X1 + (size_t)(n + 1) * blk, C, has1, lane, ahead);
+          load_frame(X0 + (size_t)(n + 1) * blk, X1 + (size_t)(n + 1) * blk, ahead);
       } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -1171,7 +1221,7 @@ struct PsyArgs {
   long long ntasks;   // npairs * F
 };
 
-template <int R, int CMODE, bool WANT_T, bool WANT_THR, int NW, int SPREAD = 0>
+template <int R, int CMODE, bool WANT_T, bool WANT_THR, int NW, int SPREAD = 0, int IOF = 0>
 __global__ __launch_bounds__(NW * 64, (R == 8 ? AC_WPE : 2)) void k_psy_fast(PsyArgs a) {
   using P = PsyGeo<R>;
   __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS_PSY + P::PSY_LDS + mf_lds(SPREAD)];
@@ -1190,20 +1240,44 @@ __global__ __launch_bounds__(NW * 64, (R == 8 ? AC_WPE : 2)) void k_psy_fast(Psy
   const size_t o0 = row_off(pq.b0, a.F, f, blk, pq.c0), o1 = row_off(pq.b1, a.F, f, blk, pq.c1);
   const size_t t0 = ((size_t)pq.b0 * a.F + (size_t)f) * C + pq.c0, t1 = ((size_t)pq.b1 * a.F + (size_t)f) * C + pq.c1;
   v4f row[R], th[R];
-  load_row<CMODE, false, R>(a.X + o0, a.X + o1, C, has1, lane, row);
+  if constexpr (IOF == 2) {
+    const int16_t* Xh = reinterpret_cast<const int16_t*>(a.X);
+    load_row_h<Bf16Fmt, CMODE, R>(Xh + o0, Xh + o1, C, has1, lane, row);
+  } else {
+    load_row<CMODE, false, R>(a.X + o0, a.X + o1, C, has1, lane, row);
+  }
   v2f tt = {0.f, 0.f};
   if (!WANT_T) {
-    tt.x = a.t_in[t0];
-    tt.y = has1 ? a.t_in[t1] : 0.f;
+    if constexpr (IOF == 2) {
+      const int16_t* th_in = reinterpret_cast<const int16_t*>(a.t_in);
+      tt.x = Bf16Fmt::dec(th_in[t0]);
+      tt.y = has1 ? Bf16Fmt::dec(th_in[t1]) : 0.f;
+    } else {
+      tt.x = a.t_in[t0];
+      tt.y = has1 ? a.t_in[t1] : 0.f;
+    }
   }
   PsyLane<R> pc;
   if (WANT_THR) pc = load_psy_lane<R>(a.psy.tab, lane, (uint32_t)(wave * WAVE_LDS_PSY));
-  psy_stage<R, WANT_T, WANT_THR, SPREAD>(row, lds, buf, pimg, pc, a.psy, lane, tt, th);
-  if (WANT_T && lane == 0) {
-    a.t_out[t0] = tt.x;
-    if (has1) a.t_out[t1] = tt.y;
+  psy_stage<R, WANT_T, WANT_THR, SPREAD, IOF == 2>(row, lds, buf, pimg, pc, a.psy, lane, tt, th);
+  if constexpr (IOF == 2) {
+    if (WANT_T && lane == 0) {
+      int16_t* t_h = reinterpret_cast<int16_t*>(a.t_out);
+      const s2 e = Bf16Fmt::enc2(tt.x, tt.y);
+      t_h[t0] = e.x;
+      if (has1) t_h[t1] = e.y;
+    }
+    if (WANT_THR) {
+      int16_t* th_h = reinterpret_cast<int16_t*>(a.thr);
+      store_row_h<Bf16Fmt, CMODE, R>(th_h + o0, th_h + o1, C, has1, lane, th);
+    }
+  } else {
+    if (WANT_T && lane == 0) {
+      a.t_out[t0] = tt.x;
+      if (has1) a.t_out[t1] = tt.y;
+    }
+    if (WANT_THR) store_row<CMODE, R>(a.thr + o0, a.thr + o1, C, has1, lane, th);
   }
-  if (WANT_THR) store_row<CMODE, R>(a.thr + o0, a.thr + o1, C, has1, lane, th);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1711,29 +1785,44 @@ static unsigned persistent_grid(int cus, int wg_per_cu, long long ntasks, int nw
   return (unsigned)g;
 }
 
-template <int R, bool PCM16>
+template <int R, int IOF>
 static void launch_fwd_R(const FwdArgs& a, bool psy, int spread, int C, unsigned grid, hipStream_t s) {
+  constexpr bool PCM16 = IOF == 1;
+  if constexpr (IOF == 2) {
+    // bfloat16 tensors: stereo and mono kernels (other channel counts are served by the LDS-FFT tier, see ac_api.hip)
+    if (psy) {
+      const dim3 blk(AC_WAVES_PSY * 64);
+      if (C == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, 2>), dim3(grid), blk, 0, s, a);
+      else if constexpr (R == 8) hipLaunchKernelGGL((k_fwd_fast<R, 2, true, AC_WAVES_PSY, 2>), dim3(grid), blk, 0, s, a);
+      return;
+    }
+    const dim3 blk(AC_WAVES * 64);
+    if (C == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, false, AC_WAVES, 2>), dim3(grid), blk, 0, s, a);
+    else hipLaunchKernelGGL((k_fwd_fast<R, 2, false, AC_WAVES, 2>), dim3(grid), blk, 0, s, a);
+    return;
+  } else {
   if (psy) {
     const dim3 blk(AC_WAVES_PSY * 64);
     // the matrix-core forms of the spreading product serve the stereo float32 kernels; the others keep the f32 product
-    if (C == 2 && !PCM16 && spread == 1) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, false, 1>), dim3(grid), blk, 0, s, a);
-    else if (C == 2 && !PCM16 && spread == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, false, 2>), dim3(grid), blk, 0, s, a);
-    else if (C == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, PCM16>), dim3(grid), blk, 0, s, a);
+    if (C == 2 && !PCM16 && spread == 1) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, 0, 1>), dim3(grid), blk, 0, s, a);
+    else if (C == 2 && !PCM16 && spread == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, 0, 2>), dim3(grid), blk, 0, s, a);
+    else if (C == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, IOF>), dim3(grid), blk, 0, s, a);
     else if (C == 1) {
       // (R = 16: the caller runs transform and masking model as two launches, see encode_fused in ac_api.hip)
-      if constexpr (R == 8) hipLaunchKernelGGL((k_fwd_fast<R, 2, true, AC_WAVES_PSY, PCM16>), dim3(grid), blk, 0, s, a);
+      if constexpr (R == 8) hipLaunchKernelGGL((k_fwd_fast<R, 2, true, AC_WAVES_PSY, IOF>), dim3(grid), blk, 0, s, a);
     } else {
-      if constexpr (R == 8 || !PCM16) hipLaunchKernelGGL((k_fwd_fast<R, 1, true, AC_WAVES_PSY, PCM16>), dim3(grid), blk, 0, s, a);
+      if constexpr (R == 8 || !PCM16) hipLaunchKernelGGL((k_fwd_fast<R, 1, true, AC_WAVES_PSY, IOF>), dim3(grid), blk, 0, s, a);
     }
     return;
   }
   const dim3 blk(AC_WAVES * 64);
-  if (C == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, false, AC_WAVES, PCM16>), dim3(grid), blk, 0, s, a);
-  else if (C == 1) hipLaunchKernelGGL((k_fwd_fast<R, 2, false, AC_WAVES, PCM16>), dim3(grid), blk, 0, s, a);
-  else hipLaunchKernelGGL((k_fwd_fast<R, 1, false, AC_WAVES, PCM16>), dim3(grid), blk, 0, s, a);
+  if (C == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, false, AC_WAVES, IOF>), dim3(grid), blk, 0, s, a);
+  else if (C == 1) hipLaunchKernelGGL((k_fwd_fast<R, 2, false, AC_WAVES, IOF>), dim3(grid), blk, 0, s, a);
+  else hipLaunchKernelGGL((k_fwd_fast<R, 1, false, AC_WAVES, IOF>), dim3(grid), blk, 0, s, a);
+  }
 }
 
-int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x, bool pcm16, float* X, float* t,
+int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x, int iof, float* X, float* t,
                     float* thr, float drown, const float* prev_block, int B, int Kin, int F, int C, hipStream_t s) {
   if (B <= 0 || C <= 0 || F <= 0) return AC_OK;
   FwdArgs a;
@@ -1776,26 +1865,28 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x
     grid = persistent_grid(p->cus, wgcu, a.nframes, nw);
   }
   if (p->N == Geo<8>::FN) {
-    if (pcm16) launch_fwd_R<8, true>(a, psy != nullptr, spread, C, grid, s);
-    else launch_fwd_R<8, false>(a, psy != nullptr, spread, C, grid, s);
+    if (iof == 2) launch_fwd_R<8, 2>(a, psy != nullptr, spread, C, grid, s);
+    else if (iof == 1) launch_fwd_R<8, 1>(a, psy != nullptr, spread, C, grid, s);
+    else launch_fwd_R<8, 0>(a, psy != nullptr, spread, C, grid, s);
   }
 #ifndef AC_NO_R16
-  else if (pcm16) launch_fwd_R<16, true>(a, psy != nullptr, spread, C, grid, s);
-  else launch_fwd_R<16, false>(a, psy != nullptr, spread, C, grid, s);
+  else if (iof == 2) launch_fwd_R<16, 2>(a, psy != nullptr, spread, C, grid, s);
+  else if (iof == 1) launch_fwd_R<16, 1>(a, psy != nullptr, spread, C, grid, s);
+  else launch_fwd_R<16, 0>(a, psy != nullptr, spread, C, grid, s);
 #endif
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }
 
-template <int R, bool PCM16>
+template <int R, int IOF>
 static void launch_inv_R(const InvArgs& a, int C, unsigned grid, hipStream_t s) {
   const dim3 blk(AC_WAVES * 64);
-  if (C == 2) hipLaunchKernelGGL((k_inv_fast<R, 0, AC_WAVES, PCM16>), dim3(grid), blk, 0, s, a);
-  else if (C == 1) hipLaunchKernelGGL((k_inv_fast<R, 2, AC_WAVES, PCM16>), dim3(grid), blk, 0, s, a);
-  else hipLaunchKernelGGL((k_inv_fast<R, 1, AC_WAVES, PCM16>), dim3(grid), blk, 0, s, a);
+  if (C == 2) hipLaunchKernelGGL((k_inv_fast<R, 0, AC_WAVES, IOF>), dim3(grid), blk, 0, s, a);
+  else if (C == 1) hipLaunchKernelGGL((k_inv_fast<R, 2, AC_WAVES, IOF>), dim3(grid), blk, 0, s, a);
+  else if constexpr (IOF != 2) hipLaunchKernelGGL((k_inv_fast<R, 1, AC_WAVES, IOF>), dim3(grid), blk, 0, s, a);
 }
 
-int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, bool pcm16, const float* tail_in, float* tail_out,
+int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, int iof, const float* tail_in, float* tail_out,
                     int B, int Kp, int nblk, int C, hipStream_t s) {
   if (B <= 0 || C <= 0 || nblk <= 0) return AC_OK;
   InvArgs a;
@@ -1821,12 +1912,14 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, bool pcm16, 
   }
   const unsigned grid = (unsigned)need;
   if (p->N == Geo<8>::FN) {
-    if (pcm16) launch_inv_R<8, true>(a, C, grid, s);
-    else launch_inv_R<8, false>(a, C, grid, s);
+    if (iof == 2) launch_inv_R<8, 2>(a, C, grid, s);
+    else if (iof == 1) launch_inv_R<8, 1>(a, C, grid, s);
+    else launch_inv_R<8, 0>(a, C, grid, s);
   }
 #ifndef AC_NO_R16
-  else if (pcm16) launch_inv_R<16, true>(a, C, grid, s);
-  else launch_inv_R<16, false>(a, C, grid, s);
+  else if (iof == 2) launch_inv_R<16, 2>(a, C, grid, s);
+  else if (iof == 1) launch_inv_R<16, 1>(a, C, grid, s);
+  else launch_inv_R<16, 0>(a, C, grid, s);
 #endif
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
@@ -1839,6 +1932,13 @@ static void launch_psy_thr(const PsyArgs& a, bool want_t, unsigned grid, hipStre
   else hipLaunchKernelGGL((k_psy_fast<R, CMODE, false, true, AC_WAVES, SPREAD>), dim3(grid), blk, 0, s, a);
 }
 template <int R, int CMODE>
+static void launch_psy_bf16(const PsyArgs& a, bool want_t, bool want_thr, unsigned grid, hipStream_t s) {
+  const dim3 blk(AC_WAVES * 64);
+  if (want_t && !want_thr) hipLaunchKernelGGL((k_psy_fast<R, CMODE, true, false, AC_WAVES, 0, 2>), dim3(grid), blk, 0, s, a);
+  else if (!want_t && want_thr) hipLaunchKernelGGL((k_psy_fast<R, CMODE, false, true, AC_WAVES, 0, 2>), dim3(grid), blk, 0, s, a);
+  else if (want_t && want_thr) hipLaunchKernelGGL((k_psy_fast<R, CMODE, true, true, AC_WAVES, 0, 2>), dim3(grid), blk, 0, s, a);
+}
+template <int R, int CMODE>
 static void launch_psy_R(const PsyArgs& a, bool want_t, bool want_thr, int spread, unsigned grid, hipStream_t s) {
   const dim3 blk(AC_WAVES * 64);
   if (CMODE == 0 && want_thr && spread == 1) return launch_psy_thr<R, 0, 1>(a, want_t, grid, s);
@@ -1849,7 +1949,7 @@ static void launch_psy_R(const PsyArgs& a, bool want_t, bool want_thr, int sprea
 }
 
 int launch_psy_fast(const ac_psy_plan* p, const float* X, const float* t_in, float* t_out, float* thr, float drown,
-                    int B, int F, int C, hipStream_t s) {
+                    int B, int F, int C, hipStream_t s, int iof) {
   if (B <= 0 || C <= 0 || F <= 0) return AC_OK;
   PsyArgs a;
   a.X = X;
@@ -1866,6 +1966,19 @@ int launch_psy_fast(const ac_psy_plan* p, const float* X, const float* t_in, flo
   if (st) return st;
   const bool want_t = (t_out != nullptr), want_thr = (thr != nullptr);
   const int cmode = (C == 2) ? 0 : (C == 1) ? 2 : 1;
+  if (iof == 2) {   // bfloat16 tensors: stereo and mono
+    if (p->N == PsyGeo<8>::FN) {
+      if (cmode == 0) launch_psy_bf16<8, 0>(a, want_t, want_thr, grid, s);
+      else launch_psy_bf16<8, 2>(a, want_t, want_thr, grid, s);
+    } else {
+#ifndef AC_NO_R16
+      if (cmode == 0) launch_psy_bf16<16, 0>(a, want_t, want_thr, grid, s);
+      else launch_psy_bf16<16, 2>(a, want_t, want_thr, grid, s);
+#endif
+    }
+    AC_HIP_CHECK(hipGetLastError());
+    return AC_OK;
+  }
   if (p->N == PsyGeo<8>::FN) {
     if (cmode == 0) launch_psy_R<8, 0>(a, want_t, want_thr, p->spread, grid, s);
     else if (cmode == 2) launch_psy_R<8, 2>(a, want_t, want_thr, p->spread, grid, s);

@@ -113,13 +113,14 @@ bool fast_psy_supported(const ac_psy_plan* p);
 int fast_mdct_plan_init(ac_mdct_plan* p);
 int fast_psy_plan_init(ac_psy_plan* p);
 // psy may be null (plain transform).  X/t/thr as in ac_encode_fused.
-// x: float32 PCM, or int16 PCM when pcm16 (then prev_block / tail state must be null)
-int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x, bool pcm16, float* X, float* t,
+// iof: 0 = float32 tensors; 1 = int16 PCM on the PCM side (x), spectra float32; 2 = bfloat16 tensors throughout (every
+// pointer then addresses 2-byte elements; C = 1 or 2 only).  prev_block / tail state must be null unless iof == 0
+int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x, int iof, float* X, float* t,
                     float* thr, float drown, const float* prev_block, int B, int Kin, int F, int C, hipStream_t s);
-int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, bool pcm16, const float* tail_in, float* tail_out,
+int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, int iof, const float* tail_in, float* tail_out,
                     int B, int Kp, int nblk, int C, hipStream_t s);
 int launch_psy_fast(const ac_psy_plan* p, const float* X, const float* t_in, float* t_out, float* thr, float drown,
-                    int B, int F, int C, hipStream_t s);
+                    int B, int F, int C, hipStream_t s, int iof = 0);
 
 int launch_tonality_bwd_generic(const ac_psy_plan* p, const float* X, const float* gt, float* gX, int accumulate, int B,
                                 int F, int C, hipStream_t s);

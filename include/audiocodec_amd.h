@@ -181,9 +181,11 @@ int ac_add_noise(const float* X, const float* thr, float* out, size_t n, uint64_
  *   AC_F32   the float32 entry points above (wave-level / LDS-FFT / generic kernels);
  *   AC_F64   float64 tensors, float64 arithmetic and float64 constants throughout (O(N^2) DCT-IV, any even
  *            filters_n): the on-device oracle the tests hold the float32 kernels against at full size;
- *   AC_BF16  bfloat16 tensors (half the bytes of float32), float32 arithmetic inside: the LDS-FFT kernels for
- *            power-of-two filters_n from 16 to 4096, the O(N^2) kernels otherwise; results carry bfloat16's output
- *            rounding (2^-9 relative) -- more accurate than the reference's all-bfloat16 op sequence.
+ *   AC_BF16  bfloat16 tensors (half the bytes of float32), float32 arithmetic inside: the wave-level kernels for mono
+ *            and stereo at filters_n 1024 / 2048 (conversion fused into their loads and stores; the fused encode rounds
+ *            X and the tonality to bfloat16 before the masking model uses them, so fused and un-fused calls agree),
+ *            else the LDS-FFT kernels for power-of-two filters_n from 16 to 4096 and the O(N^2) kernels; results carry
+ *            bfloat16's output rounding (2^-9 relative) -- more accurate than the reference's all-bfloat16 op sequence.
  * No streaming state and no backward passes for AC_F64 / AC_BF16.
  * ---------------------------------------------------------------------------------------- */
 enum { AC_F32 = 0, AC_F64 = 1, AC_BF16 = 2 };
@@ -192,6 +194,8 @@ int ac_mdct_inverse_typed(const ac_mdct_plan* plan, const void* X, void* x, int 
 int ac_tonality_typed(const ac_psy_plan* plan, const void* X, void* t, int dtype, int B, int F, int C, void* stream);
 int ac_mask_threshold_typed(const ac_psy_plan* plan, const void* X, const void* t, double drown, void* thr, int dtype,
                             int B, int F, int C, void* stream);
+int ac_encode_fused_typed(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const void* x, void* X, void* t, void* thr,
+                          double drown, int dtype, int B, int K, int C, void* stream);
 int ac_amplitude_to_db_typed(const void* a, void* out, size_t n, int norm, int dtype, void* stream);
 int ac_add_noise_typed(const void* X, const void* thr, void* out, size_t n, uint64_t seed, int dtype, void* stream);
 

@@ -543,7 +543,13 @@ def test_pcm16_at_the_boundary(N, C):
     codec = audiocodec_amd.AudioCodec(48000, N)
     X, t, thr = codec.encode(pcm)
     Xf, tf, thrf = codec.encode(pcm.float() / 32768.0)
-    assert X.dtype == torch.float32 and torch.equal(X, Xf) and torch.equal(t, tf) and torch.equal(thr, thrf)
+    assert X.dtype == torch.float32 and torch.equal(X, Xf)
+    if N == 2048 and C != 2:
+        # here the two inputs take different routes (PCM: transform + masking-model launch; float, 3 channels: one fused
+        # launch), whose compilers need not contract the same multiply-adds
+        assert float((t - tf).abs().max()) <= 1e-6 and float(((thr - thrf).abs() / thrf).max()) <= 1e-5
+    else:
+        assert torch.equal(t, tf) and torch.equal(thr, thrf)
     out = codec.decode(X, pcm16=True)
     assert out.dtype == torch.int16 and tuple(out.shape) == (B, (K + 2) * N, C)
     assert torch.equal(out[:, N:-N], pcm)
@@ -677,7 +683,7 @@ def test_float32_kernels_vs_float64_kernels_at_full_size():
 
 
 @pytest.mark.parametrize("N,wt,C", [(1024, "vorbis", 2), (256, "sine", 1), (12, "vorbis", 3), (2048, "vorbis", 2), (64, "rect", 3)])
-def test_bfloat16_filter_bank(N, wt, C):
+def test_bfloat16_filter_bank(path, N, wt, C):
     """compute_dtype = bfloat16: bfloat16 tensors, float32 arithmetic.  Tolerance: the output rounding of bfloat16
     (2^-9 of each value) on top of the float32 kernels' own error -- 4e-3 of the frame's peak."""
     rng = np.random.default_rng(N)
@@ -696,7 +702,7 @@ def test_bfloat16_filter_bank(N, wt, C):
 
 
 @pytest.mark.parametrize("sr,N,M,C", [(48000, 1024, 64, 2), (44100, 256, 48, 3), (48000, 2048, 64, 1)])
-def test_bfloat16_masking_model(sr, N, M, C):
+def test_bfloat16_masking_model(path, sr, N, M, C):
     rng = np.random.default_rng(M + C)
     env = np.logspace(-4, 0, N).reshape(1, 1, N, 1)
     X = _bf16_round(rng.uniform(-1, 1, (2, 3, N, C)) * env * rng.uniform(1e-2, 1, (2, 3, 1, C)))
@@ -714,6 +720,30 @@ def test_bfloat16_masking_model(sr, N, M, C):
     assert dB.dtype == torch.bfloat16 and np.max(np.abs(host(dB.double()) - ref)) <= 0.5   # 2^-9 of values up to 120
     y = p.add_noise(Xd, torch.full_like(Xd, 0.25), seed=3)
     assert y.dtype == torch.bfloat16 and abs(float((y.double() - Xd.double()).std()) - 0.25 / 6) < 2e-3
+
+
+@pytest.mark.parametrize("N,C", [(1024, 2), (1024, 1), (2048, 2), (2048, 1), (1024, 3)])
+def test_bfloat16_fused_encode(path, N, C):
+    """bfloat16 codec on the wave-level kernels (stereo / mono; 3 channels fall to the LDS-FFT tier): the fused encode
+    equals the three calls bit for bit (X and tonality are rounded to bfloat16 before the masking model uses them) and
+    stays within bfloat16's rounding of the oracle"""
+    rng = np.random.default_rng(N + C)
+    B, K = 3, 6
+    x = _bf16_round(rng.uniform(-1, 1, (B, K * N, C)))
+    xd = dev(x).to(torch.bfloat16)
+    codec = audiocodec_amd.AudioCodec(48000, N, compute_dtype=torch.bfloat16)
+    X, t, thr = codec.encode(xd, drown=0.1)
+    Xu = codec.mdct.transform(xd)
+    tu = codec.psy.tonality(Xu)
+    thru = codec.psy.global_masking_threshold(Xu, tu, 0.1)
+    assert torch.equal(X, Xu) and torch.equal(t, tu) and torch.equal(thr, thru)
+    om, op = MDCTOracle(N, "vorbis", np.float64), PsychoOracle(48000, N, 64, compute_dtype=np.float64)
+    assert rel_peak(host(X.double()), om.transform(x)) <= 4e-3
+    Xb, tb = host(X.double()), host(t.double())
+    assert np.max(np.abs(tb - op.tonality(Xb))) <= 4e-3
+    assert rel_elem(host(thr.double()), op.global_masking_threshold(Xb, tb, 0.1)) <= 6e-3
+    xh = codec.decode(X)
+    assert xh.dtype == torch.bfloat16 and float((xh[:, N:-N].double() - dev(x)).abs().max()) <= 2e-2
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.bfloat16])

@@ -38,6 +38,14 @@ if codec.mdct.is_fast():
     pcm_out = torch.empty((B, (K + 2) * N, C), device=dev, dtype=torch.int16)
     rows += [("encode_fused pcm16", lambda: codec.encode_into(pcm, X, t, thr), 10 * N + 4),
              ("inverse pcm16", lambda: codec.decode_into(X, pcm_out), 6 * N)]
+if codec.mdct.is_fast() and C <= 2:
+    cb = audiocodec_amd.AudioCodec(48000, N, compute_dtype=torch.bfloat16)
+    xb = x.to(torch.bfloat16); Xb = torch.empty_like(X, dtype=torch.bfloat16); tb = torch.empty_like(t, dtype=torch.bfloat16)
+    thrb = torch.empty_like(Xb); xhb = torch.empty_like(xh, dtype=torch.bfloat16)
+    cb.encode_into(xb, Xb, tb, thrb)
+    rows += [("encode_fused bf16", lambda: cb.encode_into(xb, Xb, tb, thrb), 6 * N + 2),
+             ("inverse bf16", lambda: cb.decode_into(Xb, xhb), 4 * N),
+             ("threshold bf16", lambda: cb.psy.global_masking_threshold(Xb, tb), 4 * N + 2)]
 for name, fn, bpf in rows:
     ms = timeit(fn)
     print("%-24s %8.3f ms   %7.0f GB/s (algorithmic %d B/frame)" % (name, ms, bpf * frames / ms / 1e6, bpf))
