@@ -67,22 +67,25 @@ template <int R>
 struct Geo {
   static constexpr int FH = 64 * R;                 // complex FFT points per frame
   static constexpr int FN = 128 * R;                // filters_n
-  static constexpr int I_PRE = 0;                   // [R][64] float2  exp(-i pi (e + 1/4) / N), e = lane + 64 r
-  static constexpr int I_P2 = I_PRE + 128 * R;      // [8][8]  float2  W64^(e0 k1)
+  static constexpr int I_P2 = 0;                    // [8][8]  float2  W64^(e0 k1)
   static constexpr int I_POST = I_P2 + 128;         // [R][64] float2  exp(-i pi k / N) * (1/(N sqrt 2) | 2 sqrt 2), k = lane + 64 j
   static constexpr int I_COEF = I_POST + 128 * R;   // [R][64] float2  fold (A, B)(e) | unfold (a, b)(k)
-  static constexpr int I_P1 = I_COEF + 128 * R;     // [R][64] float2  W_{64R}^(lane k0), pass-1 twiddles
+  static constexpr int I_PRE = I_COEF + 128 * R;    // [R][64] float2  exp(-i pi (e + 1/4) / N), e = lane + 64 r
+  static constexpr int I_P1 = I_PRE + 128 * R;      // [R][64] float2  W_{64R}^(lane k0), pass-1 twiddles
   static constexpr int I_TOTAL = I_P1 + 128 * R;    // floats per image in global memory
   // R = 8 holds the seven pass-1 twiddles of a lane in registers (LDS is the scarcer resource: 3 workgroups per CU);
   // R = 16 reads its fifteen from LDS (registers are: 64 for the frame alone)
   static constexpr bool P1_IN_REGS = (R == 8);
   static constexpr int I_LDS = P1_IN_REGS ? I_P1 : I_TOTAL;   // floats that live in LDS (R = 8: 12 800 bytes)
+  // a kernel short of LDS leaves the pre-twiddles out as well (I_LDS_NOPRE floats) and forms them as
+  // PRE[e] = POST[e] * (exp(-i pi / (4 N)) / scale): four more packed multiply-adds per element
+  static constexpr int I_LDS_NOPRE = I_PRE;
   static constexpr int TAB_LDS = I_LDS * 4;
 };
 // waves per SIMD the register allocator must leave room for: the strided any-channel-count variants (CMODE 1) and the
 // 2048-filter kernels get the larger budget
 template <int R, int CMODE, bool PSY = false, int SPREAD = 0>
-constexpr int wpe() { return (R == 8 && SPREAD == 0 && (CMODE == 0 || (CMODE == 2 && !PSY))) ? AC_WPE : 2; }
+constexpr int wpe() { return (R == 8 && (CMODE == 0 || (CMODE == 2 && !PSY))) ? AC_WPE : 2; }
 
 // ---- psy image (32-bit words) in ac_psy_plan::d_fast for filter_bands_n = 128 R and 64 Bark bands; the first PL_LDS
 // words are copied into LDS once per workgroup, the rest is held in registers.  The spectrum passes through the wave's
@@ -798,6 +801,7 @@ struct FwdArgs {
   int T;                     // > 0: workgroup g owns frames [g NW T, (g+1) NW T), wave w takes g NW T + w + NW t;
                              // 0: persistent waves, wave w of W takes frames w, w + W, ...
   long long nframes;         // npairs * F
+  float pre_re, pre_im;      // PRE[e] / POST[e] of the analysis image (kernels that keep no pre-twiddles in LDS)
 };
 
 // Analysis is frame-independent: frame n of a channel pair needs blocks n-1 and n of the PCM, and a wave that loads
@@ -816,12 +820,16 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY, SPREAD>())) void k_fwd
   using G = Geo<R>;
   // one LDS object: [NW wave buffers | table image | psy image | bf16 tiles of the spreading matrix (SPREAD > 0)]
   constexpr int WSTRIDE = PSY ? WAVE_LDS_PSY : WAVE_LDS;
-  __shared__ __attribute__((aligned(16))) char lds[NW * WSTRIDE + G::TAB_LDS + (PSY ? PsyGeo<R>::PSY_LDS + mf_lds(SPREAD) : 0)];
+  // the matrix-core spreading kernels at 8 points per lane pay for their bf16 tiles with the pre-twiddle table, which
+  // they rebuild from the post-twiddles: the workgroup stays under 53 760 B, three to a CU
+  constexpr bool NOPRE = (R == 8) && PSY && SPREAD > 0;
+  constexpr int TABF = NOPRE ? G::I_LDS_NOPRE : G::I_LDS;
+  __shared__ __attribute__((aligned(16))) char lds[NW * WSTRIDE + TABF * 4 + (PSY ? PsyGeo<R>::PSY_LDS + mf_lds(SPREAD) : 0)];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  load_tables<NW, WSTRIDE, G::I_LDS, PsyGeo<R>::PL_LDS, PsyGeo<R>::PL_MF, mf_lds(SPREAD)>(lds, a.tab, PSY ? a.psy.tab : nullptr);
+  load_tables<NW, WSTRIDE, TABF, PsyGeo<R>::PL_LDS, PsyGeo<R>::PL_MF, mf_lds(SPREAD)>(lds, a.tab, PSY ? a.psy.tab : nullptr);
   char* buf = lds + wave * WSTRIDE;
   gtab_t tab = reinterpret_cast<const float*>(lds + NW * WSTRIDE);
-  const uint32_t* pimg = reinterpret_cast<const uint32_t*>(lds + NW * WSTRIDE + G::TAB_LDS);
+  const uint32_t* pimg = reinterpret_cast<const uint32_t*>(lds + NW * WSTRIDE + TABF * 4);
   if (PSY) *reinterpret_cast<v2f*>(buf + ZERO_OFF) = v2f{0.f, 0.f};   // the gather lists' padding slot
   v2f p1[R];
   load_p1<R>(a.tab, lane, p1);
@@ -916,7 +924,12 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY, SPREAD>())) void k_fwd
         const v2f cur = (r < R / 2) ? (ab.y * xoc - ab.x * xec) : (ab.x * xec - ab.y * xoc);
         // element e = lane + 64 r: v[2e] + i v[N-1-2e]; for e < N/4 the real part comes from the previous block
         const C2 v = (r < R / 2) ? C2{carry, cur} : C2{cur, carry};
-        z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + G::I_PRE)[r * 64 + lane]);
+        if constexpr (NOPRE) {
+          const C2 v0 = {v.re * a.pre_re - v.im * a.pre_im, v.re * a.pre_im + v.im * a.pre_re};
+          z[r] = cmul(v0, reinterpret_cast<const v2f*>(tab + G::I_POST)[r * 64 + lane]);
+        } else {
+          z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + G::I_PRE)[r * 64 + lane]);
+        }
       }
     } else {
       // larger frames: one block at a time (registers), each with its own lane-reversal exchange
@@ -1803,9 +1816,10 @@ static void launch_fwd_R(const FwdArgs& a, bool psy, int spread, int C, unsigned
   } else {
   if (psy) {
     const dim3 blk(AC_WAVES_PSY * 64);
-    // the matrix-core forms of the spreading product serve the stereo float32 kernels; the others keep the f32 product
-    if (C == 2 && !PCM16 && spread == 1) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, 0, 1>), dim3(grid), blk, 0, s, a);
-    else if (C == 2 && !PCM16 && spread == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, 0, 2>), dim3(grid), blk, 0, s, a);
+    // the matrix-core forms of the spreading product serve the stereo kernels (float32 or 16-bit PCM input); the others
+    // keep the f32 product
+    if (C == 2 && spread == 1) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, IOF, 1>), dim3(grid), blk, 0, s, a);
+    else if (C == 2 && spread == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, IOF, 2>), dim3(grid), blk, 0, s, a);
     else if (C == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, IOF>), dim3(grid), blk, 0, s, a);
     else if (C == 1) {
       // (R = 16: the caller runs transform and masking model as two launches, see encode_fused in ac_api.hip)
@@ -1841,6 +1855,11 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x
   a.nsig = (long long)B * C;
   a.npairs = (C == 2) ? (long long)B : (a.nsig + 1) / 2;
   a.nframes = a.npairs * F;
+  {
+    const double ang = -3.14159265358979323846 / (4.0 * p->N), sc = (double)p->N * 1.4142135623730951;   // 1 / (1 / (N sqrt 2))
+    a.pre_re = (float)(std::cos(ang) * sc);
+    a.pre_im = (float)(std::sin(ang) * sc);
+  }
   // tuning hooks (read once): AC_XCD=1 groups consecutive workgroups per XCD; AC_FWD_T = frames per wave, workgroups
   // dispatched in order (default 4: measured 0.603 ms against 0.615 ms for persistent waves, B = 256, K = 468 -- fresh
   // workgroups keep the window of memory in flight contiguous); AC_FWD_T=0 = persistent waves, AC_WG_PER_CU per CU

@@ -59,8 +59,9 @@ class PsychoacousticModel:
                           the wave-level kernels (include/audiocodec_amd.h, AC_SPREAD_*): ``"f32"`` vector-ALU
                           multiply-adds, ``"bf16_mfma"`` bfloat16 operands on the matrix cores (thresholds within 5e-3),
                           ``"bf16x2_mfma"`` split-bfloat16 operands on the matrix cores (thresholds within the 1e-4
-                          parity bar).  None = the library's default (``"f32"`` unless the AC_SPREAD tuning hook says
-                          otherwise).  The matrix-core forms need filter_bands_n 1024 / 2048 and 64 Bark bands
+                          parity bar).  None = the library's default: ``"bf16x2_mfma"`` where the wave-level kernels
+                          serve the model (filter_bands_n 1024 / 2048, 64 Bark bands), ``"f32"`` otherwise (the
+                          AC_SPREAD tuning hook overrides).  Asking for a matrix-core form elsewhere is an error
 
         :raises TypeError: when compute_dtype is not float64, float32 or bfloat16 (``:42-43``).  float32 runs the
                            wave-level kernels; float64 runs float64 kernels on float64 constants (the on-device

@@ -175,6 +175,7 @@ def main():
     xh = torch.empty((B, (K + 2) * N, C), device=dev, dtype=torch.float32)
     codec = audiocodec_amd.AudioCodec(48000, N)
     assert codec.mdct.is_fast(dev) and codec.psy.is_fast(dev), "wave-level kernels not selected"
+    spreading = codec.psy.plan_spreading(dev)
 
     def step():
         codec.encode_into(x, X, t, thr)
@@ -221,7 +222,8 @@ def main():
                                    "(%.1f s), fused MDCT+tonality+masking encode then IMDCT decode" % (B, K, K * N / 48000.0),
                        "clips_per_gpu": B, "channels": C, "blocks": K, "filters_n": N, "sample_rate": 48000,
                        "sharding": "clips split across ranks, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_fwd_fast<8, 0, true, 4, false, 0> (fused encode, f32 spreading product)",
+            "roofline": {"bound": "hbm", "kernel": "k_fwd_fast<8, 0, true, 4, 0, %d> (fused encode, spreading product: %s)"
+                                   % (audiocodec_amd.PsychoacousticModel.SPREADING[spreading], spreading),
                          "achieved": enc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": enc_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_frame": ENC_BYTES, "frames_per_launch": frames_rank,
                          "avg_launch_ms": enc_ms},

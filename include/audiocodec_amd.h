@@ -89,13 +89,15 @@ int ac_psy_plan_destroy(ac_psy_plan* plan);
 
 /* Form of the band x band product with the spreading matrix (psychoacoustic.py:205-207: sum_i max(eps, P_i)^alpha S[i,j])
  * in the wave-level kernels -- BASELINE configs[3] "Bark spreading cast as band x band MFMA contraction, bf16":
- *   AC_SPREAD_F32          float32 multiply-adds on the vector ALU (what ac_psy_plan_create builds);
+ *   AC_SPREAD_F32          float32 multiply-adds on the vector ALU;
  *   AC_SPREAD_BF16_MFMA    operands rounded to bfloat16, v_mfma_f32_4x4x4_16b_bf16, float32 accumulation: thresholds
  *                          within 5e-3 relative of the float32 form (bfloat16 has 8 mantissa bits);
  *   AC_SPREAD_BF16X2_MFMA  both operands split into bfloat16 hi + lo parts, four partial products on the matrix cores:
- *                          thresholds within the 1e-4 parity bar.
- * Served for stereo float32 input by ac_encode_fused and ac_mask_threshold (other channel counts and the 16-bit PCM
- * entry points keep the float32 product).  AC_EUNSUPPORTED unless the plan runs the wave-level kernels. */
+ *                          thresholds within 1e-5 of the float32 form, i.e. inside the 1e-4 parity bar.  This is what
+ *                          ac_psy_plan_create builds where the wave-level kernels serve the plan (2 % faster fused
+ *                          encode); everywhere else it builds AC_SPREAD_F32.
+ * Served for stereo input (float32 or 16-bit PCM) by ac_encode_fused* and ac_mask_threshold; other channel counts and
+ * the bfloat16 tensors of the *_typed entry points keep the float32 product.  AC_EUNSUPPORTED unless the plan runs the wave-level kernels. */
 enum { AC_SPREAD_F32 = 0, AC_SPREAD_BF16_MFMA = 1, AC_SPREAD_BF16X2_MFMA = 2 };
 int ac_psy_plan_create_ex(int N, int M, double sample_rate, double alpha, int device, int spreading, ac_psy_plan** out);
 int ac_psy_plan_spreading(const ac_psy_plan* plan);

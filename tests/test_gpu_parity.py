@@ -269,11 +269,15 @@ def test_mfma_spreading_fused_encode(spreading, N, B, K):
     x = rng.uniform(-1, 1, (B, K * N, 2)).astype(np.float32)
     x[0, : 2 * N, 0] *= 1e-3
     codec = audiocodec_amd.AudioCodec(48000, N, spreading=spreading)
-    plain = audiocodec_amd.AudioCodec(48000, N)
+    plain = audiocodec_amd.AudioCodec(48000, N, spreading="f32")
     assert plain.psy.plan_spreading() == "f32"
+    assert audiocodec_amd.AudioCodec(48000, N).psy.plan_spreading() == "bf16x2_mfma"      # the default where it applies
+    assert audiocodec_amd.PsychoacousticModel(48000, 512).plan_spreading() == "f32"       # ... and elsewhere
     X, t, thr = codec.encode(dev(x), drown=0.2)
     X0, t0, thr0 = plain.encode(dev(x), drown=0.2)
-    assert torch.equal(X, X0) and torch.equal(t, t0)        # only the spreading product differs
+    # only the spreading product differs -- and, at N = 1024, the pre-twiddles, which these kernels rebuild from the
+    # post-twiddles (one more float32 rounding) to make room in LDS for the bf16 tiles
+    assert float((X - X0).abs().max()) <= 2e-7 and float((t - t0).abs().max()) <= 2e-6
     tol = SPREAD_TOL[spreading]
     assert float(((thr - thr0).abs() / thr0).max()) <= tol
     thru = codec.psy.global_masking_threshold(X, t, 0.2)    # stand-alone kernel, same form of the product
@@ -292,7 +296,7 @@ def test_mfma_spreading_scope():
     rng = np.random.default_rng(5)
     x = rng.uniform(-1, 1, (2, 3 * N, 3)).astype(np.float32)
     a = audiocodec_amd.AudioCodec(48000, N, spreading="bf16_mfma").encode(dev(x))
-    b = audiocodec_amd.AudioCodec(48000, N).encode(dev(x))
+    b = audiocodec_amd.AudioCodec(48000, N, spreading="f32").encode(dev(x))
     assert all(torch.equal(u, v) for u, v in zip(a, b))
     with pytest.raises(RuntimeError, match="wave-level"):
         audiocodec_amd.PsychoacousticModel(48000, filter_bands_n=512, spreading="bf16x2_mfma").tonality(dev(np.zeros((1, 1, 512, 1), np.float32)))
