@@ -37,8 +37,8 @@ def entry(v, kernel, alg):
 json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc.sh), bench workload B=256 stereo "
                    "K=468 N=1024; FETCH_SIZE doubled per the gfx950 correction (MI355X_MICROARCH.md, HBM section); counters "
                    "are in KiB; memory-side requests include Infinity-Cache hits",
-           "encode": entry(enc, "k_fwd_fast<8, 0, true, 4, false, 0>", (12 * N + 4) * frames),
-           "decode": entry(dec, "k_inv_fast<8, 0, 4, false>", 8 * N * frames)}, open(out + "/traffic.json", "w"), indent=1)
+           "encode": entry(enc, "k_fwd_fast<8, 0, true, 4, 0, 2>", (12 * N + 4) * frames),
+           "decode": entry(dec, "k_inv_fast<8, 0, 4, 0>", 8 * N * frames)}, open(out + "/traffic.json", "w"), indent=1)
 print(open(out + "/traffic.json").read())
 PY
 tools/entry_points.sh > /dev/null 2>&1; cp gpurun_out/entry_points.txt $out/entry_points.txt
