@@ -1839,6 +1839,12 @@ static void launch_fwd_R(const FwdArgs& a, bool psy, int spread, int C, unsigned
 int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x, int iof, float* X, float* t,
                     float* thr, float drown, const float* prev_block, int B, int Kin, int F, int C, hipStream_t s) {
   if (B <= 0 || C <= 0 || F <= 0) return AC_OK;
+  // combinations no kernel is instantiated for (ac_api.hip routes them elsewhere; refuse rather than launch nothing)
+  if ((iof == 2 && C > 2) || (psy && p->N == Geo<16>::FN && (C == 1 || (iof == 1 && C > 2)))) {
+    set_error("internal: no wave-level analysis kernel for filters_n = %d, %d channels, io format %d%s", p->N, C, iof,
+              psy ? ", fused masking model" : "");
+    return AC_EUNSUPPORTED;
+  }
   FwdArgs a;
   a.x = x;
   a.X = X;
@@ -1908,6 +1914,10 @@ static void launch_inv_R(const InvArgs& a, int C, unsigned grid, hipStream_t s) 
 int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, int iof, const float* tail_in, float* tail_out,
                     int B, int Kp, int nblk, int C, hipStream_t s) {
   if (B <= 0 || C <= 0 || nblk <= 0) return AC_OK;
+  if (iof == 2 && C > 2) {
+    set_error("internal: no wave-level synthesis kernel for bfloat16 tensors with %d channels", C);
+    return AC_EUNSUPPORTED;
+  }
   InvArgs a;
   a.X = X;
   a.x = x;
@@ -1985,6 +1995,10 @@ int launch_psy_fast(const ac_psy_plan* p, const float* X, const float* t_in, flo
   if (st) return st;
   const bool want_t = (t_out != nullptr), want_thr = (thr != nullptr);
   const int cmode = (C == 2) ? 0 : (C == 1) ? 2 : 1;
+  if (iof == 2 && C > 2) {
+    set_error("internal: no wave-level masking-model kernel for bfloat16 tensors with %d channels", C);
+    return AC_EUNSUPPORTED;
+  }
   if (iof == 2) {   // bfloat16 tensors: stereo and mono
     if (p->N == PsyGeo<8>::FN) {
       if (cmode == 0) launch_psy_bf16<8, 0>(a, want_t, want_thr, grid, s);
