@@ -806,3 +806,24 @@ def test_fuzz_wave_kernels_against_the_generic_kernels():
         assert float((xh - xg).abs().max()) <= 2e-6, tag
         if K > 0:
             assert float((xh[:, N:-N] - x).abs().max()) <= LSB, tag
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16])
+@pytest.mark.parametrize("N", [1024, 2048, 64])
+def test_empty_and_ragged_shapes_in_every_dtype(path, dtype, N):
+    """no blocks, no clips, a single block, odd signal counts -- in each compute dtype and on each tier"""
+    codec = audiocodec_amd.AudioCodec(48000, N, compute_dtype=dtype)
+    z = lambda *s: torch.zeros(*s, device="cuda", dtype=dtype)   # noqa: E731
+    X, t, thr = codec.encode(z(2, 0, 2))                          # K = 0: one frame of silence
+    assert tuple(X.shape) == (2, 1, N, 2) and float(X.abs().max()) == 0.0 and float(thr.min()) > 0.0
+    assert tuple(codec.decode(X).shape) == (2, 2 * N, 2)
+    X, t, thr = codec.encode(z(0, 2 * N, 1))                      # B = 0
+    assert tuple(X.shape) == (0, 3, N, 1) and tuple(t.shape) == (0, 3, 1, 1)
+    assert tuple(codec.decode(z(1, 0, N, 1)).shape) == (1, N, 1)  # no frames at all
+    x = (torch.rand(3, N, 1, device="cuda") * 2 - 1).to(dtype)    # three mono clips of one block: an odd pair count
+    X, t, thr = codec.encode(x)
+    xh = codec.decode(X)
+    tol = {torch.float32: LSB, torch.float64: 1e-12, torch.bfloat16: 2e-2}[dtype]
+    assert float((xh[:, N:-N] - x).double().abs().max()) <= tol
+    single = codec.encode(x[1:2])                                 # the middle clip alone gives the same numbers
+    assert torch.equal(single[0], X[1:2]) and torch.equal(single[1], t[1:2]) and torch.equal(single[2], thr[1:2])
