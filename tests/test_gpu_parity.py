@@ -827,3 +827,38 @@ def test_empty_and_ragged_shapes_in_every_dtype(path, dtype, N):
     assert float((xh[:, N:-N] - x).double().abs().max()) <= tol
     single = codec.encode(x[1:2])                                 # the middle clip alone gives the same numbers
     assert torch.equal(single[0], X[1:2]) and torch.equal(single[1], t[1:2]) and torch.equal(single[2], thr[1:2])
+
+
+def test_integration_md_stub_runs_against_the_library():
+    """the ctypes stub INTEGRATION.md shows to a maintainer of the reference, executed as written (only the library path is
+    substituted), gives the class API's results through raw device pointers"""
+    import os
+    import re
+    from conftest import ROOT
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(# audiocodec/_amd.py.*?)```", text, re.S).group(1)
+    code = code.replace('ctypes.CDLL("libaudiocodec_amd.so")', "ctypes.CDLL(%r)" % _lib.LIB_PATH)
+    stub = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), stub)
+    N, B, K, C = 1024, 2, 3, 2
+    x = torch.rand(B, K * N, C, device="cuda") * 2 - 1
+    X = torch.empty(B, K + 1, N, C, device="cuda")
+    t = torch.empty(B, K + 1, 1, C, device="cuda")
+    thr = torch.empty_like(X)
+    xh = torch.empty(B, (K + 2) * N, C, device="cuda")
+    mp, pp = stub["mdct_plan"](N, "vorbis"), stub["psy_plan"](N, 64, 48000.0, 0.6)
+    stream = torch.cuda.current_stream().cuda_stream
+    stub["transform"](mp, x.data_ptr(), X.data_ptr(), B, K, C, stream)
+    stub["tonality"](pp, X.data_ptr(), t.data_ptr(), B, K + 1, C, stream)
+    stub["global_masking_threshold"](pp, X.data_ptr(), t.data_ptr(), 0.25, thr.data_ptr(), B, K + 1, C, stream)
+    stub["inverse_transform"](mp, X.data_ptr(), xh.data_ptr(), B, K + 1, C, stream)
+    torch.cuda.synchronize()
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    assert torch.equal(X, codec.mdct.transform(x)) and torch.equal(t, codec.psy.tonality(X))
+    assert torch.equal(thr, codec.psy.global_masking_threshold(X, t, 0.25))
+    assert float((xh[:, N:-N] - x).abs().max()) <= LSB
+    with pytest.raises(ValueError):
+        stub["mdct_plan"](7, "vorbis")
+    lib = stub["_lib"]
+    lib.ac_mdct_plan_destroy(mp)
+    lib.ac_psy_plan_destroy(pp)
