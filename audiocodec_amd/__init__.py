@@ -7,6 +7,7 @@ Python host classes with the reference's names and signatures over hand-written 
 from .mdctransformer import MDCTransformer
 from .psychoacoustic import PsychoacousticModel
 from .codec import AudioCodec, StreamingMDCT
+from .workspace import Workspace
 
-__all__ = ["MDCTransformer", "PsychoacousticModel", "AudioCodec", "StreamingMDCT"]
+__all__ = ["MDCTransformer", "PsychoacousticModel", "AudioCodec", "StreamingMDCT", "Workspace"]
 __version__ = "0.1.0"

@@ -145,10 +145,16 @@ def other_configs(dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)    # warm-up 10 iterations, then >= 200 timed
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--settle-ms", type=float, default=100.0,
+                    help="keep the device busy with the same step for this long before the warmup steps (an idle GPU "
+                         "takes some tens of ms of load to reach its sustained clocks); reported as settle_ms")
     ap.add_argument("--clips", type=int, default=256, help="stereo clips per GPU")
     ap.add_argument("--blocks", type=int, default=468, help="blocks (hops) per clip; 468 = 10 s at 48 kHz")
+    ap.add_argument("--placement-span-gib", type=float, default=112.0,
+                    help="memory audiocodec_amd.Workspace may allocate for a moment while it looks for a good place for "
+                         "the step's tensors; 0 = plain torch allocations, no placement probing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[3] / configs[4] side measurements")
     args = ap.parse_args()
@@ -168,19 +174,33 @@ def main():
 
     B, K, C = args.clips, args.blocks, 2
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    x = torch.rand((B, K * N, C), device=dev, generator=gen, dtype=torch.float32) * 2 - 1
-    X = torch.empty((B, K + 1, N, C), device=dev, dtype=torch.float32)
-    t = torch.empty((B, K + 1, 1, C), device=dev, dtype=torch.float32)
-    thr = torch.empty((B, K + 1, N, C), device=dev, dtype=torch.float32)
-    xh = torch.empty((B, (K + 2) * N, C), device=dev, dtype=torch.float32)
     codec = audiocodec_amd.AudioCodec(48000, N)
     assert codec.mdct.is_fast(dev) and codec.psy.is_fast(dev), "wave-level kernels not selected"
     spreading = codec.psy.plan_spreading(dev)
+    placement = None
+    if args.placement_span_gib > 0:
+        # X and (thr, xh) in stretches of VRAM of different classes (audiocodec_amd/workspace.py: found by timing the
+        # encode kernel with thr in each of a row of candidate chunks; the chunks not chosen are freed again)
+        ws = audiocodec_amd.Workspace(codec, B, K, C, span_gib=args.placement_span_gib, device=dev)
+        x, X, t, thr, xh = ws.x, ws.X, ws.t, ws.thr, ws.xh
+        x.copy_(torch.rand((B, K * N, C), device=dev, generator=gen, dtype=torch.float32) * 2 - 1)
+        placement = ws.report
+    else:
+        x = torch.rand((B, K * N, C), device=dev, generator=gen, dtype=torch.float32) * 2 - 1
+        X = torch.empty((B, K + 1, N, C), device=dev, dtype=torch.float32)
+        t = torch.empty((B, K + 1, 1, C), device=dev, dtype=torch.float32)
+        thr = torch.empty((B, K + 1, N, C), device=dev, dtype=torch.float32)
+        xh = torch.empty((B, (K + 2) * N, C), device=dev, dtype=torch.float32)
 
     def step():
         codec.encode_into(x, X, t, thr)
         codec.decode_into(X, xh)
 
+    if args.settle_ms > 0:
+        t_end = time.perf_counter() + args.settle_ms * 1e-3
+        while time.perf_counter() < t_end:
+            step()
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -216,6 +236,7 @@ def main():
         out = {
             "metric": "MDCT frames/s (48 kHz, N=1024) encode+decode",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "settle_ms": args.settle_ms,
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: batch=%d stereo 48 kHz clips per GPU, N=1024, K=%d blocks "
@@ -232,11 +253,33 @@ def main():
                         "decode_ms_median": float(np.median(dec_all)), "decode_ms_min": float(np.min(dec_all)),
                         "step_frac_of_hbm_peak": (ENC_BYTES + DEC_BYTES) * (value / world) / (HBM_PEAK_GBS * 1e9)},
             "round_trip_max_abs_err": err,
+            "placement": placement,
         }
+        if placement is not None and world == 1:
+            # the same step on plain torch allocations (what a caller gets without audiocodec_amd.Workspace), for scale
+            try:
+                px = x.clone()
+                pX, pt, pthr, pxh = torch.empty_like(X), torch.empty_like(t), torch.empty_like(thr), torch.empty_like(xh)
+                for _ in range(args.warmup):
+                    codec.encode_into(px, pX, pt, pthr)
+                    codec.decode_into(pX, pxh)
+                torch.cuda.synchronize()
+                p0 = time.perf_counter()
+                for _ in range(args.steps):
+                    codec.encode_into(px, pX, pt, pthr)
+                    codec.decode_into(pX, pxh)
+                torch.cuda.synchronize()
+                pdt = time.perf_counter() - p0
+                out["plain_allocations"] = {"value": frames_rank * args.steps / pdt, "ms_per_step": pdt / args.steps * 1e3}
+                del px, pX, pt, pthr, pxh
+            except Exception as e:
+                out["plain_allocations"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if world == 1 and not args.no_other_configs:
             del x, X, t, thr, xh
+            if placement is not None:
+                del ws
             try:
                 out["other_configs"] = other_configs(dev)
             except Exception as e:   # side measurements must never cost the headline line

@@ -862,3 +862,26 @@ def test_integration_md_stub_runs_against_the_library():
     lib = stub["_lib"]
     lib.ac_mdct_plan_destroy(mp)
     lib.ac_psy_plan_destroy(pp)
+
+
+def test_workspace_places_buffers_without_changing_results():
+    """audiocodec_amd.Workspace only decides where the caller's tensors live: shapes, results and the round trip are those of
+    plain allocations, with and without the placement probing"""
+    N, B, K, C = 1024, 4, 6, 2
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    x = torch.rand(B, K * N, C, device="cuda") * 2 - 1
+    ref = codec.encode(x)
+    for tune in (True, False):
+        ws = audiocodec_amd.Workspace(codec, B, K, C, span_gib=2.0, tune=tune)
+        assert tuple(ws.x.shape) == (B, K * N, C) and tuple(ws.X.shape) == (B, K + 1, N, C)
+        assert tuple(ws.t.shape) == (B, K + 1, 1, C) and tuple(ws.thr.shape) == tuple(ws.X.shape)
+        assert tuple(ws.xh.shape) == (B, (K + 2) * N, C)
+        assert all(v.is_contiguous() and v.data_ptr() % (1 << 21) == 0 for v in (ws.x, ws.X, ws.thr, ws.xh))
+        assert ws.report["tuned"] == (tune and ws.report["chunks_probed"] > 2)
+        ws.x.copy_(x)
+        codec.encode_into(ws.x, ws.X, ws.t, ws.thr)
+        codec.decode_into(ws.X, ws.xh)
+        assert torch.equal(ws.X, ref[0]) and torch.equal(ws.t, ref[1]) and torch.equal(ws.thr, ref[2])
+        assert float((ws.xh[:, N:-N] - x).abs().max()) <= LSB
+    with pytest.raises(NotImplementedError):
+        audiocodec_amd.Workspace(audiocodec_amd.AudioCodec(48000, N, compute_dtype=torch.float64), B, K, C)
