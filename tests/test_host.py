@@ -177,12 +177,24 @@ if rank == 0:
 """
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_sharding_world_size_2_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER % ROOT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29713")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29713", str(script)],
-                         capture_output=True, text=True, env=env, timeout=300)
+    out = None
+    for attempt in range(3):   # a rendezvous port can be taken between the probe and torchrun's bind: try another one
+        port = str(_free_port())
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                              "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
+                             capture_output=True, text=True, env=env, timeout=300)
+        if out.returncode == 0:
+            break
     assert out.returncode == 0, out.stdout + out.stderr
     assert "OK 48.0 2.0" in out.stdout
