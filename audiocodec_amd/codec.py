@@ -66,6 +66,14 @@ class AudioCodec:
             _lib.check(fn(self.mdct._plan(x.device), self.psy._plan(x.device), _host.ptr(x), _host.ptr(X), _host.ptr(t),
                           _host.ptr(thr), float(drown), B, K, C, _host.stream_ptr(x.device)))
 
+    def workspace(self, batches_n, blocks_n, channels_n, **kwargs):
+        """Caller-owned ``x, X, t, thr, xh`` tensors for batches of this shape, placed for the MI355X's HBM (see
+        :class:`audiocodec_amd.workspace.Workspace`: on plain allocations the two kernels run up to 15 % slower when the
+        tensors they stream side by side happen to share a class of VRAM stretches).  Use with :meth:`encode_into` /
+        :meth:`decode_into`."""
+        from .workspace import Workspace
+        return Workspace(self, batches_n, blocks_n, channels_n, **kwargs)
+
     def decode(self, X, pcm16=False):
         """X [B, K', N, C] -> x [B, (K'+1)*N, C]; ``pcm16=True`` returns ``torch.int16`` PCM
         (clamp(round(32768 x)) applied inside the kernel's stores)."""
