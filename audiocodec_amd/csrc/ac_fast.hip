@@ -1535,12 +1535,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_psy_bwd_fast(PsyBwdArgs a) {
 // synthesis strips: short, so that the strips in flight cover a nearly contiguous window of memory (HBM rewards that:
 // 0.42 ms at 15 blocks per strip, 0.38 ms at 4 with an extra DCT-IV per strip, 0.355-0.365 ms at 3 with the hand-over
 // between the waves of a workgroup; B = 256, K = 468)
-int pick_seglen(long long pairs, int frames) {
+// (re-measured on well-placed tensors, DESIGN.md 9a: stereo N = 1024 0.343 ms at 2 blocks per strip against 0.352 at 3;
+// N = 2048 0.373 at 3 against 0.396 at 2; mono N = 1024 0.190 at 3 against 0.197 at 2)
+int pick_seglen(long long pairs, int frames, int preferred) {
   static const int fixed = [] {
     const char* e = getenv("AC_SEGLEN");   // tuning hook
-    return e ? atoi(e) : 3;
+    return e ? atoi(e) : 0;
   }();
-  int s = fixed;
+  int s = fixed > 0 ? fixed : preferred;
   if (s > frames) s = frames;
   if (s < 1) s = 1;
   return s;
@@ -1930,7 +1932,7 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, int iof, con
   a.C = C;
   a.nsig = (long long)B * C;
   a.npairs = (C == 2) ? (long long)B : (a.nsig + 1) / 2;
-  a.seglen = pick_seglen(a.npairs, nblk);
+  a.seglen = pick_seglen(a.npairs, nblk, (p->N == Geo<8>::FN && C == 2) ? 2 : 3);
   a.nseg = (nblk + a.seglen - 1) / a.seglen;
   a.ntasks = a.npairs * a.nseg;
   // one strip per wave, workgroups dispatched in order (persistent waves drift apart and measured slower here)
