@@ -19,6 +19,12 @@
  *    synchronises caller memory and never changes the current device outside *_create;
  *  - return value 0 = AC_OK, negative = error; ac_last_error() gives a thread-local message;
  *  - plans are immutable after creation and may be shared between host threads and streams.
+ *
+ * Performance note (MI355X): the kernels stream their tensors at the device's copy rate, and that rate depends on where
+ * the caller's buffers live -- when the two tensors a kernel streams side by side (X and thr for ac_encode_fused, X
+ * and x for ac_mdct_inverse) sit in stretches of VRAM of the same class, the kernel runs up to 15 % slower.  The Python
+ * package's audiocodec_amd.Workspace finds a good pair of allocations by timing the encode kernel; a C caller can do
+ * the same with a few candidate allocations.
  */
 #ifndef AUDIOCODEC_AMD_H
 #define AUDIOCODEC_AMD_H
