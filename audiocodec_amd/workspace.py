@@ -46,7 +46,7 @@ class Workspace:
         n = 2
         if tune and span_gib > 0 and B * K > 0:
             free = torch.cuda.mem_get_info(self.device)[0] / _GIB
-            n = max(2, int(min(span_gib, 0.8 * free) / chunk_gib))
+            n = max(2, min(64, int(min(span_gib, 0.8 * free) / chunk_gib)))   # (small batches: at most 64 chunks)
         self.report = {"chunk_GiB": chunk_gib, "chunks_probed": n, "tuned": False}
         chunks = []
         try:
