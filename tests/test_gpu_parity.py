@@ -885,3 +885,30 @@ def test_workspace_places_buffers_without_changing_results():
         assert float((ws.xh[:, N:-N] - x).abs().max()) <= LSB
     with pytest.raises(NotImplementedError):
         audiocodec_amd.Workspace(audiocodec_amd.AudioCodec(48000, N, compute_dtype=torch.float64), B, K, C)
+
+
+def test_bench_contract_line_on_a_small_workload():
+    """bench.py end to end on a small workload: one JSON line with the contract's keys, the roofline and placement objects
+    and a sane value (the full-size run is the driver's; this guards the script itself)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--clips", "16", "--blocks", "32", "--steps", "5",
+                          "--warmup", "2", "--no-cpu-baseline", "--no-other-configs", "--placement-span-gib", "1"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "placement", "plain_allocations"):
+        assert k in d, k
+    assert d["metric"].startswith("MDCT frames/s") and d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 5
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["config"]["clips_per_gpu"] == 16 and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["traffic"] is None                       # measured traffic is on file for the full-size workload only
+    assert d["value"] > 1e6 and d["round_trip_max_abs_err"] <= LSB
