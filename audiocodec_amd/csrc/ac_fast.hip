@@ -16,7 +16,9 @@
 //     (lane, register k2) is lane + 64 k2, so the even coefficients X[2k] are already where the store wants
 //     them and only the odd ones (X[N-1-2k]) take the lane-reversal exchange again;
 //   * coalesced 16-byte stores of X; the psychoacoustic epilogue (tonality, Bark sums, spreading, threshold)
-//     runs on the frame in registers;
+//     runs on the frame in registers; the band x band spreading product runs on the matrix cores by default
+//     (spread_mfma: split-bf16 v_mfma_f32_4x4x4_16b_bf16) or as f32 multiply-adds (AC_SPREAD_F32);
+//   * the same kernels take 16-bit PCM (IOF 1) or bfloat16 tensors (IOF 2): the conversion sits in the row loads / stores;
 //   * synthesis carries the aliased half of a frame's DCT-IV in registers along a short strip of output blocks.
 // Frames are dealt to waves in order, so the chip works on one contiguous window of every tensor.
 //
