@@ -2,6 +2,7 @@
 # Timings of every entry point on the bench-sized workloads -> gpurun_out/entry_points.txt (copied to profiles/)
 out=gpurun_out/entry_points.txt
 {
+  echo "(plain torch allocations: the stereo float32 kernels run 5-15 % faster on Workspace-placed tensors, DESIGN.md 9a)"
   echo "== N = 1024, B = 256 stereo, K = 468 (tools/microbench.py)"; python tools/microbench.py 2>/dev/null
   echo; echo "== N = 2048, B = 256 stereo, K = 234"; N=2048 python tools/microbench.py 2>/dev/null
   echo; echo "== N = 1024, B = 256 mono, K = 468"; C=1 python tools/microbench.py 2>/dev/null
