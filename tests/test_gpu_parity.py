@@ -655,13 +655,16 @@ def test_float64_masking_model_vs_oracle(sr, N, M, C):
     assert float((y64 - y32.double()).abs().max()) <= 1e-6     # the same normals for the same seed
 
 
-def test_float32_kernels_vs_float64_kernels_at_full_size():
-    """BASELINE configs[1] at its full size, element by element on the device: the wave-level float32 kernels against the
-    float64 kernels on the same input (the float64 kernels are themselves held to the oracle at 1e-12 above)."""
-    N, B, K, C = 1024, 256, 468, 2
+@pytest.mark.parametrize("N,K", [(1024, 468), (2048, 234)])
+def test_float32_kernels_vs_float64_kernels_at_full_size(N, K):
+    """BASELINE configs[1] (N = 1024) and configs[3] (N = 2048, spreading product on the matrix cores) at their full size,
+    element by element on the device: the wave-level float32 kernels against the float64 kernels on the same input (the
+    float64 kernels are themselves held to the oracle at 1e-12 above)."""
+    B, C = 256, 2
     g = torch.Generator(device="cuda").manual_seed(77)
     x = torch.rand(B, K * N, C, device="cuda", generator=g) * 2 - 1
     c32 = audiocodec_amd.AudioCodec(48000, N)
+    assert c32.psy.plan_spreading() == "bf16x2_mfma"
     X, t, thr = c32.encode(x)
     xh = c32.decode(X)
     assert float((xh[:, N:-N] - x).abs().max()) <= LSB
