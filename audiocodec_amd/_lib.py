@@ -42,6 +42,8 @@ PROTOTYPES = {
     "ac_tonality_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ac_mask_threshold_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_int, c_int, c_int, c_int,
                                         c_void_p]),
+    "ac_probe_placement": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p), c_int, c_int, c_int,
+                                   c_int, c_void_p, POINTER(c_int), POINTER(c_float)]),
     "ac_encode_fused_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_int,
                                       c_int, c_int, c_void_p]),
     "ac_amplitude_to_db_typed": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),

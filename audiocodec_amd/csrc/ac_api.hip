@@ -5,6 +5,8 @@
 #include <new>
 #include <vector>
 
+#include <algorithm>
+
 #include "ac_internal.h"
 
 namespace ac {
@@ -582,6 +584,45 @@ int ac_amplitude_to_db(const float* a, float* out, size_t n, int norm, void* str
 int ac_add_noise(const float* X, const float* thr, float* out, size_t n, uint64_t seed, void* stream) {
   AC_REQUIRE(n == 0 || (X != nullptr && thr != nullptr && out != nullptr), "NULL tensor pointer");
   return launch_add_noise(X, thr, out, n, seed, (hipStream_t)stream);
+}
+
+// ---- buffer placement probe ---------------------------------------------------------------------
+int ac_probe_placement(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t,
+                       float* const* thr_candidates, int n_candidates, int B, int K, int C, void* stream, int* best,
+                       float* ms) {
+  AC_REQUIRE(mdct != nullptr && psy != nullptr, "plan is NULL");
+  AC_REQUIRE(thr_candidates != nullptr && n_candidates >= 1 && best != nullptr, "no candidates");
+  DeviceGuard guard(mdct->device);
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  AC_HIP_CHECK(hipEventCreate(&e0));
+  AC_HIP_CHECK(hipEventCreate(&e1));
+  int st = AC_OK, arg = 0;
+  float best_ms = 0.f;
+  for (int j = 0; j < n_candidates && !st; ++j) {
+    AC_REQUIRE(thr_candidates[j] != nullptr, "candidate %d is NULL", j);
+    float med[3];
+    st = ac_encode_fused(mdct, psy, x, X, t, thr_candidates[j], 0.f, B, K, C, stream);   // warm-up
+    for (int r = 0; r < 3 && !st; ++r) {
+      if (hipEventRecord(e0, s) != hipSuccess) st = AC_EHIP;
+      if (!st) st = ac_encode_fused(mdct, psy, x, X, t, thr_candidates[j], 0.f, B, K, C, stream);
+      if (!st && (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                  hipEventElapsedTime(&med[r], e0, e1) != hipSuccess))
+        st = AC_EHIP;
+    }
+    if (st) break;
+    std::sort(med, med + 3);
+    if (ms) ms[j] = med[1];
+    if (j == 0 || med[1] < best_ms) {
+      best_ms = med[1];
+      arg = j;
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (st == AC_EHIP) set_error("HIP event call failed in ac_probe_placement");
+  if (!st) *best = arg;
+  return st;
 }
 
 // ---- compute_dtype variants ---------------------------------------------------------------------

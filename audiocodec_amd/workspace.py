@@ -60,11 +60,20 @@ class Workspace:
         self._carve_a()
         best = 1
         if len(chunks) > 2:
-            times = []
-            for j in range(1, len(chunks)):
-                self._carve_b(chunks[j])
-                times.append(self._time_encode())
-            best = 1 + int(np.argmin(times))
+            # the library's own probe (ac_probe_placement: median of three timed encode launches per candidate)
+            import ctypes
+            from . import _lib
+            lib = _lib.load()
+            n = len(chunks) - 1
+            cands = (ctypes.c_void_p * n)(*[c.data_ptr() for c in chunks[1:]])
+            ms = (ctypes.c_float * n)()
+            arg = ctypes.c_int(0)
+            with torch.cuda.device(self.device):
+                _lib.check(lib.ac_probe_placement(codec.mdct._plan(self.device), codec.psy._plan(self.device),
+                                                  _host.ptr(self.x), _host.ptr(self.X), _host.ptr(self.t), cands, n, B, K, C,
+                                                  _host.stream_ptr(self.device), ctypes.byref(arg), ms))
+            times = [float(v) for v in ms]
+            best = 1 + int(arg.value)
             self.report.update({"tuned": True, "encode_ms_by_chunk": times, "chosen_chunk": best,
                                 "chunk_addresses": ["%#x" % c.data_ptr() for c in chunks]})
         self._b = chunks[best]
@@ -83,16 +92,3 @@ class Workspace:
         for k in ("thr", "xh"):
             setattr(self, k, chunk[o: o + int(np.prod(self.shapes[k]))].view(self.shapes[k]))
             o += self._words[k]
-
-    def _time_encode(self, reps=3):
-        fn = lambda: self.codec.encode_into(self.x, self.X, self.t, self.thr)   # noqa: E731
-        fn()
-        ts = []
-        for _ in range(reps):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            fn()
-            e1.record()
-            torch.cuda.synchronize(self.device)
-            ts.append(e0.elapsed_time(e1))
-        return float(np.median(ts))

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AC_VERSION 130 /* 0.1.3: + matrix-core spreading product, compute_dtype variants (*_typed) */
+#define AC_VERSION 140 /* 0.1.4: + matrix-core spreading product, compute_dtype variants (*_typed), placement probe */
 
 enum {
   AC_OK = 0,
@@ -181,6 +181,16 @@ int ac_stream_inverse(ac_stream* s, const float* X_chunk, float* x, int k, void*
 int ac_amplitude_to_db(const float* a, float* out, size_t n, int norm, void* stream);
 /* add_noise: out = X + thr * Normal(0, 1/6), counter-based generator keyed by (seed, element-pair index). */
 int ac_add_noise(const float* X, const float* thr, float* out, size_t n, uint64_t seed, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Buffer placement probe (see the performance note at the top).  Runs ac_encode_fused with each of
+ * the n candidate threshold buffers (x, X, t fixed; contents of X, t and the candidates are overwritten), times every
+ * candidate with HIP events (median of three launches after one warm-up) and returns the index of the fastest in *best and,
+ * when ms is not NULL, the n times in milliseconds.  The one entry point that synchronises (on its own events).
+ * ---------------------------------------------------------------------------------------- */
+int ac_probe_placement(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t,
+                       float* const* thr_candidates, int n_candidates, int B, int K, int C, void* stream, int* best,
+                       float* ms);
 
 /* ------------------------------------------------------------------------------------------
  * compute_dtype variants (mdctransformer.py:13-14,22-23; psychoacoustic.py:14-15,30,42-43: the reference accepts
