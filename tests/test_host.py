@@ -116,6 +116,8 @@ def test_constructor_validation():
         _lib.check(lib.ac_mdct_fold_coefficients_host(8, 9, (ctypes.c_double * 32)()))
     assert lib.ac_mdct_forward_typed(None, None, None, 9, 1, 1, 1, None) == _lib.AC_EINVAL
     assert b"AC_F32" in lib.ac_last_error()
+    best = ctypes.c_int(-1)
+    assert lib.ac_probe_placement(None, None, None, None, None, None, 0, 1, 1, 2, None, ctypes.byref(best), None) == _lib.AC_EINVAL
     assert lib.ac_psy_plan_create_ex(1024, 64, 48000.0, 0.6, 0, 7, ctypes.byref(out)) == _lib.AC_EINVAL
     assert b"AC_SPREAD" in lib.ac_last_error()
     with pytest.raises(ValueError):
