@@ -256,7 +256,10 @@ def main():
             "kernels": {"encode_ms": enc_ms, "encode_GBs": enc_gbs, "decode_ms": dec_ms, "decode_GBs": dec_gbs,
                         "encode_ms_median": float(np.median(enc_all)), "encode_ms_min": float(np.min(enc_all)),
                         "decode_ms_median": float(np.median(dec_all)), "decode_ms_min": float(np.min(dec_all)),
-                        "step_frac_of_hbm_peak": (ENC_BYTES + DEC_BYTES) * (value / world) / (HBM_PEAK_GBS * 1e9)},
+                        "step_frac_of_hbm_peak": (ENC_BYTES + DEC_BYTES) * (value / world) / (HBM_PEAK_GBS * 1e9),
+                        # the same against the measured streaming-copy rate, and the read-only share
+                        "step_frac_of_achievable_6290_GBs": (ENC_BYTES + DEC_BYTES) * (value / world) / 6.29e12,
+                        "step_read_share_of_hbm_peak": 2 * 4 * N * (value / world) / (HBM_PEAK_GBS * 1e9)},
             "round_trip_max_abs_err": err,
             "placement": placement,
         }
