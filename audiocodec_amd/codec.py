@@ -48,20 +48,47 @@ class AudioCodec:
         self.encode_into(x, X, t, thr, drown)
         return X, t, thr
 
+    def _check_io(self, t, name, shape, dtype, device):
+        """Caller-owned tensors go to the kernels as raw pointers: shape, dtype, device and contiguity must be exact."""
+        if not isinstance(t, torch.Tensor):
+            raise TypeError("%s must be a torch.Tensor, got %s" % (name, type(t).__name__))
+        if not t.is_cuda:
+            raise RuntimeError("%s lives on %s: this package only runs on ROCm device tensors" % (name, t.device))
+        if device is not None and t.device != device:
+            raise ValueError("%s lives on %s but the input lives on %s" % (name, t.device, device))
+        if t.dtype != dtype:
+            raise ValueError("%s has dtype %s, expected %s" % (name, t.dtype, dtype))
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError("%s must have shape %s, got %s" % (name, tuple(shape), tuple(t.shape)))
+        if not t.is_contiguous():
+            raise ValueError("%s must be contiguous (got strides %s for shape %s)" % (name, t.stride(), tuple(t.shape)))
+        return t
+
     def encode_into(self, x, X, t, thr, drown=0.0):
-        """Same as :meth:`encode` into caller-owned output tensors (no allocation in the timed path)."""
+        """Same as :meth:`encode` into caller-owned output tensors (no allocation in the timed path).  Every tensor
+        must be a contiguous device tensor of exactly the shape :meth:`encode` would return; ``ValueError`` otherwise."""
+        if not isinstance(x, torch.Tensor) or x.dim() != 3:
+            raise ValueError("x must be a [batches_n, samples_n, channels_n] tensor")
+        pcm16 = x.dtype == torch.int16
+        if pcm16 and self.compute_dtype != torch.float32:
+            raise ValueError("16-bit PCM input needs compute_dtype float32")
+        self._check_io(x, "x", None, torch.int16 if pcm16 else self.compute_dtype, None)
         B, S, C = x.shape
-        K = S // self.filters_n
+        N = self.filters_n
+        if S % N != 0:
+            raise ValueError("samples_n (%d) is not a multiple of filters_n (%d)" % (S, N))
+        K = S // N
+        self._check_io(X, "X", (B, K + 1, N, C), self.compute_dtype, x.device)
+        self._check_io(t, "t", (B, K + 1, 1, C), self.compute_dtype, x.device)
+        self._check_io(thr, "thr", (B, K + 1, N, C), self.compute_dtype, x.device)
         if self.compute_dtype != torch.float32:
             # float64: the three typed entry points in sequence; bfloat16: the fused wave-level kernel where it applies
-            if x.dtype != self.compute_dtype:
-                raise ValueError("x has dtype %s but compute_dtype is %s" % (x.dtype, self.compute_dtype))
             with torch.cuda.device(x.device):
                 _lib.check(self._lib.ac_encode_fused_typed(
                     self.mdct._plan(x.device), self.psy._plan(x.device), _host.ptr(x), _host.ptr(X), _host.ptr(t),
                     _host.ptr(thr), float(drown), self.mdct._dtype_id, B, K, C, _host.stream_ptr(x.device)))
             return
-        fn = self._lib.ac_encode_fused_pcm16 if x.dtype == torch.int16 else self._lib.ac_encode_fused
+        fn = self._lib.ac_encode_fused_pcm16 if pcm16 else self._lib.ac_encode_fused
         with torch.cuda.device(x.device):
             _lib.check(fn(self.mdct._plan(x.device), self.psy._plan(x.device), _host.ptr(x), _host.ptr(X), _host.ptr(t),
                           _host.ptr(thr), float(drown), B, K, C, _host.stream_ptr(x.device)))
@@ -88,15 +115,24 @@ class AudioCodec:
         return x
 
     def decode_into(self, X, x):
+        """:meth:`decode` into a caller-owned PCM tensor ``x [B, (K'+1)*N, C]`` (``torch.int16`` selects 16-bit PCM);
+        same exactness rules as :meth:`encode_into`."""
+        if not isinstance(X, torch.Tensor) or X.dim() != 4:
+            raise ValueError("X must be a [batches_n, blocks_n, filters_n, channels_n] tensor")
+        self._check_io(X, "X", None, self.compute_dtype, None)
         B, Kp, N, C = X.shape
+        if N != self.filters_n:
+            raise ValueError("axis 2 of X (%d) != filters_n (%d)" % (N, self.filters_n))
+        pcm16 = isinstance(x, torch.Tensor) and x.dtype == torch.int16
+        if pcm16 and self.compute_dtype != torch.float32:
+            raise ValueError("16-bit PCM output needs compute_dtype float32")
+        self._check_io(x, "x", (B, (Kp + 1) * N, C), torch.int16 if pcm16 else self.compute_dtype, X.device)
         if self.compute_dtype != torch.float32:
-            if x.dtype != self.compute_dtype:
-                raise ValueError("x has dtype %s but compute_dtype is %s" % (x.dtype, self.compute_dtype))
             with torch.cuda.device(X.device):
                 _lib.check(self._lib.ac_mdct_inverse_typed(self.mdct._plan(X.device), _host.ptr(X), _host.ptr(x),
                                                            self.mdct._dtype_id, B, Kp, C, _host.stream_ptr(X.device)))
             return
-        fn = self._lib.ac_mdct_inverse_pcm16 if x.dtype == torch.int16 else self._lib.ac_mdct_inverse
+        fn = self._lib.ac_mdct_inverse_pcm16 if pcm16 else self._lib.ac_mdct_inverse
         with torch.cuda.device(X.device):
             _lib.check(fn(self.mdct._plan(X.device), _host.ptr(X), _host.ptr(x), B, Kp, C, _host.stream_ptr(X.device)))
 

@@ -592,15 +592,19 @@ int ac_probe_placement(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const f
                        float* ms) {
   AC_REQUIRE(mdct != nullptr && psy != nullptr, "plan is NULL");
   AC_REQUIRE(thr_candidates != nullptr && n_candidates >= 1 && best != nullptr, "no candidates");
+  for (int j = 0; j < n_candidates; ++j) AC_REQUIRE(thr_candidates[j] != nullptr, "candidate %d is NULL", j);
   DeviceGuard guard(mdct->device);
   hipStream_t s = (hipStream_t)stream;
   hipEvent_t e0, e1;
   AC_HIP_CHECK(hipEventCreate(&e0));
-  AC_HIP_CHECK(hipEventCreate(&e1));
+  if (hipEventCreate(&e1) != hipSuccess) {
+    (void)hipEventDestroy(e0);
+    set_error("hipEventCreate failed in ac_probe_placement");
+    return AC_EHIP;
+  }
   int st = AC_OK, arg = 0;
   float best_ms = 0.f;
   for (int j = 0; j < n_candidates && !st; ++j) {
-    AC_REQUIRE(thr_candidates[j] != nullptr, "candidate %d is NULL", j);
     float med[3];
     st = ac_encode_fused(mdct, psy, x, X, t, thr_candidates[j], 0.f, B, K, C, stream);   // warm-up
     for (int r = 0; r < 3 && !st; ++r) {

@@ -2,52 +2,105 @@
 """Benchmark of the MDCT + psychoacoustic-masking hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no torchrun environment this process starts N ranks itself (``python -m torch.distributed.run``, one
+process per GPU) *before it makes any GPU call*, relays rank 0's JSON line and exits with the children's status; under
+torchrun (RANK / WORLD_SIZE set) it is one of those ranks.  A mismatch between --gpus and the world size is an error.
 
 One "step" = one pass of the hot path over one batch of synthetic PCM resident in HBM:
 fused encode (x -> X, tonality, threshold; one HIP kernel) followed by decode (X -> x^; one HIP kernel).
-Workload (BASELINE.json configs[1] at its roofline length): 256 stereo 48 kHz clips of
-K = 468 blocks (10 s) per GPU, N = 1024 -- 3.9 GB touched per step, far beyond the 256 MiB Infinity Cache.
-Clips are independent, so with N GPUs every rank processes its own 256 clips (weak scaling, no data-path
-collective); RCCL is used only for the barrier and the max-over-ranks reduction of the elapsed time.
+Workload: N = 1 is BASELINE.json configs[1] at its roofline length: 256 stereo 48 kHz clips of
+K = 468 blocks (10 s), filters_n = 1024 -- 3.9 GB touched per step, far beyond the 256 MiB Infinity Cache.  N > 1 is
+configs[2]: every rank holds its 512-clip share of B = 4096 / 8 (weak scaling: the share per GPU is the same at
+N = 2, 4, 8).  Clips are independent (reference mdctransformer.py:292-295 folds channels into the batch axis), so the
+batch axis is sharded and there is no data-path collective; RCCL carries the barrier, the max-over-ranks time and the
+reduction of frame counts / checksums / round-trip error.
 
-Prints ONE JSON line on rank 0.  value = frames/s over all GPUs, a frame being one 1024-sample hop of one
-channel, encode + decode both done (20 484 algorithmic bytes per frame).
+All tensors are plain torch allocations (what a caller of the reference API gets).  Prints ONE JSON line on rank 0.
+value = frames/s over all GPUs, a frame being one 1024-sample hop of one channel, encode + decode both done
+(20 484 algorithmic bytes per frame).
 """
 
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import audiocodec_amd  # noqa: E402
-from audiocodec_amd import dist as acd  # noqa: E402
-
 N = 1024
 ENC_BYTES = 4 * N + (4 * N + 4 * N + 4)      # PCM in; X, thr, tonality out           = 12 292 B / frame
 DEC_BYTES = 4 * N + 4 * N                    # X in; PCM out                          =  8 192 B / frame
 HBM_PEAK_GBS = 8000.0                        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CLIPS_1GPU = 256                             # BASELINE configs[1]
+CLIPS_PER_RANK = 4096 // 8                   # BASELINE configs[2]: B = 4096 over 8 GPUs
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)    # SURVEY 8(d): warm-up 10 iterations, then >= 200 timed
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--clips", type=int, default=0,
+                    help="stereo clips per GPU; 0 = 256 at --gpus 1 (configs[1]), 512 = 4096 / 8 otherwise (configs[2])")
+    ap.add_argument("--blocks", type=int, default=468, help="blocks (hops) per clip; 468 = 10 s at 48 kHz")
+    ap.add_argument("--no-workspace", action="store_true",
+                    help="skip the side measurement of the same step on audiocodec_amd.Workspace-placed tensors")
+    ap.add_argument("--settle-ms", type=float, default=100.0,
+                    help="keep the device busy with the same step for this long before the warmup steps: an MI355X that "
+                         "has idled runs the first ~30 ms of load at reduced clocks (reported as settle_ms / settle_steps; "
+                         "cold_start in the same line is the same measurement without it)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the side measurements (f32 spreading, "
+                    "K = 46, configs[3] / configs[4])")
+    ap.add_argument("--no-smi", action="store_true", help="do not sample the GPU's clocks / power from a side process")
+    return ap.parse_args(argv)
+
+
+# ---- N > 1 without torchrun: start the ranks from here, before anything touches the GPU ---------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """Re-run this script as `--gpus N` ranks under torch.distributed.run (children of this GPU-free process) and
+    relay their output.  On a box with fewer devices than ranks the ranks share devices over gloo (rehearsal only)."""
+    import torch
+    env = dict(os.environ)
+    have = torch.cuda.device_count()          # (counting devices does not initialise the GPU on this image)
+    if have <= 0:
+        sys.exit("bench.py needs the MI355X (no HIP device visible)")
+    if have < args.gpus and "AC_BENCH_BACKEND" not in env:
+        env["AC_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env, cwd=ROOT).returncode
+
+
+# ---- CPU baseline (oracle, host cores) -------------------------------------------------------------------------------
 def cpu_baseline(seconds=12.0):
     """The oracle (closed-form numpy/scipy restatement, oracle/audiocodec_oracle.py) timed on the host cores on a
-    bounded sample of the same workload: one single-threaded process per core (oracle/cpu_bench.py), each looping
-    encode + decode over stereo clips of 46 blocks for `seconds`; frames/s summed over the processes.  Runs before
-    this process touches the GPU (child processes are started from a GPU-free parent)."""
-    cores = max(1, min(os.cpu_count() or 1, 16))
-    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    bounded sample of the same workload: single-threaded processes (oracle/cpu_bench.py), each looping encode + decode
+    over stereo clips of 46 blocks for `seconds`; frames/s summed over the processes.  Runs before this process touches
+    the GPU (child processes are started from a GPU-free parent)."""
+    host_cpus = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = host_cpus
+    procs_n = max(1, min(usable, 16))          # a 1-GPU box gives its user 16 of the host's cores
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""),
+               OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "oracle.cpu_bench", "--seconds", str(seconds)]
     procs = [subprocess.Popen(cmd + ["--seed", str(i)], cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
-             for i in range(cores)]
+             for i in range(procs_n)]
     rate, frames = 0.0, 0
     for p in procs:
         out, _ = p.communicate(timeout=seconds * 6 + 120)
@@ -60,13 +113,102 @@ def cpu_baseline(seconds=12.0):
                          timeout=600).stdout
     d = json.loads(out.strip().splitlines()[-1])
     return {
-        "value": rate, "unit": "frames/s", "cores": cores, "kind": "port",
+        "value": rate, "unit": "frames/s", "cores": procs_n, "kind": "port",
+        "host_cpus": host_cpus, "usable_cpus": usable, "processes": procs_n, "threads_per_process": 1,
         "sample": "%d single-threaded processes x %.0f s of (B=2 stereo clips, K=46 blocks, N=%d) encode+decode, "
-                  "closed-form numpy/scipy oracle; %d frames in total" % (cores, seconds, N, frames),
+                  "closed-form numpy/scipy oracle; %d frames in total" % (procs_n, seconds, N, frames),
         "reference_shaped_value_per_core": d["frames"] / d["seconds"],
         "reference_shaped_sample": "1 process, dense polyphase / DCT-III / einsum restatement of the reference's op "
                                    "sequence, %.1f s" % d["seconds"],
     }
+
+
+# ---- GPU clocks / power from a side process (sysfs; started before this process touches the GPU) -------------------
+_SMI_CHILD = r"""
+import glob, json, os, sys, time
+def rd(p):
+    try:
+        with open(p) as f: return f.read().strip()
+    except Exception: return None
+def cur(p):   # pp_dpm_*: the line marked '*'
+    s = rd(p)
+    if not s: return None
+    for line in s.splitlines():
+        if line.rstrip().endswith('*'):
+            try: return float(line.split(':')[1].strip().rstrip('*').strip().lower().replace('mhz', ''))
+            except Exception: return None
+    return None
+cards = []   # every card with a hwmon directory (one per physical GPU), keyed by its PCI address
+for d in sorted(glob.glob('/sys/class/drm/card*/device')):
+    hw = sorted(glob.glob(d + '/hwmon/hwmon*'))
+    if hw: cards.append((os.path.basename(os.path.realpath(d)), d, hw[0]))
+only = sys.argv[3] if len(sys.argv) > 3 else ''
+out = open(sys.argv[1], 'w')
+stop = sys.argv[2]
+t_end = time.time() + 900
+while time.time() < t_end and not os.path.exists(stop):
+    for bdf, dev, hw in cards:
+        if only and only.lower() not in bdf.lower(): continue
+        s = {'t': time.time(), 'bdf': bdf, 'sclk_mhz': cur(dev + '/pp_dpm_sclk'), 'mclk_mhz': cur(dev + '/pp_dpm_mclk'),
+             'fclk_mhz': cur(dev + '/pp_dpm_fclk'), 'busy': rd(dev + '/gpu_busy_percent')}
+        for k, f in (('power_uw', 'power1_input'), ('freq_hz', 'freq1_input'), ('temp_mc', 'temp2_input')):
+            v = rd(hw + '/' + f)
+            if v is not None: s[k] = v
+        out.write(json.dumps(s) + '\n')
+    out.flush()
+    time.sleep(0.002)
+"""
+
+
+class SmiSampler:
+    """Polls the amdgpu sysfs files (current sclk / mclk level, hwmon power) every ~2 ms from a child process."""
+
+    def __init__(self):
+        import tempfile
+        self.dir = tempfile.mkdtemp(prefix="ac_smi_")
+        self.log, self.stop = os.path.join(self.dir, "log.jsonl"), os.path.join(self.dir, "stop")
+        self.p = subprocess.Popen([sys.executable, "-c", _SMI_CHILD, self.log, self.stop],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+    def finish(self, t0, t1, bdf=None):
+        """Stops the child; summary of the samples of the GPU at PCI address `bdf` taken inside the wall-clock window
+        [t0, t1] (and in the half second before it)."""
+        open(self.stop, "w").close()
+        try:
+            self.p.wait(timeout=5)
+        except Exception:
+            self.p.kill()
+        rows = []
+        try:
+            with open(self.log) as f:
+                rows = [json.loads(line) for line in f if line.strip()]
+        except Exception:
+            pass
+        seen = sorted({r.get("bdf") for r in rows})
+        if bdf is not None:
+            rows = [r for r in rows if bdf.lower() in str(r.get("bdf", "")).lower()]
+        inside = [r for r in rows if t0 <= r["t"] <= t1]
+        before = [r for r in rows if t0 - 0.5 <= r["t"] < t0]
+
+        def stat(sel, key, scale=1.0):
+            v = []
+            for r in sel:
+                try:
+                    v.append(float(r[key]) * scale)
+                except Exception:
+                    pass
+            return {"n": len(v), "min": min(v), "mean": sum(v) / len(v), "max": max(v)} if v else None
+
+        out = {"source": "amdgpu sysfs (pp_dpm_*, hwmon) polled from a side process", "pci": bdf, "cards_seen": len(seen),
+               "samples_in_timed_region": len(inside)}
+        for name, sel in (("timed_region", inside), ("half_second_before", before)):
+            out[name] = {"sclk_mhz": stat(sel, "sclk_mhz"), "mclk_mhz": stat(sel, "mclk_mhz"),
+                         "fclk_mhz": stat(sel, "fclk_mhz"), "power_w": stat(sel, "power_uw", 1e-6),
+                         "freq1_mhz": stat(sel, "freq_hz", 1e-6), "gpu_busy_percent": stat(sel, "busy")}
+        if not rows or all(v is None for v in out["timed_region"].values()):
+            out["note"] = "no readable amdgpu sysfs counters on this box" if not rows or "sclk_mhz" not in rows[0] \
+                else "no sample fell inside the timed region"
+        return out
 
 
 def measured_traffic():
@@ -83,18 +225,83 @@ def measured_traffic():
     return best
 
 
-def other_configs(dev):
-    """BASELINE configs[3] and configs[4] timed beside the headline (rank 0, N = 1 only, outside the timed region; they
-    are parity-test cases first -- tests/test_gpu_parity.py -- and these are their measured rates)."""
+def make_clips(torch, dev, first_clip, clips, blocks, channels=2, n=N):
+    """Synthetic PCM, uniform(-1, 1), one Philox stream per GLOBAL clip index (seed 1234 + index): rank r of a sharded
+    run generates exactly the clips [first_clip, first_clip + clips) a single rank would hold at those positions, so
+    checksums reduced over the ranks can be compared with a one-rank run over the same clips."""
+    x = torch.empty((clips, blocks * n, channels), device=dev, dtype=torch.float32)
+    gen = torch.Generator(device=dev)
+    for b in range(clips):
+        gen.manual_seed(1234 + first_clip + b)
+        x[b].uniform_(-1.0, 1.0, generator=gen)
+    return x
+
+
+def run_steps(torch, codec, x, X, t, thr, xh, n, timed=False):
+    """Enqueues n steps (encode launch + decode launch); with timed=True returns per-step kernel times by events on the
+    stream the kernels run on (after a synchronisation)."""
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)] if timed else None
+    for i in range(n):
+        if timed:
+            ev[i][0].record()
+        codec.encode_into(x, X, t, thr)
+        if timed:
+            ev[i][1].record()
+        codec.decode_into(X, xh)
+        if timed:
+            ev[i][2].record()
+    if not timed:
+        return None
+    torch.cuda.synchronize()
+    return [e[0].elapsed_time(e[1]) for e in ev], [e[1].elapsed_time(e[2]) for e in ev]
+
+
+def settle(torch, codec, x, X, t, thr, xh, settle_ms):
+    """Keeps the device busy with the step for `settle_ms` (no idle gap longer than a synchronisation).  An MI355X that
+    has idled for more than ~5 ms runs the first ~30 ms of any sustained load at reduced clocks (DESIGN.md section 5,
+    tools/ramp_probe2.py / ramp_probe3.py: steps 3..30 after an idle gap take up to 25 % longer, whatever ran before the
+    gap); a warm-up of 5 steps ends in the middle of that.  Returns the number of steps run."""
+    if settle_ms <= 0:
+        return 0
+    n, t0 = 0, time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < settle_ms:
+        run_steps(torch, codec, x, X, t, thr, xh, 8)
+        torch.cuda.synchronize()
+        n += 8
+    return n
+
+
+def timed_loop(torch, codec, x, X, t, thr, xh, steps, warmup, barrier=None, settle_ms=0.0):
+    """Device settle (see settle()), `warmup` untimed steps, then exactly `steps` steps between synchronisations; per-step
+    kernel times by events.  Returns (elapsed_s, encode_ms list, decode_ms list, t0, t1 wall clock, settle steps)."""
+    settled = settle(torch, codec, x, X, t, thr, xh, settle_ms)
+    run_steps(torch, codec, x, X, t, thr, xh, warmup)
+    torch.cuda.synchronize()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+    if barrier is not None:
+        barrier()
+    torch.cuda.synchronize()
+    w0 = time.time()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ev[i][0].record()
+        codec.encode_into(x, X, t, thr)
+        ev[i][1].record()
+        codec.decode_into(X, xh)
+        ev[i][2].record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    w1 = time.time()
+    enc = [e[0].elapsed_time(e[1]) for e in ev]
+    dec = [e[1].elapsed_time(e[2]) for e in ev]
+    return elapsed, enc, dec, w0, w1, settled
+
+
+def other_configs(torch, np, audiocodec_amd, dev, steps, warmup, settle_ms):
+    """Side measurements beside the headline (rank 0, N = 1 only, outside the timed region): the all-float32 spreading
+    product on the headline workload, the cache-resident K = 46 length of SURVEY 8(d), BASELINE configs[3] and
+    configs[4] (parity-test cases first -- tests/test_gpu_parity.py -- these are their measured rates)."""
     out = {}
-    # configs[3]: N = 2048 long-window MDCT + masking, Bark spreading as a band x band bf16 MFMA contraction
-    n, B, K, C = 2048, 256, 234, 2
-    x = torch.rand((B, K * n, C), device=dev) * 2 - 1
-    X = torch.empty((B, K + 1, n, C), device=dev)
-    t = torch.empty((B, K + 1, 1, C), device=dev)
-    thr = torch.empty_like(X)
-    ref = torch.empty_like(X)
-    xh = torch.empty((B, (K + 2) * n, C), device=dev)
 
     def med(fn, reps=7):
         fn()
@@ -108,6 +315,37 @@ def other_configs(dev):
             ts.append(e0.elapsed_time(e1))
         return float(np.median(ts))
 
+    def alloc(B, K, n, C=2):
+        return (torch.empty((B, K + 1, n, C), device=dev), torch.empty((B, K + 1, 1, C), device=dev),
+                torch.empty((B, K + 1, n, C), device=dev), torch.empty((B, (K + 2) * n, C), device=dev))
+
+    # (a) the headline step with the band x band spreading product in float32 on the vector ALU (AC_SPREAD_F32): the
+    #     all-float32 number beside the default split-bf16 matrix-core form
+    B, K = CLIPS_1GPU, 468
+    x = make_clips(torch, dev, 0, B, K)
+    X, t, thr, xh = alloc(B, K, N)
+    codec32 = audiocodec_amd.AudioCodec(48000, N, spreading="f32")
+    el, enc, dec, _, _, _ = timed_loop(torch, codec32, x, X, t, thr, xh, steps, warmup, settle_ms=settle_ms)
+    out["f32_spreading"] = {"value": B * 2 * K * steps / el, "ms_per_step": el / steps * 1e3,
+                            "encode_ms": float(np.mean(enc)), "decode_ms": float(np.mean(dec)),
+                            "kernel": "k_fwd_fast<8, 0, true, 4, 0, 0>"}
+    del x, X, t, thr, xh
+    # (b) K = 46 (1-s clips): 96.5 MB in, 98.6 MB each for X and thr -- fits the 256 MiB Infinity Cache; reported, not
+    #     used for the roofline claim
+    K = 46
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    x = make_clips(torch, dev, 0, B, K)
+    X, t, thr, xh = alloc(B, K, N)
+    el, enc, dec, _, _, _ = timed_loop(torch, codec, x, X, t, thr, xh, steps, warmup, settle_ms=settle_ms)
+    out["k46_cache_resident"] = {"workload": "batch=256 stereo clips of K=46 blocks (1 s), N=1024", "value": B * 2 * K * steps / el,
+                                 "ms_per_step": el / steps * 1e3, "encode_ms": float(np.mean(enc)),
+                                 "decode_ms": float(np.mean(dec))}
+    del x, X, t, thr, xh
+    # (c) configs[3]: N = 2048 long-window MDCT + masking, Bark spreading as a band x band bf16 MFMA contraction
+    n, K = 2048, 234
+    x = make_clips(torch, dev, 0, B, K, n=n)
+    X, t, thr, xh = alloc(B, K, n)
+    ref = torch.empty_like(X)
     rows, codecs = {}, {}
     for mode in ("f32", "bf16x2_mfma", "bf16_mfma"):
         codecs[mode] = audiocodec_amd.AudioCodec(48000, n, spreading=mode)
@@ -116,19 +354,19 @@ def other_configs(dev):
             ref.copy_(thr)
         rows[mode] = {"thr_max_rel_dev_vs_f32": float(((thr - ref).abs() / ref).max()), "encode_ms_rounds": []}
     for _ in range(3):   # interleaved rounds, median per form
-        for mode, codec in codecs.items():
-            rows[mode]["encode_ms_rounds"].append(med(lambda: codec.encode_into(x, X, t, thr), reps=5))
+        for mode, c in codecs.items():
+            rows[mode]["encode_ms_rounds"].append(med(lambda: c.encode_into(x, X, t, thr), reps=5))
     for mode in rows:
         rows[mode]["encode_ms"] = float(np.median(rows[mode].pop("encode_ms_rounds")))
-    codec = codecs["bf16x2_mfma"]
-    dec = med(lambda: codec.decode_into(X, xh))
-    fr = B * C * K
+    c = codecs["bf16x2_mfma"]
+    dec = med(lambda: c.decode_into(X, xh))
+    fr = B * 2 * K
     out["configs[3]"] = {"workload": "batch=256 stereo 48 kHz clips, N=2048, K=234 blocks (10 s)", "spreading": rows,
                          "decode_ms": dec, "bytes_per_frame_encode": 12 * n + 4, "bytes_per_frame_decode": 8 * n,
                          "frames_per_s_bf16x2_mfma": fr / ((rows["bf16x2_mfma"]["encode_ms"] + dec) * 1e-3),
                          "encode_GBs_bf16x2_mfma": (12 * n + 4) * fr / (rows["bf16x2_mfma"]["encode_ms"] * 1e-3) / 1e9}
     del x, X, t, thr, ref, xh
-    # configs[4]: streaming overlap-add, 10 min of stereo in chunks of 256 blocks through the device-resident state
+    # (d) configs[4]: streaming overlap-add, 10 min of stereo in chunks of 256 blocks through the device-resident state
     m = audiocodec_amd.MDCTransformer(N)
     Kt, k = 28125, 256
     xs = torch.rand((1, Kt * N, 2), device=dev) * 2 - 1
@@ -148,106 +386,107 @@ def other_configs(dev):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)    # warm-up 10 iterations, then >= 200 timed
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--settle-ms", type=float, default=0.0,
-                    help="keep the device busy with the same step for this long before the warmup steps (an idle GPU "
-                         "takes some tens of ms of load to reach its sustained clocks); reported as settle_ms")
-    ap.add_argument("--clips", type=int, default=256, help="stereo clips per GPU")
-    ap.add_argument("--blocks", type=int, default=468, help="blocks (hops) per clip; 468 = 10 s at 48 kHz")
-    ap.add_argument("--placement-span-gib", type=float, default=112.0,
-                    help="memory audiocodec_amd.Workspace may allocate for a moment while it looks for a good place for "
-                         "the step's tensors; 0 = plain torch allocations, no placement probing")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[3] / configs[4] side measurements")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    in_torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not in_torchrun:
+        sys.exit(launch_ranks(args))           # nothing in this process has touched the GPU
 
-    rank, world, _ = acd.env_rank_world()
-    cpu = None
-    if world == 1 and args.gpus == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()          # before this process initialises the GPU
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d (launch with `python bench.py --gpus %d`, or with "
+                 "torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus, args.gpus))
+    cpu = smi = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()                   # before this process initialises the GPU
+    if rank == 0 and not args.no_smi:
+        smi = SmiSampler()                     # child process, started before this process initialises the GPU
+
+    import numpy as np
+    import torch
+    import audiocodec_amd
+    from audiocodec_amd import dist as acd
+
     # RCCL ("nccl") carries the barrier and the scalar reductions; AC_BENCH_BACKEND=gloo rehearses the multi-rank path
     # on a box with fewer GPUs than ranks (ranks then share devices)
     backend = os.environ.get("AC_BENCH_BACKEND", "nccl")
-    rank, world, local_rank = acd.init_process_group(backend if args.gpus > 1 else None)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    assert torch.cuda.is_available(), "bench.py needs the MI355X"
-    dev = torch.device("cuda", (local_rank % torch.cuda.device_count()) if world > 1 else 0)
+    rank, world, local_rank = acd.init_process_group(backend if world > 1 else None)
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs the MI355X")
+    ndev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and ndev < world:
+        sys.exit("bench.py: %d ranks over RCCL need %d devices, this box has %d" % (world, world, ndev))
+    dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
 
-    B, K, C = args.clips, args.blocks, 2
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    B = args.clips if args.clips > 0 else (CLIPS_1GPU if world == 1 else CLIPS_PER_RANK)
+    K, C = args.blocks, 2
     codec = audiocodec_amd.AudioCodec(48000, N)
-    assert codec.mdct.is_fast(dev) and codec.psy.is_fast(dev), "wave-level kernels not selected"
+    if not (codec.mdct.is_fast(dev) and codec.psy.is_fast(dev)):
+        sys.exit("bench.py: wave-level kernels not selected")
     spreading = codec.psy.plan_spreading(dev)
-    placement = None
-    if args.placement_span_gib > 0:
-        # X and (thr, xh) in stretches of VRAM of different classes (audiocodec_amd/workspace.py: found by timing the
-        # encode kernel with thr in each of a row of candidate chunks; the chunks not chosen are freed again)
-        ws = audiocodec_amd.Workspace(codec, B, K, C, span_gib=args.placement_span_gib, device=dev)
-        x, X, t, thr, xh = ws.x, ws.X, ws.t, ws.thr, ws.xh
-        x.copy_(torch.rand((B, K * N, C), device=dev, generator=gen, dtype=torch.float32) * 2 - 1)
-        placement = ws.report
-    else:
-        x = torch.rand((B, K * N, C), device=dev, generator=gen, dtype=torch.float32) * 2 - 1
-        X = torch.empty((B, K + 1, N, C), device=dev, dtype=torch.float32)
-        t = torch.empty((B, K + 1, 1, C), device=dev, dtype=torch.float32)
-        thr = torch.empty((B, K + 1, N, C), device=dev, dtype=torch.float32)
-        xh = torch.empty((B, (K + 2) * N, C), device=dev, dtype=torch.float32)
+    x = make_clips(torch, dev, rank * B, B, K)
+    X = torch.empty((B, K + 1, N, C), device=dev, dtype=torch.float32)
+    t = torch.empty((B, K + 1, 1, C), device=dev, dtype=torch.float32)
+    thr = torch.empty((B, K + 1, N, C), device=dev, dtype=torch.float32)
+    xh = torch.empty((B, (K + 2) * N, C), device=dev, dtype=torch.float32)
 
-    def step():
-        codec.encode_into(x, X, t, thr)
-        codec.decode_into(X, xh)
+    def barrier():
+        acd.reduce_scalars([0.0], "sum", device=dev)      # RCCL all-reduce of one scalar
 
+    # cold start, for the record: `warmup` + `steps` steps straight from an idle device (what the same command measures
+    # without the settle phase); not the headline
+    cold = None
     if args.settle_ms > 0:
-        t_end = time.perf_counter() + args.settle_ms * 1e-3
-        while time.perf_counter() < t_end:
-            step()
-            torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    # parity guard on the benchmark data itself: round trip within 1 LSB of int16
-    err = float((xh[:, N:-N] - x).abs().max())
-    assert err <= 1.0 / 32768.0, "round trip error %g" % err
-
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    acd.reduce_scalars([0.0], "sum", device=dev)      # barrier (RCCL all-reduce of one scalar)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        codec.encode_into(x, X, t, thr)
-        ev[i][1].record()
-        codec.decode_into(X, xh)
-        ev[i][2].record()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+        run_steps(torch, codec, x, X, t, thr, xh, 2)      # first-launch costs (module load) are not part of it
+        torch.cuda.synchronize()
+        time.sleep(0.25)
+        run_steps(torch, codec, x, X, t, thr, xh, args.warmup)
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        ce, cd = run_steps(torch, codec, x, X, t, thr, xh, args.steps, timed=True)
+        cel = time.perf_counter() - c0
+        cold = {"value_rank0": B * C * K * args.steps / cel, "ms_per_step": cel / args.steps * 1e3,
+                "encode_ms": float(np.mean(ce)), "decode_ms": float(np.mean(cd)),
+                "encode_ms_per_step": [round(v, 4) for v in ce[:32]],
+                "note": "the same %d + %d steps started 250 ms after the device went idle, no settle phase" % (args.warmup, args.steps)}
+    elapsed, enc_all, dec_all, w0, w1, settled = timed_loop(torch, codec, x, X, t, thr, xh, args.steps, args.warmup, barrier,
+                                                            args.settle_ms)
     elapsed_max, = acd.reduce_scalars([elapsed], "max", device=dev)   # also the closing barrier
-    enc_all = [e[0].elapsed_time(e[1]) for e in ev]
-    dec_all = [e[1].elapsed_time(e[2]) for e in ev]
-    enc_ms, dec_ms = float(np.mean(enc_all)), float(np.mean(dec_all))
-
+    # parity guard on the benchmark data itself + the cross-rank aggregates of SURVEY 8(e): frames, checksums of
+    # X / thr / PCM (float64 sums), maximum round-trip error (<= 1 LSB of int16)
+    err = float((xh[:, N:-N] - x).abs().max()) if K > 0 else 0.0
     frames_rank = B * C * K
-    frames_total = frames_rank * world * args.steps
+    sums = acd.reduce_scalars([frames_rank, float(X.sum(dtype=torch.float64)), float(thr.sum(dtype=torch.float64)),
+                               float(xh.sum(dtype=torch.float64)), float(t.sum(dtype=torch.float64))], "sum", device=dev)
+    err_max, = acd.reduce_scalars([err], "max", device=dev)
+    if err_max > 1.0 / 32768.0:
+        sys.exit("bench.py: round trip error %g exceeds 1 LSB of int16" % err_max)
+    ranks_seen = world if world == 1 else torch.distributed.get_world_size()
+    enc_ms, dec_ms = float(np.mean(enc_all)), float(np.mean(dec_all))
+    frames_total = int(sums[0]) * args.steps
     value = frames_total / elapsed_max
+
     if rank == 0:
         tr = measured_traffic() if (B, K) == (256, 468) else None
         traffic = tr["encode"]["hbm_bytes_per_launch"] if tr else None
         enc_gbs = ENC_BYTES * frames_rank / (enc_ms * 1e-3) / 1e9
         dec_gbs = DEC_BYTES * frames_rank / (dec_ms * 1e-3) / 1e9
+        cfg = "configs[1]" if world == 1 else "configs[2] (its 512-clip share of B = 4096 / 8 per rank)"
         out = {
             "metric": "MDCT frames/s (48 kHz, N=1024) encode+decode",
-            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "settle_ms": args.settle_ms,
+            "value": value, "unit": "frames/s", "n_gpus": ranks_seen, "steps": args.steps, "warmup": args.warmup,
+            "settle_ms": args.settle_ms, "settle_steps": settled,
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: batch=%d stereo 48 kHz clips per GPU, N=1024, K=%d blocks "
-                                   "(%.1f s), fused MDCT+tonality+masking encode then IMDCT decode" % (B, K, K * N / 48000.0),
-                       "clips_per_gpu": B, "channels": C, "blocks": K, "filters_n": N, "sample_rate": 48000,
-                       "sharding": "clips split across ranks, no data-path collective"},
+            "config": {"workload": "BASELINE %s: batch=%d stereo 48 kHz clips per GPU, N=1024, K=%d blocks (%.1f s), fused "
+                                   "MDCT+tonality+masking encode then IMDCT decode, plain torch allocations"
+                                   % (cfg, B, K, K * N / 48000.0),
+                       "clips_per_gpu": B, "clips_total": B * world, "channels": C, "blocks": K, "filters_n": N,
+                       "sample_rate": 48000, "sharding": "clips split across ranks, no data-path collective",
+                       "backend": backend if world > 1 else None,
+                       "devices": min(world, ndev)},
             "roofline": {"bound": "hbm", "kernel": "k_fwd_fast<8, 0, true, 4, 0, %d> (fused encode, spreading product: %s)"
                                    % (audiocodec_amd.PsychoacousticModel.SPREADING[spreading], spreading),
                          "achieved": enc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": enc_gbs / HBM_PEAK_GBS,
@@ -256,44 +495,46 @@ def main():
             "kernels": {"encode_ms": enc_ms, "encode_GBs": enc_gbs, "decode_ms": dec_ms, "decode_GBs": dec_gbs,
                         "encode_ms_median": float(np.median(enc_all)), "encode_ms_min": float(np.min(enc_all)),
                         "decode_ms_median": float(np.median(dec_all)), "decode_ms_min": float(np.min(dec_all)),
+                        "encode_ms_per_step": [round(v, 4) for v in enc_all[:64]],
+                        "decode_ms_per_step": [round(v, 4) for v in dec_all[:64]],
                         "step_frac_of_hbm_peak": (ENC_BYTES + DEC_BYTES) * (value / world) / (HBM_PEAK_GBS * 1e9),
                         # the same against the measured streaming-copy rate, and the read-only share
                         "step_frac_of_achievable_6290_GBs": (ENC_BYTES + DEC_BYTES) * (value / world) / 6.29e12,
                         "step_read_share_of_hbm_peak": 2 * 4 * N * (value / world) / (HBM_PEAK_GBS * 1e9)},
-            "round_trip_max_abs_err": err,
-            "placement": placement,
+            "reduced_over_ranks": {"frames_per_step": int(sums[0]), "checksum_X": sums[1], "checksum_thr": sums[2],
+                                   "checksum_pcm": sums[3], "checksum_tonality": sums[4],
+                                   "round_trip_max_abs_err": err_max},
+            "round_trip_max_abs_err": err_max,
         }
-        if placement is not None and world == 1:
-            # the same step on plain torch allocations (what a caller gets without audiocodec_amd.Workspace), for scale
+        if cold is not None:
+            out["cold_start"] = cold
+        if smi is not None:
+            pr = torch.cuda.get_device_properties(dev)
+            out["gpu_state"] = smi.finish(w0, w1, "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id))
+        if not args.no_workspace and world == 1:
+            # the same step on tensors placed by audiocodec_amd.Workspace, beside the headline
             try:
-                px = x.clone()
-                pX, pt, pthr, pxh = torch.empty_like(X), torch.empty_like(t), torch.empty_like(thr), torch.empty_like(xh)
-                for _ in range(args.warmup):
-                    codec.encode_into(px, pX, pt, pthr)
-                    codec.decode_into(pX, pxh)
-                torch.cuda.synchronize()
-                p0 = time.perf_counter()
-                for _ in range(args.steps):
-                    codec.encode_into(px, pX, pt, pthr)
-                    codec.decode_into(pX, pxh)
-                torch.cuda.synchronize()
-                pdt = time.perf_counter() - p0
-                out["plain_allocations"] = {"value": frames_rank * args.steps / pdt, "ms_per_step": pdt / args.steps * 1e3}
-                del px, pX, pt, pthr, pxh
+                ws = audiocodec_amd.Workspace(codec, B, K, C, device=dev)
+                ws.x.copy_(x)
+                el, e2, d2, _, _, _ = timed_loop(torch, codec, ws.x, ws.X, ws.t, ws.thr, ws.xh, args.steps, args.warmup,
+                                                 settle_ms=args.settle_ms)
+                out["workspace_placed"] = {"value": frames_rank * args.steps / el, "ms_per_step": el / args.steps * 1e3,
+                                           "encode_ms": float(np.mean(e2)), "decode_ms": float(np.mean(d2)),
+                                           "placement": ws.report}
+                del ws
             except Exception as e:
-                out["plain_allocations"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                out["workspace_placed"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if world == 1 and not args.no_other_configs:
             del x, X, t, thr, xh
-            if placement is not None:
-                del ws
             try:
-                out["other_configs"] = other_configs(dev)
+                out["other_configs"] = other_configs(torch, np, audiocodec_amd, dev, min(args.steps, 50), args.warmup, args.settle_ms)
             except Exception as e:   # side measurements must never cost the headline line
                 out["other_configs"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

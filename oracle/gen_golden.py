@@ -140,6 +140,43 @@ def main():
                 arrs["thr_%s_d%02d_%s" % (name, int(drown * 10), tag)] = p.global_masking_threshold(Xc, t, drown)
     save("psy_48000_1024_64_cases", **arrs)
 
+    # 5b. the same kind of cases for the other models the wave-level masking kernels serve: N = 2048 at 48 kHz (BASELINE
+    #     configs[3]) and 96 kHz, N = 1024 at 44.1 kHz.  Spectra: interior frames of a reference transform of uniform noise,
+    #     all-zero, single-bin delta, 1e-6 .. 1 envelope with one silent channel; drown 0 / 0.5 / 1 on rand and delta.
+    rng2 = np.random.default_rng(2)   # (its own stream: the fixtures above and below keep their values)
+    for sr, Nf in ((48000, 2048), (44100, 1024), (96000, 2048)):
+        gx = np.load(os.path.join(OUT, "mdct_n%d_rand_vorbis.npz" % Nf))
+        Xr = gx["X_ref32"][:, 1:3]                                   # [1,2,Nf,2] float32, interior frames
+        Xz = np.zeros((1, 1, Nf, 2), dtype=f32)
+        Xd = np.zeros((1, 1, Nf, 2), dtype=f32)
+        Xd[0, 0, 100, :] = 0.5
+        env = np.logspace(-6, 0, Nf).reshape(1, 1, Nf, 1)
+        Xe = (rng2.uniform(-1, 1, (1, 2, Nf, 2)) * env).astype(f32)
+        Xe[0, 1, :, 1] = 0.0
+        q64, q32 = psy(sr, Nf, 64, f64), psy(sr, Nf, 64, f32)
+        arrs = {}
+        for name, X in (("rand", Xr), ("zero", Xz), ("delta", Xd), ("envelope", Xe)):
+            arrs["X_" + name] = X
+            for tag, p, dt in (("ref64", q64, f64), ("ref32", q32, f32)):
+                Xc = X.astype(dt)
+                t = p.tonality(Xc)
+                arrs["t_%s_%s" % (name, tag)] = t
+                for drown in (0.0, 0.5, 1.0):
+                    if drown != 0.0 and name not in ("rand", "delta"):
+                        continue
+                    arrs["thr_%s_d%02d_%s" % (name, int(drown * 10), tag)] = p.global_masking_threshold(Xc, t, drown)
+        save("psy_%d_%d_64_cases" % (sr, Nf), **arrs)
+
+    # 5c. BASELINE configs[0]: one 1-s mono 48 kHz clip, N = 1024 round trip: 48 000 samples
+    #     truncated to 46 blocks, 0.8 sin(2 pi 880 t / 48000) + uniform(-0.1, 0.1) noise (default_rng(0))
+    t48 = np.arange(46 * 1024, dtype=f64)
+    x1 = (0.8 * np.sin(2.0 * np.pi * 880.0 * t48 / 48000.0)
+          + np.random.default_rng(0).uniform(-0.1, 0.1, t48.shape)).astype(f32).reshape(1, -1, 1)
+    m64, m32 = mdct(1024, "vorbis", f64), mdct(1024, "vorbis", f32)
+    X64 = m64.transform(x1.astype(f64))
+    save("mdct_n1024_mono_1s", x=x1, X_ref64=X64, X_ref32=m32.transform(x1),
+         xhat_ref64=m64.inverse_transform(X64))
+
     # the reference's own tonality test configuration (tests/test_psychoacoustic.py:32-65): sr = N = 64
     x = _sine_f32(0.8, 4, 64, 5.0)
     Xt = mdct(64, "vorbis", f32).transform(x)

@@ -51,3 +51,18 @@ def rel_elem(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.max(np.abs(a - b) / np.abs(b)))
+
+
+def tonality_err(t, t_ref):
+    """Worst |t - t_ref| in units of the bar of SURVEY 8(c): element-wise 1e-4 relative with atol 1e-6 near 0
+    (<= 1.0 passes).  Works on numpy arrays and on torch tensors."""
+    try:
+        import torch
+        if isinstance(t, torch.Tensor) or isinstance(t_ref, torch.Tensor):
+            t = t.detach().double().cpu().numpy() if isinstance(t, torch.Tensor) else t
+            t_ref = t_ref.detach().double().cpu().numpy() if isinstance(t_ref, torch.Tensor) else t_ref
+    except ImportError:
+        pass
+    t = np.asarray(t, dtype=np.float64)
+    t_ref = np.asarray(t_ref, dtype=np.float64)
+    return float(np.max(np.abs(t - t_ref) / (1e-4 * np.abs(t_ref) + 1e-6)))

@@ -1,7 +1,7 @@
 """GPU (MI355X): parity of the HIP path -- called through the C ABI -- with the oracle and the golden
 vectors.  Tolerances (BASELINE.json north star / SURVEY 8(c)):
   * MDCT coefficients: max_frame(|dX|_inf / |X|_inf) <= 1e-4 and rel-L2 <= 1e-4 vs the fp64 reference values
-  * tonality: |dt| <= 2e-5 absolute;  thresholds: element-wise relative <= 1e-4
+  * tonality: |dt| <= 1e-4 |t| + 1e-6 (conftest.tonality_err <= 1);  thresholds: element-wise relative <= 1e-4
   * round trip PCM: <= 1 LSB of int16 (3.05e-5) and identical after rounding to int16
 """
 
@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_elem, rel_l2, rel_peak
+from conftest import rel_elem, rel_l2, rel_peak, tonality_err
 
 import audiocodec_amd
 from audiocodec_amd import _lib
@@ -48,7 +48,8 @@ MDCT_CASES = [("mdct_n64_sine", 64, "vorbis"), ("mdct_n256_roundtrip", 256, "vor
               ("mdct_n1024_rand_vorbis", 1024, "vorbis"), ("mdct_n1024_rand_sine", 1024, "sine"),
               ("mdct_n2048_rand_vorbis", 2048, "vorbis"), ("mdct_n16_rand_vorbis", 16, "vorbis"),
               ("mdct_n16_rand_sine", 16, "sine"), ("mdct_n16_rand_rect", 16, "rect"),
-              ("mdct_n12_rand_vorbis", 12, "vorbis")]
+              ("mdct_n12_rand_vorbis", 12, "vorbis"),
+              ("mdct_n1024_mono_1s", 1024, "vorbis")]      # BASELINE configs[0]: one 1-s mono 48 kHz clip
 
 
 @pytest.mark.parametrize("name,N,wt", MDCT_CASES)
@@ -160,17 +161,24 @@ def test_linearity_and_shift_properties(path):
 # ---- psychoacoustic model ---------------------------------------------------------------------------
 
 @pytest.mark.parametrize("cfg,sr,N,M", [("psy_48000_1024_64_cases", 48000, 1024, 64),
-                                        ("psy_64_64_64_cases", 64, 64, 64)])
+                                        ("psy_64_64_64_cases", 64, 64, 64),
+                                        ("psy_48000_2048_64_cases", 48000, 2048, 64),     # BASELINE configs[3]'s model
+                                        ("psy_44100_1024_64_cases", 44100, 1024, 64),
+                                        ("psy_96000_2048_64_cases", 96000, 2048, 64)])
 def test_psy_golden(golden, path, cfg, sr, N, M):
+    """tonality / global_masking_threshold against values the reference's own code produced (oracle/gen_golden.py);
+    with path = auto the models at N = 1024 / 2048 run the wave-level kernels"""
     g = golden(cfg)
     p = audiocodec_amd.PsychoacousticModel(sr, filter_bands_n=N, bark_bands_n=M)
+    if path == "auto" and N in (1024, 2048):
+        assert p.is_fast()
     for key in [k for k in g if k.startswith("X_")]:
         name = key[2:]
         X = dev(g[key].astype(np.float32))
         t_ref = g["t_%s_ref64" % name]
         t = host(p.tonality(X))
         assert t.shape == t_ref.shape
-        assert np.max(np.abs(t - t_ref)) <= 2e-5, name
+        assert tonality_err(t, t_ref) <= 1.0, name
         for k2 in [k for k in g if k.startswith("thr_" + name) and k.endswith("ref64")]:
             mid = k2[len("thr_" + name):-len("ref64")].strip("_")
             drown = int(mid[1:]) / 10.0 if mid else 0.0
@@ -205,7 +213,7 @@ def test_psy_random_vs_oracle(path, sr, N, M, B, F, C):
     o = PsychoOracle(sr, N, M, compute_dtype=np.float64)
     t = host(p.tonality(dev(X)))
     to = o.tonality(X.astype(np.float64))
-    assert np.max(np.abs(t - to)) <= 2e-5
+    assert tonality_err(t, to) <= 1.0
     for drown in (0.0, 0.3, 1.0):
         thr = host(p.global_masking_threshold(dev(X), dev(to.astype(np.float32)), drown))
         assert rel_elem(thr, o.global_masking_threshold(X.astype(np.float64), to, drown)) <= TOL
@@ -223,15 +231,15 @@ def test_encode_fused_equals_unfused_and_oracle(path, B, K, C, N):
     tu = codec.psy.tonality(Xu)
     thru = codec.psy.global_masking_threshold(Xu, tu, 0.2)
     assert float((X - Xu).abs().max()) <= 1e-6
-    assert float((t - tu).abs().max()) <= 2e-5
+    assert tonality_err(t, tu) <= 1.0
     assert float(((thr - thru).abs() / thru).max()) <= TOL
     om, op = MDCTOracle(N, "vorbis", np.float64), PsychoOracle(48000, N, 64, compute_dtype=np.float64)
     Xo = om.transform(x.astype(np.float64))
     to = op.tonality(Xo)
     thro = op.global_masking_threshold(Xo, to, 0.2)
     assert rel_peak(host(X), Xo) <= TOL
-    assert np.max(np.abs(host(t) - to)) <= 2e-5
-    assert rel_elem(host(thr), thro) <= 2e-4      # threshold of the GPU's own X and t (two rounding sources)
+    assert tonality_err(host(t), to) <= 1.0
+    assert rel_elem(host(thr), thro) <= TOL       # threshold of the GPU's own X and t (two rounding sources)
     xh = host(codec.decode(X))
     assert np.max(np.abs(xh[:, N:-N] - x)) <= LSB
 
@@ -285,7 +293,7 @@ def test_mfma_spreading_fused_encode(spreading, N, B, K):
     om, op = MDCTOracle(N, "vorbis", np.float64), PsychoOracle(48000, N, 64, compute_dtype=np.float64)
     Xo = om.transform(x.astype(np.float64))
     to = op.tonality(Xo)
-    assert rel_elem(host(thr), op.global_masking_threshold(Xo, to, 0.2)) <= max(2e-4, tol)
+    assert rel_elem(host(thr), op.global_masking_threshold(Xo, to, 0.2)) <= tol
     if spreading == "bf16_mfma":
         assert float(((thr - thr0).abs() / thr0).max()) > 1e-4   # the bf16 rounding is really there
 
@@ -371,7 +379,7 @@ def test_full_size_properties(path):
     xs = host(x[:2]).astype(np.float64)
     Xo = om.transform(xs)
     assert rel_peak(host(X[:2]), Xo) <= TOL
-    assert rel_elem(host(thr[:2]), op.global_masking_threshold(Xo, op.tonality(Xo))) <= 2e-4
+    assert rel_elem(host(thr[:2]), op.global_masking_threshold(Xo, op.tonality(Xo))) <= TOL
 
 
 def test_fast_path_selection():
@@ -518,8 +526,8 @@ def test_autograd_of_the_masking_model(path, sr, N, M, C, drown):
     Xd = X.detach().double().requires_grad_(True)
     td = _torch_tonality_reference(Xd)
     thrd = _torch_psy_reference(p, Xd, td, drown)
-    assert float((t.detach().double() - td.detach()).abs().max()) <= 2e-5
-    assert float(((thr.detach().double() - thrd.detach()).abs() / thrd.detach()).max()) <= 2e-4
+    assert tonality_err(t, td) <= 1.0
+    assert float(((thr.detach().double() - thrd.detach()).abs() / thrd.detach()).max()) <= TOL
     w = torch.rand(B, F, N, C, device="cuda", generator=g) + 0.5
     (thr * w).sum().backward()
     (thrd * w.double()).sum().backward()
@@ -680,13 +688,13 @@ def test_float32_kernels_vs_float64_kernels_at_full_size(N, K):
         worst_X = max(worst_X, float((d.abs().amax(dim=2, keepdim=True) / peak).max()))
         worst_l2 = max(worst_l2, float(d.norm() / X64.norm()))
         t64 = p64.tonality(X64)
-        worst_t = max(worst_t, float((t[b:b + step].double() - t64).abs().max()))
+        worst_t = max(worst_t, tonality_err(t[b:b + step], t64))
         thr64 = p64.global_masking_threshold(X64, t64)
         worst_thr = max(worst_thr, float(((thr[b:b + step].double() - thr64).abs() / thr64).max()))
         del X64, d, t64, thr64
     assert worst_X <= TOL and worst_l2 <= TOL, (worst_X, worst_l2)
-    assert worst_t <= 2e-5, worst_t
-    assert worst_thr <= 2e-4, worst_thr                       # threshold of the float32 X and t (two rounding sources)
+    assert worst_t <= 1.0, worst_t                            # in units of the tonality bar (1e-4 |t| + 1e-6)
+    assert worst_thr <= TOL, worst_thr                        # threshold of the float32 X and t (two rounding sources)
 
 
 @pytest.mark.parametrize("N,wt,C", [(1024, "vorbis", 2), (256, "sine", 1), (12, "vorbis", 3), (2048, "vorbis", 2), (64, "rect", 3)])
@@ -804,8 +812,8 @@ def test_fuzz_wave_kernels_against_the_generic_kernels():
         peak = Xg.abs().amax(dim=2, keepdim=True).clamp_min(1e-20)
         assert float(((X - Xg).abs() / peak).max()) <= TOL, tag
         assert float(((Xs - Xg).abs() / peak).max()) <= TOL, tag
-        assert float((t - tg).abs().max()) <= 2e-5 and float((ts - tg).abs().max()) <= 2e-5, tag
-        assert float(((thr - thrg).abs() / thrg).max()) <= 2e-4 and float(((thrs - thrg).abs() / thrg).max()) <= 2e-4, tag
+        assert tonality_err(t, tg) <= 1.0 and tonality_err(ts, tg) <= 1.0, tag
+        assert float(((thr - thrg).abs() / thrg).max()) <= TOL and float(((thrs - thrg).abs() / thrg).max()) <= TOL, tag
         assert float((xh - xg).abs().max()) <= 2e-6, tag
         if K > 0:
             assert float((xh[:, N:-N] - x).abs().max()) <= LSB, tag
@@ -875,12 +883,12 @@ def test_workspace_places_buffers_without_changing_results():
     x = torch.rand(B, K * N, C, device="cuda") * 2 - 1
     ref = codec.encode(x)
     for tune in (True, False):
-        ws = audiocodec_amd.Workspace(codec, B, K, C, span_gib=2.0, tune=tune)
+        ws = audiocodec_amd.Workspace(codec, B, K, C, span_gib=2.0, max_tries=3, tune=tune)
         assert tuple(ws.x.shape) == (B, K * N, C) and tuple(ws.X.shape) == (B, K + 1, N, C)
         assert tuple(ws.t.shape) == (B, K + 1, 1, C) and tuple(ws.thr.shape) == tuple(ws.X.shape)
         assert tuple(ws.xh.shape) == (B, (K + 2) * N, C)
         assert all(v.is_contiguous() and v.data_ptr() % (1 << 21) == 0 for v in (ws.x, ws.X, ws.thr, ws.xh))
-        assert ws.report["tuned"] == (tune and ws.report["chunks_probed"] > 2)
+        assert ws.report["tuned"] == tune and (not tune or 2 <= ws.report["tries"] <= 3)
         ws.x.copy_(x)
         codec.encode_into(ws.x, ws.X, ws.t, ws.thr)
         codec.decode_into(ws.X, ws.xh)
@@ -890,23 +898,27 @@ def test_workspace_places_buffers_without_changing_results():
         audiocodec_amd.Workspace(audiocodec_amd.AudioCodec(48000, N, compute_dtype=torch.float64), B, K, C)
 
 
-def test_bench_contract_line_on_a_small_workload():
-    """bench.py end to end on a small workload: one JSON line with the contract's keys, the roofline and placement objects
-    and a sane value (the full-size run is the driver's; this guards the script itself)"""
+def _run_bench(*args):
     import json
     import os
     import subprocess
     import sys
     from conftest import ROOT
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--clips", "16", "--blocks", "32", "--steps", "5",
-                          "--warmup", "2", "--no-cpu-baseline", "--no-other-configs", "--placement-span-gib", "1"],
-                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + [str(a) for a in args],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    assert len(lines) == 1, out.stdout + out.stderr
+    return json.loads(lines[0])
+
+
+def test_bench_contract_line_on_a_small_workload():
+    """bench.py end to end on a small workload: one JSON line with the contract's keys, the roofline object, the reduced
+    checksums and a sane value (the full-size run is the driver's; this guards the script itself)"""
+    d = _run_bench("--clips", 16, "--blocks", 32, "--steps", 5, "--warmup", 2, "--settle-ms", 5, "--no-cpu-baseline",
+                   "--no-other-configs", "--no-workspace")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "placement", "plain_allocations"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "reduced_over_ranks", "settle_ms", "cold_start"):
         assert k in d, k
     assert d["metric"].startswith("MDCT frames/s") and d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 5
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["higher_is_better"] is True and d["vs_baseline"] is None
@@ -915,3 +927,51 @@ def test_bench_contract_line_on_a_small_workload():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["traffic"] is None                       # measured traffic is on file for the full-size workload only
     assert d["value"] > 1e6 and d["round_trip_max_abs_err"] <= LSB
+    assert d["reduced_over_ranks"]["frames_per_step"] == 16 * 2 * 32
+
+
+def test_bench_two_ranks_on_one_gpu_equal_one_rank():
+    """`python bench.py --gpus 2` starts its own two ranks (gloo when the box has fewer devices than ranks; both run the
+    HIP kernels on the one GPU), prints n_gpus = 2, and the frame count / checksums of X, thr, PCM, tonality reduced over
+    the ranks equal those of ONE rank over the same 16 clips: clips are independent (mdctransformer.py:292-295), sharding
+    the batch axis changes no value."""
+    two = _run_bench("--gpus", 2, "--clips", 8, "--blocks", 32, "--steps", 3, "--warmup", 1, "--settle-ms", 5)
+    one = _run_bench("--gpus", 1, "--clips", 16, "--blocks", 32, "--steps", 3, "--warmup", 1, "--settle-ms", 5,
+                     "--no-cpu-baseline", "--no-other-configs", "--no-workspace")
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["config"]["clips_per_gpu"] == 8 and two["config"]["clips_total"] == 16
+    a, b = two["reduced_over_ranks"], one["reduced_over_ranks"]
+    assert a["frames_per_step"] == b["frames_per_step"] == 16 * 2 * 32
+    for k in ("checksum_X", "checksum_thr", "checksum_pcm", "checksum_tonality"):
+        assert abs(a[k] - b[k]) <= 1e-9 * max(1.0, abs(b[k])), (k, a[k], b[k])       # float64 sums of identical float32 values
+    assert a["round_trip_max_abs_err"] <= LSB and a["round_trip_max_abs_err"] == b["round_trip_max_abs_err"]
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE" in (out.stdout + out.stderr)
+
+
+def test_config2_rank_share_512_clips():
+    """BASELINE configs[2] is B = 4096 clips over 8 GPUs: one rank's share is 512 stereo clips of 10 s.  At that size:
+    the round trip holds to 1 LSB, and the result equals, bit for bit, the two halves of the batch processed on their own
+    (what another sharding of the same clips would compute)."""
+    N, B, K, C = 1024, 512, 468, 2
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    g = torch.Generator(device="cuda").manual_seed(4096)
+    x = torch.empty(B, K * N, C, device="cuda").uniform_(-1, 1, generator=g)
+    X, t, thr = codec.encode(x)
+    xh = codec.decode(X)
+    assert float((xh[:, N:-N] - x).abs().max()) <= LSB
+    assert float(thr.min()) >= 1e-7 * (1 - 1e-6) and bool(torch.isfinite(thr).all())
+    del xh
+    for lo, hi in ((0, 256), (256, 512)):
+        Xp, tp, thrp = codec.encode(x[lo:hi])
+        assert torch.equal(Xp, X[lo:hi]) and torch.equal(tp, t[lo:hi]) and torch.equal(thrp, thr[lo:hi])
+        del Xp, tp, thrp

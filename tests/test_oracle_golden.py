@@ -15,7 +15,8 @@ MDCT_CASES = [("mdct_n64_sine", 64, "vorbis"), ("mdct_n256_roundtrip", 256, "vor
               ("mdct_n1024_rand_vorbis", 1024, "vorbis"), ("mdct_n1024_rand_sine", 1024, "sine"),
               ("mdct_n2048_rand_vorbis", 2048, "vorbis"), ("mdct_n16_rand_vorbis", 16, "vorbis"),
               ("mdct_n16_rand_sine", 16, "sine"), ("mdct_n16_rand_rect", 16, "rect"),
-              ("mdct_n12_rand_vorbis", 12, "vorbis")]
+              ("mdct_n12_rand_vorbis", 12, "vorbis"),
+              ("mdct_n1024_mono_1s", 1024, "vorbis")]      # BASELINE configs[0]: one 1-s mono 48 kHz clip
 
 
 @pytest.mark.parametrize("name,N,wt", MDCT_CASES)
@@ -42,6 +43,20 @@ def test_mdct_oracle_fp32_within_reference_envelope(golden, name, N, wt):
     if "xhat_ref64" in g:
         xh = o.inverse_transform(X)
         assert np.max(np.abs(xh - g["xhat_ref64"])) < 3e-6
+
+
+def test_config0_single_mono_clip_round_trip(golden):
+    """BASELINE configs[0] (plumbing, no GPU): x[1, 47104, 1] -> X[1, 47, 1024, 1] -> x^[1, 49152, 1] on the CPU
+    restatement; x^[:, 1024:-1024] == x within 1 LSB of int16"""
+    g = golden("mdct_n1024_mono_1s")
+    x = g["x"]
+    assert x.shape == (1, 47104, 1)
+    o = MDCTOracle(1024, "vorbis", np.float32)
+    X = o.transform(x)
+    assert X.shape == (1, 47, 1024, 1)
+    xh = o.inverse_transform(X)
+    assert xh.shape == (1, 49152, 1)
+    assert np.max(np.abs(xh[:, 1024:-1024] - x)) <= 1.0 / 32768.0
 
 
 def test_known_answer_vector(golden):
@@ -123,7 +138,10 @@ def test_tonality_like_reference():
     assert np.mean(t[0, 1:-1]) < 0.1
 
 
-@pytest.mark.parametrize("cfg,sr,N,M", [("psy_48000_1024_64_cases", 48000, 1024, 64), ("psy_64_64_64_cases", 64, 64, 64)])
+@pytest.mark.parametrize("cfg,sr,N,M", [("psy_48000_1024_64_cases", 48000, 1024, 64), ("psy_64_64_64_cases", 64, 64, 64),
+                                        ("psy_48000_2048_64_cases", 48000, 2048, 64),
+                                        ("psy_44100_1024_64_cases", 44100, 1024, 64),
+                                        ("psy_96000_2048_64_cases", 96000, 2048, 64)])
 @pytest.mark.parametrize("dt,tag,tol", [(np.float64, "ref64", 1e-13), (np.float32, "ref32", 3e-6)])
 def test_psy_cases(golden, cfg, sr, N, M, dt, tag, tol):
     g = golden(cfg)
