@@ -66,6 +66,7 @@ PROTOTYPES = {
     "ac_stream_destroy": (c_int, [c_void_p]),
     "ac_stream_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ac_stream_inverse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ac_stream_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "ac_amplitude_to_db": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "ac_add_noise": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_uint64, c_void_p]),
 }
@@ -95,7 +96,8 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 "%s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
-                "`make -C audiocodec_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+                "`make -C audiocodec_amd/csrc`.  There is no CPU fallback.%s"
+                % (LIB_PATH, ("\n--- output of the in-tree build attempt ---\n" + _build_log) if _build_log else ""))
         lib = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in PROTOTYPES.items():
             fn = getattr(lib, name)          # AttributeError here = header/library mismatch
@@ -107,16 +109,39 @@ def load():
     return _lib
 
 
+_build_log = ""
+
+
 def _build_in_tree():
     """The library is built in-tree by ``__graft_entry__.build()`` / ``make -C audiocodec_amd/csrc``; when it is missing
-    (a fresh checkout) try that once -- hipcc cross-compiles for gfx950 without a GPU.  Failure is not hidden: load()
-    raises ImportError afterwards."""
+    (a fresh checkout) try that once -- hipcc cross-compiles for gfx950 without a GPU.  Ranks importing at the same time
+    serialise on a file lock; the build links into a scratch directory and renames the library into place, so nobody can
+    dlopen a half-written file.  A failure is not hidden: load() raises ImportError with the compiler's output."""
+    global _build_log
+    import fcntl
+    import shutil
     import subprocess
-    try:
-        subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], check=True, stdout=subprocess.DEVNULL,
-                       stderr=subprocess.DEVNULL, timeout=1800)
-    except Exception:
-        pass
+    import tempfile
+    libdir = os.path.join(_HERE, "lib")
+    os.makedirs(libdir, exist_ok=True)
+    with open(os.path.join(libdir, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if os.path.exists(LIB_PATH):          # another process built it while this one waited
+                return
+            tmp = tempfile.mkdtemp(prefix="build_", dir=libdir)
+            try:
+                r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4", "OUTDIR=" + tmp],
+                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1800)
+                _build_log = r.stdout[-4000:]
+                if r.returncode == 0:
+                    os.replace(os.path.join(tmp, "libaudiocodec_amd.so"), LIB_PATH)
+            except (OSError, subprocess.SubprocessError) as e:
+                _build_log = "%s: %s" % (type(e).__name__, e)
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def check(status):

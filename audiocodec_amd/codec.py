@@ -101,6 +101,11 @@ class AudioCodec:
         from .workspace import Workspace
         return Workspace(self, batches_n, blocks_n, channels_n, **kwargs)
 
+    def stream(self, batches_n, channels_n, device=None):
+        """A :class:`StreamingMDCT` over this codec's filter bank and masking model (chunked ``encode`` / ``decode`` with
+        device-resident overlap state)."""
+        return StreamingMDCT(self.mdct, batches_n, channels_n, device=device, psy=self.psy)
+
     def decode(self, X, pcm16=False):
         """X [B, K', N, C] -> x [B, (K'+1)*N, C]; ``pcm16=True`` returns ``torch.int16`` PCM
         (clamp(round(32768 x)) applied inside the kernel's stores)."""
@@ -143,14 +148,22 @@ class StreamingMDCT:
     Feeding consecutive chunks of ``k`` blocks gives, frame for frame, the one-shot ``transform`` /
     ``inverse_transform`` result: analysis frame ``i`` of a chunk pairs block ``i`` with block ``i-1``
     (the stored last block of the previous chunk for ``i = 0``); synthesis block ``i`` overlap-adds
-    frame ``i`` with the stored aliased half of the previous frame.
+    frame ``i`` with the stored aliased half of the previous frame.  With a masking model (``psy``)
+    :meth:`encode_chunk` also returns tonality and threshold of the chunk's frames -- bit for bit what the one-shot
+    ``AudioCodec.encode`` gives for those frames.
     """
 
-    def __init__(self, mdct: MDCTransformer, batches_n, channels_n, device=None):
+    def __init__(self, mdct: MDCTransformer, batches_n, channels_n, device=None, psy: PsychoacousticModel = None):
         _host.require_float32(mdct.compute_dtype, "streaming overlap-add")
-        self.mdct = mdct
+        if psy is not None:
+            _host.require_float32(psy.compute_dtype, "streaming masking model")
+            if psy.filter_bands_n != mdct.filters_n:
+                raise ValueError("psy.filter_bands_n (%d) != mdct.filters_n (%d)" % (psy.filter_bands_n, mdct.filters_n))
+        self.mdct, self.psy = mdct, psy
         self.B, self.C = int(batches_n), int(channels_n)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self._lib = _lib.load()
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
@@ -172,28 +185,64 @@ class StreamingMDCT:
         with torch.cuda.device(self.device):
             _lib.check(self._lib.ac_stream_reset(self._handle, _host.stream_ptr(self.device)))
 
-    def transform_chunk(self, x_chunk):
+    def _check_chunk(self, x, name, ndim):
+        x = _host.check_device_tensor(x, name, self.mdct.compute_dtype, ndim)
+        if x.device != self.device:
+            raise ValueError("%s lives on %s but the stream's state lives on %s" % (name, x.device, self.device))
+        return x
+
+    def _out(self, out, name, shape, like):
+        if out is None:
+            return torch.empty(shape, dtype=like.dtype, device=like.device)
+        if not isinstance(out, torch.Tensor) or tuple(out.shape) != tuple(shape) or out.dtype != like.dtype \
+                or out.device != like.device or not out.is_contiguous():
+            raise ValueError("%s must be a contiguous %s tensor of shape %s on %s" % (name, like.dtype, tuple(shape), like.device))
+        return out
+
+    def transform_chunk(self, x_chunk, out=None):
         """x_chunk [B, k*N, C] -> X [B, k, N, C]."""
-        x = _host.check_device_tensor(x_chunk, "x_chunk", self.mdct.compute_dtype, 3)
+        x = self._check_chunk(x_chunk, "x_chunk", 3)
         B, S, C = x.shape
         N = self.mdct.filters_n
         if (B, C) != (self.B, self.C) or S % N != 0:
             raise ValueError("x_chunk must be [%d, k*%d, %d], got %s" % (self.B, N, self.C, tuple(x.shape)))
         k = S // N
-        X = torch.empty((B, k, N, C), dtype=x.dtype, device=x.device)
+        X = self._out(out, "out", (B, k, N, C), x)
         with torch.cuda.device(x.device):
             _lib.check(self._lib.ac_stream_forward(self._handle, _host.ptr(x), _host.ptr(X), k,
                                                    _host.stream_ptr(x.device)))
         return X
 
-    def inverse_chunk(self, X_chunk):
+    def encode_chunk(self, x_chunk, drown=0.0, out=None):
+        """x_chunk [B, k*N, C] -> (X [B, k, N, C], tonality [B, k, 1, C], threshold [B, k, N, C]) of the chunk's frames
+        (``ac_stream_encode``: MDCT, tonality and masking threshold in one launch where the wave-level kernels apply).
+        ``out``: optional tuple of three tensors to write into."""
+        if self.psy is None:
+            raise ValueError("this stream was created without a masking model (psy=...)")
+        x = self._check_chunk(x_chunk, "x_chunk", 3)
+        B, S, C = x.shape
+        N = self.mdct.filters_n
+        if (B, C) != (self.B, self.C) or S % N != 0:
+            raise ValueError("x_chunk must be [%d, k*%d, %d], got %s" % (self.B, N, self.C, tuple(x.shape)))
+        k = S // N
+        o = out if out is not None else (None, None, None)
+        X = self._out(o[0], "out[0]", (B, k, N, C), x)
+        t = self._out(o[1], "out[1]", (B, k, 1, C), x)
+        thr = self._out(o[2], "out[2]", (B, k, N, C), x)
+        with torch.cuda.device(x.device):
+            _lib.check(self._lib.ac_stream_encode(self._handle, self.psy._plan(x.device), _host.ptr(x), _host.ptr(X),
+                                                  _host.ptr(t), _host.ptr(thr), float(drown), k,
+                                                  _host.stream_ptr(x.device)))
+        return X, t, thr
+
+    def inverse_chunk(self, X_chunk, out=None):
         """X_chunk [B, k, N, C] -> x [B, k*N, C]."""
-        X = _host.check_device_tensor(X_chunk, "X_chunk", self.mdct.compute_dtype, 4)
+        X = self._check_chunk(X_chunk, "X_chunk", 4)
         B, k, N, C = X.shape
         if (B, C, N) != (self.B, self.C, self.mdct.filters_n):
             raise ValueError("X_chunk must be [%d, k, %d, %d], got %s" % (self.B, self.mdct.filters_n, self.C,
                                                                          tuple(X.shape)))
-        x = torch.empty((B, k * N, C), dtype=X.dtype, device=X.device)
+        x = self._out(out, "out", (B, k * N, C), X)
         with torch.cuda.device(X.device):
             _lib.check(self._lib.ac_stream_inverse(self._handle, _host.ptr(X), _host.ptr(x), k,
                                                    _host.stream_ptr(X.device)))

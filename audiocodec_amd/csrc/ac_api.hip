@@ -57,6 +57,12 @@ int ac_version(void) { return AC_VERSION; }
 const char* ac_last_error(void) { return g_err.c_str(); }
 
 int ac_set_force_generic(int on) {
+  // a test hook, not a product switch: honoured only in processes started with AC_TESTING=1 (read once)
+  static const bool testing = [] { const char* e = getenv("AC_TESTING"); return e && atoi(e) != 0; }();
+  if (!testing) {
+    set_error("ac_set_force_generic is a test hook: start the process with AC_TESTING=1 to use it");
+    return AC_EUNSUPPORTED;
+  }
   g_force_generic = on ? 1 : 0;
   return AC_OK;
 }
@@ -498,12 +504,16 @@ int ac_stream_create(const ac_mdct_plan* plan, int B, int C, ac_stream** out) {
   s->plan = plan;
   s->B = B;
   s->C = C;
+  s->N = plan->N;
+  s->device = plan->device;
   const size_t nb = (size_t)B * plan->N * C * sizeof(float);
   const size_t nt = (size_t)B * C * (plan->N / 2) * sizeof(float);
   hipError_t e = hipMalloc((void**)&s->d_prev_block, nb);
+  if (e == hipSuccess) e = hipMalloc((void**)&s->d_prev_tmp, nb);
   if (e == hipSuccess) e = hipMalloc((void**)&s->d_tail, nt);
   if (e == hipSuccess) e = hipMalloc((void**)&s->d_tail_tmp, nt);
   if (e == hipSuccess) e = hipMemset(s->d_prev_block, 0, nb);
+  if (e == hipSuccess) e = hipMemset(s->d_prev_tmp, 0, nb);
   if (e == hipSuccess) e = hipMemset(s->d_tail, 0, nt);
   if (e == hipSuccess) e = hipMemset(s->d_tail_tmp, 0, nt);
   if (e != hipSuccess) {
@@ -517,9 +527,9 @@ int ac_stream_create(const ac_mdct_plan* plan, int B, int C, ac_stream** out) {
 
 int ac_stream_reset(ac_stream* s, void* stream) {
   AC_REQUIRE(s != nullptr, "stream is NULL");
-  DeviceGuard guard(s->plan->device);
-  const size_t nb = (size_t)s->B * s->plan->N * s->C * sizeof(float);
-  const size_t nt = (size_t)s->B * s->C * (s->plan->N / 2) * sizeof(float);
+  DeviceGuard guard(s->device);
+  const size_t nb = (size_t)s->B * s->N * s->C * sizeof(float);
+  const size_t nt = (size_t)s->B * s->C * (s->N / 2) * sizeof(float);
   AC_HIP_CHECK(hipMemsetAsync(s->d_prev_block, 0, nb, (hipStream_t)stream));
   AC_HIP_CHECK(hipMemsetAsync(s->d_tail, 0, nt, (hipStream_t)stream));
   return AC_OK;
@@ -527,33 +537,63 @@ int ac_stream_reset(ac_stream* s, void* stream) {
 
 int ac_stream_destroy(ac_stream* s) {
   if (!s) return AC_OK;
-  DeviceGuard guard(s->plan->device);
+  DeviceGuard guard(s->device);   // (not s->plan->device: the plan may already be gone when a process tears down)
   (void)hipFree(s->d_prev_block);
+  (void)hipFree(s->d_prev_tmp);
   (void)hipFree(s->d_tail);
   (void)hipFree(s->d_tail_tmp);
   delete s;
   return AC_OK;
 }
 
-int ac_stream_forward(ac_stream* s, const float* x_chunk, float* X, int k, void* stream) {
+// analysis of one chunk, with or without the masking model; the wave-level kernels write the new state (the chunk's last
+// block) themselves into the second state buffer, the other tiers take a strided copy
+static int stream_analysis(ac_stream* s, const ac_psy_plan* psy, const float* x_chunk, float* X, float* t, float* thr,
+                           float drown, int k, void* stream) {
   AC_REQUIRE(s != nullptr, "stream is NULL");
   AC_REQUIRE(k >= 0, "negative chunk length %d", k);
   if (k == 0) return AC_OK;
   AC_REQUIRE(x_chunk != nullptr && X != nullptr, "NULL tensor pointer");
   const ac_mdct_plan* p = s->plan;
-  DeviceGuard guard(p->device);
+  if (psy) {
+    AC_REQUIRE(t != nullptr && thr != nullptr, "NULL tensor pointer");
+    AC_REQUIRE(p->N == psy->N, "mdct filters_n (%d) != psychoacoustic filter_bands_n (%d)", p->N, psy->N);
+    AC_REQUIRE(p->device == psy->device, "plans live on different devices");
+  }
+  DeviceGuard guard(s->device);
   hipStream_t hs = (hipStream_t)stream;
   int st;
-  if (p->fast && !g_force_generic)
-    st = launch_fwd_fast(p, nullptr, x_chunk, false, X, nullptr, nullptr, 0.f, s->d_prev_block, s->B, k, k, s->C, hs);
-  else
+  const bool fast = p->fast && !g_force_generic;
+  // (filters_n = 2048 mono: the fused kernel is not instantiated, see encode_fused)
+  const bool fused = psy && fast && psy->fast && !(p->N == 2048 && s->C == 1);
+  if (fast) {
+    st = launch_fwd_fast(p, fused ? psy : nullptr, x_chunk, false, X, fused ? t : nullptr, fused ? thr : nullptr, drown,
+                         s->d_prev_block, s->B, k, k, s->C, hs, s->d_prev_tmp);
+    if (st) return st;
+    std::swap(s->d_prev_block, s->d_prev_tmp);
+  } else {
     st = launch_fwd_generic(p, x_chunk, X, s->d_prev_block, s->B, k, k, s->C, hs);
-  if (st) return st;
-  // new state = last block of the chunk, per clip: B rows of N*C floats, source pitch k*N*C floats
-  const size_t row = (size_t)p->N * s->C * sizeof(float);
-  AC_HIP_CHECK(hipMemcpy2DAsync(s->d_prev_block, row, x_chunk + (size_t)(k - 1) * p->N * s->C, row * k, row,
-                                (size_t)s->B, hipMemcpyDeviceToDevice, hs));
-  return AC_OK;
+    if (st) return st;
+    // new state = last block of the chunk, per clip: B rows of N*C floats, source pitch k*N*C floats
+    const size_t row = (size_t)p->N * s->C * sizeof(float);
+    AC_HIP_CHECK(hipMemcpy2DAsync(s->d_prev_block, row, x_chunk + (size_t)(k - 1) * p->N * s->C, row * k, row,
+                                  (size_t)s->B, hipMemcpyDeviceToDevice, hs));
+  }
+  if (psy && !fused) {
+    st = ac_tonality(psy, X, t, s->B, k, s->C, stream);
+    if (!st) st = ac_mask_threshold(psy, X, t, drown, thr, s->B, k, s->C, stream);
+  }
+  return st;
+}
+
+int ac_stream_forward(ac_stream* s, const float* x_chunk, float* X, int k, void* stream) {
+  return stream_analysis(s, nullptr, x_chunk, X, nullptr, nullptr, 0.f, k, stream);
+}
+
+int ac_stream_encode(ac_stream* s, const ac_psy_plan* psy, const float* x_chunk, float* X, float* t, float* thr,
+                     float drown, int k, void* stream) {
+  AC_REQUIRE(psy != nullptr, "plan is NULL");
+  return stream_analysis(s, psy, x_chunk, X, t, thr, drown, k, stream);
 }
 
 int ac_stream_inverse(ac_stream* s, const float* X_chunk, float* x, int k, void* stream) {
@@ -562,7 +602,7 @@ int ac_stream_inverse(ac_stream* s, const float* X_chunk, float* x, int k, void*
   if (k == 0) return AC_OK;
   AC_REQUIRE(X_chunk != nullptr && x != nullptr, "NULL tensor pointer");
   const ac_mdct_plan* p = s->plan;
-  DeviceGuard guard(p->device);
+  DeviceGuard guard(s->device);
   hipStream_t hs = (hipStream_t)stream;
   int st;
   if (p->fast && !g_force_generic)

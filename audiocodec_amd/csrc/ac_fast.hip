@@ -54,6 +54,9 @@ typedef const float* gtab_t;   // LDS-resident table image
 #ifndef AC_NT_LOAD
 #define AC_NT_LOAD 0                // bit 0: block n, bit 1: block n-1 of the analysis, bit 2: frames of the synthesis
 #endif
+#ifndef AC_REV_DPP
+#define AC_REV_DPP 0                // 1: lane reversals in registers (row_mirror DPP + v_permlane16/32_swap); 0: through LDS
+#endif
 constexpr int WAVE_LDS = 9216;      // bytes of LDS per wave: 576 x 16-byte elements (8 rows of 64 + 8 pad)
 constexpr int S8_OFF = 8192;        // psycho: 128 chunk sums (8 bins each) behind the 8 KB intensity image
 constexpr int ZERO_OFF = 9216;      // psycho: one zero slot (padding target of the gather lists)
@@ -275,9 +278,32 @@ __device__ __forceinline__ void load_p1(const float* __restrict__ image, int lan
     p1[k] = Geo<R>::P1_IN_REGS ? reinterpret_cast<const v2f*>(image + Geo<R>::I_P1)[k * 64 + lane] : v2f{0.f, 0.f};
 }
 
+// 64-lane reversal of two registers at once, without LDS: lane index bits (b5 b4 | b3..b0).  v_permlane32_swap exchanges
+// the upper half of its first operand with the lower half of its second, i.e. it transposes "which register" with b5;
+// applied twice with the operands' roles swapped in between it complements b5 in both registers.  v_permlane16_swap does
+// the same for b4 (odd rows of the first operand <-> even rows of the second).  row_mirror (DPP) complements b3..b0.
+__device__ __forceinline__ void rev64_pair(float& a, float& b) {
+  const unsigned ia = __float_as_uint(a), ib = __float_as_uint(b);
+  const auto r = __builtin_amdgcn_permlane32_swap(ia, ib, false, false);
+  const auto q = __builtin_amdgcn_permlane32_swap(r[1], r[0], false, false);
+  const auto u = __builtin_amdgcn_permlane16_swap(q[0], q[1], false, false);
+  const auto v = __builtin_amdgcn_permlane16_swap(u[1], u[0], false, false);
+  a = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)v[0], 0x140, 0xf, 0xf, false));   // row_mirror
+  b = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)v[1], 0x140, 0xf, 0xf, false));
+}
+__device__ __forceinline__ v2f rev64(v2f v) {
+  float a = v.x, b = v.y;
+  rev64_pair(a, b);
+  return v2f{a, b};
+}
+
 // lane-reversal exchange of R (c0, c1) pairs: afterwards out[i] = in[(OFS - i) mod R] of lane 63 - lane
 template <int OFS, int R>
 __device__ __forceinline__ void rev_exchange(char* buf, int lane, const v2f (&in)[R], v2f (&out)[R]) {
+#if AC_REV_DPP
+#pragma unroll
+  for (int i = 0; i < R; ++i) out[i] = rev64(in[(OFS - i) & (R - 1)]);
+#else
   wave_sync();
   {
     char* w = buf + 8 * (63 - lane);
@@ -290,6 +316,7 @@ __device__ __forceinline__ void rev_exchange(char* buf, int lane, const v2f (&in
 #pragma unroll
     for (int i = 0; i < R; ++i) out[i] = *reinterpret_cast<const v2f*>(r + 512 * ((OFS - i) & (R - 1)));
   }
+#endif
 }
 
 // ---- the two signals a wave transforms side by side, and global <-> register movement of one natural-order row ----
@@ -794,7 +821,9 @@ struct FwdArgs {
   float* X;                  // [B, F, N, C]
   float* t;                  // [B, F, 1, C]   (PSY)
   float* thr;                // [B, F, N, C]   (PSY)
-  const float* prev_block;   // [B, N, C] or null
+  const float* prev_block;   // [B, N, C] or null: block -1 of every signal (streaming analysis state)
+  float* state_out;          // [B, N, C] or null: receives block Kin-1 of every signal (the next chunk's prev_block;
+                             // a different buffer than prev_block: other waves still read that one)
   const float* tab;          // mdct tables (analysis image)
   PsyParams psy;
   int B, Kin, F, C;
@@ -900,9 +929,28 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY, SPREAD>())) void k_fwd
       // previous block in [0, 4 KB), current block in [4 KB, 8 KB)
       v4f cb[R], pb[R];
       const bool cur_ok = issue_loads(kCur, pair, n, cb);
+#ifdef AC_EXP_NOHALO   // timing experiment only (wrong results): what the second read of every block costs
+      const bool prv_ok = true;
+#pragma unroll
+      for (int i = 0; i < R; ++i) pb[i] = cb[i] * 0.5f;
+#else
       const bool prv_ok = issue_loads(kPrv, pair, n, pb);
+#endif
       if (!cur_ok) zero_row(cb);   // edge frames only (wave-uniform)
       if (!prv_ok) zero_row(pb);
+      if constexpr (IOF == 0) {
+        if (a.state_out && n == a.Kin - 1)   // streaming: the chunk's last block is the next chunk's block -1
+          store_row<CMODE, R>(a.state_out + row_off(pq.b0, 1, 0, blk, pq.c0), a.state_out + row_off(pq.b1, 1, 0, blk, pq.c1),
+                              C, pq.has1, lane, cb);
+      }
+#if AC_REV_DPP
+      v2f xop_r[R], xoc_r[R];   // odd halves of the two blocks, from lane 63 - lane
+#pragma unroll
+      for (int c = 0; c < R; ++c) {
+        xop_r[c] = rev64(v2f{pb[c].z, pb[c].w});
+        xoc_r[c] = rev64(v2f{cb[c].z, cb[c].w});
+      }
+#else
       wave_sync();
       {
         char* w = buf + 8 * (63 - lane);
@@ -914,10 +962,15 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY, SPREAD>())) void k_fwd
       }
       wave_sync();
       const char* rd = buf + 8 * lane;
+#endif
 #pragma unroll
       for (int r = 0; r < R; ++r) {
+#if AC_REV_DPP
+        const v2f xop = xop_r[(R / 2 - 1 - r) & (R - 1)], xoc = xoc_r[(R / 2 - 1 - r) & (R - 1)];
+#else
         const v2f xop = *reinterpret_cast<const v2f*>(rd + 512 * ((R / 2 - 1 - r) & (R - 1)));
         const v2f xoc = *reinterpret_cast<const v2f*>(rd + 4096 + 512 * ((R / 2 - 1 - r) & (R - 1)));
+#endif
         const v4f& gp = pb[(r + R / 2) & (R - 1)];
         const v4f& gc = cb[(r + R / 2) & (R - 1)];
         const v2f xep = v2f{gp.x, gp.y}, xec = v2f{gc.x, gc.y};
@@ -954,6 +1007,11 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY, SPREAD>())) void k_fwd
       v4f cb[R];
       const bool cur_ok = issue_loads(kCur, pair, n, cb);
       if (!cur_ok) zero_row(cb);
+      if constexpr (IOF == 0) {
+        if (a.state_out && n == a.Kin - 1)
+          store_row<CMODE, R>(a.state_out + row_off(pq.b0, 1, 0, blk, pq.c0), a.state_out + row_off(pq.b1, 1, 0, blk, pq.c1),
+                              C, pq.has1, lane, cb);
+      }
       v2f xo_in[R], xo[R];
 #pragma unroll
       for (int c = 0; c < R; ++c) xo_in[c] = v2f{cb[c].z, cb[c].w};
@@ -1841,7 +1899,8 @@ static void launch_fwd_R(const FwdArgs& a, bool psy, int spread, int C, unsigned
 }
 
 int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x, int iof, float* X, float* t,
-                    float* thr, float drown, const float* prev_block, int B, int Kin, int F, int C, hipStream_t s) {
+                    float* thr, float drown, const float* prev_block, int B, int Kin, int F, int C, hipStream_t s,
+                    float* state_out) {
   if (B <= 0 || C <= 0 || F <= 0) return AC_OK;
   // combinations no kernel is instantiated for (ac_api.hip routes them elsewhere; refuse rather than launch nothing)
   if ((iof == 2 && C > 2) || (psy && p->N == Geo<16>::FN && (C == 1 || (iof == 1 && C > 2)))) {
@@ -1855,6 +1914,7 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x
   a.t = t;
   a.thr = thr;
   a.prev_block = prev_block;
+  a.state_out = state_out;
   a.tab = p->d_fast;
   if (psy) a.psy = psy_params(psy, drown);
   else a.psy = PsyParams{nullptr, 0.f, 0.f, 0.f};
@@ -1877,12 +1937,16 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x
   static const int wgcu = [] { const char* e = getenv("AC_WG_PER_CU"); return e ? atoi(e) : 3; }();
   static const int tper = [] { const char* e = getenv("AC_FWD_T"); return e ? atoi(e) : 4; }();
   a.xcd = xcd;
-  a.T = tper;
   const int spread = psy ? psy->spread : 0;
   const int nw = psy ? AC_WAVES_PSY : AC_WAVES;
+  // small launches (a streaming chunk of one clip): fewer frames per wave, so that the frames spread over the chip
+  // instead of queueing behind each other in a few workgroups
+  int tper_eff = tper;
+  while (tper_eff > 1 && a.nframes < (long long)nw * tper_eff * p->cus * 2) tper_eff >>= 1;
+  a.T = tper_eff;
   unsigned grid;
   if (tper > 0) {
-    const long long per = (long long)nw * tper;
+    const long long per = (long long)nw * tper_eff;
     long long g = (a.nframes + per - 1) / per;
     g = (g + 7) / 8 * 8;
     if (g > 2147483647ll) {
@@ -1935,6 +1999,8 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, int iof, con
   a.nsig = (long long)B * C;
   a.npairs = (C == 2) ? (long long)B : (a.nsig + 1) / 2;
   a.seglen = pick_seglen(a.npairs, nblk, (p->N == Geo<8>::FN && C == 2) ? 2 : 3);
+  // small launches (a streaming chunk of one clip): one block per strip, so that the blocks spread over the chip
+  if (a.npairs * ((nblk + a.seglen - 1) / a.seglen) < (long long)AC_WAVES * p->cus * 2) a.seglen = pick_seglen(a.npairs, nblk, 1);
   a.nseg = (nblk + a.seglen - 1) / a.seglen;
   a.ntasks = a.npairs * a.nseg;
   // one strip per wave, workgroups dispatched in order (persistent waves drift apart and measured slower here)

@@ -90,7 +90,9 @@ struct ac_psy_plan {
 struct ac_stream {
   const ac_mdct_plan* plan = nullptr;
   int B = 0, C = 0;
+  int N = 0, device = 0;           // copies of the plan's (the stream may outlive the plan object on teardown)
   float* d_prev_block = nullptr;   // analysis state  [B, N, C]
+  float* d_prev_tmp = nullptr;     // double buffer for the analysis state (written by the kernel that reads the other)
   float* d_tail = nullptr;         // synthesis state [B, C, N/2]  (u_last[h .. N-1])
   float* d_tail_tmp = nullptr;     // double buffer for the synthesis state
 };
@@ -115,8 +117,10 @@ int fast_psy_plan_init(ac_psy_plan* p);
 // psy may be null (plain transform).  X/t/thr as in ac_encode_fused.
 // iof: 0 = float32 tensors; 1 = int16 PCM on the PCM side (x), spectra float32; 2 = bfloat16 tensors throughout (every
 // pointer then addresses 2-byte elements; C = 1 or 2 only).  prev_block / tail state must be null unless iof == 0
+// state_out (iof == 0 only): receives block Kin-1 of every signal, the next chunk's prev_block (must not alias prev_block)
 int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x, int iof, float* X, float* t,
-                    float* thr, float drown, const float* prev_block, int B, int Kin, int F, int C, hipStream_t s);
+                    float* thr, float drown, const float* prev_block, int B, int Kin, int F, int C, hipStream_t s,
+                    float* state_out = nullptr);
 int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, int iof, const float* tail_in, float* tail_out,
                     int B, int Kp, int nblk, int C, hipStream_t s);
 int launch_psy_fast(const ac_psy_plan* p, const float* X, const float* t_in, float* t_out, float* thr, float drown,

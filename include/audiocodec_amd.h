@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AC_VERSION 140 /* 0.1.4: + matrix-core spreading product, compute_dtype variants (*_typed), placement probe */
+#define AC_VERSION 150 /* 0.1.5: + ac_stream_encode, analysis state written by the kernels, AC_TESTING gate of the test hook */
 
 enum {
   AC_OK = 0,
@@ -113,7 +113,8 @@ int ac_psy_plan_spreading(const ac_psy_plan* plan);
 int ac_mdct_plan_is_fast(const ac_mdct_plan* plan);
 int ac_psy_plan_is_fast(const ac_psy_plan* plan);
 
-/* Test/bench hook: force the generic kernels (1) or restore automatic selection (0). */
+/* Test hook (process-global): force the generic kernels (1) or restore automatic selection (0).  Honoured only in a
+ * process started with AC_TESTING=1 in its environment; AC_EUNSUPPORTED otherwise. */
 int ac_set_force_generic(int on);
 
 /* ------------------------------------------------------------------------------------------
@@ -171,6 +172,11 @@ int ac_stream_reset(ac_stream* s, void* stream);
 int ac_stream_destroy(ac_stream* s);
 /* x_chunk [B, k*N, C] -> X [B, k, N, C]  (frame i = blocks i-1, i; block -1 = state) */
 int ac_stream_forward(ac_stream* s, const float* x_chunk, float* X, int k, void* stream);
+/* the same with the masking model on the chunk's frames: X, t [B, k, 1, C], thr [B, k, N, C] equal, frame for frame and bit
+ * for bit, what ac_encode_fused returns for the whole signal (one fused launch where the wave-level kernels serve both
+ * plans; psychoacoustic.py:102-148 on mdctransformer.py:62-125) */
+int ac_stream_encode(ac_stream* s, const ac_psy_plan* psy, const float* x_chunk, float* X, float* t, float* thr,
+                     float drown, int k, void* stream);
 /* X_chunk [B, k, N, C] -> x [B, k*N, C]  (block i = frames i, i-1; frame -1 = state) */
 int ac_stream_inverse(ac_stream* s, const float* X_chunk, float* x, int k, void* stream);
 

@@ -4,6 +4,8 @@ import sys
 import numpy as np
 import pytest
 
+os.environ.setdefault("AC_TESTING", "1")   # enables the library's test hook ac_set_force_generic (read when first called)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

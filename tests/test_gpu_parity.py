@@ -31,7 +31,7 @@ def _require_gpu():
 
 @pytest.fixture(params=["auto", "generic"])
 def path(request):
-    _lib.load().ac_set_force_generic(1 if request.param == "generic" else 0)
+    assert _lib.load().ac_set_force_generic(1 if request.param == "generic" else 0) == 0, "AC_TESTING=1 not in effect"
     yield request.param
     _lib.load().ac_set_force_generic(0)
 
@@ -353,6 +353,40 @@ def test_streaming_equals_one_shot(path, N, C, chunks):
     x_stream = torch.cat(outs, dim=1)
     assert float((x_stream - x_full).abs().max()) <= 1e-6
     assert float((x_stream[:, N:-N] - x).abs().max()) <= LSB
+    st.close()
+
+
+@pytest.mark.parametrize("N,C,chunks", [(1024, 2, (3, 1, 5)), (1024, 1, (2, 4)), (1024, 3, (4, 2)), (2048, 2, (2, 3)),
+                                        (2048, 1, (3, 1)), (256, 2, (5, 2)), (1024, 2, (256, 17))])
+def test_streaming_encode_equals_one_shot(path, N, C, chunks):
+    """ac_stream_encode (MDCT + tonality + masking threshold on a chunk, analysis state kept on the device and written
+    by the kernel itself) returns, chunk by chunk, exactly the frames of the one-shot encode -- bit for bit."""
+    B, K = 2, sum(chunks)
+    g = torch.Generator(device="cuda").manual_seed(N + C)
+    x = torch.empty(B, K * N, C, device="cuda").uniform_(-1, 1, generator=g)
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    X_full, t_full, thr_full = codec.encode(x, drown=0.25)            # [B, K+1, ...]
+    st = codec.stream(B, C)
+    Xs, ts, thrs, pos = [], [], [], 0
+    for k in chunks:
+        X, t, thr = st.encode_chunk(x[:, pos * N:(pos + k) * N], drown=0.25)
+        assert tuple(X.shape) == (B, k, N, C) and tuple(t.shape) == (B, k, 1, C) and tuple(thr.shape) == (B, k, N, C)
+        Xs.append(X), ts.append(t), thrs.append(thr)
+        pos += k
+    X, t, thr = st.encode_chunk(torch.zeros(B, N, C, device="cuda"), drown=0.25)   # flush: the tail frame
+    Xs.append(X), ts.append(t), thrs.append(thr)
+    assert torch.equal(torch.cat(Xs, dim=1), X_full)
+    assert torch.equal(torch.cat(ts, dim=1), t_full)
+    assert torch.equal(torch.cat(thrs, dim=1), thr_full)
+    # into caller-owned tensors, after a reset: the same again
+    st.reset()
+    out = (torch.empty_like(Xs[0]), torch.empty_like(ts[0]), torch.empty_like(thrs[0]))
+    got = st.encode_chunk(x[:, :chunks[0] * N], drown=0.25, out=out)
+    assert got[0] is out[0] and torch.equal(out[0], Xs[0]) and torch.equal(out[1], ts[0]) and torch.equal(out[2], thrs[0])
+    with pytest.raises(ValueError):
+        st.encode_chunk(x[:, :N + 1])
+    with pytest.raises(ValueError):
+        audiocodec_amd.StreamingMDCT(codec.mdct, B, C).encode_chunk(x[:, :N])     # no masking model attached
     st.close()
 
 
