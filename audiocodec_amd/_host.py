@@ -62,6 +62,26 @@ def check_device_tensor(t, name, dtype, ndim):
     return t.contiguous()
 
 
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def on_device(device):
+    """``with on_device(dev):`` makes ``dev`` current for the call; free when it already is (the common case -- a
+    ``torch.cuda.device`` context costs several microseconds, which matters for streaming-sized launches)."""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_SWITCH
+    return torch.cuda.device(device)
+
+
 def stream_ptr(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 

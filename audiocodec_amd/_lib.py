@@ -66,6 +66,8 @@ PROTOTYPES = {
     "ac_stream_destroy": (c_int, [c_void_p]),
     "ac_stream_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ac_stream_inverse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ac_stream_run": (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                              POINTER(c_void_p), POINTER(c_void_p), c_float, c_void_p]),
     "ac_stream_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "ac_amplitude_to_db": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "ac_add_noise": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_uint64, c_void_p]),

@@ -83,13 +83,13 @@ class AudioCodec:
         self._check_io(thr, "thr", (B, K + 1, N, C), self.compute_dtype, x.device)
         if self.compute_dtype != torch.float32:
             # float64: the three typed entry points in sequence; bfloat16: the fused wave-level kernel where it applies
-            with torch.cuda.device(x.device):
+            with _host.on_device(x.device):
                 _lib.check(self._lib.ac_encode_fused_typed(
                     self.mdct._plan(x.device), self.psy._plan(x.device), _host.ptr(x), _host.ptr(X), _host.ptr(t),
                     _host.ptr(thr), float(drown), self.mdct._dtype_id, B, K, C, _host.stream_ptr(x.device)))
             return
         fn = self._lib.ac_encode_fused_pcm16 if pcm16 else self._lib.ac_encode_fused
-        with torch.cuda.device(x.device):
+        with _host.on_device(x.device):
             _lib.check(fn(self.mdct._plan(x.device), self.psy._plan(x.device), _host.ptr(x), _host.ptr(X), _host.ptr(t),
                           _host.ptr(thr), float(drown), B, K, C, _host.stream_ptr(x.device)))
 
@@ -133,12 +133,12 @@ class AudioCodec:
             raise ValueError("16-bit PCM output needs compute_dtype float32")
         self._check_io(x, "x", (B, (Kp + 1) * N, C), torch.int16 if pcm16 else self.compute_dtype, X.device)
         if self.compute_dtype != torch.float32:
-            with torch.cuda.device(X.device):
+            with _host.on_device(X.device):
                 _lib.check(self._lib.ac_mdct_inverse_typed(self.mdct._plan(X.device), _host.ptr(X), _host.ptr(x),
                                                            self.mdct._dtype_id, B, Kp, C, _host.stream_ptr(X.device)))
             return
         fn = self._lib.ac_mdct_inverse_pcm16 if pcm16 else self._lib.ac_mdct_inverse
-        with torch.cuda.device(X.device):
+        with _host.on_device(X.device):
             _lib.check(fn(self.mdct._plan(X.device), _host.ptr(X), _host.ptr(x), B, Kp, C, _host.stream_ptr(X.device)))
 
 
@@ -166,7 +166,7 @@ class StreamingMDCT:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self._lib = _lib.load()
         handle = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
+        with _host.on_device(self.device):
             _lib.check(self._lib.ac_stream_create(mdct._plan(self.device), self.B, self.C, ctypes.byref(handle)))
         self._handle = handle
 
@@ -182,7 +182,7 @@ class StreamingMDCT:
             pass
 
     def reset(self):
-        with torch.cuda.device(self.device):
+        with _host.on_device(self.device):
             _lib.check(self._lib.ac_stream_reset(self._handle, _host.stream_ptr(self.device)))
 
     def _check_chunk(self, x, name, ndim):
@@ -199,8 +199,12 @@ class StreamingMDCT:
             raise ValueError("%s must be a contiguous %s tensor of shape %s on %s" % (name, like.dtype, tuple(shape), like.device))
         return out
 
-    def transform_chunk(self, x_chunk, out=None):
-        """x_chunk [B, k*N, C] -> X [B, k, N, C]."""
+    def _stream(self, stream):
+        return _host.stream_ptr(self.device) if stream is None else ctypes.c_void_p(stream.cuda_stream)
+
+    def transform_chunk(self, x_chunk, out=None, stream=None):
+        """x_chunk [B, k*N, C] -> X [B, k, N, C].  ``stream``: a ``torch.cuda.Stream`` to enqueue on (default: the
+        current stream)."""
         x = self._check_chunk(x_chunk, "x_chunk", 3)
         B, S, C = x.shape
         N = self.mdct.filters_n
@@ -208,12 +212,11 @@ class StreamingMDCT:
             raise ValueError("x_chunk must be [%d, k*%d, %d], got %s" % (self.B, N, self.C, tuple(x.shape)))
         k = S // N
         X = self._out(out, "out", (B, k, N, C), x)
-        with torch.cuda.device(x.device):
-            _lib.check(self._lib.ac_stream_forward(self._handle, _host.ptr(x), _host.ptr(X), k,
-                                                   _host.stream_ptr(x.device)))
+        with _host.on_device(x.device):
+            _lib.check(self._lib.ac_stream_forward(self._handle, _host.ptr(x), _host.ptr(X), k, self._stream(stream)))
         return X
 
-    def encode_chunk(self, x_chunk, drown=0.0, out=None):
+    def encode_chunk(self, x_chunk, drown=0.0, out=None, stream=None):
         """x_chunk [B, k*N, C] -> (X [B, k, N, C], tonality [B, k, 1, C], threshold [B, k, N, C]) of the chunk's frames
         (``ac_stream_encode``: MDCT, tonality and masking threshold in one launch where the wave-level kernels apply).
         ``out``: optional tuple of three tensors to write into."""
@@ -229,13 +232,78 @@ class StreamingMDCT:
         X = self._out(o[0], "out[0]", (B, k, N, C), x)
         t = self._out(o[1], "out[1]", (B, k, 1, C), x)
         thr = self._out(o[2], "out[2]", (B, k, N, C), x)
-        with torch.cuda.device(x.device):
+        with _host.on_device(x.device):
             _lib.check(self._lib.ac_stream_encode(self._handle, self.psy._plan(x.device), _host.ptr(x), _host.ptr(X),
-                                                  _host.ptr(t), _host.ptr(thr), float(drown), k,
-                                                  _host.stream_ptr(x.device)))
+                                                  _host.ptr(t), _host.ptr(thr), float(drown), k, self._stream(stream)))
         return X, t, thr
 
-    def inverse_chunk(self, X_chunk, out=None):
+    def run(self, x, blocks_per_chunk, masking=True, synthesis=True, drown=0.0):
+        """A long device-resident signal ``x [1, K*N, C]`` (or a list of chunk tensors ``[B, k*N, C]``) through the stream
+        in chunks of ``blocks_per_chunk`` blocks with one library call (``ac_stream_run``: two kernel launches per chunk,
+        issued from C).  Returns ``(X, t, thr, xhat)`` -- tensors ``[1, K, ...]`` for
+        a tensor input, lists of per-chunk tensors for a list input; ``t`` / ``thr`` are None without ``masking``,
+        ``xhat`` is None without ``synthesis``.  The last chunk of a tensor input may be shorter."""
+        k, N = int(blocks_per_chunk), self.mdct.filters_n
+        if masking and self.psy is None:
+            raise ValueError("this stream was created without a masking model (psy=...)")
+        if k < 1:
+            raise ValueError("blocks_per_chunk must be positive")
+        as_list = isinstance(x, (list, tuple))
+        if as_list:
+            xs = [self._check_chunk(c, "x[%d]" % i, 3) for i, c in enumerate(x)]
+            for c in xs:
+                if tuple(c.shape) != (self.B, k * N, self.C):
+                    raise ValueError("every chunk must be [%d, %d, %d], got %s" % (self.B, k * N, self.C, tuple(c.shape)))
+            groups = [(xs, k)]
+            like = xs[0] if xs else None
+        else:
+            xt = self._check_chunk(x, "x", 3)
+            B, S, C = xt.shape
+            if B != 1 or self.B != 1 or C != self.C or S % N != 0:
+                raise ValueError("a tensor input must be [1, K*%d, %d] on a stream of one clip (pass a list of chunks "
+                                 "otherwise), got %s" % (N, self.C, tuple(xt.shape)))
+            K = S // N
+            full, rest = K // k, K % k
+            like = xt
+            Xall = torch.empty((1, K, N, C), dtype=xt.dtype, device=xt.device)
+            tall = torch.empty((1, K, 1, C), dtype=xt.dtype, device=xt.device) if masking else None
+            thrall = torch.empty_like(Xall) if masking else None
+            xhall = torch.empty_like(xt) if synthesis else None
+            groups = []
+            if full:
+                groups.append(([xt[:, i * k * N:(i + 1) * k * N] for i in range(full)], k))
+            if rest:
+                groups.append(([xt[:, full * k * N:]], rest))
+        outs = ([], [], [], [])
+        pos = 0
+        for chunks, kk in groups:
+            n = len(chunks)
+            if n == 0:
+                continue
+            if as_list:
+                Xc = [torch.empty((self.B, kk, N, self.C), dtype=like.dtype, device=like.device) for _ in range(n)]
+                tc = [torch.empty((self.B, kk, 1, self.C), dtype=like.dtype, device=like.device) for _ in range(n)] if masking else None
+                thc = [torch.empty_like(v) for v in Xc] if masking else None
+                xhc = [torch.empty_like(c) for c in chunks] if synthesis else None
+            else:
+                Xc = [Xall[:, pos + i * kk: pos + (i + 1) * kk] for i in range(n)]
+                tc = [tall[:, pos + i * kk: pos + (i + 1) * kk] for i in range(n)] if masking else None
+                thc = [thrall[:, pos + i * kk: pos + (i + 1) * kk] for i in range(n)] if masking else None
+                xhc = [xhall[:, (pos + i * kk) * N: (pos + (i + 1) * kk) * N] for i in range(n)] if synthesis else None
+            arr = lambda ts: (ctypes.c_void_p * n)(*[v.data_ptr() for v in ts]) if ts is not None else None   # noqa: E731
+            with _host.on_device(self.device):
+                _lib.check(self._lib.ac_stream_run(self._handle, self.psy._plan(self.device) if masking else None, n, kk,
+                                                   arr(chunks), arr(Xc), arr(tc), arr(thc), arr(xhc), float(drown),
+                                                   _host.stream_ptr(self.device)))
+            for o, v in zip(outs, (Xc, tc, thc, xhc)):
+                if v is not None:
+                    o.extend(v)
+            pos += n * kk
+        if as_list:
+            return outs[0], (outs[1] if masking else None), (outs[2] if masking else None), (outs[3] if synthesis else None)
+        return Xall, tall, thrall, xhall
+
+    def inverse_chunk(self, X_chunk, out=None, stream=None):
         """X_chunk [B, k, N, C] -> x [B, k*N, C]."""
         X = self._check_chunk(X_chunk, "X_chunk", 4)
         B, k, N, C = X.shape
@@ -243,7 +311,6 @@ class StreamingMDCT:
             raise ValueError("X_chunk must be [%d, k, %d, %d], got %s" % (self.B, self.mdct.filters_n, self.C,
                                                                          tuple(X.shape)))
         x = self._out(out, "out", (B, k * N, C), X)
-        with torch.cuda.device(X.device):
-            _lib.check(self._lib.ac_stream_inverse(self._handle, _host.ptr(X), _host.ptr(x), k,
-                                                   _host.stream_ptr(X.device)))
+        with _host.on_device(X.device):
+            _lib.check(self._lib.ac_stream_inverse(self._handle, _host.ptr(X), _host.ptr(x), k, self._stream(stream)))
         return x

@@ -143,7 +143,7 @@ class MDCTransformer:
             raise ValueError("samples_n (%d) is not a multiple of filters_n (%d)" % (S, N))
         K = S // N
         X = torch.empty((B, K + 1, N, C), dtype=x.dtype, device=x.device)
-        with torch.cuda.device(x.device):
+        with _host.on_device(x.device):
             _lib.check(self._lib.ac_mdct_forward_typed(self._plans.get(x.device), _host.ptr(x), _host.ptr(X),
                                                        self._dtype_id, B, K, C, _host.stream_ptr(x.device)))
         return X
@@ -166,7 +166,7 @@ class MDCTransformer:
         if N != self.filters_n:
             raise ValueError("axis 2 of mdct_amplitudes (%d) != filters_n (%d)" % (N, self.filters_n))
         x = torch.empty((B, (Kp + 1) * N, C), dtype=X.dtype, device=X.device)
-        with torch.cuda.device(X.device):
+        with _host.on_device(X.device):
             _lib.check(self._lib.ac_mdct_inverse_typed(self._plans.get(X.device), _host.ptr(X), _host.ptr(x),
                                                        self._dtype_id, B, Kp, C, _host.stream_ptr(X.device)))
         return x

@@ -141,7 +141,7 @@ class PsychoacousticModel:
             raise RuntimeError("mdct_amplitude lives on %s: no CPU fallback" % a.device)
         a = a.contiguous()
         out = torch.empty_like(a)
-        with torch.cuda.device(a.device):
+        with _host.on_device(a.device):
             _lib.check(self._lib.ac_amplitude_to_db_typed(_host.ptr(a), _host.ptr(out), a.numel(), int(norm),
                                                           self._dtype_id, _host.stream_ptr(a.device)))
         return out
@@ -172,7 +172,7 @@ class PsychoacousticModel:
         X = self._check_spectrum(mdct_amplitudes)
         B, F, N, C = X.shape
         t = torch.empty((B, F, 1, C), dtype=X.dtype, device=X.device)
-        with torch.cuda.device(X.device):
+        with _host.on_device(X.device):
             _lib.check(self._lib.ac_tonality_typed(self._plans.get(X.device), _host.ptr(X), _host.ptr(t),
                                                    self._dtype_id, B, F, C, _host.stream_ptr(X.device)))
         return t
@@ -181,7 +181,7 @@ class PsychoacousticModel:
         X = self._check_spectrum(X)
         B, F, N, C = X.shape
         gX = torch.empty_like(X)
-        with torch.cuda.device(X.device):
+        with _host.on_device(X.device):
             _lib.check(self._lib.ac_tonality_backward(self._plans.get(X.device), _host.ptr(X), _host.ptr(gt),
                                                       _host.ptr(gX), 0, B, F, C, _host.stream_ptr(X.device)))
         return gX
@@ -200,7 +200,7 @@ class PsychoacousticModel:
         t = t.contiguous()
         gX = torch.empty_like(X)
         gt = torch.empty_like(t)
-        with torch.cuda.device(X.device):
+        with _host.on_device(X.device):
             _lib.check(self._lib.ac_mask_threshold_backward(self._plans.get(X.device), _host.ptr(X), _host.ptr(t),
                                                             float(drown), _host.ptr(gthr), _host.ptr(gX), _host.ptr(gt),
                                                             B, F, C, _host.stream_ptr(X.device)))
@@ -215,7 +215,7 @@ class PsychoacousticModel:
         if t.device != X.device:
             raise ValueError("mdct_amplitudes and tonality_per_block live on different devices")
         thr = torch.empty_like(X)
-        with torch.cuda.device(X.device):
+        with _host.on_device(X.device):
             _lib.check(self._lib.ac_mask_threshold_typed(self._plans.get(X.device), _host.ptr(X), _host.ptr(t),
                                                          float(drown), _host.ptr(thr), self._dtype_id, B, F, C,
                                                          _host.stream_ptr(X.device)))
@@ -234,7 +234,7 @@ class PsychoacousticModel:
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         out = torch.empty_like(X)
-        with torch.cuda.device(X.device):
+        with _host.on_device(X.device):
             _lib.check(self._lib.ac_add_noise_typed(_host.ptr(X), _host.ptr(thr), _host.ptr(out), X.numel(),
                                                     int(seed) & (2 ** 64 - 1), self._dtype_id,
                                                     _host.stream_ptr(X.device)))

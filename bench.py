@@ -366,22 +366,92 @@ def other_configs(torch, np, audiocodec_amd, dev, steps, warmup, settle_ms):
                          "frames_per_s_bf16x2_mfma": fr / ((rows["bf16x2_mfma"]["encode_ms"] + dec) * 1e-3),
                          "encode_GBs_bf16x2_mfma": (12 * n + 4) * fr / (rows["bf16x2_mfma"]["encode_ms"] * 1e-3) / 1e9}
     del x, X, t, thr, ref, xh
-    # (d) configs[4]: streaming overlap-add, 10 min of stereo in chunks of 256 blocks through the device-resident state
-    m = audiocodec_amd.MDCTransformer(N)
-    Kt, k = 28125, 256
-    xs = torch.rand((1, Kt * N, 2), device=dev) * 2 - 1
-    st = audiocodec_amd.StreamingMDCT(m, 1, 2)
+    # (d) configs[4]: streaming overlap-add through the device-resident state, chunks of 256 blocks.  One clip gives a
+    #     launch only 256 wave tasks, so a chunk costs launch + one frame's latency, not bandwidth: reported are the
+    #     10-minute pass as one dependent chain (analysis, then synthesis of the same chunk, one stream), the same pipelined
+    #     on two streams (analysis of chunk i+1 beside synthesis of chunk i, as a codec runs them), the host-synchronised
+    #     latency of one chunk, and 64 concurrent streams (B = 64) through the same entry points.
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    k = 256
 
-    def stream_pass():
-        st.reset()
-        for p in range(0, Kt, k):
-            Xc = st.transform_chunk(xs[:, p * N:min(Kt, p + k) * N])
-            st.inverse_chunk(Xc)
+    def stream_case(Bs, Kt, fused):
+        xs = torch.rand((Bs, Kt * N, 2), device=dev) * 2 - 1
+        st = codec.stream(Bs, 2)
+        bufs = [(torch.empty((Bs, k, N, 2), device=dev), torch.empty((Bs, k, 1, 2), device=dev),
+                 torch.empty((Bs, k, N, 2), device=dev)) for _ in range(2)]
+        xo = [torch.empty((Bs, k * N, 2), device=dev) for _ in range(2)]
+        chunks = [xs[:, p * N:(p + k) * N] for p in range(0, Kt - k + 1, k)]
+        s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        done_a = [torch.cuda.Event() for _ in range(2)]
+        done_s = [torch.cuda.Event() for _ in range(2)]
 
-    ms = med(stream_pass, reps=3)
-    st.close()
-    out["configs[4]"] = {"workload": "1 stereo clip of 10 min (28125 blocks), chunks of 256 blocks, analysis + synthesis per chunk",
-                         "ms_per_10_min": ms, "frames_per_s": 2 * Kt / (ms * 1e-3), "x_real_time": 600.0 / (ms * 1e-3)}
+        def analysis(xc, b, stream=None):
+            if fused:
+                st.encode_chunk(xc, out=b, stream=stream)
+            else:
+                st.transform_chunk(xc, out=b[0], stream=stream)
+
+        def chain():
+            st.reset()
+            for i, xc in enumerate(chunks):
+                analysis(xc, bufs[0])
+                st.inverse_chunk(bufs[0][0], out=xo[0])
+
+        def pipelined():
+            st.reset()
+            torch.cuda.synchronize()
+            for i, xc in enumerate(chunks):
+                j = i & 1
+                if i >= 2:
+                    s1.wait_event(done_s[j])          # synthesis of chunk i-2 has read this buffer
+                analysis(xc, bufs[j], stream=s1)
+                done_a[j].record(s1)
+                s2.wait_event(done_a[j])
+                st.inverse_chunk(bufs[j][0], out=xo[j], stream=s2)
+                done_s[j].record(s2)
+            torch.cuda.synchronize()
+
+        def wall(fn, reps=3):
+            fn()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            return float(np.median(ts))
+
+        def one_call():          # ac_stream_run: the same chain, two launches per chunk issued from C
+            st.reset()
+            st.run(chunks if Bs > 1 else xs[:, :len(chunks) * k * N], k, masking=fused)
+
+        fr = Bs * 2 * k * len(chunks)
+        row = {"chunks": len(chunks)}
+        for name, fn in (("chain_one_stream", chain), ("pipelined_two_streams", pipelined), ("ac_stream_run", one_call)):
+            dt = wall(fn)
+            row[name] = {"ms": dt * 1e3, "frames_per_s": fr / dt, "us_per_chunk": dt / len(chunks) * 1e6,
+                         "x_real_time": (k * len(chunks) * N / 48000.0) / dt,
+                         "GBs": fr * (20484 if fused else 16384) / dt / 1e9}
+        lat = []
+        for _ in range(21):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            analysis(chunks[0], bufs[0])
+            st.inverse_chunk(bufs[0][0], out=xo[0])
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+        row["chunk_latency_us_host_synchronised"] = float(np.median(lat)) * 1e6
+        st.close()
+        return row
+
+    out["configs[4]"] = {
+        "workload": "10 min of 48 kHz stereo (28125 blocks) in chunks of 256 blocks; analysis (+ masking model) and synthesis per chunk",
+        "bytes_per_frame": {"transform+inverse": 2 * 8 * N, "encode+inverse": 12 * N + 4 + 8 * N},
+        "one_clip_transform": stream_case(1, 28125, False),
+        "one_clip_encode": stream_case(1, 28125, True),
+        "batch64_encode": dict(stream_case(64, 2048, True), workload="64 concurrent stereo streams, 2048 blocks each"),
+    }
     return out
 
 

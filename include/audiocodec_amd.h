@@ -180,6 +180,16 @@ int ac_stream_encode(ac_stream* s, const ac_psy_plan* psy, const float* x_chunk,
 /* X_chunk [B, k, N, C] -> x [B, k*N, C]  (block i = frames i, i-1; frame -1 = state) */
 int ac_stream_inverse(ac_stream* s, const float* X_chunk, float* x, int k, void* stream);
 
+/* Feeds nchunks consecutive chunks of k blocks through the stream in one call (a long device-resident signal, a ring
+ * buffer that has filled up): chunk i is analysed -- with the masking model when psy is not NULL, else t_chunks /
+ * thr_chunks are ignored -- from x_chunks[i] [B, k*N, C] into X_chunks[i] (t_chunks[i], thr_chunks[i]) and, when
+ * xhat_chunks is not NULL, synthesised from X_chunks[i] into xhat_chunks[i] [B, k*N, C].  Results are those of nchunks
+ * calls of ac_stream_encode (ac_stream_forward) and ac_stream_inverse on `stream`, issued from one host call (two kernel
+ * launches per chunk, no per-call binding overhead).  The pointer lists are host arrays. */
+int ac_stream_run(ac_stream* s, const ac_psy_plan* psy, int nchunks, int k, const float* const* x_chunks,
+                  float* const* X_chunks, float* const* t_chunks, float* const* thr_chunks, float* const* xhat_chunks,
+                  float drown, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Element-wise utilities of PsychoacousticModel (psychoacoustic.py:71-100, 150-167).
  * ---------------------------------------------------------------------------------------- */

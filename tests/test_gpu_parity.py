@@ -390,6 +390,37 @@ def test_streaming_encode_equals_one_shot(path, N, C, chunks):
     st.close()
 
 
+@pytest.mark.parametrize("N,k,K", [(1024, 16, 75), (2048, 8, 24), (256, 32, 64)])
+def test_stream_run_equals_one_shot(path, N, k, K):
+    """ac_stream_run (a resident signal through the stream in chunks with one library call) = the one-shot encode /
+    decode, bit for bit on the analysis side; the last chunk may be shorter"""
+    C = 2
+    g = torch.Generator(device="cuda").manual_seed(K)
+    x = torch.empty(1, K * N, C, device="cuda").uniform_(-1, 1, generator=g)
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    X_full, t_full, thr_full = codec.encode(x, drown=0.1)
+    xh_full = codec.decode(X_full)
+    st = codec.stream(1, C)
+    X, t, thr, xh = st.run(x, k, drown=0.1)
+    torch.cuda.synchronize()
+    assert torch.equal(X, X_full[:, :K]) and torch.equal(t, t_full[:, :K]) and torch.equal(thr, thr_full[:, :K])
+    assert float((xh - xh_full[:, :K * N]).abs().max()) <= 1e-6      # block 0 is the leading half-aliased block
+    assert float((xh[:, N:] - x[:, :-N]).abs().max()) <= LSB
+    # continues where it stopped: the next call sees the state the run left behind
+    X2, t2, thr2, xh2 = st.run(torch.zeros(1, N, C, device="cuda"), 1, synthesis=False, drown=0.1)
+    assert xh2 is None and torch.equal(X2, X_full[:, K:]) and torch.equal(thr2, thr_full[:, K:])
+    # list-of-chunks form for a batch of streams
+    B = 3
+    xb = torch.empty(B, 4 * k * N, C, device="cuda").uniform_(-1, 1, generator=g)
+    stb = codec.stream(B, C)
+    Xl, tl, thrl, xhl = stb.run([xb[:, i * k * N:(i + 1) * k * N].contiguous() for i in range(4)], k, drown=0.1)
+    Xb, tb, thrb = codec.encode(xb, drown=0.1)
+    assert torch.equal(torch.cat(Xl, dim=1), Xb[:, :-1]) and torch.equal(torch.cat(thrl, dim=1), thrb[:, :-1])
+    assert torch.equal(torch.cat(tl, dim=1), tb[:, :-1])
+    assert float((torch.cat(xhl, dim=1)[:, N:] - xb[:, :-N]).abs().max()) <= LSB
+    st.close(), stb.close()
+
+
 def test_full_size_properties(path):
     """BASELINE config 2 shape (B=256 stereo, K=46, N=1024): size-independent properties only."""
     if path == "generic":
