@@ -57,6 +57,9 @@ PROTOTYPES = {
                                            c_int, c_int, c_void_p]),
     "ac_encode_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int,
                                 c_int, c_void_p]),
+    "ac_encode_fused_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p,
+                                   c_void_p, c_uint64, c_int, c_int, c_int, c_void_p]),
+    "ac_amplitude_to_db_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "ac_mdct_forward_pcm16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ac_mdct_inverse_pcm16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ac_encode_fused_pcm16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,

@@ -48,6 +48,35 @@ class AudioCodec:
         self.encode_into(x, X, t, thr, drown)
         return X, t, thr
 
+    def encode_ex(self, x, drown=0.0, noise_seed=None, db_norm=False):
+        """:meth:`encode` with its element-wise tail computed in the same pass (``ac_encode_fused_ex``):
+
+        :param noise_seed: an int: also return ``X + thr * Normal(0, 1/6)`` -- the values
+                           ``psy.add_noise(X, thr, seed=noise_seed)`` gives (reference ``psychoacoustic.py:150-167``)
+        :param db_norm:    also return ``psy.amplitude_to_dB_norm(X)`` (``psychoacoustic.py:87-100``)
+        :return: ``(X, tonality, threshold, noisy or None, db_norm or None)``
+        """
+        _host.require_float32(self.compute_dtype, "encode_ex")
+        x = _host.check_device_tensor(x, "x", self.compute_dtype, 3)
+        B, S, C = x.shape
+        N = self.filters_n
+        if S % N != 0:
+            raise ValueError("samples_n (%d) is not a multiple of filters_n (%d)" % (S, N))
+        K = S // N
+        X = torch.empty((B, K + 1, N, C), dtype=x.dtype, device=x.device)
+        t = torch.empty((B, K + 1, 1, C), dtype=x.dtype, device=x.device)
+        thr = torch.empty_like(X)
+        noisy = torch.empty_like(X) if noise_seed is not None else None
+        dbn = torch.empty_like(X) if db_norm else None
+        flags = (1 if noisy is not None else 0) | (2 if dbn is not None else 0)
+        with _host.on_device(x.device):
+            _lib.check(self._lib.ac_encode_fused_ex(
+                self.mdct._plan(x.device), self.psy._plan(x.device), _host.ptr(x), _host.ptr(X), _host.ptr(t), _host.ptr(thr),
+                float(drown), flags, _host.ptr(noisy) if noisy is not None else None,
+                _host.ptr(dbn) if dbn is not None else None, (int(noise_seed) if noise_seed is not None else 0) & (2 ** 64 - 1),
+                B, K, C, _host.stream_ptr(x.device)))
+        return X, t, thr, noisy, dbn
+
     def _check_io(self, t, name, shape, dtype, device):
         """Caller-owned tensors go to the kernels as raw pointers: shape, dtype, device and contiguity must be exact."""
         if not isinstance(t, torch.Tensor):

@@ -483,6 +483,35 @@ int ac_encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const floa
                     float drown, int B, int K, int C, void* stream) {
   return encode_fused(mdct, psy, x, false, X, t, thr, drown, B, K, C, stream);
 }
+int ac_encode_fused_ex(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr,
+                       float drown, int flags, float* noisy, float* db_norm, uint64_t seed, int B, int K, int C,
+                       void* stream) {
+  AC_REQUIRE((flags & ~(AC_EMIT_NOISY | AC_EMIT_DB_NORM)) == 0, "unknown flags %#x", flags);
+  AC_REQUIRE(!(flags & AC_EMIT_NOISY) || noisy != nullptr || B == 0 || C == 0, "AC_EMIT_NOISY without an output tensor");
+  AC_REQUIRE(!(flags & AC_EMIT_DB_NORM) || db_norm != nullptr || B == 0 || C == 0, "AC_EMIT_DB_NORM without an output tensor");
+  float* o_noisy = (flags & AC_EMIT_NOISY) ? noisy : nullptr;
+  float* o_dbn = (flags & AC_EMIT_DB_NORM) ? db_norm : nullptr;
+  if (!o_noisy && !o_dbn) return encode_fused(mdct, psy, x, false, X, t, thr, drown, B, K, C, stream);
+  AC_REQUIRE(mdct != nullptr && psy != nullptr, "plan is NULL");
+  AC_REQUIRE(mdct->N == psy->N, "mdct filters_n (%d) != psychoacoustic filter_bands_n (%d)", mdct->N, psy->N);
+  AC_REQUIRE(mdct->device == psy->device, "plans live on different devices");
+  int st = check_dims(B, K, C);
+  if (st) return st;
+  if (B == 0 || C == 0) return AC_OK;
+  AC_REQUIRE(X != nullptr && t != nullptr && thr != nullptr && (x != nullptr || K == 0), "NULL tensor pointer");
+  if (mdct->fast && psy->fast && !g_force_generic && fast_epilogue_supported(mdct, psy, 0, C)) {
+    DeviceGuard guard(mdct->device);
+    return launch_fwd_fast(mdct, psy, x, 0, X, t, thr, drown, nullptr, B, K, K + 1, C, (hipStream_t)stream, nullptr, o_noisy,
+                           o_dbn, seed);
+  }
+  // elsewhere: the encode, then the two element-wise kernels over X (same values as the fused epilogue)
+  st = encode_fused(mdct, psy, x, false, X, t, thr, drown, B, K, C, stream);
+  const size_t n = (size_t)B * (size_t)(K + 1) * (size_t)mdct->N * (size_t)C;
+  if (!st && o_noisy) st = ac_add_noise(X, thr, o_noisy, n, seed, stream);
+  if (!st && o_dbn) st = ac_amplitude_to_db(X, o_dbn, n, 1, stream);
+  return st;
+}
+
 int ac_encode_fused_pcm16(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const int16_t* x, float* X, float* t,
                           float* thr, float drown, int B, int K, int C, void* stream) {
   return encode_fused(mdct, psy, x, true, X, t, thr, drown, B, K, C, stream);
@@ -649,8 +678,13 @@ int ac_amplitude_to_db(const float* a, float* out, size_t n, int norm, void* str
   return launch_db(a, out, n, norm, (hipStream_t)stream);
 }
 
+int ac_amplitude_to_db_backward(const float* a, const float* grad_out, float* grad_a, size_t n, int norm, void* stream) {
+  AC_REQUIRE(n == 0 || (a != nullptr && grad_out != nullptr && grad_a != nullptr), "NULL tensor pointer");
+  return launch_db_bwd(a, grad_out, grad_a, n, norm, (hipStream_t)stream);
+}
+
 int ac_add_noise(const float* X, const float* thr, float* out, size_t n, uint64_t seed, void* stream) {
-  AC_REQUIRE(n == 0 || (X != nullptr && thr != nullptr && out != nullptr), "NULL tensor pointer");
+  AC_REQUIRE(n == 0 || (thr != nullptr && out != nullptr), "NULL tensor pointer");   // X == NULL: zeros
   return launch_add_noise(X, thr, out, n, seed, (hipStream_t)stream);
 }
 

@@ -675,15 +675,27 @@ __device__ __forceinline__ v2f spread_mfma(v2f Q, const char* mf, int lane) {
 
 // buf = the wave's LDS region (WAVE_LDS_PSY bytes), pimg = the workgroup's copy of the psy image
 // lds0 = base of the workgroup's LDS object (the absolute offsets of PsyLane count from it)
-template <int R, bool WANT_T, bool WANT_THR, int SPREAD = 0, bool T_BF16 = false>
+struct NoEmit {
+  __device__ __forceinline__ void begin() {}
+  __device__ __forceinline__ void operator()(int, const v4f&) {}
+};
+// EMIT: begin() once the masking model has its per-entry values, then (i, threshold of granule 64 i + lane) as each granule
+// of the threshold row comes out of the entry lookup (the kernels with element-wise epilogues consume it there instead of
+// holding the whole row)
+template <int R, bool WANT_T, bool WANT_THR, int SPREAD = 0, bool T_BF16 = false, class EMIT = NoEmit>
 __device__ __forceinline__ void psy_stage(const v4f (&xq)[R], char* lds0, char* buf, const uint32_t* pimg,
-                                          const PsyLane<R>& pc, const PsyParams& pp, int lane, v2f& t, v4f (&thr)[R]) {
+                                          const PsyLane<R>& pc, const PsyParams& pp, int lane, v2f& t, v4f (&thr)[R],
+                                          EMIT emit = EMIT()) {
   using P = PsyGeo<R>;
   if (WANT_T) {
     v2f slog = {0.f, 0.f}, ssq = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      const v4f I = xq[i] * xq[i];
+      v4f I = xq[i] * xq[i];
+      // the squares stay rounded products: left to -ffp-contract=fast, the compiler fuses one of the two squares of
+      // ie + io into the sum -- which one differs between instantiations of this code (fused encode with / without
+      // element-wise epilogues, 16-bit PCM input, stand-alone tonality), and with it the last bit of the tonality
+      asm("" : "+v"(I));
       const v2f ie = v2f{I.x, I.y}, io = v2f{I.z, I.w};
       ssq += ie + io;
       // ln max(eps, a) + ln max(eps, b) = ln(max(eps, a) max(eps, b)): one v_log per two bins; the product stays
@@ -782,6 +794,7 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[R], char* lds0, char* 
   *reinterpret_cast<v4f*>(buf + 16 * lane) = v4f{__builtin_amdgcn_sqrtf(A0.x), __builtin_amdgcn_sqrtf(A0.y),
                                                  __builtin_amdgcn_sqrtf(A1.x), __builtin_amdgcn_sqrtf(A1.y)};   // entry e at byte 8 e
   wave_sync();
+  emit.begin();
 #pragma unroll
   for (int i = 0; i < R; ++i) {
     const v4f ww = pc.idx[i >> 2];
@@ -789,7 +802,8 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[R], char* lds0, char* 
     const uint32_t w = in_loop(__float_as_uint(wf));
     const v2f a0 = *reinterpret_cast<const v2f*>(lds0 + (w & 0xffffu));
     const v2f a1 = *reinterpret_cast<const v2f*>(lds0 + (w >> 16));
-    thr[i] = v4f{a0.x, a0.y, a1.x, a1.y};
+    if constexpr (std::is_same<EMIT, NoEmit>::value) thr[i] = v4f{a0.x, a0.y, a1.x, a1.y};
+    else emit(i, v4f{a0.x, a0.y, a1.x, a1.y});
   }
 }
 
@@ -813,6 +827,31 @@ __device__ __forceinline__ void load_tables(char* lds, const float* __restrict__
   __syncthreads();
 }
 
+// EMIT of the fused encode with AC_EMIT_NOISY (stereo float32 rows)
+template <int R>
+struct NoisyEmit {
+  const v4f* X_row;   // this lane's granules of the spectrum row the wave has just stored
+  v4f* thr_row;
+  v4f* noisy_row;
+  uint64_t i4base, key;
+  v4f xr[R];
+  __device__ __forceinline__ void begin() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's own stores of X have landed
+#pragma unroll
+    for (int i = 0; i < R; ++i) xr[i] = X_row[64 * i];
+  }
+  __device__ __forceinline__ void operator()(int i, const v4f& th_i) {
+    __builtin_nontemporal_store(th_i, thr_row + 64 * i);
+    float g0, g1, g2, g3;
+    const uint64_t i4 = i4base + 64u * i;
+    normal_pair(key, 2 * i4, g0, g1);
+    normal_pair(key, 2 * i4 + 1, g2, g3);
+    __builtin_nontemporal_store(v4f{noisy_of(xr[i].x, th_i.x, g0), noisy_of(xr[i].y, th_i.y, g1), noisy_of(xr[i].z, th_i.z, g2),
+                                    noisy_of(xr[i].w, th_i.w, g3)}, noisy_row + 64 * i);
+    __builtin_amdgcn_sched_barrier(0);   // one granule at a time: interleaved, the sixteen draws of a row spill registers
+  }
+};
+
 // ------------------------------------------------------------------------------------------------------
 // analysis (+ fused epilogue)
 // ------------------------------------------------------------------------------------------------------
@@ -826,6 +865,11 @@ struct FwdArgs {
                              // a different buffer than prev_block: other waves still read that one)
   const float* tab;          // mdct tables (analysis image)
   PsyParams psy;
+  // optional element-wise epilogues of the fused encode (EPI kernels): X + thr * Normal(0, 1/6) and amplitude_to_dB_norm(X),
+  // both [B, F, N, C]; either may be null
+  float* noisy;
+  float* dbn;
+  uint64_t noise_key;        // mix64(seed) of ac_add_noise
   int B, Kin, F, C;
   long long npairs, nsig;    // wave tasks per frame index (see Pair) and B * C
   int xcd;                   // 1: consecutive logical workgroups share an XCD (gridDim.x is a multiple of 8)
@@ -846,8 +890,9 @@ struct FwdArgs {
 // register (r + 4) & 7) and the odd sample of granule 767 - e (lane 63 - lane, register (3 - r) & 7).
 // With (A, B) = COEF[e]:  carried part (block n-1) = B xe + A xo;  current part (block n) = B xo - A xe (r < 4),
 // A xe - B xo (r >= 4)   (Princen-Bradley windows make the 2x2 fold blocks rotations).
-template <int R, int CMODE, bool PSY, int NW, int IOF = 0, int SPREAD = 0>
+template <int R, int CMODE, bool PSY, int NW, int IOF = 0, int SPREAD = 0, bool EPI = false>
 __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY, SPREAD>())) void k_fwd_fast(FwdArgs a) {
+  static_assert(!EPI || (PSY && CMODE == 0 && IOF == 0), "the element-wise epilogues ride on the stereo float32 fused encode");
   using G = Geo<R>;
   // one LDS object: [NW wave buffers | table image | psy image | bf16 tiles of the spreading matrix (SPREAD > 0)]
   constexpr int WSTRIDE = PSY ? WAVE_LDS_PSY : WAVE_LDS;
@@ -862,8 +907,10 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY, SPREAD>())) void k_fwd
   gtab_t tab = reinterpret_cast<const float*>(lds + NW * WSTRIDE);
   const uint32_t* pimg = reinterpret_cast<const uint32_t*>(lds + NW * WSTRIDE + TABF * 4);
   if (PSY) *reinterpret_cast<v2f*>(buf + ZERO_OFF) = v2f{0.f, 0.f};   // the gather lists' padding slot
+  // (the kernels with element-wise epilogues are short of registers at the end of the masking model: they fetch the
+  // lane's pass-1 twiddles per frame, beside the frame's PCM, instead of holding them across the loop)
   v2f p1[R];
-  load_p1<R>(a.tab, lane, p1);
+  if constexpr (!EPI) load_p1<R>(a.tab, lane, p1);
   PsyLane<R> pc;
   if (PSY) pc = load_psy_lane<R>(a.psy.tab, lane, (uint32_t)(wave * WSTRIDE));
   int g = blockIdx.x;
@@ -929,6 +976,7 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY, SPREAD>())) void k_fwd
       // previous block in [0, 4 KB), current block in [4 KB, 8 KB)
       v4f cb[R], pb[R];
       const bool cur_ok = issue_loads(kCur, pair, n, cb);
+      if constexpr (EPI) load_p1<R>(a.tab, lane, p1);
 #ifdef AC_EXP_NOHALO   // timing experiment only (wrong results): what the second read of every block costs
       const bool prv_ok = true;
 #pragma unroll
@@ -1049,6 +1097,14 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY, SPREAD>())) void k_fwd
     } else {
       store_row<CMODE, R>(a.X + o0, a.X + o1, C, pq.has1, lane, row);
     }
+    if constexpr (EPI) {
+      if (a.dbn) {   // amplitude_to_dB_norm of the coefficients (psychoacoustic.py:87-100), from the registers
+        v4f d[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) d[i] = v4f{db_of(row[i].x, 1), db_of(row[i].y, 1), db_of(row[i].z, 1), db_of(row[i].w, 1)};
+        store_row<CMODE, R>(a.dbn + o0, a.dbn + o1, C, pq.has1, lane, d);
+      }
+    }
     // next frame of this wave
     pair += dpair;
     n += dn;
@@ -1068,7 +1124,25 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY, SPREAD>())) void k_fwd
           row[i] = v4f{Bf16Fmt::dec(lo.x), Bf16Fmt::dec(lo.y), Bf16Fmt::dec(hi.x), Bf16Fmt::dec(hi.y)};
         }
       }
-      psy_stage<R, true, true, SPREAD, IOF == 2>(row, lds, buf, pimg, pc, a.psy, lane, tt, th);
+      bool emitted = false;
+      if constexpr (EPI) {
+        if (a.noisy) {
+          // add_noise (psychoacoustic.py:150-167) on the frame: the coefficients are no longer in registers (the masking
+          // model needed them all), so the row the wave stored a moment ago comes back from L2; each granule of the
+          // threshold row is stored and turned into its noisy coefficients as it comes out of the entry lookup.  Element
+          // pairs of the flattened tensor share one Box-Muller draw, exactly as in ac_add_noise (granule i4 = elements
+          // 4 i4 .. 4 i4 + 3)
+          NoisyEmit<R> emit;
+          emit.X_row = reinterpret_cast<const v4f*>(a.X + o0) + lane;
+          emit.thr_row = reinterpret_cast<v4f*>(a.thr + o0) + lane;
+          emit.noisy_row = reinterpret_cast<v4f*>(a.noisy + o0) + lane;
+          emit.i4base = (uint64_t)(o0 >> 2) + (uint64_t)lane;
+          emit.key = a.noise_key;
+          psy_stage<R, true, true, SPREAD, false, NoisyEmit<R>&>(row, lds, buf, pimg, pc, a.psy, lane, tt, th, emit);
+          emitted = true;
+        }
+      }
+      if (!emitted) psy_stage<R, true, true, SPREAD, IOF == 2>(row, lds, buf, pimg, pc, a.psy, lane, tt, th);
       if constexpr (IOF == 2) {
         int16_t* th_h = reinterpret_cast<int16_t*>(a.thr);
         int16_t* t_h = reinterpret_cast<int16_t*>(a.t);
@@ -1079,7 +1153,7 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY, SPREAD>())) void k_fwd
           if (pq.has1) t_h[t1] = e.y;
         }
       } else {
-        store_row<CMODE, R>(a.thr + o0, a.thr + o1, C, pq.has1, lane, th);
+        if (!emitted) store_row<CMODE, R>(a.thr + o0, a.thr + o1, C, pq.has1, lane, th);
         if (lane == 0) {
           a.t[t0] = tt.x;
           if (pq.has1) a.t[t1] = tt.y;
@@ -1860,9 +1934,23 @@ static unsigned persistent_grid(int cus, int wg_per_cu, long long ntasks, int nw
   return (unsigned)g;
 }
 
+// the element-wise epilogues (EPI kernels) serve stereo float32 input at 8 points per lane (filters_n = 1024)
+bool fast_epilogue_supported(const ac_mdct_plan* p, const ac_psy_plan* psy, int iof, int C) {
+  // (the plain-bf16 matrix-core form of the spreading product would spill three registers here: it takes the un-fused path)
+  return psy != nullptr && p->N == Geo<8>::FN && iof == 0 && C == 2 && psy->spread != 1;
+}
+
 template <int R, int IOF>
 static void launch_fwd_R(const FwdArgs& a, bool psy, int spread, int C, unsigned grid, hipStream_t s) {
   constexpr bool PCM16 = IOF == 1;
+  if constexpr (R == 8 && IOF == 0) {
+    if (psy && C == 2 && (a.noisy || a.dbn)) {
+      const dim3 blk(AC_WAVES_PSY * 64);
+      if (spread == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, 0, 2, true>), dim3(grid), blk, 0, s, a);
+      else hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, 0, 0, true>), dim3(grid), blk, 0, s, a);
+      return;
+    }
+  }
   if constexpr (IOF == 2) {
     // bfloat16 tensors: stereo and mono kernels (other channel counts are served by the LDS-FFT tier, see ac_api.hip)
     if (psy) {
@@ -1900,7 +1988,7 @@ static void launch_fwd_R(const FwdArgs& a, bool psy, int spread, int C, unsigned
 
 int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x, int iof, float* X, float* t,
                     float* thr, float drown, const float* prev_block, int B, int Kin, int F, int C, hipStream_t s,
-                    float* state_out) {
+                    float* state_out, float* noisy, float* dbn, uint64_t seed) {
   if (B <= 0 || C <= 0 || F <= 0) return AC_OK;
   // combinations no kernel is instantiated for (ac_api.hip routes them elsewhere; refuse rather than launch nothing)
   if ((iof == 2 && C > 2) || (psy && p->N == Geo<16>::FN && (C == 1 || (iof == 1 && C > 2)))) {
@@ -1915,6 +2003,13 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x
   a.thr = thr;
   a.prev_block = prev_block;
   a.state_out = state_out;
+  a.noisy = noisy;
+  a.dbn = dbn;
+  a.noise_key = mix64(seed);
+  if ((noisy || dbn) && !fast_epilogue_supported(p, psy, iof, C)) {
+    set_error("internal: no fused element-wise epilogue for this configuration");
+    return AC_EUNSUPPORTED;
+  }
   a.tab = p->d_fast;
   if (psy) a.psy = psy_params(psy, drown);
   else a.psy = PsyParams{nullptr, 0.f, 0.f, 0.f};

@@ -640,13 +640,7 @@ __global__ __launch_bounds__(kThreads) void k_threshold_bwd_generic(
 // ------------------------------------------------------------------------------------------------
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-// amplitude_to_dB (psychoacoustic.py:83-85) and its [0, 1] normalisation (:98-100): 10 log10 = 3.0103 log2 (v_log_f32)
-__device__ __forceinline__ float db_of(float v, int norm) {
-  float dB = 3.0102999566398120f * __builtin_amdgcn_logf(fmaxf(kEps, v * v)) + 120.f;
-  if (norm) dB = (dB + 20.f) * (1.0f / 140.f);
-  return dB;
-}
-
+// (db_of, normal_pair, noisy_of: ac_internal.h, shared with the fused encode epilogue)
 // 16-byte vectors (n4 of them) + a scalar tail; a, out 16-byte aligned when n4 > 0
 __global__ __launch_bounds__(256) void k_db(const float* __restrict__ a, float* __restrict__ out, size_t n, size_t n4,
                                             int norm) {
@@ -660,40 +654,36 @@ __global__ __launch_bounds__(256) void k_db(const float* __restrict__ a, float* 
   for (size_t i = 4 * n4 + tid; i < n; i += stride) out[i] = db_of(a[i], norm);
 }
 
-// counter-based generator: a 64-bit mix (splitmix64) of (seed, pair index) -> Box-Muller, both outputs used:
-// elements 2p and 2p+1 take R cos(theta) and R sin(theta)
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-__device__ __forceinline__ void normal_pair(uint64_t key, uint64_t pair, float& g0, float& g1) {
-  const uint64_t r = mix64(key ^ pair);
-  const float u1 = ((float)(uint32_t)(r >> 40) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
-  const float u2 = (float)(uint32_t)((r >> 8) & 0xFFFFFFu) * (1.0f / 16777216.0f);   // [0, 1): one revolution
-  const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
-  g0 = rad * __builtin_amdgcn_cosf(u2);   // v_cos_f32 / v_sin_f32 take revolutions
-  g1 = rad * __builtin_amdgcn_sinf(u2);
+// d amplitude_to_dB / d a = (20 / ln 10) / a where a^2 > eps, else 0 (the clamp); the normalised form scales by 1 / 140
+__global__ __launch_bounds__(256) void k_db_bwd(const float* __restrict__ a, const float* __restrict__ g,
+                                                float* __restrict__ ga, size_t n, int norm) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const float c = norm ? (8.685889638065035f / 140.f) : 8.685889638065035f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = a[i];
+    ga[i] = (v * v > kEps) ? g[i] * (c / v) : 0.f;
+  }
 }
 
-// add_noise (psychoacoustic.py:150-167): out = X + thr * Normal(0, 1/6)
+// add_noise (psychoacoustic.py:150-167): out = X + thr * Normal(0, 1/6); X == nullptr stands for zeros (the gradient of
+// add_noise with respect to the threshold is add_noise(0, grad_out) under the same seed)
 __global__ __launch_bounds__(256) void k_add_noise(const float* __restrict__ X, const float* __restrict__ thr,
                                                    float* __restrict__ out, size_t n, size_t n4, uint64_t seed) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t key = mix64(seed);
   for (size_t i = tid; i < n4; i += stride) {
-    const f4 x = reinterpret_cast<const f4*>(X)[i], t = reinterpret_cast<const f4*>(thr)[i];
+    const f4 x = X ? reinterpret_cast<const f4*>(X)[i] : f4{0.f, 0.f, 0.f, 0.f}, t = reinterpret_cast<const f4*>(thr)[i];
     float g0, g1, g2, g3;
     normal_pair(key, 2 * i, g0, g1);
     normal_pair(key, 2 * i + 1, g2, g3);
-    __builtin_nontemporal_store(x + t * (f4{g0, g1, g2, g3} * (1.0f / 6.0f)), reinterpret_cast<f4*>(out) + i);
+    __builtin_nontemporal_store(f4{noisy_of(x.x, t.x, g0), noisy_of(x.y, t.y, g1), noisy_of(x.z, t.z, g2), noisy_of(x.w, t.w, g3)},
+                                reinterpret_cast<f4*>(out) + i);
   }
   for (size_t i = 4 * n4 + tid; i < n; i += stride) {
     float g0, g1;
     normal_pair(key, i >> 1, g0, g1);
-    out[i] = X[i] + thr[i] * (((i & 1) ? g1 : g0) * (1.0f / 6.0f));
+    out[i] = noisy_of(X ? X[i] : 0.f, thr[i], (i & 1) ? g1 : g0);
   }
 }
 
@@ -717,7 +707,7 @@ __global__ __launch_bounds__(256) void k_add_noise_typed(const TIO* __restrict__
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float g0, g1;
     normal_pair(key, i >> 1, g0, g1);
-    stv(out + i, (TC)ldv(X + i) + (TC)ldv(thr + i) * ((TC)((i & 1) ? g1 : g0) / (TC)6));
+    stv(out + i, (X ? (TC)ldv(X + i) : (TC)0) + (TC)ldv(thr + i) * ((TC)((i & 1) ? g1 : g0) / (TC)6));
   }
 }
 
@@ -853,6 +843,14 @@ int launch_db(const float* a, float* out, size_t n, int norm, hipStream_t s) {
   const size_t n4 = al ? n / 4 : 0;
   const unsigned grid = (unsigned)std::min<size_t>((std::max<size_t>(n4, n - 4 * n4) + 255) / 256, 8192);
   hipLaunchKernelGGL(k_db, dim3(grid), dim3(256), 0, s, a, out, n, n4, norm);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+int launch_db_bwd(const float* a, const float* g, float* ga, size_t n, int norm, hipStream_t s) {
+  if (n == 0) return AC_OK;
+  const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 16384);
+  hipLaunchKernelGGL(k_db_bwd, dim3(grid), dim3(256), 0, s, a, g, ga, n, norm);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }

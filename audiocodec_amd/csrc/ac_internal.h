@@ -46,6 +46,37 @@ struct DeviceGuard {
 
 extern int g_force_generic;
 
+// ---- element-wise pieces shared by the stand-alone utilities (ac_generic.hip) and the fused encode epilogue (ac_fast.hip):
+// one definition, so that fused and un-fused results agree bit for bit
+// counter-based generator: a 64-bit mix (splitmix64) of (seed, pair index) -> Box-Muller, both outputs used:
+// elements 2p and 2p+1 of the flattened tensor take R cos(theta) and R sin(theta)
+__host__ __device__ inline uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ void normal_pair(uint64_t key, uint64_t pair, float& g0, float& g1) {
+  const uint64_t r = mix64(key ^ pair);
+  const float u1 = ((float)(uint32_t)(r >> 40) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
+  const float u2 = (float)(uint32_t)((r >> 8) & 0xFFFFFFu) * (1.0f / 16777216.0f);   // [0, 1): one revolution
+  const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
+  g0 = rad * __builtin_amdgcn_cosf(u2);   // v_cos_f32 / v_sin_f32 take revolutions
+  g1 = rad * __builtin_amdgcn_sinf(u2);
+}
+// add_noise (psychoacoustic.py:150-167): x + thr * Normal(0, 1/6), g a standard normal
+__device__ __forceinline__ float noisy_of(float x, float thr, float g) { return __builtin_fmaf(thr, g * (1.0f / 6.0f), x); }
+// amplitude_to_dB (psychoacoustic.py:83-85) and its [0, 1] normalisation (:98-100): 10 log10 = 3.0103 log2 (v_log_f32)
+__device__ __forceinline__ float db_of(float v, int norm) {
+  float dB = __builtin_fmaf(3.0102999566398120f, __builtin_amdgcn_logf(fmaxf(1e-14f, v * v)), 120.f);
+  // (the reference subtracts _dB_MIN = amplitude_to_dB(eps), the same expression, so its normalised scale starts at
+  // exactly 0: the clamp keeps that under the rounding of the multiply-add above)
+  if (norm) dB = fmaxf((dB + 20.f) * (1.0f / 140.f), 0.f);
+  return dB;
+}
+#endif
+
 typedef __bf16 bf16_t;   // storage type of the AC_BF16 tensors (device code converts with v_cvt_pk_bf16_f32)
 
 }  // namespace ac
@@ -120,7 +151,9 @@ int fast_psy_plan_init(ac_psy_plan* p);
 // state_out (iof == 0 only): receives block Kin-1 of every signal, the next chunk's prev_block (must not alias prev_block)
 int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x, int iof, float* X, float* t,
                     float* thr, float drown, const float* prev_block, int B, int Kin, int F, int C, hipStream_t s,
-                    float* state_out = nullptr);
+                    float* state_out = nullptr, float* noisy = nullptr, float* dbn = nullptr, uint64_t seed = 0);
+// noisy / dbn (either may be null): the element-wise epilogues of ac_encode_fused_ex, where fast_epilogue_supported()
+bool fast_epilogue_supported(const ac_mdct_plan* p, const ac_psy_plan* psy, int iof, int C);
 int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, int iof, const float* tail_in, float* tail_out,
                     int B, int Kp, int nblk, int C, hipStream_t s);
 int launch_psy_fast(const ac_psy_plan* p, const float* X, const float* t_in, float* t_out, float* thr, float drown,
@@ -148,6 +181,7 @@ int launch_threshold_bf16(const ac_psy_plan* p, const bf16_t* X, const bf16_t* t
 int launch_db_typed(const void* a, void* out, size_t n, int norm, int dtype, hipStream_t s);
 int launch_add_noise_typed(const void* X, const void* thr, void* out, size_t n, uint64_t seed, int dtype, hipStream_t s);
 int launch_db(const float* a, float* out, size_t n, int norm, hipStream_t s);
+int launch_db_bwd(const float* a, const float* g, float* ga, size_t n, int norm, hipStream_t s);
 int launch_add_noise(const float* X, const float* thr, float* out, size_t n, uint64_t seed, hipStream_t s);
 
 }  // namespace ac

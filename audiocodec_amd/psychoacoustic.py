@@ -48,6 +48,40 @@ class _ThresholdFn(torch.autograd.Function):
         return gX, gt, None, None
 
 
+class _AddNoiseFn(torch.autograd.Function):
+    """Differentiable ``add_noise`` (a plain differentiable op chain in the reference, ``psychoacoustic.py:150-167``):
+    out = X + thr * n with n ~ Normal(0, 1/6) fixed by the seed, so d out / d X = 1 and d out / d thr = n; the second is
+    the same kernel run on (0, grad_out) under the same seed."""
+
+    @staticmethod
+    def forward(ctx, X, thr, model, seed):
+        ctx.model, ctx.seed = model, seed
+        return model._add_noise(X, thr, seed)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        gX = g if ctx.needs_input_grad[0] else None
+        gthr = ctx.model._add_noise(None, g, ctx.seed) if ctx.needs_input_grad[1] else None
+        return gX, gthr, None, None
+
+
+class _DbFn(torch.autograd.Function):
+    """Differentiable ``amplitude_to_dB`` / ``amplitude_to_dB_norm`` (``psychoacoustic.py:71-100``): the adjoint kernel
+    ``ac_amplitude_to_db_backward`` (zero inside the clamp at ``_INTENSITY_EPS``)."""
+
+    @staticmethod
+    def forward(ctx, a, model, norm):
+        ctx.model, ctx.norm = model, norm
+        ctx.save_for_backward(a)
+        return model._elementwise_db(a, norm)
+
+    @staticmethod
+    def backward(ctx, g):
+        (a,) = ctx.saved_tensors
+        return ctx.model._db_backward(a, g.contiguous(), ctx.norm), None, None
+
+
 class PsychoacousticModel:
     SPREADING = {"f32": 0, "bf16_mfma": 1, "bf16x2_mfma": 2}
 
@@ -146,13 +180,29 @@ class PsychoacousticModel:
                                                           self._dtype_id, _host.stream_ptr(a.device)))
         return out
 
+    def _db_backward(self, a, g, norm):
+        ga = torch.empty_like(a)
+        with _host.on_device(a.device):
+            _lib.check(self._lib.ac_amplitude_to_db_backward(_host.ptr(a.contiguous()), _host.ptr(g), _host.ptr(ga),
+                                                             a.numel(), int(norm), _host.stream_ptr(a.device)))
+        return ga
+
+    def _db(self, mdct_amplitude, norm):
+        a = mdct_amplitude
+        if isinstance(a, torch.Tensor) and a.requires_grad and torch.is_grad_enabled():
+            _host.require_float32(self.compute_dtype, "the backward pass of amplitude_to_dB")
+            return _DbFn.apply(a, self, norm)
+        return self._elementwise_db(a, norm)
+
     def amplitude_to_dB(self, mdct_amplitude):
-        """``amplitude_to_dB`` (``psychoacoustic.py:71-85``): [-1,1] amplitude -> dB in [_dB_MIN, _dB_MAX]."""
-        return self._elementwise_db(mdct_amplitude, False)
+        """``amplitude_to_dB`` (``psychoacoustic.py:71-85``): [-1,1] amplitude -> dB in [_dB_MIN, _dB_MAX].
+        Differentiable (float32)."""
+        return self._db(mdct_amplitude, False)
 
     def amplitude_to_dB_norm(self, mdct_amplitude):
-        """``amplitude_to_dB_norm`` (``psychoacoustic.py:87-100``): dB scale normalised to [0, 1]."""
-        return self._elementwise_db(mdct_amplitude, True)
+        """``amplitude_to_dB_norm`` (``psychoacoustic.py:87-100``): dB scale normalised to [0, 1].  Differentiable
+        (float32)."""
+        return self._db(mdct_amplitude, True)
 
     # ---- per-frame model -------------------------------------------------------------------------
     def _check_spectrum(self, X, name="mdct_amplitudes"):
@@ -226,6 +276,7 @@ class PsychoacousticModel:
 
         The generator is counter-based (seed, element index); the stream differs from TensorFlow's, so
         parity is statistical (mean 0, sigma = thr / 6).  ``seed=None`` draws one from torch's generator.
+        Differentiable with respect to both inputs (float32): the noise is a constant of the seed.
         """
         X = self._check_spectrum(mdct_amplitudes)
         thr = _host.check_device_tensor(masking_threshold, "masking_threshold", self.compute_dtype, 4)
@@ -233,11 +284,18 @@ class PsychoacousticModel:
             raise ValueError("masking_threshold must match mdct_amplitudes in shape and device")
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        out = torch.empty_like(X)
-        with _host.on_device(X.device):
-            _lib.check(self._lib.ac_add_noise_typed(_host.ptr(X), _host.ptr(thr), _host.ptr(out), X.numel(),
-                                                    int(seed) & (2 ** 64 - 1), self._dtype_id,
-                                                    _host.stream_ptr(X.device)))
+        seed = int(seed) & (2 ** 64 - 1)
+        if (X.requires_grad or thr.requires_grad) and torch.is_grad_enabled():
+            _host.require_float32(self.compute_dtype, "the backward pass of add_noise")
+            return _AddNoiseFn.apply(X, thr, self, seed)
+        return self._add_noise(X, thr, seed)
+
+    def _add_noise(self, X, thr, seed):
+        """X may be None (zeros): thr * Normal(0, 1/6) under the same seed."""
+        out = torch.empty_like(thr)
+        with _host.on_device(thr.device):
+            _lib.check(self._lib.ac_add_noise_typed(_host.ptr(X) if X is not None else None, _host.ptr(thr), _host.ptr(out),
+                                                    thr.numel(), seed, self._dtype_id, _host.stream_ptr(thr.device)))
         return out
 
     # ---- Bark scale (host precompute helpers, psychoacoustic.py:333-339) ------------------------------

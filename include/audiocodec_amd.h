@@ -152,6 +152,17 @@ int ac_mask_threshold_backward(const ac_psy_plan* plan, const float* X, const fl
 int ac_encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t,
                     float* thr, float drown, int B, int K, int C, void* stream);
 
+/* The fused encode with its element-wise tail (psychoacoustic.py:150-167 and :87-100 on the frames just computed), so
+ * that a caller who wants them does not pay another pass over X and thr:
+ *   AC_EMIT_NOISY    noisy   [B,K+1,N,C] = X + thr * Normal(0, 1/6): the values ac_add_noise(X, thr, seed) gives, bit for bit;
+ *   AC_EMIT_DB_NORM  db_norm [B,K+1,N,C] = amplitude_to_dB_norm(X): the values ac_amplitude_to_db(X, norm = 1) gives.
+ * One launch for stereo float32 input on the wave-level kernels at filters_n = 1024; elsewhere the encode followed by
+ * the two element-wise kernels.  flags = 0 is ac_encode_fused. */
+enum { AC_EMIT_NOISY = 1, AC_EMIT_DB_NORM = 2 };
+int ac_encode_fused_ex(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr,
+                       float drown, int flags, float* noisy, float* db_norm, uint64_t seed, int B, int K, int C,
+                       void* stream);
+
 /* 16-bit PCM at the boundary (extension; the reference takes float PCM in [-1, 1] only, mdctransformer.py:104):
  * x = pcm / 32768 on the way in, pcm = clamp(round(32768 x), -32768, 32767) on the way out, fused into the kernels'
  * loads / stores, so a frame moves 2 bytes per sample instead of 4.  Served by the wave-level kernels (filters_n 1024
@@ -195,7 +206,12 @@ int ac_stream_run(ac_stream* s, const ac_psy_plan* psy, int nchunks, int k, cons
  * ---------------------------------------------------------------------------------------- */
 /* amplitude_to_dB (norm = 0) / amplitude_to_dB_norm (norm = 1) on n floats. */
 int ac_amplitude_to_db(const float* a, float* out, size_t n, int norm, void* stream);
-/* add_noise: out = X + thr * Normal(0, 1/6), counter-based generator keyed by (seed, element-pair index). */
+/* d amplitude_to_dB(_norm) / d a: grad_a = grad_out * (20 / ln 10) / a where a^2 > 1e-14 (0 inside the clamp), / 140 for
+ * the normalised form. */
+int ac_amplitude_to_db_backward(const float* a, const float* grad_out, float* grad_a, size_t n, int norm, void* stream);
+/* add_noise: out = X + thr * Normal(0, 1/6), counter-based generator keyed by (seed, element-pair index).  X == NULL
+ * stands for zeros: ac_add_noise(NULL, g, out, n, seed) is the gradient of add_noise with respect to the threshold
+ * (the gradient with respect to X is g itself). */
 int ac_add_noise(const float* X, const float* thr, float* out, size_t n, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------

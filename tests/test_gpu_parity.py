@@ -447,6 +447,81 @@ def test_full_size_properties(path):
     assert rel_elem(host(thr[:2]), op.global_masking_threshold(Xo, op.tonality(Xo))) <= TOL
 
 
+@pytest.mark.parametrize("N,C,spreading", [(1024, 2, None), (1024, 2, "f32"), (1024, 2, "bf16_mfma"), (2048, 2, None),
+                                           (1024, 1, None), (256, 2, None)])
+def test_encode_ex_equals_encode_plus_elementwise_tail(path, golden, N, C, spreading):
+    """ac_encode_fused_ex (AC_EMIT_NOISY | AC_EMIT_DB_NORM): one launch for stereo float32 at N = 1024, the encode plus
+    the two element-wise kernels elsewhere -- either way X, t, thr equal encode()'s and the tail equals add_noise /
+    amplitude_to_dB_norm on them, bit for bit (same generator, same formula; psychoacoustic.py:150-167, :87-100)"""
+    B, K = 3, 7
+    g = torch.Generator(device="cuda").manual_seed(N + C)
+    x = torch.empty(B, K * N, C, device="cuda").uniform_(-1, 1, generator=g)
+    x[0, : 2 * N] *= 1e-4
+    codec = audiocodec_amd.AudioCodec(48000, N, spreading=spreading) if N in (1024, 2048) else audiocodec_amd.AudioCodec(48000, N)
+    X, t, thr = codec.encode(x, drown=0.3)
+    X2, t2, thr2, noisy, dbn = codec.encode_ex(x, drown=0.3, noise_seed=1234567, db_norm=True)
+    assert torch.equal(X, X2) and torch.equal(t, t2) and torch.equal(thr, thr2)
+    assert torch.equal(noisy, codec.psy.add_noise(X2, thr2, seed=1234567))
+    assert torch.equal(dbn, codec.psy.amplitude_to_dB_norm(X2))
+    # one flag at a time, and none
+    a = codec.encode_ex(x, drown=0.3, noise_seed=99)
+    assert a[4] is None and torch.equal(a[3], codec.psy.add_noise(a[0], a[2], seed=99)) and torch.equal(a[2], thr2)
+    b = codec.encode_ex(x, drown=0.3, db_norm=True)
+    assert b[3] is None and torch.equal(b[4], dbn) and torch.equal(b[0], X) and torch.equal(b[2], thr2)
+    c = codec.encode_ex(x, drown=0.3)
+    assert c[3] is None and c[4] is None and torch.equal(c[2], thr)
+    # statistics of the fused noise: (noisy - X) / thr ~ Normal(0, 1/6)
+    z = ((noisy - X2) / thr2).double()
+    assert abs(float(z.mean())) < 3e-3 and abs(float(z.std()) - 1.0 / 6.0) < 3e-3
+    assert float((z.abs() > 0.5).double().mean()) < 0.006          # 3 sigma: 0.27 %
+    # exact-formula check of the dB normalisation against the reference-generated values
+    gd = golden("db_utils")
+    p = codec.psy
+    np.testing.assert_allclose(host(p.amplitude_to_dB_norm(dev(gd["a"]))), gd["dBn_ref64"], rtol=0, atol=2e-6)
+    assert float(dbn.min()) >= 0.0 and float(dbn.max()) <= 1.0 + 1e-6
+
+
+def test_autograd_of_add_noise_and_db(path):
+    """add_noise and amplitude_to_dB(_norm) are differentiable like the reference's plain TF op chains
+    (psychoacoustic.py:150-167, 71-100): gradients against torch.autograd on a torch restatement"""
+    p = audiocodec_amd.PsychoacousticModel(48000, 1024)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    X = (torch.rand(2, 3, 1024, 2, device="cuda", generator=g) * 2 - 1).requires_grad_(True)
+    thr = (torch.rand(2, 3, 1024, 2, device="cuda", generator=g) * 0.1 + 1e-3).requires_grad_(True)
+    w = torch.rand(2, 3, 1024, 2, device="cuda", generator=g)
+    y = p.add_noise(X, thr, seed=77)
+    assert y.requires_grad
+    (y * w).sum().backward()
+    n = (p.add_noise(torch.zeros_like(X), torch.ones_like(thr), seed=77)).detach()      # the normals of seed 77 (x 1/6)
+    assert torch.equal(X.grad, w)
+    assert float((thr.grad - w * n).abs().max()) <= 1e-7
+    # only one input needs a gradient
+    y2 = p.add_noise(X.detach(), thr.detach().requires_grad_(True), seed=77)
+    assert y2.requires_grad and torch.equal(y2, y.detach())
+    for norm in (False, True):
+        a = (torch.rand(4, 5, 64, 2, device="cuda", generator=g) * 2 - 1)
+        a[0, 0, :4] = 0.0                                   # inside the clamp: gradient 0
+        a[0, 1, :4] = 1e-8
+        a = a.requires_grad_(True)
+        f = p.amplitude_to_dB_norm if norm else p.amplitude_to_dB
+        d = f(a)
+        wa = torch.rand_like(a)
+        (d * wa).sum().backward()
+        ad = a.detach().double().requires_grad_(True)
+        dd = 10.0 * torch.log10(torch.clamp(ad * ad, min=1e-14)) + 120.0
+        if norm:
+            dd = (dd + 20.0) / 140.0
+        (dd * wa.double()).sum().backward()
+        assert float((d.detach().double() - dd.detach()).abs().max()) <= (2e-6 if norm else 2e-4)
+        ref = ad.grad
+        err = (a.grad.double() - ref).abs() / (ref.abs() + 1e-3)
+        assert float(err.max()) <= 1e-5
+        assert float(a.grad[0, 0, :4].abs().max()) == 0.0 and float(a.grad[0, 1, :4].abs().max()) == 0.0
+    with pytest.raises(NotImplementedError):
+        p64 = audiocodec_amd.PsychoacousticModel(48000, 64, compute_dtype=torch.float64)
+        p64.amplitude_to_dB(torch.rand(1, 1, 64, 1, device="cuda", dtype=torch.float64).requires_grad_(True))
+
+
 def test_fast_path_selection():
     """The wave-level kernels serve N = 1024 with a Princen-Bradley window; everything else runs the generic kernels
     (the rectangular window's fold blocks are not rotations)."""
