@@ -1666,6 +1666,353 @@ __global__ __launch_bounds__(NW * 64, 2) void k_psy_bwd_fast(PsyBwdArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Several short frames per wave: filters_n = 512 and 256 (the reference's own test sizes,
+// audiocodec/tests/test_mdctransformer.py:23).  A frame of 128 R' filters keeps the wave-level scheme when NFR = 64 / LB
+// frames share a wave, each on a group of LB consecutive lanes with eight complex points per lane:
+//   filters_n = 512: NFR = 2 frames x 256 points on LB = 32 lanes;   filters_n = 256: NFR = 4 frames x 128 points on 16.
+// With the frame index in the TOP lane bits (lane = l + LB f) the 8 LB-point FFT is 8 x (8 / NFR) x 8 with exactly the
+// two LDS exchanges of the 512-point transform: element e = l + LB r; pass 1 over r (radix 8, twiddle W_{8 LB}^(l k0));
+// exchange 1 hands lane (a = k0, m0) the eight values m0 + 8 e1 of row k0, and e1 = e1' + (8 / NFR) f, so pass 2 is NFR
+// independent transforms of 8 / NFR points (one per frame, twiddle W_LB^(m0 k1')); exchange 2 and pass 3 (radix 8 over
+// e0) are unchanged, and lane l + LB f ends up with the bins l + LB j of frame f: the layout the row loads / stores and
+// the fold want, with LB in the place of 64.  Lane reversals stay inside a group: row_mirror DPP for LB = 16, row_mirror
+// + two v_permlane16_swap per register pair for LB = 32 -- no LDS.  Table images have the Geo<8> layout, every entry
+// replicated to the 64 lanes by the host (index r * 64 + lane as in the one-frame kernels).
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dft4(C2& x0, C2& x1, C2& x2, C2& x3) {
+  const C2 t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = mul_mi(csub(x1, x3));
+  x0 = cadd(t0, t2);
+  x2 = csub(t0, t2);
+  x1 = cadd(t1, t3);
+  x3 = csub(t1, t3);
+}
+__device__ __forceinline__ void dft2(C2& x0, C2& x1) {
+  const C2 s = cadd(x0, x1), d = csub(x0, x1);
+  x0 = s;
+  x1 = d;
+}
+
+template <int NFR>
+__device__ __forceinline__ void fft_wave_multi(C2 (&z)[8], char* buf, gtab_t tab, const v2f (&p1)[8], int lane) {
+  constexpr int Q2 = 8 / NFR;
+  const int a = lane >> 3, m0 = lane & 7;
+  dft8(z);
+#pragma unroll
+  for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], p1[k]);
+  C2 y[8];
+  wave_sync();
+  {
+    char* w1 = buf + 16 * lane;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lds_put(w1 + 1152 * k, z[k]);
+  }
+  wave_sync();
+  {
+    const char* r1 = buf + 16 * (a * 72 + m0);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) y[r] = lds_get(r1 + 128 * r);
+  }
+  if (NFR == 2) {
+    dft4(y[0], y[1], y[2], y[3]);
+    dft4(y[4], y[5], y[6], y[7]);
+  } else {
+    dft2(y[0], y[1]);
+    dft2(y[2], y[3]);
+    dft2(y[4], y[5]);
+    dft2(y[6], y[7]);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    z[k] = (k % Q2 == 0) ? y[k] : cmul(y[k], reinterpret_cast<const v2f*>(tab + Geo<8>::I_P2)[k * 8 + m0]);
+  wave_sync();
+  {
+    char* w2 = buf + 16 * (9 * a + m0);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) lds_put(w2 + 16 * 72 * kk, z[kk]);
+  }
+  wave_sync();
+  {
+    const char* r2 = buf + 144 * lane;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) y[r] = lds_get(r2 + 16 * r);
+  }
+  dft8(y);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) z[j] = y[j];
+}
+
+// lane reversal inside a group of LB lanes (lane -> lane ^ (LB - 1)), both halves of a (c0, c1) pair
+template <int LB>
+__device__ __forceinline__ v2f rev_group(v2f v) {
+  unsigned a = __float_as_uint(v.x), b = __float_as_uint(v.y);
+  if (LB == 32) {   // complement lane bit 4: v_permlane16_swap twice, the operands' roles exchanged in between
+    const auto u = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    const auto w = __builtin_amdgcn_permlane16_swap(u[1], u[0], false, false);
+    a = w[0];
+    b = w[1];
+  }
+  return v2f{__uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x140, 0xf, 0xf, false)),    // row_mirror
+             __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x140, 0xf, 0xf, false))};
+}
+// out[i] = in[(OFS - i) mod 8] of the mirrored lane of the group
+template <int LB, int OFS>
+__device__ __forceinline__ void rev_exchange_g(const v2f (&in)[8], v2f (&out)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = rev_group<LB>(in[(OFS - i) & 7]);
+}
+
+// one natural-order row of a short frame: lane l of its group moves granules l + LB i, i = 0..7
+// CMODE 0: two channels, 16-byte interleaved granules; CMODE 2: one channel, two signals side by side, 8-byte granules
+template <int CMODE, int LB>
+__device__ __forceinline__ void load_rowm(const float* r0, const float* r1, bool has1, int l, v4f (&v)[8]) {
+  if (CMODE == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = reinterpret_cast<const v4f*>(r0)[LB * i + l];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const v2f u = reinterpret_cast<const v2f*>(r0)[LB * i + l];
+      v[i] = v4f{u.x, 0.f, u.y, 0.f};
+    }
+    if (has1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const v2f w = reinterpret_cast<const v2f*>(r1)[LB * i + l];
+        v[i].y = w.x;
+        v[i].w = w.y;
+      }
+    }
+  }
+}
+template <int CMODE, int LB>
+__device__ __forceinline__ void store_rowm(float* r0, float* r1, bool has1, int l, const v4f (&v)[8]) {
+  if (CMODE == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#if AC_NT_STORE
+      __builtin_nontemporal_store(v[i], reinterpret_cast<v4f*>(r0) + LB * i + l);
+#else
+      reinterpret_cast<v4f*>(r0)[LB * i + l] = v[i];
+#endif
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) reinterpret_cast<v2f*>(r0)[LB * i + l] = v2f{v[i].x, v[i].z};
+    if (has1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) reinterpret_cast<v2f*>(r1)[LB * i + l] = v2f{v[i].y, v[i].w};
+    }
+  }
+}
+
+struct FwdMArgs {
+  const float* x;    // [B, Kin*N, C]
+  float* X;          // [B, F, N, C]
+  const float* tab;  // analysis image (Geo<8> layout, lane-replicated)
+  int Kin, F, C;
+  int cpp;           // chunks of NFR consecutive frames per signal pair: ceil(F / NFR)
+  int T;             // chunks per wave: workgroup g owns chunks [g NW T, (g+1) NW T), wave w takes g NW T + w + NW t
+  long long nsig, ntasks;   // B * C and npairs * cpp
+};
+
+// analysis: the lanes of group f transform frame NFR c + f of the wave's signal pair (a group whose frame index is past
+// the last frame idles); fold and twiddles as in k_fwd_fast with LB in the place of 64
+template <int NFR, int CMODE, int NW>
+__global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
+  using G = Geo<8>;
+  constexpr int LB = 64 / NFR;
+  __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS + G::TAB_LDS];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  load_tables<NW, WAVE_LDS, G::I_LDS, 0>(lds, a.tab, nullptr);
+  char* buf = lds + wave * WAVE_LDS;
+  gtab_t tab = reinterpret_cast<const float*>(lds + NW * WAVE_LDS);
+  v2f p1[8];
+  load_p1<8>(a.tab, lane, p1);
+  const int f = lane / LB, l = lane & (LB - 1);
+  const int C = a.C;
+  const size_t blk = (size_t)(16 * LB) * C;   // floats per block / frame row over all channels
+  long long task = (long long)blockIdx.x * NW * a.T + wave;
+  for (int t = 0; t < a.T && task < a.ntasks; ++t, task += NW) {
+    const long long pair = task / a.cpp;
+    const int c = (int)(task - pair * a.cpp);
+    const Pair pq = make_pair<CMODE>(pair, C, a.nsig);
+    const int n = c * NFR + f;
+    const bool cur_ok = n < a.Kin, prv_ok = n >= 1 && n <= a.Kin, frame_ok = n < a.F;
+    // a missing block (before the first / after the last) is read from a neighbouring valid row and zeroed afterwards
+    const int bc = cur_ok ? n : a.Kin - 1, bp = prv_ok ? n - 1 : 0;
+    const float* x0 = a.x + row_off(pq.b0, a.Kin, 0, blk, pq.c0);
+    const float* x1 = a.x + row_off(pq.b1, a.Kin, 0, blk, pq.c1);
+    v4f cb[8], pb[8];
+    load_rowm<CMODE, LB>(x0 + (size_t)bc * blk, x1 + (size_t)bc * blk, pq.has1, l, cb);
+    load_rowm<CMODE, LB>(x0 + (size_t)bp * blk, x1 + (size_t)bp * blk, pq.has1, l, pb);
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      cb[i] = cur_ok ? cb[i] : zero;
+      pb[i] = prv_ok ? pb[i] : zero;
+    }
+    C2 z[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const v4f& go_p = pb[(3 - r) & 7];
+      const v4f& go_c = cb[(3 - r) & 7];
+      const v2f xop = rev_group<LB>(v2f{go_p.z, go_p.w}), xoc = rev_group<LB>(v2f{go_c.z, go_c.w});
+      const v4f& gp = pb[(r + 4) & 7];
+      const v4f& gc = cb[(r + 4) & 7];
+      const v2f xep = v2f{gp.x, gp.y}, xec = v2f{gc.x, gc.y};
+      const v2f ab = reinterpret_cast<const v2f*>(tab + G::I_COEF)[r * 64 + lane];
+      const v2f carry = ab.y * xep + ab.x * xop;
+      const v2f cur = (r < 4) ? (ab.y * xoc - ab.x * xec) : (ab.x * xec - ab.y * xoc);
+      const C2 v = (r < 4) ? C2{carry, cur} : C2{cur, carry};
+      z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + G::I_PRE)[r * 64 + lane]);
+    }
+    fft_wave_multi<NFR>(z, buf, tab, p1, lane);
+    v4f row[8];
+    {
+      v2f xe[8], xo_in[8], xo[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const C2 r = cmul_negim(z[j], reinterpret_cast<const v2f*>(tab + G::I_POST)[j * 64 + lane]);
+        xe[j] = r.re;
+        xo_in[j] = r.im;
+      }
+      rev_exchange_g<LB, 7>(xo_in, xo);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) row[i] = v4f{xe[i].x, xe[i].y, xo[i].x, xo[i].y};
+    }
+    if (frame_ok) {
+      const int nn = n;
+      store_rowm<CMODE, LB>(a.X + row_off(pq.b0, a.F, nn, blk, pq.c0), a.X + row_off(pq.b1, a.F, nn, blk, pq.c1), pq.has1, l, row);
+    }
+  }
+}
+
+struct InvMArgs {
+  const float* X;    // [B, Kp, N, C]
+  float* x;          // [B, nblk*N, C]
+  const float* tab;  // analysis image; the synthesis image follows at Geo<8>::I_TOTAL floats
+  int Kp, nblk, C;
+  int cpp;           // chunks of NFR consecutive output blocks per signal pair: ceil(nblk / NFR)
+  int spc;           // chunks per strip
+  int nstrips;       // strips per signal pair
+  long long nsig, ntasks;   // B * C and npairs * nstrips
+};
+
+// synthesis: a wave walks a strip of chunks; in a chunk the lanes of group f transform frame n = NFR c + f and finish
+// output block n from it and the aliased half of frame n - 1, which the group below has (one shift by LB lanes through
+// LDS); group 0 takes it from the chunk before (kept in registers), and a strip that does not start a signal begins with
+// the DCT-IV of the chunk before it.  Unfold as in k_inv_fast.
+template <int NFR, int CMODE, int NW>
+__global__ __launch_bounds__(NW * 64, AC_WPE) void k_inv_multi(InvMArgs a) {
+  using G = Geo<8>;
+  constexpr int LB = 64 / NFR;
+  __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS + G::TAB_LDS];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  load_tables<NW, WAVE_LDS, G::I_LDS, 0>(lds, a.tab + G::I_TOTAL, nullptr);
+  char* buf = lds + wave * WAVE_LDS;
+  gtab_t tab = reinterpret_cast<const float*>(lds + NW * WAVE_LDS);
+  v2f p1[8];
+  load_p1<8>(a.tab + G::I_TOTAL, lane, p1);
+  const long long task = (long long)blockIdx.x * NW + wave;
+  if (task >= a.ntasks) return;   // (no workgroup barrier below)
+  const int f = lane / LB, l = lane & (LB - 1);
+  const int C = a.C;
+  const size_t blk = (size_t)(16 * LB) * C;
+  const long long pair = task / a.nstrips;
+  const int strip = (int)(task - pair * a.nstrips);
+  const Pair pq = make_pair<CMODE>(pair, C, a.nsig);
+  const int c0 = strip * a.spc, c1 = min(a.cpp, c0 + a.spc);
+  const float* X0 = a.X + row_off(pq.b0, a.Kp, 0, blk, pq.c0);
+  const float* X1 = a.X + row_off(pq.b1, a.Kp, 0, blk, pq.c1);
+  const v4f zero = {0.f, 0.f, 0.f, 0.f};
+
+  // DCT-IV of the frames of chunk c: (now, nxt) per output element k = l + LB j of the group's frame
+  auto dct_chunk = [&](int c, v2f (&now)[8], v2f (&nxt)[8]) {
+    const int n = c * NFR + f;
+    const bool ok = n >= 0 && n < a.Kp;
+    const int fr = ok ? n : 0;
+    v4f frm[8];
+    load_rowm<CMODE, LB>(X0 + (size_t)fr * blk, X1 + (size_t)fr * blk, pq.has1, l, frm);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) frm[i] = ok ? frm[i] : zero;
+    C2 z[8];
+    {
+      v2f xo_in[8], xo[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xo_in[q] = v2f{frm[q].z, frm[q].w};
+      rev_exchange_g<LB, 7>(xo_in, xo);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const C2 v = {v2f{frm[r].x, frm[r].y}, xo[r]};
+        z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + G::I_PRE)[r * 64 + lane]);
+      }
+    }
+    fft_wave_multi<NFR>(z, buf, tab, p1, lane);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const C2 r = cmul_negim(z[j], reinterpret_cast<const v2f*>(tab + G::I_POST)[j * 64 + lane]);
+      if (j < 4) {
+        now[j] = r.re;
+        nxt[j] = r.im;
+      } else {
+        now[j] = r.im;
+        nxt[j] = r.re;
+      }
+    }
+  };
+  // every lane receives the value of the lane LB below (the lowest group: of the highest group)
+  auto shift_up = [&](const v2f (&v)[8], v2f (&out)[8]) {
+    wave_sync();
+    {
+      char* w = buf + 8 * ((lane + LB) & 63);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<v2f*>(w + 512 * j) = v[j];
+    }
+    wave_sync();
+    {
+      const char* r = buf + 8 * lane;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) out[j] = *reinterpret_cast<const v2f*>(r + 512 * j);
+    }
+  };
+
+  v2f pend[8];   // in the lanes of group 0: the aliased half of the frame before the next chunk
+#pragma unroll
+  for (int j = 0; j < 8; ++j) pend[j] = v2f{0.f, 0.f};
+  if (c0 > 0) {
+    v2f now[8], nxt[8];
+    dct_chunk(c0 - 1, now, nxt);
+    shift_up(nxt, pend);
+  }
+  for (int c = c0; c < c1; ++c) {
+    v2f now[8], nxt[8], sh[8];
+    dct_chunk(c, now, nxt);
+    shift_up(nxt, sh);
+    const int n = c * NFR + f;
+    v4f row[8];
+    {
+      v2f xe[8], xo_in[8], xo[8];
+#pragma unroll
+      for (int j2 = 0; j2 < 8; ++j2) {
+        const v2f cin = (f == 0) ? pend[j2] : sh[j2];
+        const v2f ab = reinterpret_cast<const v2f*>(tab + G::I_COEF)[j2 * 64 + lane];
+        const v2f o1 = ab.x * now[j2] + ab.y * cin;
+        const v2f o2 = ab.y * now[j2] - ab.x * cin;
+        xe[(j2 + 4) & 7] = (j2 < 4) ? o2 : o1;
+        xo_in[j2] = (j2 < 4) ? o1 : o2;
+      }
+      rev_exchange_g<LB, 3>(xo_in, xo);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) row[i] = v4f{xe[i].x, xe[i].y, xo[i].x, xo[i].y};
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pend[j] = sh[j];
+    if (n < a.nblk)
+      store_rowm<CMODE, LB>(a.x + row_off(pq.b0, a.nblk, n, blk, pq.c0), a.x + row_off(pq.b1, a.nblk, n, blk, pq.c1), pq.has1, l, row);
+  }
+}
+
 // synthesis strips: short, so that the strips in flight cover a nearly contiguous window of memory (HBM rewards that:
 // 0.42 ms at 15 blocks per strip, 0.38 ms at 4 with an extra DCT-IV per strip, 0.355-0.365 ms at 3 with the hand-over
 // between the waves of a workgroup; B = 256, K = 468)
@@ -1756,13 +2103,78 @@ static bool build_mdct_fast_R(int N, int window, std::vector<float>* out) {
   return true;
 }
 
+// Table images of the several-frames-per-wave kernels (filters_n = 16 LB, LB = 32 or 16 lanes per frame): the Geo<8>
+// layout with every entry replicated to the 64 lanes, l = lane mod LB taking the place of the lane.
+static bool build_mdct_multi(int N, int window, std::vector<float>* out) {
+  using G = Geo<8>;
+  if (N != 512 && N != 256) return false;
+  const int LB = N / 16, Q2 = LB / 8, h = N / 2, FH = 8 * LB;
+  FoldCoef c;
+  fold_coefficients(N, window, c);
+  std::vector<float> t(2 * G::I_TOTAL, 0.f);
+  float* tf = t.data();
+  float* ti = t.data() + G::I_TOTAL;
+  const double pi = 3.14159265358979323846;
+  auto put2 = [](float* base, int i, double re, double im) {
+    base[2 * i] = (float)re;
+    base[2 * i + 1] = (float)im;
+  };
+  auto same = [](double x, double y) { return std::fabs(x - y) <= 1e-8; };
+  for (int r = 0; r < 8; ++r) {
+    for (int lane = 0; lane < 64; ++lane) {
+      const int l = lane % LB, i = r * 64 + lane;
+      const int e = l + LB * r, k = l + LB * r;
+      double ang = -pi * (e + 0.25) / N;
+      put2(tf + G::I_PRE, i, std::cos(ang), std::sin(ang));
+      put2(ti + G::I_PRE, i, std::cos(ang), std::sin(ang));
+      ang = -2.0 * pi * (double)(l * r) / (double)FH;               // pass 1: W_{8 LB}^(l k0), k0 = r
+      put2(tf + G::I_P1, i, std::cos(ang), std::sin(ang));
+      put2(ti + G::I_P1, i, std::cos(ang), std::sin(ang));
+      if (lane < 8) {
+        ang = -2.0 * pi * (double)(lane * (r % Q2)) / (double)LB;   // pass 2: [k = r][m0 = lane]  W_LB^(m0 k1'), k1' = k mod Q2
+        put2(tf + G::I_P2, r * 8 + lane, std::cos(ang), std::sin(ang));
+        put2(ti + G::I_P2, r * 8 + lane, std::cos(ang), std::sin(ang));
+      }
+      ang = -pi * (double)k / N;
+      const double sf = 1.0 / (N * std::sqrt(2.0)), si = 2.0 * std::sqrt(2.0);
+      put2(tf + G::I_POST, i, std::cos(ang) * sf, std::sin(ang) * sf);
+      put2(ti + G::I_POST, i, std::cos(ang) * si, std::sin(ang) * si);
+      double cE, cO, kE, kO;
+      if (e < h / 2) {
+        const int jc = h - 1 - 2 * e, jk = 2 * e;
+        cE = c.a2[jc]; cO = c.a1[jc]; kE = c.a4[jk]; kO = c.a3[jk];
+        if (!same(cE, -kO) || !same(cO, kE)) return false;
+      } else {
+        const int pidx = e - h / 2;
+        const int jc = 2 * pidx, jk = h - 1 - 2 * pidx;
+        cE = c.a1[jc]; cO = c.a2[jc]; kE = c.a3[jk]; kO = c.a4[jk];
+        if (!same(cE, kO) || !same(cO, -kE)) return false;
+      }
+      put2(tf + G::I_COEF, i, kO, kE);
+      const int j = (k < h / 2) ? (h - 1 - 2 * k) : (2 * k - h);
+      if (!same(c.s3[j], c.s2[j]) || !same(c.s4[j], -c.s1[j])) return false;
+      put2(ti + G::I_COEF, i, c.s1[j], c.s2[j]);
+    }
+  }
+  if (out) *out = t;
+  return true;
+}
+
 // Builds the two table images; false when the size is not served (filters_n 1024 and 2048 are) or the window's fold
 // blocks are not rotations (the rectangular "window", mdctransformer.py:209-211), which the two-coefficient fold
 // cannot express.
 static bool build_mdct_fast(int N, int window, std::vector<float>* out) {
   if (N == Geo<8>::FN) return build_mdct_fast_R<8>(N, window, out);
   if (N == Geo<16>::FN) return build_mdct_fast_R<16>(N, window, out);
+  if (N == 512 || N == 256) return build_mdct_multi(N, window, out);
   return false;
+}
+
+// frames per wave of the plan's kernels: 1 (filters_n 1024 / 2048), 2 (512) or 4 (256)
+int fast_mdct_frames_per_wave(int N) { return N == 512 ? 2 : N == 256 ? 4 : 1; }
+// what the several-frames-per-wave kernels serve: float32 tensors, mono or stereo, at least one block, no streaming state
+bool fast_multi_serves(const ac_mdct_plan* p, int C, int iof, int blocks, bool streaming) {
+  return fast_mdct_frames_per_wave(p->N) > 1 && (C == 1 || C == 2) && iof == 0 && blocks >= 1 && !streaming;
 }
 
 bool fast_mdct_supported(int N, int window) { return build_mdct_fast(N, window, nullptr); }
@@ -1934,6 +2346,72 @@ static unsigned persistent_grid(int cus, int wg_per_cu, long long ntasks, int nw
   return (unsigned)g;
 }
 
+template <int NFR>
+static void launch_fwd_multi_N(const FwdMArgs& a, int C, unsigned grid, hipStream_t s) {
+  const dim3 blk(AC_WAVES * 64);
+  if (C == 2) hipLaunchKernelGGL((k_fwd_multi<NFR, 0, AC_WAVES>), dim3(grid), blk, 0, s, a);
+  else hipLaunchKernelGGL((k_fwd_multi<NFR, 2, AC_WAVES>), dim3(grid), blk, 0, s, a);
+}
+static int launch_fwd_multi(const ac_mdct_plan* p, const float* x, float* X, int B, int Kin, int F, int C, hipStream_t s) {
+  const int nfr = fast_mdct_frames_per_wave(p->N);
+  FwdMArgs a;
+  a.x = x;
+  a.X = X;
+  a.tab = p->d_fast;
+  a.Kin = Kin;
+  a.F = F;
+  a.C = C;
+  a.cpp = (F + nfr - 1) / nfr;
+  a.nsig = (long long)B * C;
+  const long long npairs = (C == 2) ? (long long)B : (a.nsig + 1) / 2;
+  a.ntasks = npairs * a.cpp;
+  static const int tper = [] { const char* e = getenv("AC_FWD_T"); return e ? atoi(e) : 4; }();
+  int T = tper > 0 ? tper : 4;
+  while (T > 1 && a.ntasks < (long long)AC_WAVES * T * p->cus * 2) T >>= 1;
+  a.T = T;
+  unsigned grid;
+  const int st = grid_for(a.ntasks, AC_WAVES * T, &grid);
+  if (st) return st;
+  if (nfr == 2) launch_fwd_multi_N<2>(a, C, grid, s);
+  else launch_fwd_multi_N<4>(a, C, grid, s);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+template <int NFR>
+static void launch_inv_multi_N(const InvMArgs& a, int C, unsigned grid, hipStream_t s) {
+  const dim3 blk(AC_WAVES * 64);
+  if (C == 2) hipLaunchKernelGGL((k_inv_multi<NFR, 0, AC_WAVES>), dim3(grid), blk, 0, s, a);
+  else hipLaunchKernelGGL((k_inv_multi<NFR, 2, AC_WAVES>), dim3(grid), blk, 0, s, a);
+}
+static int launch_inv_multi(const ac_mdct_plan* p, const float* X, float* x, int B, int Kp, int nblk, int C, hipStream_t s) {
+  const int nfr = fast_mdct_frames_per_wave(p->N);
+  InvMArgs a;
+  a.X = X;
+  a.x = x;
+  a.tab = p->d_fast;
+  a.Kp = Kp;
+  a.nblk = nblk;
+  a.C = C;
+  a.cpp = (nblk + nfr - 1) / nfr;
+  a.nsig = (long long)B * C;
+  const long long npairs = (C == 2) ? (long long)B : (a.nsig + 1) / 2;
+  // chunks per strip: every strip but a signal's first pays one more DCT-IV pass for the frame before it
+  static const int spc_env = [] { const char* e = getenv("AC_SPC"); return e ? atoi(e) : 0; }();
+  int spc = spc_env > 0 ? spc_env : 8;
+  while (spc > 1 && npairs * ((a.cpp + spc - 1) / spc) < (long long)AC_WAVES * p->cus * 2) spc >>= 1;
+  a.spc = spc;
+  a.nstrips = (a.cpp + spc - 1) / spc;
+  a.ntasks = npairs * a.nstrips;
+  unsigned grid;
+  const int st = grid_for(a.ntasks, AC_WAVES, &grid);
+  if (st) return st;
+  if (nfr == 2) launch_inv_multi_N<2>(a, C, grid, s);
+  else launch_inv_multi_N<4>(a, C, grid, s);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
 // the element-wise epilogues (EPI kernels) serve stereo float32 input at 8 points per lane (filters_n = 1024)
 bool fast_epilogue_supported(const ac_mdct_plan* p, const ac_psy_plan* psy, int iof, int C) {
   // (the plain-bf16 matrix-core form of the spreading product would spill three registers here: it takes the un-fused path)
@@ -1990,6 +2468,13 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x
                     float* thr, float drown, const float* prev_block, int B, int Kin, int F, int C, hipStream_t s,
                     float* state_out, float* noisy, float* dbn, uint64_t seed) {
   if (B <= 0 || C <= 0 || F <= 0) return AC_OK;
+  if (fast_mdct_frames_per_wave(p->N) > 1) {
+    if (psy || thr || t || state_out || noisy || dbn || !fast_multi_serves(p, C, iof, Kin, prev_block != nullptr)) {
+      set_error("internal: no wave-level analysis kernel for filters_n = %d, %d channels, io format %d here", p->N, C, iof);
+      return AC_EUNSUPPORTED;
+    }
+    return launch_fwd_multi(p, static_cast<const float*>(x), X, B, Kin, F, C, s);
+  }
   // combinations no kernel is instantiated for (ac_api.hip routes them elsewhere; refuse rather than launch nothing)
   if ((iof == 2 && C > 2) || (psy && p->N == Geo<16>::FN && (C == 1 || (iof == 1 && C > 2)))) {
     set_error("internal: no wave-level analysis kernel for filters_n = %d, %d channels, io format %d%s", p->N, C, iof,
@@ -2077,6 +2562,13 @@ static void launch_inv_R(const InvArgs& a, int C, unsigned grid, hipStream_t s) 
 int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, int iof, const float* tail_in, float* tail_out,
                     int B, int Kp, int nblk, int C, hipStream_t s) {
   if (B <= 0 || C <= 0 || nblk <= 0) return AC_OK;
+  if (fast_mdct_frames_per_wave(p->N) > 1) {
+    if (!fast_multi_serves(p, C, iof, Kp, tail_in != nullptr || tail_out != nullptr)) {
+      set_error("internal: no wave-level synthesis kernel for filters_n = %d, %d channels, io format %d here", p->N, C, iof);
+      return AC_EUNSUPPORTED;
+    }
+    return launch_inv_multi(p, X, static_cast<float*>(x), B, Kp, nblk, C, s);
+  }
   if (iof == 2 && C > 2) {
     set_error("internal: no wave-level synthesis kernel for bfloat16 tensors with %d channels", C);
     return AC_EUNSUPPORTED;

@@ -523,19 +523,60 @@ def test_autograd_of_add_noise_and_db(path):
 
 
 def test_fast_path_selection():
-    """The wave-level kernels serve N = 1024 with a Princen-Bradley window; everything else runs the generic kernels
-    (the rectangular window's fold blocks are not rotations)."""
+    """The wave-level kernels serve N = 256, 512 (several frames per wave), 1024 and 2048 with a Princen-Bradley window;
+    everything else runs the LDS-FFT / generic kernels (the rectangular window's fold blocks are not rotations)."""
     _lib.load().ac_set_force_generic(0)
     assert audiocodec_amd.MDCTransformer(1024, "vorbis").is_fast()
     assert audiocodec_amd.MDCTransformer(1024, "sine").is_fast()
     assert not audiocodec_amd.MDCTransformer(1024, "rect").is_fast()
     assert audiocodec_amd.MDCTransformer(2048, "vorbis").is_fast()
     assert not audiocodec_amd.MDCTransformer(2048, "rect").is_fast()
-    assert not audiocodec_amd.MDCTransformer(512).is_fast()
+    assert audiocodec_amd.MDCTransformer(512).is_fast() and audiocodec_amd.MDCTransformer(256, "sine").is_fast()
+    assert not audiocodec_amd.MDCTransformer(512, "rect").is_fast()
+    assert not audiocodec_amd.MDCTransformer(128).is_fast() and not audiocodec_amd.MDCTransformer(4096).is_fast()
     assert audiocodec_amd.PsychoacousticModel(48000, 1024, 64).is_fast()
     assert audiocodec_amd.PsychoacousticModel(48000, 2048, 64).is_fast()
     assert not audiocodec_amd.PsychoacousticModel(48000, 512, 64).is_fast()
     assert not audiocodec_amd.PsychoacousticModel(48000, 1024, 32).is_fast()
+
+
+@pytest.mark.parametrize("N,wt,B,K,C", [(512, "vorbis", 3, 9, 2), (512, "sine", 2, 1, 2), (512, "vorbis", 5, 40, 1),
+                                        (512, "vorbis", 1, 2, 1), (256, "vorbis", 3, 11, 2), (256, "sine", 2, 1, 2),
+                                        (256, "vorbis", 3, 70, 1), (256, "vorbis", 4, 4, 2), (256, "vorbis", 1, 3, 1),
+                                        (512, "vorbis", 2, 130, 2), (256, "vorbis", 2, 6, 3), (512, "vorbis", 2, 5, 4)])
+def test_short_frames_on_the_wave_level_kernels(N, wt, B, K, C):
+    """filters_n = 512 / 256 (the reference's own test sizes, tests/test_mdctransformer.py:23): two / four frames per wave.
+    Frame counts that leave lane groups idle (K + 1 not a multiple of 2 / 4), odd mono clip counts, signals longer than a
+    synthesis strip, single blocks; against the fp64 oracle and against the LDS-FFT tier of this library.  Other channel
+    counts at these sizes take the LDS-FFT tier and must agree too."""
+    rng = np.random.default_rng(N + 10 * K + C)
+    x = rng.uniform(-1, 1, (B, K * N, C)).astype(np.float32)
+    m = audiocodec_amd.MDCTransformer(N, window_type=wt)
+    assert m.is_fast()
+    o = MDCTOracle(N, wt, np.float64)
+    xd = dev(x)
+    X = m.transform(xd)
+    Xo = o.transform(x.astype(np.float64))
+    assert tuple(X.shape) == (B, K + 1, N, C)
+    assert rel_peak(host(X), Xo) <= TOL and rel_l2(host(X), Xo) <= TOL
+    xh = m.inverse_transform(X)
+    assert tuple(xh.shape) == (B, (K + 2) * N, C)
+    assert float((xh[:, N:-N] - xd).abs().max()) <= LSB
+    assert np.max(np.abs(host(xh) - o.inverse_transform(Xo))) <= LSB
+    lib = _lib.load()
+    assert lib.ac_set_force_generic(1) == 0
+    try:
+        Xg = m.transform(xd)
+        xg = m.inverse_transform(X)
+    finally:
+        lib.ac_set_force_generic(0)
+    peak = Xg.abs().amax(dim=2, keepdim=True).clamp_min(1e-20)
+    assert float(((X - Xg).abs() / peak).max()) <= TOL and float((xh - xg).abs().max()) <= 2e-6
+    # clips are independent and frames depend on two blocks only
+    if B > 1:
+        assert torch.equal(m.transform(xd[1:2].contiguous()), X[1:2])
+    if K >= 4:
+        assert torch.equal(m.transform(xd[:, N:3 * N].contiguous())[:, 1], X[:, 2])
 
 
 @pytest.mark.parametrize("wt", ["rect", None])

@@ -33,12 +33,12 @@ rows = [
     ("torch fill X (0R:1W)", lambda: thr.fill_(1.0), 4 * N),
     ("torch sum X (1R:0W)", lambda: X.sum(), 4 * N),
 ]
-if codec.mdct.is_fast():
+if codec.mdct.is_fast() and N >= 1024:
     pcm = (x * 32767).to(torch.int16)
     pcm_out = torch.empty((B, (K + 2) * N, C), device=dev, dtype=torch.int16)
     rows += [("encode_fused pcm16", lambda: codec.encode_into(pcm, X, t, thr), 10 * N + 4),
              ("inverse pcm16", lambda: codec.decode_into(X, pcm_out), 6 * N)]
-if codec.mdct.is_fast() and C <= 2:
+if codec.mdct.is_fast() and C <= 2 and N >= 1024:
     cb = audiocodec_amd.AudioCodec(48000, N, compute_dtype=torch.bfloat16)
     xb = x.to(torch.bfloat16); Xb = torch.empty_like(X, dtype=torch.bfloat16); tb = torch.empty_like(t, dtype=torch.bfloat16)
     thrb = torch.empty_like(Xb); xhb = torch.empty_like(xh, dtype=torch.bfloat16)
