@@ -348,9 +348,9 @@ int ac_psy_plan_spreading(const ac_psy_plan* p) { return p ? p->spread : 0; }
 // ---- hot path -------------------------------------------------------------------------------------
 
 // whether the wave-level kernels take this call (plans at filters_n 512 / 256 serve a subset, see ac_internal.h)
-static bool wave_level(const ac_mdct_plan* p, int C, int iof, int blocks, bool streaming) {
+static bool wave_level(const ac_mdct_plan* p, int C, int iof, int blocks) {
   if (!p->fast || g_force_generic) return false;
-  return fast_mdct_frames_per_wave(p->N) == 1 || fast_multi_serves(p, C, iof, blocks, streaming);
+  return fast_mdct_frames_per_wave(p->N) == 1 || fast_multi_serves(p, C, iof, blocks);
 }
 
 static int check_dims(int B, int K, int C) {
@@ -366,7 +366,7 @@ static int mdct_forward(const ac_mdct_plan* p, const void* x, bool pcm16, float*
   AC_REQUIRE(X != nullptr && (x != nullptr || K == 0), "NULL tensor pointer");
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
-  if (wave_level(p, C, pcm16 ? 1 : 0, K, false))
+  if (wave_level(p, C, pcm16 ? 1 : 0, K))
     return launch_fwd_fast(p, nullptr, x, pcm16, X, nullptr, nullptr, 0.f, nullptr, B, K, K + 1, C, s);
   if (pcm16) {
     set_error("16-bit PCM is served by the wave-level kernels only (filters_n 1024 or 2048, 'vorbis' or 'sine' window)");
@@ -383,7 +383,7 @@ static int mdct_inverse(const ac_mdct_plan* p, const float* X, void* x, bool pcm
   AC_REQUIRE(x != nullptr && (X != nullptr || Kp == 0), "NULL tensor pointer");
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
-  if (wave_level(p, C, pcm16 ? 1 : 0, Kp, false)) return launch_inv_fast(p, X, x, pcm16, nullptr, nullptr, B, Kp, Kp + 1, C, s);
+  if (wave_level(p, C, pcm16 ? 1 : 0, Kp)) return launch_inv_fast(p, X, x, pcm16, nullptr, nullptr, B, Kp, Kp + 1, C, s);
   if (pcm16) {
     set_error("16-bit PCM is served by the wave-level kernels only (filters_n 1024 or 2048, 'vorbis' or 'sine' window)");
     return AC_EUNSUPPORTED;
@@ -598,7 +598,7 @@ static int stream_analysis(ac_stream* s, const ac_psy_plan* psy, const float* x_
   DeviceGuard guard(s->device);
   hipStream_t hs = (hipStream_t)stream;
   int st;
-  const bool fast = wave_level(p, s->C, 0, k, true);
+  const bool fast = wave_level(p, s->C, 0, k);
   // (filters_n = 2048 mono: the fused kernel is not instantiated, see encode_fused)
   const bool fused = psy && fast && psy->fast && !(p->N == 2048 && s->C == 1);
   if (fast) {
@@ -643,7 +643,7 @@ int ac_stream_inverse(ac_stream* s, const float* X_chunk, float* x, int k, void*
   DeviceGuard guard(s->device);
   hipStream_t hs = (hipStream_t)stream;
   int st;
-  if (wave_level(p, s->C, 0, k, true))
+  if (wave_level(p, s->C, 0, k))
     st = launch_inv_fast(p, X_chunk, x, false, s->d_tail, s->d_tail_tmp, s->B, k, k, s->C, hs);
   else
     st = launch_inv_generic(p, X_chunk, x, s->d_tail, s->d_tail_tmp, s->B, k, k, s->C, hs);
@@ -751,7 +751,7 @@ int ac_mdct_forward_typed(const ac_mdct_plan* p, const void* x, void* X, int dty
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == AC_F64) return launch_fwd_f64(p, static_cast<const double*>(x), static_cast<double*>(X), B, K, K + 1, C, s);
-  if (wave_level(p, C, 2, K, false) && C <= 2)   // bfloat16 on the wave-level kernels (stereo / mono)
+  if (wave_level(p, C, 2, K) && C <= 2)   // bfloat16 on the wave-level kernels (stereo / mono)
     return launch_fwd_fast(p, nullptr, x, 2, static_cast<float*>(X), nullptr, nullptr, 0.f, nullptr, B, K, K + 1, C, s);
   return launch_fwd_bf16(p, static_cast<const bf16_t*>(x), static_cast<bf16_t*>(X), B, K, K + 1, C, s);
 }
@@ -767,7 +767,7 @@ int ac_mdct_inverse_typed(const ac_mdct_plan* p, const void* X, void* x, int dty
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == AC_F64) return launch_inv_f64(p, static_cast<const double*>(X), static_cast<double*>(x), B, Kp, Kp + 1, C, s);
-  if (wave_level(p, C, 2, Kp, false) && C <= 2)
+  if (wave_level(p, C, 2, Kp) && C <= 2)
     return launch_inv_fast(p, static_cast<const float*>(X), x, 2, nullptr, nullptr, B, Kp, Kp + 1, C, s);
   return launch_inv_bf16(p, static_cast<const bf16_t*>(X), static_cast<bf16_t*>(x), B, Kp, Kp + 1, C, s);
 }

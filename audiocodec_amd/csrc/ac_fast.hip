@@ -1809,6 +1809,8 @@ __device__ __forceinline__ void store_rowm(float* r0, float* r1, bool has1, int 
 struct FwdMArgs {
   const float* x;    // [B, Kin*N, C]
   float* X;          // [B, F, N, C]
+  const float* prev_block;   // [B, N, C] or null: block -1 of every signal (streaming analysis state)
+  float* state_out;          // [B, N, C] or null: receives block Kin-1 (another buffer than prev_block)
   const float* tab;  // analysis image (Geo<8> layout, lane-replicated)
   int Kin, F, C;
   int cpp;           // chunks of NFR consecutive frames per signal pair: ceil(F / NFR)
@@ -1838,14 +1840,24 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
     const int c = (int)(task - pair * a.cpp);
     const Pair pq = make_pair<CMODE>(pair, C, a.nsig);
     const int n = c * NFR + f;
-    const bool cur_ok = n < a.Kin, prv_ok = n >= 1 && n <= a.Kin, frame_ok = n < a.F;
+    const bool from_state = a.prev_block != nullptr && n == 0;   // streaming: block -1 is the stored state
+    const bool cur_ok = n < a.Kin, prv_ok = (n >= 1 && n <= a.Kin) || from_state, frame_ok = n < a.F;
     // a missing block (before the first / after the last) is read from a neighbouring valid row and zeroed afterwards
-    const int bc = cur_ok ? n : a.Kin - 1, bp = prv_ok ? n - 1 : 0;
+    const int bc = cur_ok ? n : a.Kin - 1, bp = (n >= 1 && n <= a.Kin) ? n - 1 : 0;
     const float* x0 = a.x + row_off(pq.b0, a.Kin, 0, blk, pq.c0);
     const float* x1 = a.x + row_off(pq.b1, a.Kin, 0, blk, pq.c1);
+    const float* p0 = x0 + (size_t)bp * blk;
+    const float* p1r = x1 + (size_t)bp * blk;
+    if (from_state) {
+      p0 = a.prev_block + row_off(pq.b0, 1, 0, blk, pq.c0);
+      p1r = a.prev_block + row_off(pq.b1, 1, 0, blk, pq.c1);
+    }
     v4f cb[8], pb[8];
     load_rowm<CMODE, LB>(x0 + (size_t)bc * blk, x1 + (size_t)bc * blk, pq.has1, l, cb);
-    load_rowm<CMODE, LB>(x0 + (size_t)bp * blk, x1 + (size_t)bp * blk, pq.has1, l, pb);
+    load_rowm<CMODE, LB>(p0, p1r, pq.has1, l, pb);
+    if (a.state_out && n == a.Kin - 1)   // streaming: the chunk's last block is the next chunk's block -1
+      store_rowm<CMODE, LB>(a.state_out + row_off(pq.b0, 1, 0, blk, pq.c0), a.state_out + row_off(pq.b1, 1, 0, blk, pq.c1),
+                            pq.has1, l, cb);
     const v4f zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -1891,6 +1903,8 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
 struct InvMArgs {
   const float* X;    // [B, Kp, N, C]
   float* x;          // [B, nblk*N, C]
+  const float* tail_in;   // [B, C, N/2] or null: aliased half of the frame before frame 0 (streaming synthesis state)
+  float* tail_out;        // [B, C, N/2] or null: receives the aliased half of frame nblk - 1
   const float* tab;  // analysis image; the synthesis image follows at Geo<8>::I_TOTAL floats
   int Kp, nblk, C;
   int cpp;           // chunks of NFR consecutive output blocks per signal pair: ceil(nblk / NFR)
@@ -1977,9 +1991,20 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_inv_multi(InvMArgs a) {
     }
   };
 
+  constexpr int FHs = 8 * LB;   // outputs per block half
+  const size_t ts0 = ((size_t)pq.b0 * C + pq.c0) * FHs, ts1 = ((size_t)pq.b1 * C + pq.c1) * FHs;   // stream state rows
   v2f pend[8];   // in the lanes of group 0: the aliased half of the frame before the next chunk
 #pragma unroll
   for (int j = 0; j < 8; ++j) pend[j] = v2f{0.f, 0.f};
+  if (c0 == 0 && a.tail_in) {
+#pragma unroll
+    for (int j2 = 0; j2 < 8; ++j2) {
+      const int k = l + LB * j2;
+      const int j = (j2 < 4) ? (FHs - 1 - 2 * k) : (2 * k - FHs);
+      pend[j2].x = a.tail_in[ts0 + j];
+      pend[j2].y = pq.has1 ? a.tail_in[ts1 + j] : 0.f;
+    }
+  }
   if (c0 > 0) {
     v2f now[8], nxt[8];
     dct_chunk(c0 - 1, now, nxt);
@@ -2008,6 +2033,15 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_inv_multi(InvMArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) pend[j] = sh[j];
+    if (a.tail_out && n == a.nblk - 1) {   // streaming: the last frame's aliased half is the next chunk's state
+#pragma unroll
+      for (int j2 = 0; j2 < 8; ++j2) {
+        const int k = l + LB * j2;
+        const int j = (j2 < 4) ? (FHs - 1 - 2 * k) : (2 * k - FHs);
+        a.tail_out[ts0 + j] = nxt[j2].x;
+        if (pq.has1) a.tail_out[ts1 + j] = nxt[j2].y;
+      }
+    }
     if (n < a.nblk)
       store_rowm<CMODE, LB>(a.x + row_off(pq.b0, a.nblk, n, blk, pq.c0), a.x + row_off(pq.b1, a.nblk, n, blk, pq.c1), pq.has1, l, row);
   }
@@ -2172,9 +2206,9 @@ static bool build_mdct_fast(int N, int window, std::vector<float>* out) {
 
 // frames per wave of the plan's kernels: 1 (filters_n 1024 / 2048), 2 (512) or 4 (256)
 int fast_mdct_frames_per_wave(int N) { return N == 512 ? 2 : N == 256 ? 4 : 1; }
-// what the several-frames-per-wave kernels serve: float32 tensors, mono or stereo, at least one block, no streaming state
-bool fast_multi_serves(const ac_mdct_plan* p, int C, int iof, int blocks, bool streaming) {
-  return fast_mdct_frames_per_wave(p->N) > 1 && (C == 1 || C == 2) && iof == 0 && blocks >= 1 && !streaming;
+// what the several-frames-per-wave kernels serve: float32 tensors, mono or stereo, at least one block
+bool fast_multi_serves(const ac_mdct_plan* p, int C, int iof, int blocks) {
+  return fast_mdct_frames_per_wave(p->N) > 1 && (C == 1 || C == 2) && iof == 0 && blocks >= 1;
 }
 
 bool fast_mdct_supported(int N, int window) { return build_mdct_fast(N, window, nullptr); }
@@ -2352,11 +2386,14 @@ static void launch_fwd_multi_N(const FwdMArgs& a, int C, unsigned grid, hipStrea
   if (C == 2) hipLaunchKernelGGL((k_fwd_multi<NFR, 0, AC_WAVES>), dim3(grid), blk, 0, s, a);
   else hipLaunchKernelGGL((k_fwd_multi<NFR, 2, AC_WAVES>), dim3(grid), blk, 0, s, a);
 }
-static int launch_fwd_multi(const ac_mdct_plan* p, const float* x, float* X, int B, int Kin, int F, int C, hipStream_t s) {
+static int launch_fwd_multi(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, float* state_out, int B,
+                            int Kin, int F, int C, hipStream_t s) {
   const int nfr = fast_mdct_frames_per_wave(p->N);
   FwdMArgs a;
   a.x = x;
   a.X = X;
+  a.prev_block = prev_block;
+  a.state_out = state_out;
   a.tab = p->d_fast;
   a.Kin = Kin;
   a.F = F;
@@ -2384,11 +2421,14 @@ static void launch_inv_multi_N(const InvMArgs& a, int C, unsigned grid, hipStrea
   if (C == 2) hipLaunchKernelGGL((k_inv_multi<NFR, 0, AC_WAVES>), dim3(grid), blk, 0, s, a);
   else hipLaunchKernelGGL((k_inv_multi<NFR, 2, AC_WAVES>), dim3(grid), blk, 0, s, a);
 }
-static int launch_inv_multi(const ac_mdct_plan* p, const float* X, float* x, int B, int Kp, int nblk, int C, hipStream_t s) {
+static int launch_inv_multi(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out, int B,
+                            int Kp, int nblk, int C, hipStream_t s) {
   const int nfr = fast_mdct_frames_per_wave(p->N);
   InvMArgs a;
   a.X = X;
   a.x = x;
+  a.tail_in = tail_in;
+  a.tail_out = tail_out;
   a.tab = p->d_fast;
   a.Kp = Kp;
   a.nblk = nblk;
@@ -2469,11 +2509,11 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x
                     float* state_out, float* noisy, float* dbn, uint64_t seed) {
   if (B <= 0 || C <= 0 || F <= 0) return AC_OK;
   if (fast_mdct_frames_per_wave(p->N) > 1) {
-    if (psy || thr || t || state_out || noisy || dbn || !fast_multi_serves(p, C, iof, Kin, prev_block != nullptr)) {
+    if (psy || thr || t || noisy || dbn || !fast_multi_serves(p, C, iof, Kin)) {
       set_error("internal: no wave-level analysis kernel for filters_n = %d, %d channels, io format %d here", p->N, C, iof);
       return AC_EUNSUPPORTED;
     }
-    return launch_fwd_multi(p, static_cast<const float*>(x), X, B, Kin, F, C, s);
+    return launch_fwd_multi(p, static_cast<const float*>(x), X, prev_block, state_out, B, Kin, F, C, s);
   }
   // combinations no kernel is instantiated for (ac_api.hip routes them elsewhere; refuse rather than launch nothing)
   if ((iof == 2 && C > 2) || (psy && p->N == Geo<16>::FN && (C == 1 || (iof == 1 && C > 2)))) {
@@ -2563,11 +2603,11 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, int iof, con
                     int B, int Kp, int nblk, int C, hipStream_t s) {
   if (B <= 0 || C <= 0 || nblk <= 0) return AC_OK;
   if (fast_mdct_frames_per_wave(p->N) > 1) {
-    if (!fast_multi_serves(p, C, iof, Kp, tail_in != nullptr || tail_out != nullptr)) {
+    if (!fast_multi_serves(p, C, iof, Kp)) {
       set_error("internal: no wave-level synthesis kernel for filters_n = %d, %d channels, io format %d here", p->N, C, iof);
       return AC_EUNSUPPORTED;
     }
-    return launch_inv_multi(p, X, static_cast<float*>(x), B, Kp, nblk, C, s);
+    return launch_inv_multi(p, X, static_cast<float*>(x), tail_in, tail_out, B, Kp, nblk, C, s);
   }
   if (iof == 2 && C > 2) {
     set_error("internal: no wave-level synthesis kernel for bfloat16 tensors with %d channels", C);

@@ -143,9 +143,9 @@ int launch_threshold_generic(const ac_psy_plan* p, const float* X, const float* 
 // wave-level FFT kernels (ac_fast.hip)
 bool fast_mdct_supported(int N, int window);
 // filters_n 512 / 256 run several frames per wave (2 / 4); those kernels serve float32 mono / stereo tensors with at least
-// one block and no streaming state -- everything else at these sizes takes the LDS-FFT tier
+// one block (streaming state included) -- everything else at these sizes takes the LDS-FFT tier
 int fast_mdct_frames_per_wave(int N);
-bool fast_multi_serves(const ac_mdct_plan* p, int C, int iof, int blocks, bool streaming);
+bool fast_multi_serves(const ac_mdct_plan* p, int C, int iof, int blocks);
 bool fast_psy_supported(const ac_psy_plan* p);
 int fast_mdct_plan_init(ac_mdct_plan* p);
 int fast_psy_plan_init(ac_psy_plan* p);
