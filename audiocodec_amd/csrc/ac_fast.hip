@@ -338,6 +338,12 @@ __device__ __forceinline__ Pair make_pair(long long p, int C, long long nsig) {
     q.c0 = 0;
     q.c1 = 1;
     q.has1 = true;
+  } else if (CMODE == 2) {   // one channel: signal = clip (no 64-bit divisions on the scalar unit)
+    const long long s0 = 2 * p, s1 = s0 + 1;
+    q.has1 = s1 < nsig;
+    q.b0 = s0;
+    q.b1 = q.has1 ? s1 : s0;
+    q.c0 = q.c1 = 0;
   } else {
     const long long s0 = 2 * p, s1 = s0 + 1;
     q.has1 = s1 < nsig;
@@ -1835,9 +1841,13 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
   const int C = a.C;
   const size_t blk = (size_t)(16 * LB) * C;   // floats per block / frame row over all channels
   long long task = (long long)blockIdx.x * NW * a.T + wave;
-  for (int t = 0; t < a.T && task < a.ntasks; ++t, task += NW) {
-    const long long pair = task / a.cpp;
-    const int c = (int)(task - pair * a.cpp);
+  long long pair = task / a.cpp;          // (one 64-bit division per wave; the task index then advances without)
+  int c = (int)(task - pair * a.cpp);
+  for (int t = 0; t < a.T && task < a.ntasks; ++t, task += NW, c += NW) {
+    while (c >= a.cpp) {
+      c -= a.cpp;
+      ++pair;
+    }
     const Pair pq = make_pair<CMODE>(pair, C, a.nsig);
     const int n = c * NFR + f;
     const bool from_state = a.prev_block != nullptr && n == 0;   // streaming: block -1 is the stored state

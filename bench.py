@@ -604,7 +604,10 @@ def main():
                 out["other_configs"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out), flush=True)
     if world > 1:
-        torch.distributed.barrier()
+        if backend == "nccl":
+            torch.distributed.barrier(device_ids=[dev.index])
+        else:
+            torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

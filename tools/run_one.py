@@ -7,7 +7,7 @@ import audiocodec_amd
 what = sys.argv[1] if len(sys.argv) > 1 else "encode"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 N = int(os.environ.get("N", 1024))
-B, K, C = int(os.environ.get("B", 256)), int(os.environ.get("K", 468 * 1024 // N)), 2
+B, K, C = int(os.environ.get("B", 256)), int(os.environ.get("K", 468 * 1024 // N)), int(os.environ.get("C", 2))
 dev = torch.device("cuda")
 x = torch.rand((B, K * N, C), device=dev) * 2 - 1
 codec = audiocodec_amd.AudioCodec(48000, N)
