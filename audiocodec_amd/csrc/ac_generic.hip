@@ -641,17 +641,19 @@ __global__ __launch_bounds__(kThreads) void k_threshold_bwd_generic(
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 // (db_of, normal_pair, noisy_of: ac_internal.h, shared with the fused encode epilogue)
-// 16-byte vectors (n4 of them) + a scalar tail; a, out 16-byte aligned when n4 > 0
+// 16-byte vectors (n4 of them), one per thread, workgroups in address order (4 KB per workgroup: the store pattern the
+// memory system rewards most, tools/ubench_write_pattern.hip) + a scalar tail; a, out 16-byte aligned when n4 > 0
 __global__ __launch_bounds__(256) void k_db(const float* __restrict__ a, float* __restrict__ out, size_t n, size_t n4,
                                             int norm) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (size_t i = tid; i < n4; i += stride) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) {
     const f4 v = reinterpret_cast<const f4*>(a)[i];
     __builtin_nontemporal_store(f4{db_of(v.x, norm), db_of(v.y, norm), db_of(v.z, norm), db_of(v.w, norm)},
                                 reinterpret_cast<f4*>(out) + i);
+  } else {
+    const size_t j = 4 * n4 + (i - n4);
+    if (j < n) out[j] = db_of(a[j], norm);
   }
-  for (size_t i = 4 * n4 + tid; i < n; i += stride) out[i] = db_of(a[i], norm);
 }
 
 // d amplitude_to_dB / d a = (20 / ln 10) / a where a^2 > eps, else 0 (the clamp); the normalised form scales by 1 / 140
@@ -669,21 +671,22 @@ __global__ __launch_bounds__(256) void k_db_bwd(const float* __restrict__ a, con
 // add_noise with respect to the threshold is add_noise(0, grad_out) under the same seed)
 __global__ __launch_bounds__(256) void k_add_noise(const float* __restrict__ X, const float* __restrict__ thr,
                                                    float* __restrict__ out, size_t n, size_t n4, uint64_t seed) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t key = mix64(seed);
-  for (size_t i = tid; i < n4; i += stride) {
+  if (i < n4) {
     const f4 x = X ? reinterpret_cast<const f4*>(X)[i] : f4{0.f, 0.f, 0.f, 0.f}, t = reinterpret_cast<const f4*>(thr)[i];
     float g0, g1, g2, g3;
     normal_pair(key, 2 * i, g0, g1);
     normal_pair(key, 2 * i + 1, g2, g3);
     __builtin_nontemporal_store(f4{noisy_of(x.x, t.x, g0), noisy_of(x.y, t.y, g1), noisy_of(x.z, t.z, g2), noisy_of(x.w, t.w, g3)},
                                 reinterpret_cast<f4*>(out) + i);
-  }
-  for (size_t i = 4 * n4 + tid; i < n; i += stride) {
-    float g0, g1;
-    normal_pair(key, i >> 1, g0, g1);
-    out[i] = noisy_of(X ? X[i] : 0.f, thr[i], (i & 1) ? g1 : g0);
+  } else {
+    const size_t j = 4 * n4 + (i - n4);
+    if (j < n) {
+      float g0, g1;
+      normal_pair(key, j >> 1, g0, g1);
+      out[j] = noisy_of(X ? X[j] : 0.f, thr[j], (j & 1) ? g1 : g0);
+    }
   }
 }
 
@@ -841,8 +844,12 @@ int launch_db(const float* a, float* out, size_t n, int norm, hipStream_t s) {
   // 16-byte vectors when both pointers allow it, else element by element
   const bool al = (((uintptr_t)a | (uintptr_t)out) & 15) == 0;
   const size_t n4 = al ? n / 4 : 0;
-  const unsigned grid = (unsigned)std::min<size_t>((std::max<size_t>(n4, n - 4 * n4) + 255) / 256, 8192);
-  hipLaunchKernelGGL(k_db, dim3(grid), dim3(256), 0, s, a, out, n, n4, norm);
+  const size_t nblk = (n4 + (n - 4 * n4) + 255) / 256;   // one thread per 16-byte vector, then one per tail element
+  if (nblk > 2147483647ull) {
+    set_error("tensor too large for one launch (%zu elements)", n);
+    return AC_EINVAL;
+  }
+  hipLaunchKernelGGL(k_db, dim3((unsigned)nblk), dim3(256), 0, s, a, out, n, n4, norm);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }
@@ -859,8 +866,12 @@ int launch_add_noise(const float* X, const float* thr, float* out, size_t n, uin
   if (n == 0) return AC_OK;
   const bool al = (((uintptr_t)X | (uintptr_t)thr | (uintptr_t)out) & 15) == 0;
   const size_t n4 = al ? n / 4 : 0;
-  const unsigned grid = (unsigned)std::min<size_t>((std::max<size_t>(n4, n - 4 * n4) + 255) / 256, 8192);
-  hipLaunchKernelGGL(k_add_noise, dim3(grid), dim3(256), 0, s, X, thr, out, n, n4, seed);
+  const size_t nblk = (n4 + (n - 4 * n4) + 255) / 256;
+  if (nblk > 2147483647ull) {
+    set_error("tensor too large for one launch (%zu elements)", n);
+    return AC_EINVAL;
+  }
+  hipLaunchKernelGGL(k_add_noise, dim3((unsigned)nblk), dim3(256), 0, s, X, thr, out, n, n4, seed);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }

@@ -4,8 +4,11 @@ import audiocodec_amd
 p = audiocodec_amd.PsychoacousticModel(48000)
 X = torch.rand(256, 469, 1024, 2, device="cuda") - 0.5
 thr = torch.rand_like(X) * 0.1
-def timeit(fn, n=5):
-    fn(); torch.cuda.synchronize()
+def timeit(fn, n=20):
+    import time
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.1:      # settle the device
+        fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): fn()
@@ -15,3 +18,6 @@ nb = X.numel() * 4
 print("add_noise   %.3f ms  %.0f GB/s" % ((t := timeit(lambda: p.add_noise(X, thr, seed=1))), 3 * nb / t / 1e6))
 print("dB          %.3f ms  %.0f GB/s" % ((t := timeit(lambda: p.amplitude_to_dB(X))), 2 * nb / t / 1e6))
 print("dB_norm     %.3f ms  %.0f GB/s" % ((t := timeit(lambda: p.amplitude_to_dB_norm(X))), 2 * nb / t / 1e6))
+out = torch.empty_like(X)
+print("torch add (2R:1W) %.3f ms  %.0f GB/s" % ((t := timeit(lambda: torch.add(X, thr, out=out))), 3 * nb / t / 1e6))
+print("torch abs (1R:1W) %.3f ms  %.0f GB/s" % ((t := timeit(lambda: torch.abs(X, out=out))), 2 * nb / t / 1e6))
