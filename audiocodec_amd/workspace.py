@@ -41,6 +41,8 @@ class Workspace:
 
     CLASS_GAP = 0.93
     SPACER_GIB = 12.0
+    GOOD_RATE = 5.7e12        # algorithmic bytes / s of the fused encode that only a two-class placement reaches (stereo,
+                              # filters_n 1024: 5.9-6.0e12 against 5.1-5.4e12 in one class)
 
     def __init__(self, codec, batches_n, blocks_n, channels_n, max_tries=8, span_gib=96.0, tune=True, device=None):
         _host.require_float32(codec.compute_dtype, "Workspace")
@@ -87,6 +89,9 @@ class Workspace:
                                                       ctypes.byref(arg), ms))
                 times.append(float(ms[0]))
                 if len(times) >= 2 and min(times) <= self.CLASS_GAP * max(times):
+                    break
+                enc_bytes = 4.0 * (words["x"] + words["X"] + words["thr"] + words["t"])
+                if enc_bytes / (times[-1] * 1e-3) >= self.GOOD_RATE:     # already a two-class placement
                     break
                 spacers.add(self.SPACER_GIB)                     # the next try comes from further along the VRAM
             best = int(np.argmin(times))
