@@ -296,6 +296,10 @@ int ac_psy_plan_create_ex(int N, int M, double sample_rate, double alpha, int de
     st = fast_psy_plan_init(p);
     if (!st) p->fast = 1;
   }
+  if (!st && !p->fast && mid_psy_supported(p)) {
+    st = mid_psy_plan_init(p);
+    if (!st) p->mid = 1;
+  }
   if (!st && spreading != AC_SPREAD_F32) {
     if (p->fast) {
       p->spread = spreading;
@@ -337,6 +341,7 @@ int ac_psy_plan_destroy(ac_psy_plan* p) {
   (void)hipFree(p->d_quiet64);
   (void)hipFree(p->d_beta64);
   (void)hipFree(p->d_fast);
+  (void)hipFree(p->d_mid);
   delete p;
   return AC_OK;
 }
@@ -344,6 +349,7 @@ int ac_psy_plan_destroy(ac_psy_plan* p) {
 int ac_mdct_plan_is_fast(const ac_mdct_plan* p) { return p ? p->fast : 0; }
 int ac_psy_plan_is_fast(const ac_psy_plan* p) { return p ? p->fast : 0; }
 int ac_psy_plan_spreading(const ac_psy_plan* p) { return p ? p->spread : 0; }
+int ac_psy_plan_tier(const ac_psy_plan* p) { return !p ? 0 : p->fast ? 2 : p->mid ? 1 : 0; }
 
 // ---- hot path -------------------------------------------------------------------------------------
 
@@ -413,6 +419,7 @@ int ac_tonality(const ac_psy_plan* p, const float* X, float* t, int B, int F, in
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
   if (p->fast && !g_force_generic) return launch_psy_fast(p, X, nullptr, t, nullptr, 0.f, B, F, C, s);
+  if (p->mid && !g_force_generic && C <= 2) return launch_psy_mid(p, X, nullptr, t, nullptr, 0.f, B, F, C, s);
   return launch_tonality_generic(p, X, t, B, F, C, s);
 }
 
@@ -426,6 +433,7 @@ int ac_mask_threshold(const ac_psy_plan* p, const float* X, const float* t, floa
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
   if (p->fast && !g_force_generic) return launch_psy_fast(p, X, t, nullptr, thr, drown, B, F, C, s);
+  if (p->mid && !g_force_generic && C <= 2) return launch_psy_mid(p, X, t, nullptr, thr, drown, B, F, C, s);
   return launch_threshold_generic(p, X, t, drown, thr, B, F, C, s);
 }
 
@@ -478,8 +486,10 @@ static int encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const 
     if (!st) st = launch_psy_fast(psy, X, nullptr, t, thr, drown, B, K + 1, C, s);
     return st;
   }
-  // un-fused composition for configurations the fused kernel does not cover
+  // un-fused composition for configurations the fused kernel does not cover: the transform, then tonality + threshold in
+  // one wave-level pass over X where the general-layout masking kernels serve the plan, else the two generic kernels
   st = mdct_forward(mdct, x, pcm16, X, B, K, C, stream);
+  if (!st && psy->mid && !g_force_generic && C <= 2) return launch_psy_mid(psy, X, nullptr, t, thr, drown, B, K + 1, C, s);
   if (!st) st = ac_tonality(psy, X, t, B, K + 1, C, stream);
   if (!st) st = ac_mask_threshold(psy, X, t, drown, thr, B, K + 1, C, stream);
   return st;
@@ -618,6 +628,7 @@ static int stream_analysis(ac_stream* s, const ac_psy_plan* psy, const float* x_
     // the same second step encode_fused takes for these configurations (so that chunked and one-shot results agree bit
     // for bit): tonality + threshold in one wave-level pass over X, or the two generic kernels
     if (fast && psy->fast) return launch_psy_fast(psy, X, nullptr, t, thr, drown, s->B, k, s->C, hs);
+    if (psy->mid && !g_force_generic && s->C <= 2) return launch_psy_mid(psy, X, nullptr, t, thr, drown, s->B, k, s->C, hs);
     st = ac_tonality(psy, X, t, s->B, k, s->C, stream);
     if (!st) st = ac_mask_threshold(psy, X, t, drown, thr, s->B, k, s->C, stream);
   }

@@ -116,6 +116,10 @@ struct ac_psy_plan {
   // fast-path tables (ac_fast.hip)
   float* d_fast = nullptr;
   size_t fast_bytes = 0;
+  // wave-level masking model for general band layouts (ac_psy_mid.hip): filter_bands_n 256 / 512 / 1024, <= 64 bands
+  int mid = 0;
+  uint32_t* d_mid = nullptr;
+  int mid_words = 0;
 };
 
 struct ac_stream {
@@ -162,6 +166,12 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, int iof, con
                     int B, int Kp, int nblk, int C, hipStream_t s);
 int launch_psy_fast(const ac_psy_plan* p, const float* X, const float* t_in, float* t_out, float* thr, float drown,
                     int B, int F, int C, hipStream_t s, int iof = 0);
+
+// wave-level masking model for general band layouts (ac_psy_mid.hip); mono / stereo float32
+bool mid_psy_supported(const ac_psy_plan* p);
+int mid_psy_plan_init(ac_psy_plan* p);
+int launch_psy_mid(const ac_psy_plan* p, const float* X, const float* t_in, float* t_out, float* thr, float drown, int B,
+                   int F, int C, hipStream_t s);
 
 int launch_tonality_bwd_generic(const ac_psy_plan* p, const float* X, const float* gt, float* gX, int accumulate, int B,
                                 int F, int C, hipStream_t s);

@@ -1,0 +1,357 @@
+// Wave-level masking model for the configurations the fused epilogue of ac_fast.hip does not serve: filter_bands_n 256,
+// 512 or 1024 with any Bark-band count up to 64 and any band layout (a bin may overlap several bands, bands may share
+// bins freely) -- e.g. the models beside the several-frames-per-wave MDCT kernels (filters_n 256 / 512), where the
+// O(N)-per-workgroup generic kernels ran at 0.5-0.8 TB/s.  gfx950 only.
+//
+// One 64-lane wave per (frame, channel pair) as in k_psy_fast: the row is loaded with coalesced 16-byte (stereo) or
+// 8-byte (mono, two signals side by side) accesses, tonality comes from DPP wave sums, the intensities go through an LDS
+// image, lane j < M owns Bark band j and walks its list of (bin, weight) entries (W "by band": psychoacoustic.py:301-315),
+// the band x band spreading product reads S from LDS with the Q_i broadcast (psychoacoustic.py:205-207, tonality offset
+// pulled out of the sum: SURVEY App. A.3), and every bin gathers its <= WI (band, weight) entries of W_inv from a
+// fixed-width table (psychoacoustic.py:317-331).  All constant tables sit in one image copied to LDS per workgroup.
+#include <cstring>
+#include <vector>
+
+#include "ac_internal.h"
+
+namespace ac {
+namespace {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr float kEps = 1e-14f;   // _INTENSITY_EPS, psychoacoustic.py:56
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int iv = __builtin_bit_cast(int, v);
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, iv, CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum(float v) {   // as in ac_fast.hip: xor butterflies per row of 16, two row broadcasts
+  v = dpp_add<0xB1, 0xf>(v);
+  v = dpp_add<0x4E, 0xf>(v);
+  v = dpp_add<0x141, 0xf>(v);
+  v = dpp_add<0x140, 0xf>(v);
+  v = dpp_add<0x142, 0xa>(v);
+  v = dpp_add<0x143, 0xc>(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ v2f log2v(v2f x) { return v2f{__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)}; }
+__device__ __forceinline__ v2f exp2v(v2f x) { return v2f{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
+__device__ __forceinline__ v2f maxv(v2f a, float b) { return v2f{fmaxf(a.x, b), fmaxf(a.y, b)}; }
+
+struct MidArgs {
+  const float* X;
+  const float* t_in;
+  float* t_out;
+  float* thr;
+  const uint32_t* img;   // ac_psy_plan::d_mid
+  int img_words;
+  int N, M, C, F;
+  int wi_w;              // entries per bin in the fixed-width W_inv table
+  int off_S, off_band, off_wbe, off_wi;   // word offsets inside the image
+  float alpha, inv_alpha, drown;
+  long long nsig, ntasks;
+};
+
+// image layout (32-bit words):
+//   off_S:    S[i * M + j]                       M * M floats
+//   off_band: per band j: {first entry, count, quiet, beta}   4 words
+//   off_wbe:  W by band entries: {byte offset of I[bin] in the wave's image, weight}   2 words each
+//   off_wi:   per bin f: wi_w x {byte offset of G[band] in the wave's G area, weight}  (weight 0 pads)
+// wave buffer: [N] v2f intensities (c0, c1) | [64] v2f Q | [64] v2f G
+template <int R, int CMODE, bool WANT_T, bool WANT_THR>
+__global__ __launch_bounds__(256) void k_psy_mid(MidArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int N = 128 * R;
+  constexpr int WAVE_BYTES = 8 * N + 1024;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  uint32_t* img = reinterpret_cast<uint32_t*>(smem);
+  if (WANT_THR) {
+    for (int i = threadIdx.x; i < a.img_words / 4; i += blockDim.x)
+      reinterpret_cast<uint4*>(img)[i] = reinterpret_cast<const uint4*>(a.img)[i];
+    __syncthreads();
+  }
+  const long long task = (long long)blockIdx.x * nw + wave;
+  if (task >= a.ntasks) return;
+  char* buf = smem + (size_t)a.img_words * 4 + (size_t)wave * WAVE_BYTES;
+  const int C = a.C, M = a.M;
+  const int f = (int)(task % a.F);
+  const long long p = task / a.F;
+  // the two signals of the wave: stereo = the two channels of clip p; mono = clips 2 p and 2 p + 1
+  const bool has1 = CMODE == 0 ? true : (2 * p + 1 < a.nsig);
+  const long long b0 = CMODE == 0 ? p : 2 * p, b1 = CMODE == 0 ? p : (has1 ? 2 * p + 1 : 2 * p);
+  const size_t blk = (size_t)N * C;
+  const size_t o0 = ((size_t)b0 * a.F + (size_t)f) * blk, o1 = ((size_t)b1 * a.F + (size_t)f) * blk;
+  const size_t t0 = ((size_t)b0 * a.F + (size_t)f) * C, t1 = CMODE == 0 ? t0 + 1 : ((size_t)b1 * a.F + (size_t)f) * C;
+
+  // granule q = lane + 64 i: (X[2q], X[2q+1]) x (s0, s1)
+  v4f xq[R];
+  if (CMODE == 0) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) xq[i] = reinterpret_cast<const v4f*>(a.X + o0)[64 * i + lane];
+  } else {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const v2f u = reinterpret_cast<const v2f*>(a.X + o0)[64 * i + lane];
+      xq[i] = v4f{u.x, 0.f, u.y, 0.f};
+    }
+    if (has1) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const v2f w = reinterpret_cast<const v2f*>(a.X + o1)[64 * i + lane];
+        xq[i].y = w.x;
+        xq[i].w = w.y;
+      }
+    }
+  }
+  v2f t = {0.f, 0.f};
+  if (WANT_T) {   // psychoacoustic.py:102-120 (the arithmetic of psy_stage in ac_fast.hip)
+    v2f slog = {0.f, 0.f}, ssq = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      v4f I = xq[i] * xq[i];
+      asm("" : "+v"(I));   // the squares stay rounded products (see psy_stage)
+      const v2f ie = v2f{I.x, I.y}, io = v2f{I.z, I.w};
+      ssq += ie + io;
+      slog += log2v(maxv(ie, kEps) * maxv(io, kEps));
+    }
+    slog.x = wave_sum(slog.x);
+    slog.y = wave_sum(slog.y);
+    ssq.x = wave_sum(ssq.x);
+    ssq.y = wave_sum(ssq.y);
+    const v2f am = ssq * (1.0f / N) + kEps;
+    const v2f sfm = 3.0102999566398120f * (slog * (1.0f / N) - log2v(am));
+    const v2f tt = sfm * (-1.0f / 60.0f);
+    t = v2f{fminf(tt.x, 1.0f), fminf(tt.y, 1.0f)};
+    if (lane == 0) {
+      a.t_out[t0] = t.x;
+      if (has1) a.t_out[t1] = t.y;
+    }
+  } else {
+    t.x = a.t_in[t0];
+    t.y = has1 ? a.t_in[t1] : 0.f;
+  }
+  if (!WANT_THR) return;
+
+  // intensities in natural order: bin f at byte 8 f (c0, c1)
+#pragma unroll
+  for (int i = 0; i < R; ++i) *reinterpret_cast<v4f*>(buf + 16 * (64 * i + lane)) = xq[i] * xq[i];
+  wave_sync();
+  v2f* Qb = reinterpret_cast<v2f*>(buf + 8 * N);
+  v2f* Gb = Qb + 64;
+  const uint32_t* band = img + a.off_band;
+  float quiet = 0.f, beta = 0.f;
+  if (lane < M) {   // P_j = sum_f I_f W[f, j]  (:312-313)
+    const uint4 bw = reinterpret_cast<const uint4*>(band)[lane];
+    quiet = __uint_as_float(bw.z);
+    beta = __uint_as_float(bw.w);
+    const uint2* e = reinterpret_cast<const uint2*>(img + a.off_wbe) + bw.x;
+    v2f P0 = {0.f, 0.f}, P1 = {0.f, 0.f};
+    const int cnt = (int)bw.y;
+    int k = 0;
+    for (; k + 1 < cnt; k += 2) {
+      const uint2 e0 = e[k], e1 = e[k + 1];
+      P0 += *reinterpret_cast<const v2f*>(buf + e0.x) * __uint_as_float(e0.y);
+      P1 += *reinterpret_cast<const v2f*>(buf + e1.x) * __uint_as_float(e1.y);
+    }
+    if (k < cnt) {
+      const uint2 e0 = e[k];
+      P0 += *reinterpret_cast<const v2f*>(buf + e0.x) * __uint_as_float(e0.y);
+    }
+    Qb[lane] = exp2v(a.alpha * log2v(maxv(P0 + P1, kEps)));   // max(eps, P)^alpha  (:206)
+  }
+  wave_sync();
+  if (lane < M) {   // sum_i Q_i S[i, j], offset factor outside the sum  (:185-208)
+    const float* S = reinterpret_cast<const float*>(img + a.off_S) + lane;
+    v2f acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+    int i = 0;
+    for (; i + 1 < M; i += 2) {
+      const v4f qq = *reinterpret_cast<const v4f*>(Qb + i);   // Q_i, Q_{i+1} (broadcast read)
+      acc0 += v2f{qq.x, qq.y} * S[(size_t)i * M];
+      acc1 += v2f{qq.z, qq.w} * S[(size_t)(i + 1) * M];
+    }
+    if (i < M) acc0 += Qb[i] * S[(size_t)i * M];
+    const v2f offset = (1.0f - a.drown) * (t * beta + 9.0f * t + 5.5f);
+    const v2f fac = exp2v(offset * (-a.alpha * 0.33219280948873623f));                 // 10^(-alpha O / 10)
+    const v2f T = exp2v(a.inv_alpha * log2v(maxv(fac * (acc0 + acc1), kEps)));          // (:208)
+    Gb[lane] = maxv(T, quiet);                                                          // (:144)
+  }
+  wave_sync();
+  // thr_f = sqrt(max(eps, sum_j G_j W_inv[j, f]))  (:330-331)
+  const uint2* wi = reinterpret_cast<const uint2*>(img + a.off_wi);
+  const int W = a.wi_w;
+  v4f th[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int q = 64 * i + lane;
+    v2f s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
+    const uint2* r0 = wi + (size_t)(2 * q) * W;
+    const uint2* r1 = r0 + W;
+    for (int e = 0; e < W; ++e) {
+      const uint2 a0 = r0[e], a1 = r1[e];
+      s0 += *reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(Gb) + a0.x) * __uint_as_float(a0.y);
+      s1 += *reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(Gb) + a1.x) * __uint_as_float(a1.y);
+    }
+    s0 = maxv(s0, kEps);
+    s1 = maxv(s1, kEps);
+    th[i] = v4f{__builtin_amdgcn_sqrtf(s0.x), __builtin_amdgcn_sqrtf(s0.y), __builtin_amdgcn_sqrtf(s1.x), __builtin_amdgcn_sqrtf(s1.y)};
+  }
+  if (CMODE == 0) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) __builtin_nontemporal_store(th[i], reinterpret_cast<v4f*>(a.thr + o0) + 64 * i + lane);
+  } else {
+#pragma unroll
+    for (int i = 0; i < R; ++i) reinterpret_cast<v2f*>(a.thr + o0)[64 * i + lane] = v2f{th[i].x, th[i].z};
+    if (has1) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) reinterpret_cast<v2f*>(a.thr + o1)[64 * i + lane] = v2f{th[i].y, th[i].w};
+    }
+  }
+}
+
+struct MidLayout {
+  int wi_w = 0, off_S = 0, off_band = 0, off_wbe = 0, off_wi = 0, words = 0;
+};
+
+bool build_mid(const ac_psy_plan* p, std::vector<uint32_t>* out, MidLayout* lay) {
+  const PsyTables& t = p->host;
+  const int N = t.N, M = t.M;
+  if (!(N == 256 || N == 512 || N == 1024) || M < 1 || M > 64) return false;
+  SparseRows wb, wi;
+  w_by_band(t, wb);
+  winv_by_bin(t, wi);
+  if (wi.max_row < 1 || wi.max_row > 6) return false;
+  MidLayout L;
+  L.wi_w = wi.max_row;
+  L.off_S = 0;
+  L.off_band = L.off_S + M * M;
+  L.off_band = (L.off_band + 3) / 4 * 4;                  // 16-byte aligned rows of four words
+  L.off_wbe = L.off_band + 4 * 64;
+  L.off_wi = L.off_wbe + 2 * (int)wb.idx.size();
+  L.off_wi = (L.off_wi + 1) / 2 * 2;
+  L.words = L.off_wi + 2 * N * L.wi_w;
+  L.words = (L.words + 3) / 4 * 4;
+  std::vector<uint32_t> w((size_t)L.words, 0u);
+  auto putf = [&](int i, float v) { uint32_t u; memcpy(&u, &v, 4); w[(size_t)i] = u; };
+  for (int i = 0; i < M; ++i)
+    for (int j = 0; j < M; ++j) putf(L.off_S + i * M + j, (float)t.S[(size_t)i * M + j]);
+  for (int j = 0; j < M; ++j) {
+    w[(size_t)L.off_band + 4 * j + 0] = (uint32_t)wb.ptr[j];
+    w[(size_t)L.off_band + 4 * j + 1] = (uint32_t)(wb.ptr[j + 1] - wb.ptr[j]);
+    putf(L.off_band + 4 * j + 2, (float)t.quiet[j]);
+    putf(L.off_band + 4 * j + 3, t.beta[j]);
+    for (int e = wb.ptr[j]; e < wb.ptr[j + 1]; ++e) {
+      w[(size_t)L.off_wbe + 2 * e] = (uint32_t)(8 * wb.idx[e]);          // byte offset of I[bin] (v2f per bin)
+      putf(L.off_wbe + 2 * e + 1, wb.val[e]);
+    }
+  }
+  for (int f = 0; f < N; ++f) {
+    int k = 0;
+    for (int e = wi.ptr[f]; e < wi.ptr[f + 1]; ++e, ++k) {
+      w[(size_t)L.off_wi + 2 * ((size_t)f * L.wi_w + k)] = (uint32_t)(8 * wi.idx[e]);   // byte offset of G[band]
+      putf(L.off_wi + 2 * (f * L.wi_w + k) + 1, wi.val[e]);
+    }
+  }
+  if (out) *out = w;
+  if (lay) *lay = L;
+  return true;
+}
+
+size_t mid_lds_bytes(int N, int words, int nw) { return (size_t)words * 4 + (size_t)nw * (8 * (size_t)N + 1024); }
+
+template <int R, int CMODE>
+int launch_mid_R(const MidArgs& a, bool want_t, bool want_thr, unsigned grid, int nw, size_t lds, hipStream_t s) {
+  const dim3 blk(64 * nw);
+  auto go = [&](auto kernel) -> int {
+    if (lds > 64 * 1024)
+      AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3(grid), blk, lds, s, a);
+    return AC_OK;
+  };
+  if (want_t && want_thr) return go(k_psy_mid<R, CMODE, true, true>);
+  if (want_thr) return go(k_psy_mid<R, CMODE, false, true>);
+  return go(k_psy_mid<R, CMODE, true, false>);
+}
+
+}  // namespace
+
+bool mid_psy_supported(const ac_psy_plan* p) { return build_mid(p, nullptr, nullptr); }
+
+int mid_psy_plan_init(ac_psy_plan* p) {
+  std::vector<uint32_t> w;
+  MidLayout L;
+  if (!build_mid(p, &w, &L)) {
+    set_error("internal: wave-level masking model (general band layout) not supported for this configuration");
+    return AC_EUNSUPPORTED;
+  }
+  p->mid_words = L.words;
+  AC_HIP_CHECK(hipMalloc((void**)&p->d_mid, w.size() * sizeof(uint32_t)));
+  AC_HIP_CHECK(hipMemcpy(p->d_mid, w.data(), w.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  return AC_OK;
+}
+
+// t_out != null: tonality (from X); thr != null: threshold (from t_out when given, else from t_in)
+int launch_psy_mid(const ac_psy_plan* p, const float* X, const float* t_in, float* t_out, float* thr, float drown, int B,
+                   int F, int C, hipStream_t s) {
+  if (B <= 0 || C <= 0 || F <= 0) return AC_OK;
+  if (C != 1 && C != 2) {
+    set_error("internal: the wave-level masking model serves mono and stereo tensors");
+    return AC_EUNSUPPORTED;
+  }
+  MidLayout L;
+  build_mid(p, nullptr, &L);
+  MidArgs a;
+  a.X = X;
+  a.t_in = t_in;
+  a.t_out = t_out;
+  a.thr = thr;
+  a.img = p->d_mid;
+  a.img_words = L.words;
+  a.N = p->N;
+  a.M = p->M;
+  a.C = C;
+  a.F = F;
+  a.wi_w = L.wi_w;
+  a.off_S = L.off_S;
+  a.off_band = L.off_band;
+  a.off_wbe = L.off_wbe;
+  a.off_wi = L.off_wi;
+  a.alpha = (float)p->alpha;
+  a.inv_alpha = (float)(1.0 / p->alpha);
+  a.drown = drown;
+  a.nsig = (long long)B * C;
+  a.ntasks = ((C == 2) ? (long long)B : (a.nsig + 1) / 2) * F;
+  const bool want_t = t_out != nullptr, want_thr = thr != nullptr;
+  // four waves per workgroup when the image and the wave buffers fit three workgroups to a CU, else two
+  int nw = 4;
+  if (mid_lds_bytes(p->N, L.words, nw) > 53 * 1024) nw = 2;
+  const size_t lds = want_thr ? mid_lds_bytes(p->N, L.words, nw) : 0;
+  if (lds > 160 * 1024) {
+    set_error("internal: masking-model tables too large for LDS (%zu bytes)", lds);
+    return AC_EUNSUPPORTED;
+  }
+  const long long g = (a.ntasks + nw - 1) / nw;
+  if (g > 2147483647ll) {
+    set_error("problem too large for one launch (%lld workgroups)", g);
+    return AC_EINVAL;
+  }
+  const unsigned grid = (unsigned)g;
+  int st;
+  const int R = p->N / 128;
+  if (C == 2) st = R == 2 ? launch_mid_R<2, 0>(a, want_t, want_thr, grid, nw, lds, s)
+                 : R == 4 ? launch_mid_R<4, 0>(a, want_t, want_thr, grid, nw, lds, s)
+                          : launch_mid_R<8, 0>(a, want_t, want_thr, grid, nw, lds, s);
+  else st = R == 2 ? launch_mid_R<2, 2>(a, want_t, want_thr, grid, nw, lds, s)
+            : R == 4 ? launch_mid_R<4, 2>(a, want_t, want_thr, grid, nw, lds, s)
+                     : launch_mid_R<8, 2>(a, want_t, want_thr, grid, nw, lds, s);
+  if (st) return st;
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+}  // namespace ac

@@ -158,6 +158,12 @@ class PsychoacousticModel:
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         return bool(self._lib.ac_psy_plan_is_fast(self._plans.get(dev)))
 
+    def tier(self, device=None):
+        """2: wave-level kernels fused into the encode; 1: wave-level kernels for general band layouts; 0: generic kernels
+        (``ac_psy_plan_tier``)."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        return int(self._lib.ac_psy_plan_tier(self._plans.get(dev)))
+
     def plan_spreading(self, device=None):
         """The form of the spreading product the plan on ``device`` runs (a key of ``SPREADING``)."""
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)

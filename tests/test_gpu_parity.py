@@ -522,6 +522,44 @@ def test_autograd_of_add_noise_and_db(path):
         p64.amplitude_to_dB(torch.rand(1, 1, 64, 1, device="cuda", dtype=torch.float64).requires_grad_(True))
 
 
+@pytest.mark.parametrize("sr,N,M,B,F,C", [(48000, 512, 64, 3, 5, 2), (48000, 256, 64, 2, 7, 2), (16000, 512, 64, 3, 4, 1),
+                                          (44100, 256, 48, 2, 5, 2), (48000, 1024, 32, 2, 3, 2), (96000, 512, 64, 1, 3, 1),
+                                          (48000, 256, 17, 5, 2, 1), (8000, 512, 64, 2, 3, 2)])
+def test_masking_model_general_band_layouts(sr, N, M, B, F, C):
+    """filter_bands_n 256 / 512 (and 1024 with other band counts): the wave-level masking kernels for general band layouts
+    (ac_psy_mid.hip; a bin may overlap three or four Bark bands here) against the fp64 oracle, against the generic kernels,
+    and the one-launch tonality + threshold of the un-fused encode against the two separate calls"""
+    rng = np.random.default_rng(N + M + C)
+    env = np.logspace(-5, 0, N).reshape(1, 1, N, 1)
+    X = (rng.uniform(-1, 1, (B, F, N, C)) * env * rng.uniform(1e-3, 1, (B, F, 1, C))).astype(np.float32)
+    X[0, 0, :, 0] = 0.0
+    p = audiocodec_amd.PsychoacousticModel(sr, filter_bands_n=N, bark_bands_n=M)
+    assert p.tier() == 1 and not p.is_fast()
+    o = PsychoOracle(sr, N, M, compute_dtype=np.float64)
+    Xd = dev(X)
+    t = p.tonality(Xd)
+    to = o.tonality(X.astype(np.float64))
+    assert tonality_err(host(t), to) <= 1.0
+    lib = _lib.load()
+    for drown in (0.0, 0.4, 1.0):
+        thr = p.global_masking_threshold(Xd, dev(to.astype(np.float32)), drown)
+        assert rel_elem(host(thr), o.global_masking_threshold(X.astype(np.float64), to, drown)) <= TOL
+        assert lib.ac_set_force_generic(1) == 0
+        try:
+            thrg = p.global_masking_threshold(Xd, dev(to.astype(np.float32)), drown)
+            tg = p.tonality(Xd)
+        finally:
+            lib.ac_set_force_generic(0)
+        assert float(((thr - thrg).abs() / thrg).max()) <= TOL and tonality_err(t, tg) <= 1.0
+    # the un-fused encode at these sizes: transform, then tonality + threshold in one launch
+    codec = audiocodec_amd.AudioCodec(sr, N, bark_bands_n=M)
+    x = dev(rng.uniform(-1, 1, (B, 6 * N, C)).astype(np.float32))
+    Xe, te, thre = codec.encode(x, drown=0.2)
+    assert torch.equal(Xe, codec.mdct.transform(x))
+    assert tonality_err(te, codec.psy.tonality(Xe)) <= 1e-3          # same arithmetic; another instantiation may round one ulp apart
+    assert float(((thre - codec.psy.global_masking_threshold(Xe, te, 0.2)).abs() / thre).max()) <= 1e-6
+
+
 def test_fast_path_selection():
     """The wave-level kernels serve N = 256, 512 (several frames per wave), 1024 and 2048 with a Princen-Bradley window;
     everything else runs the LDS-FFT / generic kernels (the rectangular window's fold blocks are not rotations)."""
