@@ -1179,6 +1179,7 @@ struct InvArgs {
   float* tail_out;         // [B, C, N/2] or null
   const float* tab;
   int B, Kp, nblk, C, seglen, nseg;
+  int rev;                 // 1: workgroups walk the spectrum from its end (AC_INV_REV tuning hook)
   long long npairs, nsig;  // see Pair
   long long ntasks;        // npairs * nseg
 };
@@ -1235,7 +1236,7 @@ __global__ __launch_bounds__(NW * 64, (IOF != 0 ? 2 : wpe<R, CMODE>())) void k_i
   // its last frame through LDS -- only the first wave of a workgroup pays an extra DCT-IV (of the frame before its
   // strip).  Workgroups are dispatched in order, which keeps the window of memory in flight contiguous.
   constexpr bool COOP = (R == 8);   // hand-over between waves (the 2048-filter kernel has no registers to spare)
-  const long long task_raw = (long long)blockIdx.x * NW + wave;
+  const long long task_raw = (long long)(a.rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * NW + wave;
   const bool valid = task_raw < a.ntasks;
   const long long task = valid ? task_raw : a.ntasks - 1;   // idle waves of the last workgroup only join the barriers
   const int sgm = (int)(task % a.nseg);
@@ -2640,6 +2641,11 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, int iof, con
   if (a.npairs * ((nblk + a.seglen - 1) / a.seglen) < (long long)AC_WAVES * p->cus * 2) a.seglen = pick_seglen(a.npairs, nblk, 1);
   a.nseg = (nblk + a.seglen - 1) / a.seglen;
   a.ntasks = a.npairs * a.nseg;
+#ifndef AC_INV_REV_DEFAULT
+#define AC_INV_REV_DEFAULT 0
+#endif
+  static const int inv_rev = [] { const char* e = getenv("AC_INV_REV"); return e ? atoi(e) : AC_INV_REV_DEFAULT; }();
+  a.rev = inv_rev;
   // one strip per wave, workgroups dispatched in order (persistent waves drift apart and measured slower here)
   const long long need = (a.ntasks + AC_WAVES - 1) / AC_WAVES;
   if (need > 2147483647ll) {
