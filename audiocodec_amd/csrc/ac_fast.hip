@@ -1674,10 +1674,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_psy_bwd_fast(PsyBwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Several short frames per wave: filters_n = 512 and 256 (the reference's own test sizes,
-// audiocodec/tests/test_mdctransformer.py:23).  A frame of 128 R' filters keeps the wave-level scheme when NFR = 64 / LB
+// Several short frames per wave: filters_n = 512, 256 (the reference's own test sizes,
+// audiocodec/tests/test_mdctransformer.py:23) and 128.  A short frame keeps the wave-level scheme when NFR = 64 / LB
 // frames share a wave, each on a group of LB consecutive lanes with eight complex points per lane:
-//   filters_n = 512: NFR = 2 frames x 256 points on LB = 32 lanes;   filters_n = 256: NFR = 4 frames x 128 points on 16.
+//   filters_n = 512: NFR = 2 frames x 256 points on LB = 32 lanes;   256: NFR = 4 frames x 128 points on 16;
+//   128: NFR = 8 frames x 64 points on 8 lanes (pass 2 below is then the identity: 64 = 8 x 8).
 // With the frame index in the TOP lane bits (lane = l + LB f) the 8 LB-point FFT is 8 x (8 / NFR) x 8 with exactly the
 // two LDS exchanges of the 512-point transform: element e = l + LB r; pass 1 over r (radix 8, twiddle W_{8 LB}^(l k0));
 // exchange 1 hands lane (a = k0, m0) the eight values m0 + 8 e1 of row k0, and e1 = e1' + (8 / NFR) f, so pass 2 is NFR
@@ -1702,11 +1703,20 @@ __device__ __forceinline__ void dft2(C2& x0, C2& x1) {
 
 template <int NFR>
 __device__ __forceinline__ void fft_wave_multi(C2 (&z)[8], char* buf, gtab_t tab, const v2f (&p1)[8], int lane) {
-  constexpr int Q2 = 8 / NFR;
+  constexpr int Q2 = NFR >= 8 ? 1 : 8 / NFR;   // points of pass 2 per frame; 1: the pass is the identity, the exchanges remain
+  static_assert(NFR == 2 || NFR == 4 || NFR == 8 || NFR == 16, "frames per wave");
   const int a = lane >> 3, m0 = lane & 7;
-  dft8(z);
+  if (NFR == 16) {   // two frames of four points each (see the 64-filter layout below)
+    dft4(z[0], z[1], z[2], z[3]);
+    dft4(z[4], z[5], z[6], z[7]);
 #pragma unroll
-  for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], p1[k]);
+    for (int k = 1; k < 8; ++k)
+      if (k != 4) z[k] = cmul(z[k], p1[k]);
+  } else {
+    dft8(z);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], p1[k]);
+  }
   C2 y[8];
   wave_sync();
   {
@@ -1723,7 +1733,7 @@ __device__ __forceinline__ void fft_wave_multi(C2 (&z)[8], char* buf, gtab_t tab
   if (NFR == 2) {
     dft4(y[0], y[1], y[2], y[3]);
     dft4(y[4], y[5], y[6], y[7]);
-  } else {
+  } else if (NFR == 4) {
     dft2(y[0], y[1]);
     dft2(y[2], y[3]);
     dft2(y[4], y[5]);
@@ -1759,8 +1769,9 @@ __device__ __forceinline__ v2f rev_group(v2f v) {
     a = w[0];
     b = w[1];
   }
-  return v2f{__uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x140, 0xf, 0xf, false)),    // row_mirror
-             __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x140, 0xf, 0xf, false))};
+  constexpr int MIRROR = (LB == 4) ? 0x1b : (LB == 8) ? 0x141 : 0x140;   // quad_perm [3,2,1,0] / row_half_mirror / row_mirror
+  return v2f{__uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)a, MIRROR, 0xf, 0xf, false)),
+             __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)b, MIRROR, 0xf, 0xf, false))};
 }
 // out[i] = in[(OFS - i) mod 8] of the mirrored lane of the group
 template <int LB, int OFS>
@@ -1813,6 +1824,38 @@ __device__ __forceinline__ void store_rowm(float* r0, float* r1, bool has1, int 
   }
 }
 
+// filters_n = 64: a frame is a 32-point transform = 4 x 8.  INPUT rows sit on 8 lanes x 4 registers, two frames in the
+// register halves (lane = l8 + 8 g, register 4 fb + i4 holds granule l8 + 8 i4 of frame 2 g + fb); pass 1 is a radix-4
+// over i4, the exchanges are the usual ones, pass 3 the radix-8 over l8, and the OUTPUT lands on 4 lanes x 8 registers
+// (lane = l4 + 4 f, register j holds bin l4 + 4 j of frame f = 2 g + fb): the LB = 4 form of the layouts above.
+template <int CMODE>
+__device__ __forceinline__ void load_half(const float* r0, const float* r1, bool has1, int l8, v4f* v) {
+  if (CMODE == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = reinterpret_cast<const v4f*>(r0)[8 * i + l8];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const v2f u = reinterpret_cast<const v2f*>(r0)[8 * i + l8];
+      const v2f w = has1 ? reinterpret_cast<const v2f*>(r1)[8 * i + l8] : v2f{0.f, 0.f};
+      v[i] = v4f{u.x, w.x, u.y, w.y};
+    }
+  }
+}
+template <int CMODE>
+__device__ __forceinline__ void store_half(float* r0, float* r1, bool has1, int l8, const v4f* v) {
+  if (CMODE == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) reinterpret_cast<v4f*>(r0)[8 * i + l8] = v[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      reinterpret_cast<v2f*>(r0)[8 * i + l8] = v2f{v[i].x, v[i].z};
+      if (has1) reinterpret_cast<v2f*>(r1)[8 * i + l8] = v2f{v[i].y, v[i].w};
+    }
+  }
+}
+
 struct FwdMArgs {
   const float* x;    // [B, Kin*N, C]
   float* X;          // [B, F, N, C]
@@ -1851,44 +1894,91 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
     }
     const Pair pq = make_pair<CMODE>(pair, C, a.nsig);
     const int n = c * NFR + f;
-    const bool from_state = a.prev_block != nullptr && n == 0;   // streaming: block -1 is the stored state
-    const bool cur_ok = n < a.Kin, prv_ok = (n >= 1 && n <= a.Kin) || from_state, frame_ok = n < a.F;
-    // a missing block (before the first / after the last) is read from a neighbouring valid row and zeroed afterwards
-    const int bc = cur_ok ? n : a.Kin - 1, bp = (n >= 1 && n <= a.Kin) ? n - 1 : 0;
+    const bool frame_ok = n < a.F;
     const float* x0 = a.x + row_off(pq.b0, a.Kin, 0, blk, pq.c0);
     const float* x1 = a.x + row_off(pq.b1, a.Kin, 0, blk, pq.c1);
-    const float* p0 = x0 + (size_t)bp * blk;
-    const float* p1r = x1 + (size_t)bp * blk;
-    if (from_state) {
-      p0 = a.prev_block + row_off(pq.b0, 1, 0, blk, pq.c0);
-      p1r = a.prev_block + row_off(pq.b1, 1, 0, blk, pq.c1);
-    }
-    v4f cb[8], pb[8];
-    load_rowm<CMODE, LB>(x0 + (size_t)bc * blk, x1 + (size_t)bc * blk, pq.has1, l, cb);
-    load_rowm<CMODE, LB>(p0, p1r, pq.has1, l, pb);
-    if (a.state_out && n == a.Kin - 1)   // streaming: the chunk's last block is the next chunk's block -1
-      store_rowm<CMODE, LB>(a.state_out + row_off(pq.b0, 1, 0, blk, pq.c0), a.state_out + row_off(pq.b1, 1, 0, blk, pq.c1),
-                            pq.has1, l, cb);
     const v4f zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      cb[i] = cur_ok ? cb[i] : zero;
-      pb[i] = prv_ok ? pb[i] : zero;
-    }
+    v4f cb[8], pb[8];
+    // rows of frame m: the current block m and the block before it (streaming: block -1 is the stored state); a missing
+    // block (before the first / after the last) is read from a neighbouring valid row and zeroed afterwards
+    auto rows_of = [&](int m, const float*& c0p, const float*& c1p, const float*& p0p, const float*& p1p, bool& cur_ok,
+                       bool& prv_ok) {
+      const bool from_state = a.prev_block != nullptr && m == 0;
+      cur_ok = m < a.Kin;
+      prv_ok = (m >= 1 && m <= a.Kin) || from_state;
+      const int bc = cur_ok ? m : a.Kin - 1, bp = (m >= 1 && m <= a.Kin) ? m - 1 : 0;
+      c0p = x0 + (size_t)bc * blk;
+      c1p = x1 + (size_t)bc * blk;
+      p0p = x0 + (size_t)bp * blk;
+      p1p = x1 + (size_t)bp * blk;
+      if (from_state) {
+        p0p = a.prev_block + row_off(pq.b0, 1, 0, blk, pq.c0);
+        p1p = a.prev_block + row_off(pq.b1, 1, 0, blk, pq.c1);
+      }
+    };
     C2 z[8];
+    if (NFR == 16) {
+      const int l8 = lane & 7, g = lane >> 3;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const v4f& go_p = pb[(3 - r) & 7];
-      const v4f& go_c = cb[(3 - r) & 7];
-      const v2f xop = rev_group<LB>(v2f{go_p.z, go_p.w}), xoc = rev_group<LB>(v2f{go_c.z, go_c.w});
-      const v4f& gp = pb[(r + 4) & 7];
-      const v4f& gc = cb[(r + 4) & 7];
-      const v2f xep = v2f{gp.x, gp.y}, xec = v2f{gc.x, gc.y};
-      const v2f ab = reinterpret_cast<const v2f*>(tab + G::I_COEF)[r * 64 + lane];
-      const v2f carry = ab.y * xep + ab.x * xop;
-      const v2f cur = (r < 4) ? (ab.y * xoc - ab.x * xec) : (ab.x * xec - ab.y * xoc);
-      const C2 v = (r < 4) ? C2{carry, cur} : C2{cur, carry};
-      z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + G::I_PRE)[r * 64 + lane]);
+      for (int fb = 0; fb < 2; ++fb) {
+        const int m = c * NFR + 2 * g + fb;
+        const float *c0p, *c1p, *p0p, *p1p;
+        bool cur_ok, prv_ok;
+        rows_of(m, c0p, c1p, p0p, p1p, cur_ok, prv_ok);
+        load_half<CMODE>(c0p, c1p, pq.has1, l8, cb + 4 * fb);
+        load_half<CMODE>(p0p, p1p, pq.has1, l8, pb + 4 * fb);
+        if (a.state_out && m == a.Kin - 1)   // streaming: the chunk's last block is the next chunk's block -1
+          store_half<CMODE>(a.state_out + row_off(pq.b0, 1, 0, blk, pq.c0), a.state_out + row_off(pq.b1, 1, 0, blk, pq.c1),
+                            pq.has1, l8, cb + 4 * fb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          cb[4 * fb + i] = cur_ok ? cb[4 * fb + i] : zero;
+          pb[4 * fb + i] = prv_ok ? pb[4 * fb + i] : zero;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int fb4 = r & 4, r4 = r & 3;
+        const v4f& go_p = pb[fb4 + ((1 - r4) & 3)];
+        const v4f& go_c = cb[fb4 + ((1 - r4) & 3)];
+        const v2f xop = rev_group<8>(v2f{go_p.z, go_p.w}), xoc = rev_group<8>(v2f{go_c.z, go_c.w});
+        const v4f& gp = pb[fb4 + ((r4 + 2) & 3)];
+        const v4f& gc = cb[fb4 + ((r4 + 2) & 3)];
+        const v2f xep = v2f{gp.x, gp.y}, xec = v2f{gc.x, gc.y};
+        const v2f ab = reinterpret_cast<const v2f*>(tab + G::I_COEF)[r * 64 + lane];
+        const v2f carry = ab.y * xep + ab.x * xop;
+        const v2f cur = (r4 < 2) ? (ab.y * xoc - ab.x * xec) : (ab.x * xec - ab.y * xoc);
+        const C2 v = (r4 < 2) ? C2{carry, cur} : C2{cur, carry};
+        z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + G::I_PRE)[r * 64 + lane]);
+      }
+    } else {
+      const float *c0p, *c1p, *p0p, *p1p;
+      bool cur_ok, prv_ok;
+      rows_of(n, c0p, c1p, p0p, p1p, cur_ok, prv_ok);
+      load_rowm<CMODE, LB>(c0p, c1p, pq.has1, l, cb);
+      load_rowm<CMODE, LB>(p0p, p1p, pq.has1, l, pb);
+      if (a.state_out && n == a.Kin - 1)   // streaming: the chunk's last block is the next chunk's block -1
+        store_rowm<CMODE, LB>(a.state_out + row_off(pq.b0, 1, 0, blk, pq.c0), a.state_out + row_off(pq.b1, 1, 0, blk, pq.c1),
+                              pq.has1, l, cb);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        cb[i] = cur_ok ? cb[i] : zero;
+        pb[i] = prv_ok ? pb[i] : zero;
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const v4f& go_p = pb[(3 - r) & 7];
+        const v4f& go_c = cb[(3 - r) & 7];
+        const v2f xop = rev_group<LB>(v2f{go_p.z, go_p.w}), xoc = rev_group<LB>(v2f{go_c.z, go_c.w});
+        const v4f& gp = pb[(r + 4) & 7];
+        const v4f& gc = cb[(r + 4) & 7];
+        const v2f xep = v2f{gp.x, gp.y}, xec = v2f{gc.x, gc.y};
+        const v2f ab = reinterpret_cast<const v2f*>(tab + G::I_COEF)[r * 64 + lane];
+        const v2f carry = ab.y * xep + ab.x * xop;
+        const v2f cur = (r < 4) ? (ab.y * xoc - ab.x * xec) : (ab.x * xec - ab.y * xoc);
+        const C2 v = (r < 4) ? C2{carry, cur} : C2{cur, carry};
+        z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + G::I_PRE)[r * 64 + lane]);
+      }
     }
     fft_wave_multi<NFR>(z, buf, tab, p1, lane);
     v4f row[8];
@@ -1954,24 +2044,41 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_inv_multi(InvMArgs a) {
 
   // DCT-IV of the frames of chunk c: (now, nxt) per output element k = l + LB j of the group's frame
   auto dct_chunk = [&](int c, v2f (&now)[8], v2f (&nxt)[8]) {
-    const int n = c * NFR + f;
-    const bool ok = n >= 0 && n < a.Kp;
-    const int fr = ok ? n : 0;
     v4f frm[8];
-    load_rowm<CMODE, LB>(X0 + (size_t)fr * blk, X1 + (size_t)fr * blk, pq.has1, l, frm);
+    v2f xo[8];
+    if (NFR == 16) {   // input on 8 lanes x 4 registers, two frames in the register halves
+      const int l8 = lane & 7, g = lane >> 3;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) frm[i] = ok ? frm[i] : zero;
-    C2 z[8];
-    {
-      v2f xo_in[8], xo[8];
+      for (int fb = 0; fb < 2; ++fb) {
+        const int m = c * NFR + 2 * g + fb;
+        const bool ok = m >= 0 && m < a.Kp;
+        const int fr = ok ? m : 0;
+        load_half<CMODE>(X0 + (size_t)fr * blk, X1 + (size_t)fr * blk, pq.has1, l8, frm + 4 * fb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) frm[4 * fb + i] = ok ? frm[4 * fb + i] : zero;
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const v4f& s = frm[(r & 4) + (3 - (r & 3))];
+        xo[r] = rev_group<8>(v2f{s.z, s.w});
+      }
+    } else {
+      const int n = c * NFR + f;
+      const bool ok = n >= 0 && n < a.Kp;
+      const int fr = ok ? n : 0;
+      load_rowm<CMODE, LB>(X0 + (size_t)fr * blk, X1 + (size_t)fr * blk, pq.has1, l, frm);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) frm[i] = ok ? frm[i] : zero;
+      v2f xo_in[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) xo_in[q] = v2f{frm[q].z, frm[q].w};
       rev_exchange_g<LB, 7>(xo_in, xo);
+    }
+    C2 z[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const C2 v = {v2f{frm[r].x, frm[r].y}, xo[r]};
-        z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + G::I_PRE)[r * 64 + lane]);
-      }
+    for (int r = 0; r < 8; ++r) {
+      const C2 v = {v2f{frm[r].x, frm[r].y}, xo[r]};
+      z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + G::I_PRE)[r * 64 + lane]);
     }
     fft_wave_multi<NFR>(z, buf, tab, p1, lane);
 #pragma unroll
@@ -2152,8 +2259,9 @@ static bool build_mdct_fast_R(int N, int window, std::vector<float>* out) {
 // layout with every entry replicated to the 64 lanes, l = lane mod LB taking the place of the lane.
 static bool build_mdct_multi(int N, int window, std::vector<float>* out) {
   using G = Geo<8>;
-  if (N != 512 && N != 256) return false;
-  const int LB = N / 16, Q2 = LB / 8, h = N / 2, FH = 8 * LB;
+  if (N != 512 && N != 256 && N != 128 && N != 64) return false;
+  const int LB = N / 16, Q2 = LB >= 8 ? LB / 8 : 1, h = N / 2, FH = 8 * LB;
+  const bool two_halves = N == 64;   // input side on 8 lanes x 4 registers (see load_half), output side on LB = 4 lanes
   FoldCoef c;
   fold_coefficients(N, window, c);
   std::vector<float> t(2 * G::I_TOTAL, 0.f);
@@ -2168,11 +2276,12 @@ static bool build_mdct_multi(int N, int window, std::vector<float>* out) {
   for (int r = 0; r < 8; ++r) {
     for (int lane = 0; lane < 64; ++lane) {
       const int l = lane % LB, i = r * 64 + lane;
-      const int e = l + LB * r, k = l + LB * r;
+      const int le = two_halves ? lane % 8 : l, k0 = two_halves ? r % 4 : r;   // input side: lane of the group, pass-1 index
+      const int e = two_halves ? le + 8 * (r % 4) : l + LB * r, k = l + LB * r;
       double ang = -pi * (e + 0.25) / N;
       put2(tf + G::I_PRE, i, std::cos(ang), std::sin(ang));
       put2(ti + G::I_PRE, i, std::cos(ang), std::sin(ang));
-      ang = -2.0 * pi * (double)(l * r) / (double)FH;               // pass 1: W_{8 LB}^(l k0), k0 = r
+      ang = -2.0 * pi * (double)(le * k0) / (double)FH;             // pass 1: W_{8 LB}^(l k0)
       put2(tf + G::I_P1, i, std::cos(ang), std::sin(ang));
       put2(ti + G::I_P1, i, std::cos(ang), std::sin(ang));
       if (lane < 8) {
@@ -2211,12 +2320,12 @@ static bool build_mdct_multi(int N, int window, std::vector<float>* out) {
 static bool build_mdct_fast(int N, int window, std::vector<float>* out) {
   if (N == Geo<8>::FN) return build_mdct_fast_R<8>(N, window, out);
   if (N == Geo<16>::FN) return build_mdct_fast_R<16>(N, window, out);
-  if (N == 512 || N == 256) return build_mdct_multi(N, window, out);
+  if (N == 512 || N == 256 || N == 128 || N == 64) return build_mdct_multi(N, window, out);
   return false;
 }
 
-// frames per wave of the plan's kernels: 1 (filters_n 1024 / 2048), 2 (512) or 4 (256)
-int fast_mdct_frames_per_wave(int N) { return N == 512 ? 2 : N == 256 ? 4 : 1; }
+// frames per wave of the plan's kernels: 1 (filters_n 1024 / 2048), 2 (512), 4 (256), 8 (128) or 16 (64)
+int fast_mdct_frames_per_wave(int N) { return N == 512 ? 2 : N == 256 ? 4 : N == 128 ? 8 : N == 64 ? 16 : 1; }
 // what the several-frames-per-wave kernels serve: float32 tensors, mono or stereo, at least one block
 bool fast_multi_serves(const ac_mdct_plan* p, int C, int iof, int blocks) {
   return fast_mdct_frames_per_wave(p->N) > 1 && (C == 1 || C == 2) && iof == 0 && blocks >= 1;
@@ -2421,7 +2530,9 @@ static int launch_fwd_multi(const ac_mdct_plan* p, const float* x, float* X, con
   const int st = grid_for(a.ntasks, AC_WAVES * T, &grid);
   if (st) return st;
   if (nfr == 2) launch_fwd_multi_N<2>(a, C, grid, s);
-  else launch_fwd_multi_N<4>(a, C, grid, s);
+  else if (nfr == 4) launch_fwd_multi_N<4>(a, C, grid, s);
+  else if (nfr == 8) launch_fwd_multi_N<8>(a, C, grid, s);
+  else launch_fwd_multi_N<16>(a, C, grid, s);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }
@@ -2458,7 +2569,9 @@ static int launch_inv_multi(const ac_mdct_plan* p, const float* X, float* x, con
   const int st = grid_for(a.ntasks, AC_WAVES, &grid);
   if (st) return st;
   if (nfr == 2) launch_inv_multi_N<2>(a, C, grid, s);
-  else launch_inv_multi_N<4>(a, C, grid, s);
+  else if (nfr == 4) launch_inv_multi_N<4>(a, C, grid, s);
+  else if (nfr == 8) launch_inv_multi_N<8>(a, C, grid, s);
+  else launch_inv_multi_N<16>(a, C, grid, s);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }

@@ -329,7 +329,8 @@ def test_db_and_noise(golden, path):
 # ---- streaming ------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("N,C,chunks", [(1024, 2, (3, 1, 4, 2)), (256, 1, (2, 2, 5)), (1024, 1, (5, 3)),
-                                        (2048, 2, (2, 5, 1))])
+                                        (2048, 2, (2, 5, 1)), (128, 2, (3, 9, 1, 4)), (128, 1, (11, 2)), (512, 2, (1, 3, 2)),
+                                        (64, 2, (5, 17, 1, 16)), (64, 1, (33, 2))])
 def test_streaming_equals_one_shot(path, N, C, chunks):
     B, K = 2, sum(chunks)
     x = torch.rand(B, K * N, C, device="cuda") * 2 - 1
@@ -561,7 +562,7 @@ def test_masking_model_general_band_layouts(sr, N, M, B, F, C):
 
 
 def test_fast_path_selection():
-    """The wave-level kernels serve N = 256, 512 (several frames per wave), 1024 and 2048 with a Princen-Bradley window;
+    """The wave-level kernels serve N = 64, 128, 256, 512 (several frames per wave), 1024 and 2048 with a Princen-Bradley window;
     everything else runs the LDS-FFT / generic kernels (the rectangular window's fold blocks are not rotations)."""
     _lib.load().ac_set_force_generic(0)
     assert audiocodec_amd.MDCTransformer(1024, "vorbis").is_fast()
@@ -571,7 +572,9 @@ def test_fast_path_selection():
     assert not audiocodec_amd.MDCTransformer(2048, "rect").is_fast()
     assert audiocodec_amd.MDCTransformer(512).is_fast() and audiocodec_amd.MDCTransformer(256, "sine").is_fast()
     assert not audiocodec_amd.MDCTransformer(512, "rect").is_fast()
-    assert not audiocodec_amd.MDCTransformer(128).is_fast() and not audiocodec_amd.MDCTransformer(4096).is_fast()
+    assert audiocodec_amd.MDCTransformer(128).is_fast() and not audiocodec_amd.MDCTransformer(128, "rect").is_fast()
+    assert audiocodec_amd.MDCTransformer(64).is_fast() and not audiocodec_amd.MDCTransformer(64, "rect").is_fast()
+    assert not audiocodec_amd.MDCTransformer(32).is_fast() and not audiocodec_amd.MDCTransformer(4096).is_fast()
     assert audiocodec_amd.PsychoacousticModel(48000, 1024, 64).is_fast()
     assert audiocodec_amd.PsychoacousticModel(48000, 2048, 64).is_fast()
     assert not audiocodec_amd.PsychoacousticModel(48000, 512, 64).is_fast()
@@ -581,10 +584,15 @@ def test_fast_path_selection():
 @pytest.mark.parametrize("N,wt,B,K,C", [(512, "vorbis", 3, 9, 2), (512, "sine", 2, 1, 2), (512, "vorbis", 5, 40, 1),
                                         (512, "vorbis", 1, 2, 1), (256, "vorbis", 3, 11, 2), (256, "sine", 2, 1, 2),
                                         (256, "vorbis", 3, 70, 1), (256, "vorbis", 4, 4, 2), (256, "vorbis", 1, 3, 1),
-                                        (512, "vorbis", 2, 130, 2), (256, "vorbis", 2, 6, 3), (512, "vorbis", 2, 5, 4)])
+                                        (512, "vorbis", 2, 130, 2), (256, "vorbis", 2, 6, 3), (512, "vorbis", 2, 5, 4),
+                                        (128, "vorbis", 3, 13, 2), (128, "sine", 2, 1, 2), (128, "vorbis", 3, 150, 1),
+                                        (128, "vorbis", 1, 7, 1), (128, "vorbis", 2, 300, 2), (128, "vorbis", 2, 9, 3),
+                                        (64, "vorbis", 3, 21, 2), (64, "sine", 2, 1, 2), (64, "vorbis", 3, 301, 1),
+                                        (64, "vorbis", 1, 15, 1), (64, "vorbis", 2, 16, 2), (64, "vorbis", 2, 600, 2),
+                                        (64, "vorbis", 2, 9, 3)])
 def test_short_frames_on_the_wave_level_kernels(N, wt, B, K, C):
-    """filters_n = 512 / 256 (the reference's own test sizes, tests/test_mdctransformer.py:23): two / four frames per wave.
-    Frame counts that leave lane groups idle (K + 1 not a multiple of 2 / 4), odd mono clip counts, signals longer than a
+    """filters_n = 512 / 256 / 64 (the reference's own test sizes, tests/test_mdctransformer.py:23,42) and 128: two / four /
+    sixteen / eight frames per wave.  Frame counts that leave lane groups idle (K + 1 not a multiple of 2 / 4 / 8 / 16), odd mono clip counts, signals longer than a
     synthesis strip, single blocks; against the fp64 oracle and against the LDS-FFT tier of this library.  Other channel
     counts at these sizes take the LDS-FFT tier and must agree too."""
     rng = np.random.default_rng(N + 10 * K + C)

@@ -9,7 +9,9 @@ out=gpurun_out/entry_points.txt
   echo; echo "== N = 512 (two frames per wave), B = 256 stereo, K = 936"; N=512 python tools/microbench.py 2>/dev/null | sed -n 1,5p
   echo; echo "== N = 512, B = 256 mono, K = 936"; N=512 C=1 python tools/microbench.py 2>/dev/null | sed -n 1,5p
   echo; echo "== N = 256 (four frames per wave), B = 256 stereo, K = 1872"; N=256 python tools/microbench.py 2>/dev/null | sed -n 1,5p
-  echo; echo "== N = 128 (LDS-FFT tier), B = 256 stereo, K = 3744"; N=128 python tools/microbench.py 2>/dev/null | sed -n 2,3p
+  echo; echo "== N = 128 (eight frames per wave), B = 256 stereo, K = 3744"; N=128 python tools/microbench.py 2>/dev/null | sed -n 2,3p
+  echo; echo "== N = 64 (sixteen frames per wave), B = 256 stereo, K = 7488"; N=64 python tools/microbench.py 2>/dev/null | sed -n 2,3p
+  echo; echo "== N = 32 (LDS-FFT tier), B = 256 stereo, K = 14976"; N=32 python tools/microbench.py 2>/dev/null | sed -n 2,3p
   echo; echo "== backward passes, N = 1024, B = 256 stereo, K = 468 (tools/bwd_bench.py)"; python tools/bwd_bench.py 2>/dev/null
   echo; echo "== element-wise utilities on X [256, 469, 1024, 2] (tools/ew_bench.py)"; python tools/ew_bench.py 2>/dev/null
 } > $out
