@@ -268,8 +268,9 @@ class StreamingMDCT:
 
     def run(self, x, blocks_per_chunk, masking=True, synthesis=True, drown=0.0):
         """A long device-resident signal ``x [1, K*N, C]`` (or a list of chunk tensors ``[B, k*N, C]``) through the stream
-        in chunks of ``blocks_per_chunk`` blocks with one library call (``ac_stream_run``: two kernel launches per chunk,
-        issued from C).  Returns ``(X, t, thr, xhat)`` -- tensors ``[1, K, ...]`` for
+        in chunks of ``blocks_per_chunk`` blocks with one library call (``ac_stream_run``: launches issued from C; with
+        ``synthesis`` and chunks small enough to be latency-bound, the analysis of chunk i + 1 and the synthesis of chunk i
+        share one launch).  Returns ``(X, t, thr, xhat)`` -- tensors ``[1, K, ...]`` for
         a tensor input, lists of per-chunk tensors for a list input; ``t`` / ``thr`` are None without ``masking``,
         ``xhat`` is None without ``synthesis``.  The last chunk of a tensor input may be shorter."""
         k, N = int(blocks_per_chunk), self.mdct.filters_n

@@ -676,10 +676,48 @@ int ac_stream_run(ac_stream* s, const ac_psy_plan* psy, int nchunks, int k, cons
     AC_REQUIRE(psy == nullptr || (t_chunks[i] != nullptr && thr_chunks[i] != nullptr), "chunk %d: NULL tensor pointer", i);
     AC_REQUIRE(xhat_chunks == nullptr || xhat_chunks[i] != nullptr, "chunk %d: NULL tensor pointer", i);
   }
-  // one dependent chain on the caller's stream.  (Synthesis of chunk i on a second stream beside the analysis of chunk
-  // i + 1 was measured slower on MI355X: 25-30 us per chunk of 256 stereo frames against 17-20 us -- a cross-stream
-  // event hop costs more than the ~7 us kernel it would hide)
+  // Small chunks with synthesis (one clip, a few hundred frames per chunk): the analysis of chunk i + 1 rides in the same
+  // launch as the synthesis of chunk i (k_duplex_fast) -- the two are independent, and a chunk's two dependent launches
+  // of ~8 us each are latency, not bandwidth.  (Synthesis on a second HIP stream beside the analysis was measured slower
+  // on MI355X: 25-30 us per chunk of 256 stereo frames against 17-20 us -- a cross-stream event hop costs more than
+  // the ~7 us kernel it would hide)  Same kernel bodies: the results equal the chain's.
+  const ac_mdct_plan* p = s->plan;
+  hipStream_t hs = (hipStream_t)stream;
+  if (psy) {
+    AC_REQUIRE(p->N == psy->N, "mdct filters_n (%d) != psychoacoustic filter_bands_n (%d)", p->N, psy->N);
+    AC_REQUIRE(p->device == psy->device, "plans live on different devices");
+  }
   int st = AC_OK;
+  bool duplex = xhat_chunks && nchunks >= 2 && wave_level(p, s->C, 0, k) && fast_duplex_serves(p, psy, s->B, s->C, k, k);
+  if (duplex) {
+    // the two halves of a launch must not touch each other's tensors: a caller that reuses one X (or PCM) buffer for
+    // consecutive chunks gets the dependent chain
+    const size_t nX = (size_t)s->B * k * p->N * s->C, nt = (size_t)s->B * k * s->C;
+    auto apart = [](const float* a, size_t na, const float* b, size_t nb) { return a + na <= b || b + nb <= a; };
+    for (int i = 0; i + 1 < nchunks && duplex; ++i) {
+      duplex = apart(X_chunks[i], nX, X_chunks[i + 1], nX) && apart(xhat_chunks[i], nX, x_chunks[i + 1], nX) &&
+               apart(xhat_chunks[i], nX, X_chunks[i + 1], nX) && apart(X_chunks[i], nX, x_chunks[i + 1], nX);
+      if (duplex && psy)
+        duplex = apart(X_chunks[i], nX, thr_chunks[i + 1], nX) && apart(xhat_chunks[i], nX, thr_chunks[i + 1], nX) &&
+                 apart(X_chunks[i], nX, t_chunks[i + 1], nt) && apart(xhat_chunks[i], nX, t_chunks[i + 1], nt);
+    }
+  }
+  if (duplex) {
+    DeviceGuard guard(s->device);
+    st = stream_analysis(s, psy, x_chunks[0], X_chunks[0], psy ? t_chunks[0] : nullptr, psy ? thr_chunks[0] : nullptr, drown,
+                         k, stream);
+    for (int i = 0; i + 1 < nchunks && !st; ++i) {
+      st = launch_duplex_fast(p, psy, x_chunks[i + 1], X_chunks[i + 1], psy ? t_chunks[i + 1] : nullptr,
+                              psy ? thr_chunks[i + 1] : nullptr, drown, s->d_prev_block, s->d_prev_tmp, k, X_chunks[i],
+                              xhat_chunks[i], s->d_tail, s->d_tail_tmp, k, s->B, s->C, hs);
+      if (!st) {
+        std::swap(s->d_prev_block, s->d_prev_tmp);
+        std::swap(s->d_tail, s->d_tail_tmp);
+      }
+    }
+    if (!st) st = ac_stream_inverse(s, X_chunks[nchunks - 1], xhat_chunks[nchunks - 1], k, stream);
+    return st;
+  }
   for (int i = 0; i < nchunks && !st; ++i) {
     st = stream_analysis(s, psy, x_chunks[i], X_chunks[i], psy ? t_chunks[i] : nullptr, psy ? thr_chunks[i] : nullptr,
                          drown, k, stream);

@@ -896,17 +896,25 @@ struct FwdArgs {
 // register (r + 4) & 7) and the odd sample of granule 767 - e (lane 63 - lane, register (3 - r) & 7).
 // With (A, B) = COEF[e]:  carried part (block n-1) = B xe + A xo;  current part (block n) = B xo - A xe (r < 4),
 // A xe - B xo (r >= 4)   (Princen-Bradley windows make the 2x2 fold blocks rotations).
+// one LDS object: [NW wave buffers | table image | psy image | bf16 tiles of the spreading matrix (SPREAD > 0)]
+// the matrix-core spreading kernels at 8 points per lane pay for their bf16 tiles with the pre-twiddle table, which
+// they rebuild from the post-twiddles: the workgroup stays under 53 760 B, three to a CU
+template <int R, bool PSY, int SPREAD>
+constexpr bool fwd_nopre() { return (R == 8) && PSY && SPREAD > 0; }
+template <int R, bool PSY, int NW, int SPREAD>
+constexpr int fwd_lds_bytes() {
+  return NW * (PSY ? WAVE_LDS_PSY : WAVE_LDS) + (fwd_nopre<R, PSY, SPREAD>() ? Geo<R>::I_LDS_NOPRE : Geo<R>::I_LDS) * 4 +
+         (PSY ? PsyGeo<R>::PSY_LDS + mf_lds(SPREAD) : 0);
+}
+// the kernel's body: workgroup `bid` of `nblocks` (the kernel below passes blockIdx.x / gridDim.x; the streaming duplex
+// kernel runs it on the first part of its grid), lds = fwd_lds_bytes() bytes of LDS, 16-byte aligned
 template <int R, int CMODE, bool PSY, int NW, int IOF = 0, int SPREAD = 0, bool EPI = false>
-__global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY, SPREAD>())) void k_fwd_fast(FwdArgs a) {
+__device__ __forceinline__ void fwd_fast_body(const FwdArgs& a, char* lds, const int bid, const int nblocks) {
   static_assert(!EPI || (PSY && CMODE == 0 && IOF == 0), "the element-wise epilogues ride on the stereo float32 fused encode");
   using G = Geo<R>;
-  // one LDS object: [NW wave buffers | table image | psy image | bf16 tiles of the spreading matrix (SPREAD > 0)]
   constexpr int WSTRIDE = PSY ? WAVE_LDS_PSY : WAVE_LDS;
-  // the matrix-core spreading kernels at 8 points per lane pay for their bf16 tiles with the pre-twiddle table, which
-  // they rebuild from the post-twiddles: the workgroup stays under 53 760 B, three to a CU
-  constexpr bool NOPRE = (R == 8) && PSY && SPREAD > 0;
+  constexpr bool NOPRE = fwd_nopre<R, PSY, SPREAD>();
   constexpr int TABF = NOPRE ? G::I_LDS_NOPRE : G::I_LDS;
-  __shared__ __attribute__((aligned(16))) char lds[NW * WSTRIDE + TABF * 4 + (PSY ? PsyGeo<R>::PSY_LDS + mf_lds(SPREAD) : 0)];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   load_tables<NW, WSTRIDE, TABF, PsyGeo<R>::PL_LDS, PsyGeo<R>::PL_MF, mf_lds(SPREAD)>(lds, a.tab, PSY ? a.psy.tab : nullptr);
   char* buf = lds + wave * WSTRIDE;
@@ -919,12 +927,12 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY, SPREAD>())) void k_fwd
   if constexpr (!EPI) load_p1<R>(a.tab, lane, p1);
   PsyLane<R> pc;
   if (PSY) pc = load_psy_lane<R>(a.psy.tab, lane, (uint32_t)(wave * WSTRIDE));
-  int g = blockIdx.x;
-  if (a.xcd) g = (g & 7) * (gridDim.x >> 3) + (g >> 3);
+  int g = bid;
+  if (a.xcd) g = (g & 7) * (nblocks >> 3) + (g >> 3);
   const int C = a.C;
   const size_t blk = (size_t)G::FN * C;   // floats per block / frame row over all channels
   // frame f = (pair, n); everything about it is wave-uniform and lives in scalar registers, advanced without divisions
-  const long long stride = a.T > 0 ? (long long)NW : (long long)gridDim.x * NW;
+  const long long stride = a.T > 0 ? (long long)NW : (long long)nblocks * NW;
   const long long f0 = (a.T > 0 ? (long long)g * NW * a.T : (long long)g * NW) + wave;
   int left = a.T > 0 ? a.T : 0x7fffffff;
   const long long dpair = stride / a.F;
@@ -1169,6 +1177,12 @@ __global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY, SPREAD>())) void k_fwd
   }
 }
 
+template <int R, int CMODE, bool PSY, int NW, int IOF = 0, int SPREAD = 0, bool EPI = false>
+__global__ __launch_bounds__(NW * 64, (wpe<R, CMODE, PSY, SPREAD>())) void k_fwd_fast(FwdArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[fwd_lds_bytes<R, PSY, NW, SPREAD>()];
+  fwd_fast_body<R, CMODE, PSY, NW, IOF, SPREAD, EPI>(a, lds, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // synthesis
 // ------------------------------------------------------------------------------------------------------
@@ -1218,10 +1232,9 @@ __device__ __forceinline__ void idct_frame(const v4f (&frm)[R], char* buf, gtab_
 }
 
 template <int R, int CMODE, int NW, int IOF = 0>
-__global__ __launch_bounds__(NW * 64, (IOF != 0 ? 2 : wpe<R, CMODE>())) void k_inv_fast(InvArgs a) {
+__device__ __forceinline__ void inv_fast_body(const InvArgs& a, char* lds, const int bid, const int nblocks) {
   using G = Geo<R>;
   constexpr int FH = G::FH;
-  __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS + G::TAB_LDS];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   load_tables<NW, WAVE_LDS, G::I_LDS, 0>(lds, a.tab + G::I_TOTAL, nullptr);
   char* buf = lds + wave * WAVE_LDS;
@@ -1236,7 +1249,7 @@ __global__ __launch_bounds__(NW * 64, (IOF != 0 ? 2 : wpe<R, CMODE>())) void k_i
   // its last frame through LDS -- only the first wave of a workgroup pays an extra DCT-IV (of the frame before its
   // strip).  Workgroups are dispatched in order, which keeps the window of memory in flight contiguous.
   constexpr bool COOP = (R == 8);   // hand-over between waves (the 2048-filter kernel has no registers to spare)
-  const long long task_raw = (long long)(a.rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * NW + wave;
+  const long long task_raw = (long long)(a.rev ? nblocks - 1 - bid : bid) * NW + wave;
   const bool valid = task_raw < a.ntasks;
   const long long task = valid ? task_raw : a.ntasks - 1;   // idle waves of the last workgroup only join the barriers
   const int sgm = (int)(task % a.nseg);
@@ -1359,6 +1372,24 @@ __global__ __launch_bounds__(NW * 64, (IOF != 0 ? 2 : wpe<R, CMODE>())) void k_i
     __syncthreads();   // every hand-over has been read: the buffers may be reused for the last exchange
     if (deferred) emit(n0, now0, cin);
   }
+}
+
+template <int R, int CMODE, int NW, int IOF = 0>
+__global__ __launch_bounds__(NW * 64, (IOF != 0 ? 2 : wpe<R, CMODE>())) void k_inv_fast(InvArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS + Geo<R>::TAB_LDS];
+  inv_fast_body<R, CMODE, NW, IOF>(a, lds, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Streaming duplex (BASELINE configs[4]): the analysis of chunk i + 1 and the synthesis of chunk i in ONE launch -- the
+// first nfwd workgroups run the analysis body, the others the synthesis body.  A chunk of one clip is a few hundred wave
+// tasks: two dependent launches of ~8 us each are latency, not bandwidth, and the two halves are independent.
+template <int R, int CMODE, bool PSY, int NW, int SPREAD>
+__global__ __launch_bounds__(NW * 64, 2) void k_duplex_fast(FwdArgs fa, InvArgs ia, int nfwd) {
+  constexpr int LF = fwd_lds_bytes<R, PSY, NW, SPREAD>(), LI = NW * WAVE_LDS + Geo<R>::TAB_LDS;
+  __shared__ __attribute__((aligned(16))) char lds[LF > LI ? LF : LI];
+  const int b = (int)blockIdx.x;   // (uniform per workgroup: the barriers inside the bodies stay consistent)
+  if (b < nfwd) fwd_fast_body<R, CMODE, PSY, NW, 0, SPREAD, false>(fa, lds, b, nfwd);
+  else inv_fast_body<R, CMODE, NW, 0>(ia, lds, b - nfwd, (int)gridDim.x - nfwd);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2628,24 +2659,16 @@ static void launch_fwd_R(const FwdArgs& a, bool psy, int spread, int C, unsigned
   }
 }
 
-int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x, int iof, float* X, float* t,
-                    float* thr, float drown, const float* prev_block, int B, int Kin, int F, int C, hipStream_t s,
-                    float* state_out, float* noisy, float* dbn, uint64_t seed) {
-  if (B <= 0 || C <= 0 || F <= 0) return AC_OK;
-  if (fast_mdct_frames_per_wave(p->N) > 1) {
-    if (psy || thr || t || noisy || dbn || !fast_multi_serves(p, C, iof, Kin)) {
-      set_error("internal: no wave-level analysis kernel for filters_n = %d, %d channels, io format %d here", p->N, C, iof);
-      return AC_EUNSUPPORTED;
-    }
-    return launch_fwd_multi(p, static_cast<const float*>(x), X, prev_block, state_out, B, Kin, F, C, s);
-  }
+// arguments and grid of the one-frame-per-wave analysis kernels (filters_n 1024 / 2048)
+static int prep_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x, int iof, float* X, float* t,
+                         float* thr, float drown, const float* prev_block, int B, int Kin, int F, int C, float* state_out,
+                         float* noisy, float* dbn, uint64_t seed, FwdArgs& a, unsigned& grid) {
   // combinations no kernel is instantiated for (ac_api.hip routes them elsewhere; refuse rather than launch nothing)
   if ((iof == 2 && C > 2) || (psy && p->N == Geo<16>::FN && (C == 1 || (iof == 1 && C > 2)))) {
     set_error("internal: no wave-level analysis kernel for filters_n = %d, %d channels, io format %d%s", p->N, C, iof,
               psy ? ", fused masking model" : "");
     return AC_EUNSUPPORTED;
   }
-  FwdArgs a;
   a.x = x;
   a.X = X;
   a.t = t;
@@ -2681,14 +2704,12 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x
   static const int wgcu = [] { const char* e = getenv("AC_WG_PER_CU"); return e ? atoi(e) : 3; }();
   static const int tper = [] { const char* e = getenv("AC_FWD_T"); return e ? atoi(e) : 4; }();
   a.xcd = xcd;
-  const int spread = psy ? psy->spread : 0;
   const int nw = psy ? AC_WAVES_PSY : AC_WAVES;
   // small launches (a streaming chunk of one clip): fewer frames per wave, so that the frames spread over the chip
   // instead of queueing behind each other in a few workgroups
   int tper_eff = tper;
   while (tper_eff > 1 && a.nframes < (long long)nw * tper_eff * p->cus * 2) tper_eff >>= 1;
   a.T = tper_eff;
-  unsigned grid;
   if (tper > 0) {
     const long long per = (long long)nw * tper_eff;
     long long g = (a.nframes + per - 1) / per;
@@ -2701,6 +2722,25 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x
   } else {
     grid = persistent_grid(p->cus, wgcu, a.nframes, nw);
   }
+  return AC_OK;
+}
+
+int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x, int iof, float* X, float* t,
+                    float* thr, float drown, const float* prev_block, int B, int Kin, int F, int C, hipStream_t s,
+                    float* state_out, float* noisy, float* dbn, uint64_t seed) {
+  if (B <= 0 || C <= 0 || F <= 0) return AC_OK;
+  if (fast_mdct_frames_per_wave(p->N) > 1) {
+    if (psy || thr || t || noisy || dbn || !fast_multi_serves(p, C, iof, Kin)) {
+      set_error("internal: no wave-level analysis kernel for filters_n = %d, %d channels, io format %d here", p->N, C, iof);
+      return AC_EUNSUPPORTED;
+    }
+    return launch_fwd_multi(p, static_cast<const float*>(x), X, prev_block, state_out, B, Kin, F, C, s);
+  }
+  FwdArgs a;
+  unsigned grid;
+  const int st = prep_fwd_fast(p, psy, x, iof, X, t, thr, drown, prev_block, B, Kin, F, C, state_out, noisy, dbn, seed, a, grid);
+  if (st) return st;
+  const int spread = psy ? psy->spread : 0;
   if (p->N == Geo<8>::FN) {
     if (iof == 2) launch_fwd_R<8, 2>(a, psy != nullptr, spread, C, grid, s);
     else if (iof == 1) launch_fwd_R<8, 1>(a, psy != nullptr, spread, C, grid, s);
@@ -2723,21 +2763,13 @@ static void launch_inv_R(const InvArgs& a, int C, unsigned grid, hipStream_t s) 
   else if constexpr (IOF != 2) hipLaunchKernelGGL((k_inv_fast<R, 1, AC_WAVES, IOF>), dim3(grid), blk, 0, s, a);
 }
 
-int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, int iof, const float* tail_in, float* tail_out,
-                    int B, int Kp, int nblk, int C, hipStream_t s) {
-  if (B <= 0 || C <= 0 || nblk <= 0) return AC_OK;
-  if (fast_mdct_frames_per_wave(p->N) > 1) {
-    if (!fast_multi_serves(p, C, iof, Kp)) {
-      set_error("internal: no wave-level synthesis kernel for filters_n = %d, %d channels, io format %d here", p->N, C, iof);
-      return AC_EUNSUPPORTED;
-    }
-    return launch_inv_multi(p, X, static_cast<float*>(x), tail_in, tail_out, B, Kp, nblk, C, s);
-  }
+// arguments and grid of the one-frame-per-wave synthesis kernels (filters_n 1024 / 2048)
+static int prep_inv_fast(const ac_mdct_plan* p, const float* X, void* x, int iof, const float* tail_in, float* tail_out,
+                         int B, int Kp, int nblk, int C, InvArgs& a, unsigned& grid) {
   if (iof == 2 && C > 2) {
     set_error("internal: no wave-level synthesis kernel for bfloat16 tensors with %d channels", C);
     return AC_EUNSUPPORTED;
   }
-  InvArgs a;
   a.X = X;
   a.x = x;
   a.tail_in = tail_in;
@@ -2765,7 +2797,24 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, int iof, con
     set_error("problem too large for one launch (%lld workgroups)", need);
     return AC_EINVAL;
   }
-  const unsigned grid = (unsigned)need;
+  grid = (unsigned)need;
+  return AC_OK;
+}
+
+int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, int iof, const float* tail_in, float* tail_out,
+                    int B, int Kp, int nblk, int C, hipStream_t s) {
+  if (B <= 0 || C <= 0 || nblk <= 0) return AC_OK;
+  if (fast_mdct_frames_per_wave(p->N) > 1) {
+    if (!fast_multi_serves(p, C, iof, Kp)) {
+      set_error("internal: no wave-level synthesis kernel for filters_n = %d, %d channels, io format %d here", p->N, C, iof);
+      return AC_EUNSUPPORTED;
+    }
+    return launch_inv_multi(p, X, static_cast<float*>(x), tail_in, tail_out, B, Kp, nblk, C, s);
+  }
+  InvArgs a;
+  unsigned grid;
+  const int st = prep_inv_fast(p, X, x, iof, tail_in, tail_out, B, Kp, nblk, C, a, grid);
+  if (st) return st;
   if (p->N == Geo<8>::FN) {
     if (iof == 2) launch_inv_R<8, 2>(a, C, grid, s);
     else if (iof == 1) launch_inv_R<8, 1>(a, C, grid, s);
@@ -2775,6 +2824,57 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, int iof, con
   else if (iof == 2) launch_inv_R<16, 2>(a, C, grid, s);
   else if (iof == 1) launch_inv_R<16, 1>(a, C, grid, s);
   else launch_inv_R<16, 0>(a, C, grid, s);
+#endif
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+// ---- streaming duplex: analysis of one chunk and synthesis of another in one launch (k_duplex_fast) ----
+// Served: float32, mono / stereo, filters_n 1024 / 2048, without the masking model or (1024, stereo) with the fused
+// one in its f32 / split-bf16 spreading forms -- and only launches small enough to be latency-bound: at most two waves
+// per SIMD over both halves, where a chunk's two dependent launches cost more than their sum of work.
+bool fast_duplex_serves(const ac_mdct_plan* p, const ac_psy_plan* psy, int B, int C, int k_fwd, int k_inv) {
+  static const int off = [] { const char* e = getenv("AC_NO_DUPLEX"); return e ? atoi(e) : 0; }();   // tuning hook
+  if (off || fast_mdct_frames_per_wave(p->N) != 1 || (C != 1 && C != 2) || k_fwd < 1 || k_inv < 1) return false;
+  if (psy && !(p->N == Geo<8>::FN && C == 2 && psy->fast && psy->spread != 1)) return false;
+  const long long pairs = (C == 2) ? B : (B + 1) / 2;
+  return pairs * ((long long)k_fwd + k_inv) <= (long long)p->cus * 8;
+}
+
+template <int R>
+static void launch_duplex_R(const FwdArgs& fa, const InvArgs& ia, unsigned gf, unsigned gi, bool psy, int spread, int C,
+                            hipStream_t s) {
+  const dim3 grid(gf + gi), blk(AC_WAVES * 64);
+  static_assert(AC_WAVES == AC_WAVES_PSY, "one workgroup shape for both halves");
+  if constexpr (R == 8) {
+    if (psy) {
+      if (spread == 2) hipLaunchKernelGGL((k_duplex_fast<8, 0, true, AC_WAVES, 2>), grid, blk, 0, s, fa, ia, (int)gf);
+      else hipLaunchKernelGGL((k_duplex_fast<8, 0, true, AC_WAVES, 0>), grid, blk, 0, s, fa, ia, (int)gf);
+      return;
+    }
+  }
+  if (C == 2) hipLaunchKernelGGL((k_duplex_fast<R, 0, false, AC_WAVES, 0>), grid, blk, 0, s, fa, ia, (int)gf);
+  else hipLaunchKernelGGL((k_duplex_fast<R, 2, false, AC_WAVES, 0>), grid, blk, 0, s, fa, ia, (int)gf);
+}
+
+int launch_duplex_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr,
+                       float drown, const float* prev_block, float* state_out, int k_fwd, const float* X_inv, float* x_inv,
+                       const float* tail_in, float* tail_out, int k_inv, int B, int C, hipStream_t s) {
+  if (!fast_duplex_serves(p, psy, B, C, k_fwd, k_inv)) {
+    set_error("internal: the streaming duplex kernel does not serve this configuration");
+    return AC_EUNSUPPORTED;
+  }
+  FwdArgs fa;
+  InvArgs ia;
+  unsigned gf, gi;
+  int st = prep_fwd_fast(p, psy, x, 0, X, psy ? t : nullptr, psy ? thr : nullptr, drown, prev_block, B, k_fwd, k_fwd, C,
+                         state_out, nullptr, nullptr, 0, fa, gf);
+  if (!st) st = prep_inv_fast(p, X_inv, x_inv, 0, tail_in, tail_out, B, k_inv, k_inv, C, ia, gi);
+  if (st) return st;
+  const int spread = psy ? psy->spread : 0;
+  if (p->N == Geo<8>::FN) launch_duplex_R<8>(fa, ia, gf, gi, psy != nullptr, spread, C, s);
+#ifndef AC_NO_R16
+  else launch_duplex_R<16>(fa, ia, gf, gi, false, 0, C, s);
 #endif
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;

@@ -166,6 +166,12 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, int iof, con
                     int B, int Kp, int nblk, int C, hipStream_t s);
 int launch_psy_fast(const ac_psy_plan* p, const float* X, const float* t_in, float* t_out, float* thr, float drown,
                     int B, int F, int C, hipStream_t s, int iof = 0);
+// streaming duplex: the analysis of a chunk of k_fwd blocks (psy: with the fused masking model) and the synthesis of a
+// chunk of k_inv frames in one launch, where fast_duplex_serves() -- small float32 mono / stereo launches
+bool fast_duplex_serves(const ac_mdct_plan* p, const ac_psy_plan* psy, int B, int C, int k_fwd, int k_inv);
+int launch_duplex_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr,
+                       float drown, const float* prev_block, float* state_out, int k_fwd, const float* X_inv, float* x_inv,
+                       const float* tail_in, float* tail_out, int k_inv, int B, int C, hipStream_t s);
 
 // wave-level masking model for general band layouts (ac_psy_mid.hip); mono / stereo float32
 bool mid_psy_supported(const ac_psy_plan* p);

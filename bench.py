@@ -422,7 +422,7 @@ def other_configs(torch, np, audiocodec_amd, dev, steps, warmup, settle_ms):
                 ts.append(time.perf_counter() - t0)
             return float(np.median(ts))
 
-        def one_call():          # ac_stream_run: the same chain, two launches per chunk issued from C
+        def one_call():          # ac_stream_run: issued from C; one clip: analysis of chunk i+1 + synthesis of chunk i per launch
             st.reset()
             st.run(chunks if Bs > 1 else xs[:, :len(chunks) * k * N], k, masking=fused)
 

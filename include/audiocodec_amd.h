@@ -200,8 +200,11 @@ int ac_stream_inverse(ac_stream* s, const float* X_chunk, float* x, int k, void*
  * buffer that has filled up): chunk i is analysed -- with the masking model when psy is not NULL, else t_chunks /
  * thr_chunks are ignored -- from x_chunks[i] [B, k*N, C] into X_chunks[i] (t_chunks[i], thr_chunks[i]) and, when
  * xhat_chunks is not NULL, synthesised from X_chunks[i] into xhat_chunks[i] [B, k*N, C].  Results are those of nchunks
- * calls of ac_stream_encode (ac_stream_forward) and ac_stream_inverse on `stream`, issued from one host call (two kernel
- * launches per chunk, no per-call binding overhead).  The pointer lists are host arrays. */
+ * calls of ac_stream_encode (ac_stream_forward) and ac_stream_inverse on `stream`, issued from one host call (no per-call
+ * binding overhead).  With synthesis, chunks small enough to be latency-bound (one or a few clips) and distinct buffers
+ * per chunk, the analysis of chunk i + 1 and the synthesis of chunk i share ONE launch (float32, mono / stereo,
+ * filters_n 1024 / 2048): nchunks + 1 launches instead of 2 nchunks, same results bit for bit.  A caller that reuses
+ * one buffer for consecutive chunks gets the dependent chain.  The pointer lists are host arrays. */
 int ac_stream_run(ac_stream* s, const ac_psy_plan* psy, int nchunks, int k, const float* const* x_chunks,
                   float* const* X_chunks, float* const* t_chunks, float* const* thr_chunks, float* const* xhat_chunks,
                   float drown, void* stream);

@@ -422,6 +422,50 @@ def test_stream_run_equals_one_shot(path, N, k, K):
     st.close(), stb.close()
 
 
+@pytest.mark.parametrize("N,C,k,K,masking", [(1024, 2, 16, 80, False), (1024, 1, 8, 40, False), (2048, 2, 8, 32, False),
+                                              (2048, 1, 4, 20, False), (1024, 2, 256, 1024, True), (1024, 2, 7, 30, True)])
+def test_stream_run_duplex_equals_the_chain(N, C, k, K, masking):
+    """ac_stream_run with synthesis on small chunks: analysis of chunk i + 1 and synthesis of chunk i share one launch
+    (k_duplex_fast).  Same results, bit for bit, as the chunk-by-chunk calls of the streaming API -- and a caller that
+    hands over ONE X buffer for all chunks (so the two halves would collide) gets the dependent chain, same results."""
+    g = torch.Generator(device="cuda").manual_seed(N + K + C)
+    x = torch.empty(1, K * N, C, device="cuda").uniform_(-1, 1, generator=g)
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    st = codec.stream(1, C)
+    X, t, thr, xh = st.run(x, k, masking=masking, drown=0.2)
+    ref = codec.stream(1, C)
+    Xs, ts, thrs, xs = [], [], [], []
+    for i in range(0, K, k):
+        chunk = x[:, i * N:(i + k) * N]
+        if masking:
+            Xc, tc, thc = ref.encode_chunk(chunk, drown=0.2)
+            ts.append(tc), thrs.append(thc)
+        else:
+            Xc = ref.transform_chunk(chunk)
+        Xs.append(Xc), xs.append(ref.inverse_chunk(Xc))
+    assert torch.equal(X, torch.cat(Xs, dim=1)) and torch.equal(xh, torch.cat(xs, dim=1))
+    if masking:
+        assert torch.equal(t, torch.cat(ts, dim=1)) and torch.equal(thr, torch.cat(thrs, dim=1))
+    assert float((xh[:, N:] - x[:, :-N]).abs().max()) <= LSB
+    # one X / t / thr buffer for every chunk, through the C ABI: the last chunk's spectrum, the whole signal's PCM
+    import ctypes
+    from audiocodec_amd import _host
+    lib = _lib.load()
+    n = K // k
+    st2 = codec.stream(1, C)
+    Xone = torch.empty(1, k, N, C, device="cuda")
+    tone, throne = torch.empty(1, k, 1, C, device="cuda"), torch.empty(1, k, N, C, device="cuda")
+    xh2 = torch.empty_like(x)
+    arr = lambda ps: (ctypes.c_void_p * n)(*ps)   # noqa: E731
+    _lib.check(lib.ac_stream_run(st2._handle, codec.psy._plan(x.device) if masking else None, n, k,
+                                 arr([x[:, i * k * N:].data_ptr() for i in range(n)]), arr([Xone.data_ptr()] * n),
+                                 arr([tone.data_ptr()] * n) if masking else None, arr([throne.data_ptr()] * n) if masking else None,
+                                 arr([xh2[:, i * k * N:].data_ptr() for i in range(n)]), 0.2, _host.stream_ptr(x.device)))
+    torch.cuda.synchronize()
+    assert torch.equal(xh2[:, :n * k * N], xh[:, :n * k * N]) and torch.equal(Xone, Xs[n - 1])
+    st.close(), ref.close(), st2.close()
+
+
 def test_full_size_properties(path):
     """BASELINE config 2 shape (B=256 stereo, K=46, N=1024): size-independent properties only."""
     if path == "generic":
