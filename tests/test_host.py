@@ -200,3 +200,19 @@ def test_sharding_world_size_2_gloo(tmp_path):
             break
     assert out.returncode == 0, out.stdout + out.stderr
     assert "OK 48.0 2.0" in out.stdout
+
+
+def test_host_table_builders_under_sanitizers(tmp_path):
+    """The host-side constant builders (ac_tables.cpp: windows, fold coefficients, Bark tables, CSR forms) compiled with
+    AddressSanitizer + UBSan and swept over sizes / band counts / sample rates (tests/native/sanitize_tables.cpp).  GPU
+    sanitizers are not available on this pool; this is the part of the native code a CPU sanitizer can see."""
+    exe = str(tmp_path / "sanitize_tables")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-I" + os.path.join(ROOT, "audiocodec_amd", "csrc"), os.path.join(ROOT, "tests", "native", "sanitize_tables.cpp"),
+           os.path.join(ROOT, "audiocodec_amd", "csrc", "ac_tables.cpp"), "-o", exe]
+    build = subprocess.run(cmd, capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr and "cannot find" in build.stderr:
+        pytest.skip("this g++ has no sanitizer runtime")
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and run.stdout.strip() == "ok", run.stdout + run.stderr
