@@ -7,8 +7,11 @@
 // 8-byte (mono, two signals side by side) accesses, tonality comes from DPP wave sums, the intensities go through an LDS
 // image, lane j < M owns Bark band j and walks its list of (bin, weight) entries (W "by band": psychoacoustic.py:301-315),
 // the band x band spreading product reads S from LDS with the Q_i broadcast (psychoacoustic.py:205-207, tonality offset
-// pulled out of the sum: SURVEY App. A.3), and every bin gathers its <= WI (band, weight) entries of W_inv from a
-// fixed-width table (psychoacoustic.py:317-331).  All constant tables sit in one image copied to LDS per workgroup.
+// pulled out of the sum: SURVEY App. A.3; S is Toeplitz, S[i][j] = g[M - i + j] (:223-228), so the image holds the 2 M
+// prototype values instead of M x M), and every bin gathers its <= WI (band, weight) entries of W_inv from a fixed-width
+// table stored entry-major (psychoacoustic.py:317-331).  All constant tables sit in one image copied to LDS per
+// workgroup; a wave walks T frames so that the copy is paid once per 4 T frames.
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -44,6 +47,15 @@ __device__ __forceinline__ v2f log2v(v2f x) { return v2f{__builtin_amdgcn_logf(x
 __device__ __forceinline__ v2f exp2v(v2f x) { return v2f{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
 __device__ __forceinline__ v2f maxv(v2f a, float b) { return v2f{fmaxf(a.x, b), fmaxf(a.y, b)}; }
 
+// acc += q * s.x (lo) / q * s.y (hi) on both halves of q: one packed multiply-add with the scalar taken from one half of
+// a register pair through op_sel (the compiler would duplicate the scalar into a pair of its own: 128 registers for S)
+__device__ __forceinline__ void pk_fma_lo(v2f& acc, v2f q, v2f s) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(q), "v"(s));
+}
+__device__ __forceinline__ void pk_fma_hi(v2f& acc, v2f q, v2f s) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(q), "v"(s));
+}
+
 struct MidArgs {
   const float* X;
   const float* t_in;
@@ -52,6 +64,7 @@ struct MidArgs {
   const uint32_t* img;   // ac_psy_plan::d_mid
   int img_words;
   int N, M, C, F;
+  int T;                 // frames per wave: workgroup g owns tasks [g nw T, (g + 1) nw T), wave w takes g nw T + w + nw t
   int wi_w;              // entries per bin in the fixed-width W_inv table
   int off_S, off_band, off_wbe, off_wi;   // word offsets inside the image
   float alpha, inv_alpha, drown;
@@ -59,13 +72,14 @@ struct MidArgs {
 };
 
 // image layout (32-bit words):
-//   off_S:    S[i * M + j]                       M * M floats
-//   off_band: per band j: {first entry, count, quiet, beta}   4 words
-//   off_wbe:  W by band entries: {byte offset of I[bin] in the wave's image, weight}   2 words each
-//   off_wi:   per bin f: wi_w x {byte offset of G[band] in the wave's G area, weight}  (weight 0 pads)
+//   off_S:    gp[0 .. 128): S[i][j] = gp[64 + j - i] = g[M - i + j], 0 where |j - i| >= M   (psychoacoustic.py:223-228)
+//   off_band: per band j: {first entry, count | first bin << 16, quiet, beta}   4 words
+//   off_wbe:  W by band: the weights of the band's bins first bin, first bin + 1, ...  (a band's bins are contiguous: both
+//             loads of a step have addresses that depend on nothing loaded before)
+//   off_wi:   entry-major: [e < wi_w][bin f] {byte offset of G[band] in the wave's G area, weight}  (weight 0 pads)
 // wave buffer: [N] v2f intensities (c0, c1) | [64] v2f Q | [64] v2f G
 template <int R, int CMODE, bool WANT_T, bool WANT_THR>
-__global__ __launch_bounds__(256) void k_psy_mid(MidArgs a) {
+__global__ __launch_bounds__(256, (R == 8 ? 3 : 4)) void k_psy_mid(MidArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int N = 128 * R;
   constexpr int WAVE_BYTES = 8 * N + 1024;
@@ -76,10 +90,19 @@ __global__ __launch_bounds__(256) void k_psy_mid(MidArgs a) {
       reinterpret_cast<uint4*>(img)[i] = reinterpret_cast<const uint4*>(a.img)[i];
     __syncthreads();
   }
-  const long long task = (long long)blockIdx.x * nw + wave;
-  if (task >= a.ntasks) return;
   char* buf = smem + (size_t)a.img_words * 4 + (size_t)wave * WAVE_BYTES;
   const int C = a.C, M = a.M;
+  // the lane's column of the spreading matrix, S[i][lane] = gp[64 + lane - i], in registers for all the wave's frames
+  // (the product below always runs over 64 rows: rows beyond the M bands meet Q_i = 0, lanes beyond them are not read)
+  v2f Scol[32];   // (S[2 i][lane], S[2 i + 1][lane])
+  if (WANT_THR) {
+    const float* gp = reinterpret_cast<const float*>(img + a.off_S) + 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) Scol[i] = v2f{gp[-2 * i], gp[-2 * i - 1]};
+  }
+  long long task = (long long)blockIdx.x * nw * a.T + wave;
+  for (int tt = 0; tt < a.T && task < a.ntasks; ++tt, task += nw) {   // (no workgroup barrier inside)
+  wave_sync();   // the previous frame's reads of the wave's buffers are done
   const int f = (int)(task % a.F);
   const long long p = task / a.F;
   // the two signals of the wave: stereo = the two channels of clip p; mono = clips 2 p and 2 p + 1
@@ -136,7 +159,7 @@ __global__ __launch_bounds__(256) void k_psy_mid(MidArgs a) {
     t.x = a.t_in[t0];
     t.y = has1 ? a.t_in[t1] : 0.f;
   }
-  if (!WANT_THR) return;
+  if (!WANT_THR) continue;
 
   // intensities in natural order: bin f at byte 8 f (c0, c1)
 #pragma unroll
@@ -150,32 +173,31 @@ __global__ __launch_bounds__(256) void k_psy_mid(MidArgs a) {
     const uint4 bw = reinterpret_cast<const uint4*>(band)[lane];
     quiet = __uint_as_float(bw.z);
     beta = __uint_as_float(bw.w);
-    const uint2* e = reinterpret_cast<const uint2*>(img + a.off_wbe) + bw.x;
+    const float* wt = reinterpret_cast<const float*>(img + a.off_wbe) + bw.x;
+    const v2f* Ib = reinterpret_cast<const v2f*>(buf) + (bw.y >> 16);
     v2f P0 = {0.f, 0.f}, P1 = {0.f, 0.f};
-    const int cnt = (int)bw.y;
+    const int cnt = (int)(bw.y & 0xffffu);
     int k = 0;
+#pragma unroll 4
     for (; k + 1 < cnt; k += 2) {
-      const uint2 e0 = e[k], e1 = e[k + 1];
-      P0 += *reinterpret_cast<const v2f*>(buf + e0.x) * __uint_as_float(e0.y);
-      P1 += *reinterpret_cast<const v2f*>(buf + e1.x) * __uint_as_float(e1.y);
+      P0 += Ib[k] * wt[k];
+      P1 += Ib[k + 1] * wt[k + 1];
     }
-    if (k < cnt) {
-      const uint2 e0 = e[k];
-      P0 += *reinterpret_cast<const v2f*>(buf + e0.x) * __uint_as_float(e0.y);
-    }
+    if (k < cnt) P0 += Ib[k] * wt[k];
     Qb[lane] = exp2v(a.alpha * log2v(maxv(P0 + P1, kEps)));   // max(eps, P)^alpha  (:206)
+  } else {
+    Qb[lane] = v2f{0.f, 0.f};
   }
   wave_sync();
-  if (lane < M) {   // sum_i Q_i S[i, j], offset factor outside the sum  (:185-208)
-    const float* S = reinterpret_cast<const float*>(img + a.off_S) + lane;
+  {   // sum_i Q_i S[i, j], offset factor outside the sum  (:185-208); even rows into acc0, odd rows into acc1
     v2f acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
-    int i = 0;
-    for (; i + 1 < M; i += 2) {
+#pragma unroll
+    for (int i = 0; i < 64; i += 2) {
       const v4f qq = *reinterpret_cast<const v4f*>(Qb + i);   // Q_i, Q_{i+1} (broadcast read)
-      acc0 += v2f{qq.x, qq.y} * S[(size_t)i * M];
-      acc1 += v2f{qq.z, qq.w} * S[(size_t)(i + 1) * M];
+      pk_fma_lo(acc0, v2f{qq.x, qq.y}, Scol[i / 2]);
+      pk_fma_hi(acc1, v2f{qq.z, qq.w}, Scol[i / 2]);
+      if ((i & 14) == 14) __builtin_amdgcn_sched_barrier(0);   // eight broadcast reads in flight at a time, not thirty-two
     }
-    if (i < M) acc0 += Qb[i] * S[(size_t)i * M];
     const v2f offset = (1.0f - a.drown) * (t * beta + 9.0f * t + 5.5f);
     const v2f fac = exp2v(offset * (-a.alpha * 0.33219280948873623f));                 // 10^(-alpha O / 10)
     const v2f T = exp2v(a.inv_alpha * log2v(maxv(fac * (acc0 + acc1), kEps)));          // (:208)
@@ -183,19 +205,17 @@ __global__ __launch_bounds__(256) void k_psy_mid(MidArgs a) {
   }
   wave_sync();
   // thr_f = sqrt(max(eps, sum_j G_j W_inv[j, f]))  (:330-331)
-  const uint2* wi = reinterpret_cast<const uint2*>(img + a.off_wi);
+  const uint4* wi = reinterpret_cast<const uint4*>(img + a.off_wi);   // [e][granule q]: the entries of bins 2 q, 2 q + 1
   const int W = a.wi_w;
   v4f th[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) {
     const int q = 64 * i + lane;
     v2f s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
-    const uint2* r0 = wi + (size_t)(2 * q) * W;
-    const uint2* r1 = r0 + W;
     for (int e = 0; e < W; ++e) {
-      const uint2 a0 = r0[e], a1 = r1[e];
-      s0 += *reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(Gb) + a0.x) * __uint_as_float(a0.y);
-      s1 += *reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(Gb) + a1.x) * __uint_as_float(a1.y);
+      const uint4 en = wi[(size_t)e * (N / 2) + q];
+      s0 += *reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(Gb) + en.x) * __uint_as_float(en.y);
+      s1 += *reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(Gb) + en.z) * __uint_as_float(en.w);
     }
     s0 = maxv(s0, kEps);
     s1 = maxv(s1, kEps);
@@ -212,6 +232,7 @@ __global__ __launch_bounds__(256) void k_psy_mid(MidArgs a) {
       for (int i = 0; i < R; ++i) reinterpret_cast<v2f*>(a.thr + o1)[64 * i + lane] = v2f{th[i].y, th[i].w};
     }
   }
+  }   // frames of the wave
 }
 
 struct MidLayout {
@@ -229,32 +250,50 @@ bool build_mid(const ac_psy_plan* p, std::vector<uint32_t>* out, MidLayout* lay)
   MidLayout L;
   L.wi_w = wi.max_row;
   L.off_S = 0;
-  L.off_band = L.off_S + M * M;
+  L.off_band = L.off_S + 128;
   L.off_band = (L.off_band + 3) / 4 * 4;                  // 16-byte aligned rows of four words
   L.off_wbe = L.off_band + 4 * 64;
-  L.off_wi = L.off_wbe + 2 * (int)wb.idx.size();
-  L.off_wi = (L.off_wi + 1) / 2 * 2;
+  // a band's weights cover the run of bins from its first to its last non-zero (zeros in between, if any, stay zeros)
+  std::vector<int> first(M, 0), count(M, 0), start(M, 0);
+  int total = 0;
+  for (int j = 0; j < M; ++j) {
+    if (wb.ptr[j + 1] > wb.ptr[j]) {
+      int lo = N, hi = -1;
+      for (int e = wb.ptr[j]; e < wb.ptr[j + 1]; ++e) {
+        lo = std::min(lo, (int)wb.idx[e]);
+        hi = std::max(hi, (int)wb.idx[e]);
+      }
+      first[j] = lo;
+      count[j] = hi - lo + 1;
+    }
+    start[j] = total;
+    total += count[j];
+  }
+  if (total > 4 * N) return false;   // (bands that each span most of the spectrum: not a Bark mapping; other tiers)
+  L.off_wi = L.off_wbe + total;
+  L.off_wi = (L.off_wi + 3) / 4 * 4;                      // 16-byte reads: the entries of two adjacent bins
   L.words = L.off_wi + 2 * N * L.wi_w;
   L.words = (L.words + 3) / 4 * 4;
   std::vector<uint32_t> w((size_t)L.words, 0u);
   auto putf = [&](int i, float v) { uint32_t u; memcpy(&u, &v, 4); w[(size_t)i] = u; };
+  // S is Toeplitz by construction; the kernel reads it through the prototype.  Refuse anything else.
+  if ((int)t.g.size() != 2 * M) return false;
   for (int i = 0; i < M; ++i)
-    for (int j = 0; j < M; ++j) putf(L.off_S + i * M + j, (float)t.S[(size_t)i * M + j]);
+    for (int j = 0; j < M; ++j)
+      if ((float)t.S[(size_t)i * M + j] != (float)t.g[(size_t)(M - i + j)]) return false;
+  for (int d = -(M - 1); d <= M - 1; ++d) putf(L.off_S + 64 + d, (float)t.g[(size_t)(M + d)]);
   for (int j = 0; j < M; ++j) {
-    w[(size_t)L.off_band + 4 * j + 0] = (uint32_t)wb.ptr[j];
-    w[(size_t)L.off_band + 4 * j + 1] = (uint32_t)(wb.ptr[j + 1] - wb.ptr[j]);
+    w[(size_t)L.off_band + 4 * j + 0] = (uint32_t)start[j];
+    w[(size_t)L.off_band + 4 * j + 1] = (uint32_t)count[j] | ((uint32_t)first[j] << 16);
     putf(L.off_band + 4 * j + 2, (float)t.quiet[j]);
     putf(L.off_band + 4 * j + 3, t.beta[j]);
-    for (int e = wb.ptr[j]; e < wb.ptr[j + 1]; ++e) {
-      w[(size_t)L.off_wbe + 2 * e] = (uint32_t)(8 * wb.idx[e]);          // byte offset of I[bin] (v2f per bin)
-      putf(L.off_wbe + 2 * e + 1, wb.val[e]);
-    }
+    for (int e = wb.ptr[j]; e < wb.ptr[j + 1]; ++e) putf(L.off_wbe + start[j] + (wb.idx[e] - first[j]), wb.val[e]);
   }
   for (int f = 0; f < N; ++f) {
     int k = 0;
     for (int e = wi.ptr[f]; e < wi.ptr[f + 1]; ++e, ++k) {
-      w[(size_t)L.off_wi + 2 * ((size_t)f * L.wi_w + k)] = (uint32_t)(8 * wi.idx[e]);   // byte offset of G[band]
-      putf(L.off_wi + 2 * (f * L.wi_w + k) + 1, wi.val[e]);
+      w[(size_t)L.off_wi + 2 * ((size_t)k * N + f)] = (uint32_t)(8 * wi.idx[e]);   // byte offset of G[band]
+      putf(L.off_wi + 2 * (k * N + f) + 1, wi.val[e]);
     }
   }
   if (out) *out = w;
@@ -335,7 +374,19 @@ int launch_psy_mid(const ac_psy_plan* p, const float* X, const float* t_in, floa
     set_error("internal: masking-model tables too large for LDS (%zu bytes)", lds);
     return AC_EUNSUPPORTED;
   }
-  const long long g = (a.ntasks + nw - 1) / nw;
+  // frames per wave: as many as keep every CU supplied with a few workgroups (the image copy is paid per workgroup)
+  int cus = 256;
+  {
+    hipDeviceProp_t prop;
+    static int cached = 0;
+    if (!cached && hipGetDeviceProperties(&prop, p->device) == hipSuccess) cached = prop.multiProcessorCount;
+    if (cached) cus = cached;
+  }
+  int T = want_thr ? 8 : 1;
+  while (T > 1 && a.ntasks < (long long)nw * T * cus * 6) T >>= 1;
+  a.T = T;
+  const long long per = (long long)nw * T;
+  const long long g = (a.ntasks + per - 1) / per;
   if (g > 2147483647ll) {
     set_error("problem too large for one launch (%lld workgroups)", g);
     return AC_EINVAL;

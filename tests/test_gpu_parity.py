@@ -466,6 +466,33 @@ def test_stream_run_duplex_equals_the_chain(N, C, k, K, masking):
     st.close(), ref.close(), st2.close()
 
 
+def test_encode_decode_under_graph_capture():
+    """The entry points only enqueue kernels on the caller's stream (no allocation, no synchronisation once the plans
+    exist), so an encode + decode pair is capturable into a HIP graph; a replay on new input gives the eager result."""
+    N, B, K, C = 1024, 4, 12, 2
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.empty(B, K * N, C, device="cuda").uniform_(-1, 1, generator=g)
+    X, t = torch.empty(B, K + 1, N, C, device="cuda"), torch.empty(B, K + 1, 1, C, device="cuda")
+    thr, xh = torch.empty_like(X), torch.empty(B, (K + 2) * N, C, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                      # plans are built here, outside the capture
+        codec.encode_into(x, X, t, thr)
+        codec.decode_into(X, xh)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        codec.encode_into(x, X, t, thr, drown=0.3)
+        codec.decode_into(X, xh)
+    x.uniform_(-1, 1, generator=g)                     # new input in the captured buffers
+    graph.replay()
+    torch.cuda.synchronize()
+    Xe, te, thre = codec.encode(x, drown=0.3)
+    assert torch.equal(X, Xe) and torch.equal(t, te) and torch.equal(thr, thre) and torch.equal(xh, codec.decode(Xe))
+    assert float((xh[:, N:-N] - x).abs().max()) <= LSB
+
+
 def test_full_size_properties(path):
     """BASELINE config 2 shape (B=256 stereo, K=46, N=1024): size-independent properties only."""
     if path == "generic":
