@@ -145,9 +145,10 @@ __global__ __launch_bounds__(kThreads) void k_inv_generic(const TIO* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// Middle tier: any power-of-two filters_n from 16 to 4096 that the wave-level kernels do not serve (and any window,
-// the rectangular one included).  Same O(N) fold / unfold as above, the DCT-IV as an N/2-point complex FFT in LDS
-// (radix-2 Stockham, fp32), one workgroup per (signal, frame / block).
+// Middle tier: any filters_n from 16 to 4096 whose half is 5-smooth (2^a 3^b 5^c: the powers of two, and the 120 / 240 /
+// 480 / 960 and 192 / 576 families of the speech and music codecs) that the wave-level kernels do not serve, with any
+// window, the rectangular one included.  Same O(N) fold / unfold as above, the DCT-IV as an N/2-point complex FFT in LDS
+// (mixed-radix Stockham -- radix 4 while it divides, then 2, 3, 5 -- fp32), one group of threads per (signal, frame).
 // ------------------------------------------------------------------------------------------------
 // Two channels of a clip ride side by side (c0, c0 + 1; the last one alone when C is odd): every value is a float2
 // over the pair, a complex value a cpair.
@@ -196,9 +197,27 @@ __device__ __forceinline__ void st2(bf16_t* p, float2 v, int C, bool has1) {
   if (has1) p[1] = (bf16_t)v.y;
 }
 
+__device__ __forceinline__ cpair cadd(cpair a, cpair b) {
+  return {make_float2(a.re.x + b.re.x, a.re.y + b.re.y), make_float2(a.im.x + b.im.x, a.im.y + b.im.y)};
+}
+__device__ __forceinline__ cpair csub(cpair a, cpair b) {
+  return {make_float2(a.re.x - b.re.x, a.re.y - b.re.y), make_float2(a.im.x - b.im.x, a.im.y - b.im.y)};
+}
+__device__ __forceinline__ cpair cscale(cpair a, float s) {
+  return {make_float2(a.re.x * s, a.re.y * s), make_float2(a.im.x * s, a.im.y * s)};
+}
+__device__ __forceinline__ cpair cmul_mi(cpair a) {   // a * (-i)
+  return {a.im, make_float2(-a.re.x, -a.re.y)};
+}
+// radix of the next Stockham pass over what is left of the transform length (4 while it divides, then 2, 3, 5)
+static inline __host__ __device__ int next_radix(int rem) { return rem % 4 == 0 ? 4 : rem % 2 == 0 ? 2 : rem % 3 == 0 ? 3 : 5; }
+
 // v[N] (LDS, float2 per entry) -> y[k] = sum_m v[m] cos(pi/N (m + 1/2)(k + 1/2)) written back into v;
-// A, B: N/2 cpairs each (LDS).  Executed by a group of nt threads (tid = index inside the group); every group of the
-// workgroup runs it at the same time on its own buffers (the barriers are workgroup-wide).
+// A, B: N/2 cpairs each (LDS), tw[k] = exp(-2 pi i k / (N/2)), k < N/2.  Executed by a group of nt threads (tid = index
+// inside the group); every group of the workgroup runs it at the same time on its own buffers (the barriers are
+// workgroup-wide).  Stockham autosort, decimation in time: a pass of radix r joins r transforms of length L into one of
+// length r L -- butterfly j = (p, q), q < L: x_s = src[q + L (p + s m)] W_{rL}^{q s}, m = H / (r L);
+// dst[q + L (r p + t)] = sum_s x_s w_r^{s t}.
 __device__ void dct4_lds(float2* v, cpair* A, cpair* B, const float* __restrict__ ctab, const float2* __restrict__ tw,
                          int N, int tid, int nt) {
   const int H = N >> 1;
@@ -211,24 +230,55 @@ __device__ void dct4_lds(float2* v, cpair* A, cpair* B, const float* __restrict_
   __syncthreads();
   cpair* src = A;
   cpair* dst = B;
-  for (int L = 1; L < H; L <<= 1) {
-    const int m = H / (2 * L);   // exp(-2 pi i q / (2 L)) = exp(-2 pi i (q m) / H) = tw[q m]
-    for (int j = tid; j < H / 2; j += nt) {
+  int rem = H;
+  for (int L = 1; L < H;) {
+    const int r = next_radix(rem);
+    const int m = H / (r * L);   // exp(-2 pi i q s / (r L)) = exp(-2 pi i (q s m) / H) = tw[q s m]
+    for (int j = tid; j < H / r; j += nt) {
       const int p = j / L, q = j - p * L;
-      const cpair c0 = src[q + L * p];
-      const cpair c1 = cmulw(src[q + L * (p + m)], tw[q * m]);
-      cpair s, d;
-      s.re = make_float2(c0.re.x + c1.re.x, c0.re.y + c1.re.y);
-      s.im = make_float2(c0.im.x + c1.im.x, c0.im.y + c1.im.y);
-      d.re = make_float2(c0.re.x - c1.re.x, c0.re.y - c1.re.y);
-      d.im = make_float2(c0.im.x - c1.im.x, c0.im.y - c1.im.y);
-      dst[q + 2 * L * p] = s;
-      dst[q + 2 * L * p + L] = d;
+      const cpair* in = src + q + L * p;
+      cpair* out = dst + q + L * r * p;
+      const cpair x0 = in[0];
+      if (r == 4) {
+        const cpair x1 = cmulw(in[L * m], tw[q * m]), x2 = cmulw(in[2 * L * m], tw[2 * q * m]);
+        const cpair x3 = cmulw(in[3 * L * m], tw[3 * q * m]);
+        const cpair t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = cmul_mi(csub(x1, x3));
+        out[0] = cadd(t0, t2);
+        out[L] = cadd(t1, t3);
+        out[2 * L] = csub(t0, t2);
+        out[3 * L] = csub(t1, t3);
+      } else if (r == 2) {
+        const cpair x1 = cmulw(in[L * m], tw[q * m]);
+        out[0] = cadd(x0, x1);
+        out[L] = csub(x0, x1);
+      } else if (r == 3) {
+        const cpair x1 = cmulw(in[L * m], tw[q * m]), x2 = cmulw(in[2 * L * m], tw[2 * q * m]);
+        const cpair sm = cadd(x1, x2), m1 = csub(x0, cscale(sm, 0.5f));
+        const cpair m2 = cscale(cmul_mi(csub(x1, x2)), 0.86602540378443865f);   // -i sin(2 pi / 3) (x1 - x2)
+        out[0] = cadd(x0, sm);
+        out[L] = cadd(m1, m2);
+        out[2 * L] = csub(m1, m2);
+      } else {   // 5
+        const cpair x1 = cmulw(in[L * m], tw[q * m]), x2 = cmulw(in[2 * L * m], tw[2 * q * m]);
+        const cpair x3 = cmulw(in[3 * L * m], tw[3 * q * m]), x4 = cmulw(in[4 * L * m], tw[4 * q * m]);
+        const cpair a1 = cadd(x1, x4), a2 = cadd(x2, x3), b1 = csub(x1, x4), b2 = csub(x2, x3);
+        constexpr float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;   // cos(2 pi / 5), cos(4 pi / 5)
+        constexpr float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;    // sin(2 pi / 5), sin(4 pi / 5)
+        const cpair e1 = cadd(x0, cadd(cscale(a1, c1), cscale(a2, c2))), e2 = cadd(x0, cadd(cscale(a1, c2), cscale(a2, c1)));
+        const cpair d1 = cmul_mi(cadd(cscale(b1, s1), cscale(b2, s2))), d2 = cmul_mi(csub(cscale(b1, s2), cscale(b2, s1)));
+        out[0] = cadd(x0, cadd(a1, a2));
+        out[L] = cadd(e1, d1);
+        out[2 * L] = cadd(e2, d2);
+        out[3 * L] = csub(e2, d2);
+        out[4 * L] = csub(e1, d1);
+      }
     }
     __syncthreads();
     cpair* t = src;
     src = dst;
     dst = t;
+    L *= r;
+    rem /= r;
   }
   for (int k = tid; k < H; k += nt) {
     const cpair r = cmulw(src[k], cis_neg(ctab, 4 * k, N));   // exp(-i pi k / N)
@@ -238,16 +288,18 @@ __device__ void dct4_lds(float2* v, cpair* A, cpair* B, const float* __restrict_
   __syncthreads();
 }
 
-// the FFT's twiddles exp(-2 pi i k / (N/2)), k < N/4, once per workgroup into LDS (every thread takes part; the caller
+// the FFT's twiddles exp(-2 pi i k / (N/2)), k < N/2, once per workgroup into LDS (every thread takes part; the caller
 // synchronises before the first use)
 __device__ __forceinline__ void fill_twiddles(float2* tw, const float* __restrict__ ctab, int N) {
-  for (int k = threadIdx.x; k < N / 4; k += kThreads) tw[k] = cis_neg(ctab, 16 * k, N);   // exp(-i pi (16 k) / (4 N))
+  for (int k = threadIdx.x; k < N / 2; k += kThreads) tw[k] = cis_neg(ctab, 16 * k, N);   // exp(-i pi (16 k) / (4 N))
 }
 
-// threads per group: enough for the N/4 butterflies of a stage, at least one wave; a workgroup holds kThreads / nt groups
+// threads per group: a power of two (a workgroup holds kThreads / nt groups) near the N/8 butterflies of a radix-4
+// stage, at least one wave
 static inline __host__ __device__ int lds_group_threads(int N) {
-  const int want = N / 4;
-  return want >= kThreads ? kThreads : (want < 64 ? 64 : want);
+  int nt = 64;
+  while (nt < kThreads && nt < N / 8) nt <<= 1;
+  return nt;
 }
 
 // one group per (clip, channel pair, frame)
@@ -259,7 +311,7 @@ __global__ __launch_bounds__(kThreads) void k_fwd_lds(const TIO* __restrict__ x,
                                                       int N, long long ntasks) {
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int nt = lds_group_threads(N), grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
-  float2* tw = reinterpret_cast<float2*>(smem + (size_t)(kThreads / nt) * 6 * N);   // [N/4] behind the groups' buffers
+  float2* tw = reinterpret_cast<float2*>(smem + (size_t)(kThreads / nt) * 6 * N);   // [N/2] behind the groups' buffers
   fill_twiddles(tw, ctab, N);
   float* base = smem + (size_t)grp * 6 * N;
   float2* v = reinterpret_cast<float2*>(base);             // [N]
@@ -315,7 +367,7 @@ __global__ __launch_bounds__(kThreads) void k_inv_lds(const TIO* __restrict__ X,
                                                       long long ntasks) {
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int nt = lds_group_threads(N), grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
-  float2* tw = reinterpret_cast<float2*>(smem + (size_t)(kThreads / nt) * 7 * N);   // [N/4] behind the groups' buffers
+  float2* tw = reinterpret_cast<float2*>(smem + (size_t)(kThreads / nt) * 7 * N);   // [N/2] behind the groups' buffers
   fill_twiddles(tw, ctab, N);
   float* base = smem + (size_t)grp * 7 * N;
   float2* v = reinterpret_cast<float2*>(base);             // [N]
@@ -717,8 +769,14 @@ __global__ __launch_bounds__(256) void k_add_noise_typed(const TIO* __restrict__
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-// power of two from 16 to 4096 (7 N floats of LDS <= 112 KB of the CU's 160 KB): the LDS-FFT middle tier applies
-static bool lds_fft_ok(int N) { return N >= 16 && N <= 4096 && (N & (N - 1)) == 0; }
+// even, from 16 to 4096, half of it 5-smooth (8 N floats of LDS <= 128 KB of the CU's 160 KB): the LDS-FFT middle tier applies
+static bool lds_fft_ok(int N) {
+  if (N < 16 || N > 4096 || (N & 1)) return false;
+  int h = N / 2;
+  for (int r : {2, 3, 5})
+    while (h % r == 0) h /= r;
+  return h == 1;
+}
 // dynamic LDS beyond the default 64 KB cap must be requested once per kernel (and per device)
 template <typename K>
 static int allow_lds(K kernel, size_t bytes) {
@@ -745,7 +803,7 @@ int launch_fwd_generic(const ac_mdct_plan* p, const float* x, float* X, const fl
   if (lds_fft_ok(p->N) && !g_force_generic) {
     const int CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const long long ntasks = (long long)B * CP * F;
-    const size_t lds2 = ((size_t)gpw * 6 * p->N + p->N / 2) * sizeof(float);
+    const size_t lds2 = ((size_t)gpw * 6 * p->N + p->N) * sizeof(float);
     const int st2 = allow_lds(k_fwd_lds<float>, lds2);
     if (st2) return st2;
     hipLaunchKernelGGL(k_fwd_lds<float>, dim3((unsigned)((ntasks + gpw - 1) / gpw)), dim3(kThreads), lds2, s, x, X, prev_block,
@@ -771,7 +829,7 @@ int launch_inv_generic(const ac_mdct_plan* p, const float* X, float* x, const fl
     const int seg = 8, CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const int nseg = (per_sig + seg - 1) / seg;
     const long long ntasks = (long long)B * CP * nseg;
-    const size_t lds2 = ((size_t)gpw * 7 * p->N + p->N / 2) * sizeof(float);
+    const size_t lds2 = ((size_t)gpw * 7 * p->N + p->N) * sizeof(float);
     const int st2 = allow_lds(k_inv_lds<float>, lds2);
     if (st2) return st2;
     hipLaunchKernelGGL(k_inv_lds<float>, dim3((unsigned)((ntasks + gpw - 1) / gpw)), dim3(kThreads), lds2, s, X, x, tail_in,
@@ -877,7 +935,7 @@ int launch_add_noise(const float* X, const float* thr, float* out, size_t n, uin
 }
 
 // ---- compute_dtype variants: double = O(N^2) kernels in fp64 with fp64 tables; bfloat16 = bfloat16 tensors, float32
-// arithmetic, the LDS-FFT middle tier for power-of-two filters_n (O(N^2) kernels otherwise) ----
+// arithmetic, the LDS-FFT middle tier where filters_n / 2 is 5-smooth (O(N^2) kernels otherwise) ----
 int launch_fwd_f64(const ac_mdct_plan* p, const double* x, double* X, int B, int Kin, int F, int C, hipStream_t s) {
   const long long nwg = (long long)B * C * F;
   const int st = check_grid(nwg);
@@ -909,7 +967,7 @@ int launch_fwd_bf16(const ac_mdct_plan* p, const bf16_t* x, bf16_t* X, int B, in
   if (lds_fft_ok(p->N) && !g_force_generic) {
     const int CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const long long ntasks = (long long)B * CP * F;
-    const size_t lds2 = ((size_t)gpw * 6 * p->N + p->N / 2) * sizeof(float);
+    const size_t lds2 = ((size_t)gpw * 6 * p->N + p->N) * sizeof(float);
     const int st2 = allow_lds(k_fwd_lds<bf16_t>, lds2);
     if (st2) return st2;
     hipLaunchKernelGGL(k_fwd_lds<bf16_t>, dim3((unsigned)((ntasks + gpw - 1) / gpw)), dim3(kThreads), lds2, s, x, X,
@@ -933,7 +991,7 @@ int launch_inv_bf16(const ac_mdct_plan* p, const bf16_t* X, bf16_t* x, int B, in
     const int seg = 8, CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const int nseg = (nblk + seg - 1) / seg;
     const long long ntasks = (long long)B * CP * nseg;
-    const size_t lds2 = ((size_t)gpw * 7 * p->N + p->N / 2) * sizeof(float);
+    const size_t lds2 = ((size_t)gpw * 7 * p->N + p->N) * sizeof(float);
     const int st2 = allow_lds(k_inv_lds<bf16_t>, lds2);
     if (st2) return st2;
     hipLaunchKernelGGL(k_inv_lds<bf16_t>, dim3((unsigned)((ntasks + gpw - 1) / gpw)), dim3(kThreads), lds2, s, X, x,

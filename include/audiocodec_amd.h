@@ -109,7 +109,7 @@ int ac_psy_plan_create_ex(int N, int M, double sample_rate, double alpha, int de
 int ac_psy_plan_spreading(const ac_psy_plan* plan);
 
 /* 1 when the plan runs the wave-level kernels (filters_n 1024 / 2048, Princen-Bradley window; 64 Bark bands), 0 when it
- * runs the LDS-FFT middle tier (power-of-two filters_n from 16 to 4096) or the generic O(N^2) kernels. */
+ * runs the LDS-FFT middle tier (filters_n from 16 to 4096 with a 5-smooth half: 2^a 3^b 5^c) or the generic O(N^2) kernels. */
 int ac_mdct_plan_is_fast(const ac_mdct_plan* plan);
 int ac_psy_plan_is_fast(const ac_psy_plan* plan);
 /* Which kernels serve the masking model of a plan: 2 = the wave-level kernels fused into the encode (filter_bands_n 1024 /
@@ -242,7 +242,7 @@ int ac_probe_placement(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const f
  *   AC_BF16  bfloat16 tensors (half the bytes of float32), float32 arithmetic inside: the wave-level kernels for mono
  *            and stereo at filters_n 1024 / 2048 (conversion fused into their loads and stores; the fused encode rounds
  *            X and the tonality to bfloat16 before the masking model uses them, so fused and un-fused calls agree),
- *            else the LDS-FFT kernels for power-of-two filters_n from 16 to 4096 and the O(N^2) kernels; results carry
+ *            else the LDS-FFT kernels for filters_n from 16 to 4096 with a 5-smooth half and the O(N^2) kernels; results carry
  *            bfloat16's output rounding (2^-9 relative) -- more accurate than the reference's all-bfloat16 op sequence.
  * No streaming state and no backward passes for AC_F64 / AC_BF16.
  * ---------------------------------------------------------------------------------------- */

@@ -95,7 +95,11 @@ def test_shape_like_reference(path):
 @pytest.mark.parametrize("B,K,C,N", [(3, 5, 2, 1024), (2, 3, 1, 1024), (2, 4, 3, 1024), (1, 1, 2, 1024),
                                      (5, 7, 2, 256), (2, 2, 5, 64), (1, 3, 2, 2048), (2, 37, 2, 1024),
                                      (3, 9, 2, 2048), (2, 5, 1, 2048), (1, 6, 3, 2048), (2, 3, 4, 1024), (1, 2, 5, 1024),
-                                     (3, 4, 1, 1024), (2, 3, 2, 512), (1, 5, 1, 4096), (2, 2, 3, 32)])
+                                     (3, 4, 1, 1024), (2, 3, 2, 512), (1, 5, 1, 4096), (2, 2, 3, 32),
+                                     # filters_n whose half is 5-smooth: the mixed-radix LDS-FFT tier (Opus / MP3 sizes)
+                                     (2, 5, 2, 960), (3, 4, 1, 480), (2, 7, 2, 240), (1, 9, 3, 120), (2, 3, 2, 576),
+                                     (2, 4, 1, 192), (1, 2, 2, 1920), (1, 2, 2, 3072), (2, 3, 2, 30), (1, 3, 2, 1536),
+                                     (2, 2, 2, 2000), (1, 4, 2, 36)])
 def test_mdct_random_vs_oracle(path, B, K, C, N):
     rng = np.random.default_rng(B * 1000 + K * 10 + C)
     x = rng.uniform(-1, 1, (B, K * N, C)).astype(np.float32)
@@ -328,7 +332,7 @@ def test_db_and_noise(golden, path):
 
 # ---- streaming ------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("N,C,chunks", [(1024, 2, (3, 1, 4, 2)), (256, 1, (2, 2, 5)), (1024, 1, (5, 3)),
+@pytest.mark.parametrize("N,C,chunks", [(1024, 2, (3, 1, 4, 2)), (256, 1, (2, 2, 5)), (1024, 1, (5, 3)), (960, 2, (2, 3, 1)),
                                         (2048, 2, (2, 5, 1)), (128, 2, (3, 9, 1, 4)), (128, 1, (11, 2)), (512, 2, (1, 3, 2)),
                                         (64, 2, (5, 17, 1, 16)), (64, 1, (33, 2))])
 def test_streaming_equals_one_shot(path, N, C, chunks):

@@ -6,6 +6,7 @@
 #   bench_kernel_stats_timed_region.csv   the same trace restricted to the `steps` timed dispatches of each kernel
 #   pmc_encode.txt, pmc_decode.txt   rocprofv3 --pmc, separate passes (tools/pmc.sh)
 #   traffic.json                FETCH_SIZE (doubled: gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE per launch
+#   pmc_short_frames_n256.txt   the same counters for transform / inverse / threshold at filters_n = 256
 #   entry_points.txt            every entry point on bench-sized workloads (tools/entry_points.sh)
 # Copy the directory's files into profiles/rNN afterwards.
 r=${1:-r2}
@@ -70,6 +71,17 @@ json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, to
            "decode": entry(dec, "k_inv_fast<8, 0, 4, 0>", 8 * N * frames)}, open(out + "/traffic.json", "w"), indent=1)
 print(open(out + "/traffic.json").read())
 PY
+# the several-frames-per-wave kernels and the masking model for general band layouts at filters_n = 256: counters + traffic
+{
+  for what in transform inverse psy; do
+    N=256 tools/pmc.sh $what ${r}_n256_$what > /dev/null 2>&1
+    echo "== filters_n = 256, B = 256 stereo, K = 1872: $what (algorithmic bytes per launch: $(python3 -c "
+f = 256 * 2 * 1872
+print({'transform': 2048 * f, 'inverse': 2048 * f, 'psy': 2052 * f}['$what'])"); FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE to be doubled on gfx950)"
+    cat gpurun_out/pmc_${r}_n256_$what.txt
+  done
+} > $out/pmc_short_frames_n256.txt
+echo "pmc short frames done"
 tools/entry_points.sh > /dev/null 2>&1; cp gpurun_out/entry_points.txt $out/entry_points.txt
 echo "entry points done"
 ls -la $out
