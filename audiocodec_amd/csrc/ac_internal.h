@@ -116,7 +116,7 @@ struct ac_psy_plan {
   // fast-path tables (ac_fast.hip)
   float* d_fast = nullptr;
   size_t fast_bytes = 0;
-  // wave-level masking model for general band layouts (ac_psy_mid.hip): filter_bands_n 256 / 512 / 1024, <= 64 bands
+  // wave-level masking model for general band layouts (ac_psy_mid.hip): any even filter_bands_n <= 1024, <= 64 bands
   int mid = 0;
   uint32_t* d_mid = nullptr;
   int mid_words = 0;

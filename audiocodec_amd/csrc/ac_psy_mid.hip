@@ -1,5 +1,6 @@
-// Wave-level masking model for the configurations the fused epilogue of ac_fast.hip does not serve: filter_bands_n 256,
-// 512 or 1024 with any Bark-band count up to 64 and any band layout (a bin may overlap several bands, bands may share
+// Wave-level masking model for the configurations the fused epilogue of ac_fast.hip does not serve: any even
+// filter_bands_n up to 1024 (a frame is up to R = 1, 2, 4 or 8 granule registers per lane, the last ones partly filled
+// when filter_bands_n is not a multiple of 128: 960, 576, 480 ...) with any Bark-band count up to 64 and any band layout (a bin may overlap several bands, bands may share
 // bins freely) -- e.g. the models beside the several-frames-per-wave MDCT kernels (filters_n 256 / 512), where the
 // O(N)-per-workgroup generic kernels ran at 0.5-0.8 TB/s.  gfx950 only.
 //
@@ -68,6 +69,7 @@ struct MidArgs {
   int wi_w;              // entries per bin in the fixed-width W_inv table
   int off_S, off_band, off_wbe, off_wi;   // word offsets inside the image
   float alpha, inv_alpha, drown;
+  float inv_n;           // 1 / N
   long long nsig, ntasks;
 };
 
@@ -81,8 +83,8 @@ struct MidArgs {
 template <int R, int CMODE, bool WANT_T, bool WANT_THR>
 __global__ __launch_bounds__(256, (R == 8 ? 3 : 4)) void k_psy_mid(MidArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int N = 128 * R;
-  constexpr int WAVE_BYTES = 8 * N + 1024;
+  const int N = a.N, half = N >> 1;          // bins per frame (even, <= 128 R), granules per frame
+  const int WAVE_BYTES = 8 * N + 1024;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   uint32_t* img = reinterpret_cast<uint32_t*>(smem);
   if (WANT_THR) {
@@ -112,21 +114,22 @@ __global__ __launch_bounds__(256, (R == 8 ? 3 : 4)) void k_psy_mid(MidArgs a) {
   const size_t o0 = ((size_t)b0 * a.F + (size_t)f) * blk, o1 = ((size_t)b1 * a.F + (size_t)f) * blk;
   const size_t t0 = ((size_t)b0 * a.F + (size_t)f) * C, t1 = CMODE == 0 ? t0 + 1 : ((size_t)b1 * a.F + (size_t)f) * C;
 
-  // granule q = lane + 64 i: (X[2q], X[2q+1]) x (s0, s1)
+  // granule q = lane + 64 i: (X[2q], X[2q+1]) x (s0, s1); granules past the frame (q >= N/2) read as zero
+  auto in = [&](int i) { return R * 128 == N || 64 * i + lane < half; };
   v4f xq[R];
   if (CMODE == 0) {
 #pragma unroll
-    for (int i = 0; i < R; ++i) xq[i] = reinterpret_cast<const v4f*>(a.X + o0)[64 * i + lane];
+    for (int i = 0; i < R; ++i) xq[i] = in(i) ? reinterpret_cast<const v4f*>(a.X + o0)[64 * i + lane] : v4f{0.f, 0.f, 0.f, 0.f};
   } else {
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      const v2f u = reinterpret_cast<const v2f*>(a.X + o0)[64 * i + lane];
+      const v2f u = in(i) ? reinterpret_cast<const v2f*>(a.X + o0)[64 * i + lane] : v2f{0.f, 0.f};
       xq[i] = v4f{u.x, 0.f, u.y, 0.f};
     }
     if (has1) {
 #pragma unroll
       for (int i = 0; i < R; ++i) {
-        const v2f w = reinterpret_cast<const v2f*>(a.X + o1)[64 * i + lane];
+        const v2f w = in(i) ? reinterpret_cast<const v2f*>(a.X + o1)[64 * i + lane] : v2f{0.f, 0.f};
         xq[i].y = w.x;
         xq[i].w = w.y;
       }
@@ -141,14 +144,15 @@ __global__ __launch_bounds__(256, (R == 8 ? 3 : 4)) void k_psy_mid(MidArgs a) {
       asm("" : "+v"(I));   // the squares stay rounded products (see psy_stage)
       const v2f ie = v2f{I.x, I.y}, io = v2f{I.z, I.w};
       ssq += ie + io;
-      slog += log2v(maxv(ie, kEps) * maxv(io, kEps));
+      const v2f lg = log2v(maxv(ie, kEps) * maxv(io, kEps));
+      slog += in(i) ? lg : v2f{0.f, 0.f};
     }
     slog.x = wave_sum(slog.x);
     slog.y = wave_sum(slog.y);
     ssq.x = wave_sum(ssq.x);
     ssq.y = wave_sum(ssq.y);
-    const v2f am = ssq * (1.0f / N) + kEps;
-    const v2f sfm = 3.0102999566398120f * (slog * (1.0f / N) - log2v(am));
+    const v2f am = ssq * a.inv_n + kEps;
+    const v2f sfm = 3.0102999566398120f * (slog * a.inv_n - log2v(am));
     const v2f tt = sfm * (-1.0f / 60.0f);
     t = v2f{fminf(tt.x, 1.0f), fminf(tt.y, 1.0f)};
     if (lane == 0) {
@@ -163,7 +167,8 @@ __global__ __launch_bounds__(256, (R == 8 ? 3 : 4)) void k_psy_mid(MidArgs a) {
 
   // intensities in natural order: bin f at byte 8 f (c0, c1)
 #pragma unroll
-  for (int i = 0; i < R; ++i) *reinterpret_cast<v4f*>(buf + 16 * (64 * i + lane)) = xq[i] * xq[i];
+  for (int i = 0; i < R; ++i)
+    if (in(i)) *reinterpret_cast<v4f*>(buf + 16 * (64 * i + lane)) = xq[i] * xq[i];
   wave_sync();
   v2f* Qb = reinterpret_cast<v2f*>(buf + 8 * N);
   v2f* Gb = Qb + 64;
@@ -212,8 +217,8 @@ __global__ __launch_bounds__(256, (R == 8 ? 3 : 4)) void k_psy_mid(MidArgs a) {
   for (int i = 0; i < R; ++i) {
     const int q = 64 * i + lane;
     v2f s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
-    for (int e = 0; e < W; ++e) {
-      const uint4 en = wi[(size_t)e * (N / 2) + q];
+    for (int e = 0; e < W && in(i); ++e) {
+      const uint4 en = wi[(size_t)e * half + q];
       s0 += *reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(Gb) + en.x) * __uint_as_float(en.y);
       s1 += *reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(Gb) + en.z) * __uint_as_float(en.w);
     }
@@ -223,13 +228,16 @@ __global__ __launch_bounds__(256, (R == 8 ? 3 : 4)) void k_psy_mid(MidArgs a) {
   }
   if (CMODE == 0) {
 #pragma unroll
-    for (int i = 0; i < R; ++i) __builtin_nontemporal_store(th[i], reinterpret_cast<v4f*>(a.thr + o0) + 64 * i + lane);
+    for (int i = 0; i < R; ++i)
+      if (in(i)) __builtin_nontemporal_store(th[i], reinterpret_cast<v4f*>(a.thr + o0) + 64 * i + lane);
   } else {
 #pragma unroll
-    for (int i = 0; i < R; ++i) reinterpret_cast<v2f*>(a.thr + o0)[64 * i + lane] = v2f{th[i].x, th[i].z};
+    for (int i = 0; i < R; ++i)
+      if (in(i)) reinterpret_cast<v2f*>(a.thr + o0)[64 * i + lane] = v2f{th[i].x, th[i].z};
     if (has1) {
 #pragma unroll
-      for (int i = 0; i < R; ++i) reinterpret_cast<v2f*>(a.thr + o1)[64 * i + lane] = v2f{th[i].y, th[i].w};
+      for (int i = 0; i < R; ++i)
+        if (in(i)) reinterpret_cast<v2f*>(a.thr + o1)[64 * i + lane] = v2f{th[i].y, th[i].w};
     }
   }
   }   // frames of the wave
@@ -242,7 +250,7 @@ struct MidLayout {
 bool build_mid(const ac_psy_plan* p, std::vector<uint32_t>* out, MidLayout* lay) {
   const PsyTables& t = p->host;
   const int N = t.N, M = t.M;
-  if (!(N == 256 || N == 512 || N == 1024) || M < 1 || M > 64) return false;
+  if (N < 2 || N > 1024 || (N & 1) || M < 1 || M > 64) return false;
   SparseRows wb, wi;
   w_by_band(t, wb);
   winv_by_bin(t, wi);
@@ -363,6 +371,7 @@ int launch_psy_mid(const ac_psy_plan* p, const float* X, const float* t_in, floa
   a.alpha = (float)p->alpha;
   a.inv_alpha = (float)(1.0 / p->alpha);
   a.drown = drown;
+  a.inv_n = 1.0f / (float)p->N;
   a.nsig = (long long)B * C;
   a.ntasks = ((C == 2) ? (long long)B : (a.nsig + 1) / 2) * F;
   const bool want_t = t_out != nullptr, want_thr = thr != nullptr;
@@ -393,11 +402,13 @@ int launch_psy_mid(const ac_psy_plan* p, const float* X, const float* t_in, floa
   }
   const unsigned grid = (unsigned)g;
   int st;
-  const int R = p->N / 128;
-  if (C == 2) st = R == 2 ? launch_mid_R<2, 0>(a, want_t, want_thr, grid, nw, lds, s)
+  const int R = p->N <= 128 ? 1 : p->N <= 256 ? 2 : p->N <= 512 ? 4 : 8;   // granule registers per lane
+  if (C == 2) st = R == 1 ? launch_mid_R<1, 0>(a, want_t, want_thr, grid, nw, lds, s)
+                 : R == 2 ? launch_mid_R<2, 0>(a, want_t, want_thr, grid, nw, lds, s)
                  : R == 4 ? launch_mid_R<4, 0>(a, want_t, want_thr, grid, nw, lds, s)
                           : launch_mid_R<8, 0>(a, want_t, want_thr, grid, nw, lds, s);
-  else st = R == 2 ? launch_mid_R<2, 2>(a, want_t, want_thr, grid, nw, lds, s)
+  else st = R == 1 ? launch_mid_R<1, 2>(a, want_t, want_thr, grid, nw, lds, s)
+            : R == 2 ? launch_mid_R<2, 2>(a, want_t, want_thr, grid, nw, lds, s)
             : R == 4 ? launch_mid_R<4, 2>(a, want_t, want_thr, grid, nw, lds, s)
                      : launch_mid_R<8, 2>(a, want_t, want_thr, grid, nw, lds, s);
   if (st) return st;

@@ -191,6 +191,29 @@ def main():
             arrs["thr_%s_%s" % (name, tag)] = p.global_masking_threshold(X.astype(dt), t)
     save("psy_64_64_64_cases", **arrs)
 
+    # 5d. sizes beside the powers of two and the masking model on general band layouts: filters_n = 960 (the 20-ms frame
+    #     of a 48 kHz speech / music codec; mixed-radix tier) and 512 (bins overlap three to four Bark bands): transform,
+    #     round trip, tonality and thresholds of interior frames (drown 0 / 0.5), float64 and float32 reference runs
+    rng3 = np.random.default_rng(3)   # (its own stream again)
+    for Nf in (960, 512):
+        xr = rng3.uniform(-1, 1, (1, 5 * Nf, 2)).astype(f32)
+        m64, m32 = mdct(Nf, "vorbis", f64), mdct(Nf, "vorbis", f32)
+        X64 = m64.transform(xr.astype(f64))
+        X32 = m32.transform(xr)
+        arrs = {"x": xr, "X_ref64": X64, "X_ref32": X32, "xhat_ref64": m64.inverse_transform(X64)}
+        env = np.logspace(-5, 0, Nf).reshape(1, 1, Nf, 1)
+        Xe = (rng3.uniform(-1, 1, (1, 2, Nf, 2)) * env).astype(f32)
+        q64, q32 = psy(48000, Nf, 64, f64), psy(48000, Nf, 64, f32)
+        for name, X in (("rand", np.asarray(X32)[:, 1:4]), ("envelope", Xe)):
+            arrs["Xp_" + name] = X
+            for tag, pm, dt in (("ref64", q64, f64), ("ref32", q32, f32)):
+                Xc = X.astype(dt)
+                t = pm.tonality(Xc)
+                arrs["t_%s_%s" % (name, tag)] = t
+                for drown in (0.0, 0.5):
+                    arrs["thr_%s_d%02d_%s" % (name, int(drown * 10), tag)] = pm.global_masking_threshold(Xc, t, drown)
+        save("codec_48000_%d_64_cases" % Nf, **arrs)
+
     # 6. dB utilities (psychoacoustic.py:71-100)
     a = np.array([0.0, 1e-7, 1e-3, 0.5, 1.0, -0.25], dtype=f32)
     save("db_utils", a=a, dB_ref32=p32.amplitude_to_dB(a), dBn_ref32=p32.amplitude_to_dB_norm(a),

@@ -191,6 +191,30 @@ def test_psy_golden(golden, path, cfg, sr, N, M):
             assert thr.min() >= 1e-7 * (1 - 1e-6)
 
 
+@pytest.mark.parametrize("N", [960, 512])
+def test_codec_golden_beside_the_powers_of_two(golden, path, N):
+    """filters_n = 960 (mixed-radix LDS-FFT tier) and 512 (two frames per wave), each with the masking model for general
+    band layouts, against values the reference's own code produced (oracle/gen_golden.py 5d)"""
+    g = golden("codec_48000_%d_64_cases" % N)
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    X = host(codec.mdct.transform(dev(g["x"])))
+    assert rel_peak(X, g["X_ref64"]) <= TOL and rel_l2(X, g["X_ref64"]) <= TOL
+    xh = host(codec.mdct.inverse_transform(dev(g["X_ref32"])))
+    assert np.max(np.abs(xh - g["xhat_ref64"])) <= LSB
+    if path == "auto":
+        assert codec.psy.tier() == 1
+    for name in ("rand", "envelope"):
+        Xp = dev(g["Xp_" + name])
+        t_ref = g["t_%s_ref64" % name]
+        assert tonality_err(host(codec.psy.tonality(Xp)), t_ref) <= 1.0
+        for drown in (0.0, 0.5):
+            thr = host(codec.psy.global_masking_threshold(Xp, dev(t_ref.astype(np.float32)), drown))
+            assert rel_elem(thr, g["thr_%s_d%02d_ref64" % (name, int(drown * 10))]) <= TOL
+    # the codec's encode on the fixture's PCM: same spectrum, thresholds of its own spectrum within the bar of the model
+    Xe, te, thre = codec.encode(dev(g["x"]))
+    assert rel_peak(host(Xe), g["X_ref64"]) <= TOL
+
+
 def test_tonality_like_reference(path):
     """tests/test_psychoacoustic.py:32-65"""
     N = 64
@@ -600,9 +624,14 @@ def test_autograd_of_add_noise_and_db(path):
 
 @pytest.mark.parametrize("sr,N,M,B,F,C", [(48000, 512, 64, 3, 5, 2), (48000, 256, 64, 2, 7, 2), (16000, 512, 64, 3, 4, 1),
                                           (44100, 256, 48, 2, 5, 2), (48000, 1024, 32, 2, 3, 2), (96000, 512, 64, 1, 3, 1),
-                                          (48000, 256, 17, 5, 2, 1), (8000, 512, 64, 2, 3, 2)])
+                                          (48000, 256, 17, 5, 2, 1), (8000, 512, 64, 2, 3, 2),
+                                          # filter_bands_n that are not multiples of 128: partly filled granule registers
+                                          (48000, 960, 64, 2, 4, 2), (48000, 480, 64, 3, 3, 1), (44100, 576, 48, 2, 3, 2),
+                                          (16000, 240, 32, 2, 5, 1), (48000, 120, 20, 3, 4, 2),
+                                          (48000, 30, 8, 2, 2, 1), (48000, 1000, 64, 1, 3, 2)])
 def test_masking_model_general_band_layouts(sr, N, M, B, F, C):
-    """filter_bands_n 256 / 512 (and 1024 with other band counts): the wave-level masking kernels for general band layouts
+    """filter_bands_n other than 1024 / 2048 with 64 bands (256, 512, 960, 480 ...; 1024 with other band counts): the
+    wave-level masking kernels for general band layouts
     (ac_psy_mid.hip; a bin may overlap three or four Bark bands here) against the fp64 oracle, against the generic kernels,
     and the one-launch tonality + threshold of the un-fused encode against the two separate calls"""
     rng = np.random.default_rng(N + M + C)

@@ -160,6 +160,30 @@ def test_psy_cases(golden, cfg, sr, N, M, dt, tag, tol):
                 assert rel_elem(thr, g[k2]) < tol
 
 
+@pytest.mark.parametrize("N", [960, 512])
+def test_codec_cases_beside_the_powers_of_two(golden, N):
+    """filters_n = 960 (no power of two) and 512 (bins overlap several Bark bands): transform, round trip, tonality and
+    thresholds of the reference's own code (oracle/gen_golden.py 5d) against the oracle"""
+    g = golden("codec_48000_%d_64_cases" % N)
+    o = MDCTOracle(N, "vorbis", np.float64)
+    for dense in (False, True):
+        X = o.transform(g["x"].astype(np.float64), dense=dense)
+        assert rel_peak(X, g["X_ref64"]) < REF_SQRT2_REL
+        xh = o.inverse_transform(g["X_ref64"], dense=dense)
+        assert np.max(np.abs(xh - g["xhat_ref64"])) < REF_SQRT2_REL * max(1.0, np.max(np.abs(g["xhat_ref64"])))
+    assert rel_peak(MDCTOracle(N, "vorbis", np.float32).transform(g["x"]), g["X_ref64"]) < 1e-5
+    for dt, tag, tol in ((np.float64, "ref64", 1e-13), (np.float32, "ref32", 3e-6)):
+        p = PsychoOracle(48000, N, 64, compute_dtype=dt)
+        for name in ("rand", "envelope"):
+            X = g["Xp_" + name].astype(dt)
+            t_ref = g["t_%s_%s" % (name, tag)]
+            assert np.max(np.abs(p.tonality(X) - t_ref)) < max(tol, 1e-6 if dt == np.float32 else 0)
+            for drown in (0.0, 0.5):
+                ref = g["thr_%s_d%02d_%s" % (name, int(drown * 10), tag)]
+                for dense in (False, True):
+                    assert rel_elem(p.global_masking_threshold(X, t_ref.astype(dt), drown, dense=dense), ref) < tol
+
+
 def test_probe_values_from_survey(golden):
     """SURVEY.md 8(c) fixture 5: all-zero and single-bin-delta spectra at 48 kHz / 1024 / 64."""
     p = PsychoOracle(48000, 1024, 64)
