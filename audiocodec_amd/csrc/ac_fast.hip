@@ -1384,7 +1384,7 @@ __global__ __launch_bounds__(NW * 64, (IOF != 0 ? 2 : wpe<R, CMODE>())) void k_i
 // first nfwd workgroups run the analysis body, the others the synthesis body.  A chunk of one clip is a few hundred wave
 // tasks: two dependent launches of ~8 us each are latency, not bandwidth, and the two halves are independent.
 template <int R, int CMODE, bool PSY, int NW, int SPREAD>
-__global__ __launch_bounds__(NW * 64, 2) void k_duplex_fast(FwdArgs fa, InvArgs ia, int nfwd) {
+__global__ __launch_bounds__(NW * 64, (CMODE == 0 ? wpe<R, CMODE, PSY, SPREAD>() : 2)) void k_duplex_fast(FwdArgs fa, InvArgs ia, int nfwd) {
   constexpr int LF = fwd_lds_bytes<R, PSY, NW, SPREAD>(), LI = NW * WAVE_LDS + Geo<R>::TAB_LDS;
   __shared__ __attribute__((aligned(16))) char lds[LF > LI ? LF : LI];
   const int b = (int)blockIdx.x;   // (uniform per workgroup: the barriers inside the bodies stay consistent)
@@ -2831,14 +2831,17 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, int iof, con
 
 // ---- streaming duplex: analysis of one chunk and synthesis of another in one launch (k_duplex_fast) ----
 // Served: float32, mono / stereo, filters_n 1024 / 2048, without the masking model or (1024, stereo) with the fused
-// one in its f32 / split-bf16 spreading forms -- and only launches small enough to be latency-bound: at most two waves
-// per SIMD over both halves, where a chunk's two dependent launches cost more than their sum of work.
+// one in its f32 / split-bf16 spreading forms -- and only launches that leave the chip partly idle on their own: up to
+// 256 wave tasks per CU over both halves (64 stereo streams in chunks of 256 blocks: 116 us per chunk against 124 for
+// the chain; one stream: 11.6 against 18 -- a chunk's two dependent launches are latency there).  Beyond that each launch
+// fills the chip by itself.  AC_DUPLEX_MAX_TASKS overrides the limit (tuning hook).
 bool fast_duplex_serves(const ac_mdct_plan* p, const ac_psy_plan* psy, int B, int C, int k_fwd, int k_inv) {
   static const int off = [] { const char* e = getenv("AC_NO_DUPLEX"); return e ? atoi(e) : 0; }();   // tuning hook
   if (off || fast_mdct_frames_per_wave(p->N) != 1 || (C != 1 && C != 2) || k_fwd < 1 || k_inv < 1) return false;
   if (psy && !(p->N == Geo<8>::FN && C == 2 && psy->fast && psy->spread != 1)) return false;
   const long long pairs = (C == 2) ? B : (B + 1) / 2;
-  return pairs * ((long long)k_fwd + k_inv) <= (long long)p->cus * 8;
+  static const long long max_tasks = [] { const char* e = getenv("AC_DUPLEX_MAX_TASKS"); return e ? atoll(e) : 0ll; }();
+  return pairs * ((long long)k_fwd + k_inv) <= (max_tasks > 0 ? max_tasks : (long long)p->cus * 256);
 }
 
 template <int R>

@@ -18,7 +18,7 @@ for f in sorted(glob.glob('gpurun_out/pmc_${tag}_*/*/*_counter_collection.csv'))
     for r in csv.DictReader(open(f)):
         k=r['Kernel_Name']
         if 'ac::' not in k: continue
-        k=k.split('(')[0].replace('void ac::(anonymous namespace)::','')[:40]
+        k=k.replace('void ac::(anonymous namespace)::','').split('(')[0][:48]
         agg[(k, r['VGPR_Count'], r['LDS_Block_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
 for k,v in agg.items():
     print(k, file=out)
