@@ -381,6 +381,8 @@ def other_configs(torch, np, audiocodec_amd, dev, steps, warmup, settle_ms):
                  torch.empty((Bs, k, N, 2), device=dev)) for _ in range(2)]
         xo = [torch.empty((Bs, k * N, 2), device=dev) for _ in range(2)]
         chunks = [xs[:, p * N:(p + k) * N] for p in range(0, Kt - k + 1, k)]
+        if Bs > 1:   # a batch of streams hands over one contiguous buffer per chunk (a slice of [B, K N, C] is not one)
+            chunks = [c.contiguous() for c in chunks]
         s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
         done_a = [torch.cuda.Event() for _ in range(2)]
         done_s = [torch.cuda.Event() for _ in range(2)]
