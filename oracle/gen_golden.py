@@ -192,10 +192,10 @@ def main():
     save("psy_64_64_64_cases", **arrs)
 
     # 5d. sizes beside the powers of two and the masking model on general band layouts: filters_n = 960 (the 20-ms frame
-    #     of a 48 kHz speech / music codec; mixed-radix tier) and 512 (bins overlap three to four Bark bands): transform,
+    #     of a 48 kHz speech / music codec; mixed-radix tier), 512 and 128 (bins overlap several Bark bands): transform,
     #     round trip, tonality and thresholds of interior frames (drown 0 / 0.5), float64 and float32 reference runs
     rng3 = np.random.default_rng(3)   # (its own stream again)
-    for Nf in (960, 512):
+    for Nf in (960, 512, 128):   # (128: eight frames per wave; appended last, the streams of the first two are unchanged)
         xr = rng3.uniform(-1, 1, (1, 5 * Nf, 2)).astype(f32)
         m64, m32 = mdct(Nf, "vorbis", f64), mdct(Nf, "vorbis", f32)
         X64 = m64.transform(xr.astype(f64))

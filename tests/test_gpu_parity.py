@@ -191,7 +191,7 @@ def test_psy_golden(golden, path, cfg, sr, N, M):
             assert thr.min() >= 1e-7 * (1 - 1e-6)
 
 
-@pytest.mark.parametrize("N", [960, 512])
+@pytest.mark.parametrize("N", [960, 512, 128])
 def test_codec_golden_beside_the_powers_of_two(golden, path, N):
     """filters_n = 960 (mixed-radix LDS-FFT tier) and 512 (two frames per wave), each with the masking model for general
     band layouts, against values the reference's own code produced (oracle/gen_golden.py 5d)"""
@@ -1144,6 +1144,46 @@ def test_fuzz_wave_kernels_against_the_generic_kernels():
         assert float(((X - Xg).abs() / peak).max()) <= TOL, tag
         assert float(((Xs - Xg).abs() / peak).max()) <= TOL, tag
         assert tonality_err(t, tg) <= 1.0 and tonality_err(ts, tg) <= 1.0, tag
+        assert float(((thr - thrg).abs() / thrg).max()) <= TOL and float(((thrs - thrg).abs() / thrg).max()) <= TOL, tag
+        assert float((xh - xg).abs().max()) <= 2e-6, tag
+        if K > 0:
+            assert float((xh[:, N:-N] - x).abs().max()) <= LSB, tag
+
+
+def test_fuzz_other_sizes_against_the_generic_kernels():
+    """the same for the other tiers: several frames per wave (filters_n 64 ... 512), the mixed-radix LDS-FFT tier (960,
+    480, 240, 120, 576, 192, 96), the masking model for general band layouts beside them; ragged shapes, block counts
+    that leave lane groups idle, K = 0"""
+    rng = np.random.default_rng(4096)
+    lib = _lib.load()
+    for case in range(48):
+        N = int(rng.choice([64, 128, 256, 512, 960, 480, 240, 120, 576, 192, 96]))
+        wt = str(rng.choice(["vorbis", "sine"]))
+        B, K, C = int(rng.integers(1, 6)), int(rng.integers(0, 40)), int(rng.integers(1, 4))
+        M = int(rng.choice([64, 32, 20])) if N >= 128 else int(rng.choice([16, 8]))
+        drown = float(rng.choice([0.0, 0.25, 1.0]))
+        x = torch.from_numpy(rng.uniform(-1, 1, (B, K * N, C)).astype(np.float32)).cuda()
+        if K > 1:
+            x[0, N:2 * N] *= 1e-4
+        codec = audiocodec_amd.AudioCodec(48000, N, bark_bands_n=M, window_type=wt)
+        lib.ac_set_force_generic(0)
+        X, t, thr = codec.encode(x, drown=drown)
+        Xs = codec.mdct.transform(x)
+        thrs = codec.psy.global_masking_threshold(X, t, drown)
+        xh = codec.decode(X)
+        lib.ac_set_force_generic(1)
+        try:
+            Xg = codec.mdct.transform(x)
+            tg = codec.psy.tonality(X)                         # the masking model on the same spectrum: at these frame
+            thrg = codec.psy.global_masking_threshold(X, t, drown)   # sizes a rounding of X moves the tonality measurably
+            xg = codec.decode(X)
+        finally:
+            lib.ac_set_force_generic(0)
+        tag = "case %d: N=%d %s B=%d K=%d C=%d M=%d tier %d" % (case, N, wt, B, K, C, M, codec.psy.tier())
+        assert tuple(X.shape) == (B, K + 1, N, C) and tuple(xh.shape) == (B, (K + 2) * N, C), tag
+        peak = Xg.abs().amax(dim=2, keepdim=True).clamp_min(1e-20)
+        assert float(((X - Xg).abs() / peak).max()) <= TOL and torch.equal(X, Xs), tag
+        assert tonality_err(t, tg) <= 1.0, tag
         assert float(((thr - thrg).abs() / thrg).max()) <= TOL and float(((thrs - thrg).abs() / thrg).max()) <= TOL, tag
         assert float((xh - xg).abs().max()) <= 2e-6, tag
         if K > 0:

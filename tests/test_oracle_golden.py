@@ -160,7 +160,7 @@ def test_psy_cases(golden, cfg, sr, N, M, dt, tag, tol):
                 assert rel_elem(thr, g[k2]) < tol
 
 
-@pytest.mark.parametrize("N", [960, 512])
+@pytest.mark.parametrize("N", [960, 512, 128])
 def test_codec_cases_beside_the_powers_of_two(golden, N):
     """filters_n = 960 (no power of two) and 512 (bins overlap several Bark bands): transform, round trip, tonality and
     thresholds of the reference's own code (oracle/gen_golden.py 5d) against the oracle"""
