@@ -198,8 +198,10 @@ class StreamingMDCT:
         with _host.on_device(self.device):
             _lib.check(self._lib.ac_stream_create(mdct._plan(self.device), self.B, self.C, ctypes.byref(handle)))
         self._handle = handle
+        self._graphs = {}       # run(..., graph=True): captured calls by input buffers and arguments
 
     def close(self):
+        self._graphs = {}       # (the graphs hold launches that address the stream's state)
         if self._handle is not None:
             self._lib.ac_stream_destroy(self._handle)
             self._handle = None
@@ -266,13 +268,20 @@ class StreamingMDCT:
                                                   _host.ptr(t), _host.ptr(thr), float(drown), k, self._stream(stream)))
         return X, t, thr
 
-    def run(self, x, blocks_per_chunk, masking=True, synthesis=True, drown=0.0):
+    def run(self, x, blocks_per_chunk, masking=True, synthesis=True, drown=0.0, graph=False):
         """A long device-resident signal ``x [1, K*N, C]`` (or a list of chunk tensors ``[B, k*N, C]``) through the stream
         in chunks of ``blocks_per_chunk`` blocks with one library call (``ac_stream_run``: launches issued from C; with
         ``synthesis`` and chunks small enough to be latency-bound, the analysis of chunk i + 1 and the synthesis of chunk i
         share one launch).  Returns ``(X, t, thr, xhat)`` -- tensors ``[1, K, ...]`` for
         a tensor input, lists of per-chunk tensors for a list input; ``t`` / ``thr`` are None without ``masking``,
-        ``xhat`` is None without ``synthesis``.  The last chunk of a tensor input may be shorter."""
+        ``xhat`` is None without ``synthesis``.  The last chunk of a tensor input may be shorter.
+
+        ``graph=True``: the launches of the call are captured into a HIP graph the first time these input buffers (same
+        addresses, shapes and arguments) are seen, and replayed from then on -- the gaps between the dependent launches
+        go (one stereo clip in chunks of 256 blocks: 7.9 us per chunk against 11.9).  A replay reads the CURRENT contents
+        of the same input buffers and overwrites the output tensors of the first call, which are returned again."""
+        if graph:
+            return self._run_graph(x, blocks_per_chunk, masking, synthesis, drown)
         k, N = int(blocks_per_chunk), self.mdct.filters_n
         if masking and self.psy is None:
             raise ValueError("this stream was created without a masking model (psy=...)")
@@ -332,6 +341,27 @@ class StreamingMDCT:
         if as_list:
             return outs[0], (outs[1] if masking else None), (outs[2] if masking else None), (outs[3] if synthesis else None)
         return Xall, tall, thrall, xhall
+
+    def _run_graph(self, x, blocks_per_chunk, masking, synthesis, drown):
+        chunks = list(x) if isinstance(x, (list, tuple)) else [x]
+        for c in chunks:
+            self._check_chunk(c, "x", 3)
+        key = (tuple((c.data_ptr(), tuple(c.shape)) for c in chunks), isinstance(x, (list, tuple)), int(blocks_per_chunk),
+               bool(masking), bool(synthesis), float(drown))
+        hit = self._graphs.get(key)
+        if hit is None:
+            with _host.on_device(self.device):
+                self.mdct._plan(self.device)                       # plans are built outside the capture
+                if masking:
+                    if self.psy is None:
+                        raise ValueError("this stream was created without a masking model (psy=...)")
+                    self.psy._plan(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    outs = self.run(x, blocks_per_chunk, masking=masking, synthesis=synthesis, drown=drown)
+            hit = self._graphs[key] = (g, outs, chunks)            # (the inputs stay alive with their graph)
+        hit[0].replay()
+        return hit[1]
 
     def inverse_chunk(self, X_chunk, out=None, stream=None):
         """X_chunk [B, k, N, C] -> x [B, k*N, C]."""

@@ -663,6 +663,22 @@ int ac_stream_inverse(ac_stream* s, const float* X_chunk, float* x, int k, void*
   return AC_OK;
 }
 
+// The state buffers swap roles with every chunk; after an odd number of chunks the current state sits in the other
+// buffer.  ac_stream_run leaves the state where it found it (one small device copy), so that the launches of a call
+// captured into a HIP graph can be replayed: a replay reads and writes the same addresses as the captured call.
+static int settle_state(ac_stream* s, float* prev0, float* tail0, hipStream_t hs) {
+  DeviceGuard guard(s->device);
+  if (s->d_prev_block != prev0) {
+    AC_HIP_CHECK(hipMemcpyAsync(prev0, s->d_prev_block, (size_t)s->B * s->N * s->C * sizeof(float), hipMemcpyDeviceToDevice, hs));
+    std::swap(s->d_prev_block, s->d_prev_tmp);
+  }
+  if (s->d_tail != tail0) {
+    AC_HIP_CHECK(hipMemcpyAsync(tail0, s->d_tail, (size_t)s->B * s->C * (s->N / 2) * sizeof(float), hipMemcpyDeviceToDevice, hs));
+    std::swap(s->d_tail, s->d_tail_tmp);
+  }
+  return AC_OK;
+}
+
 int ac_stream_run(ac_stream* s, const ac_psy_plan* psy, int nchunks, int k, const float* const* x_chunks,
                   float* const* X_chunks, float* const* t_chunks, float* const* thr_chunks, float* const* xhat_chunks,
                   float drown, void* stream) {
@@ -687,6 +703,8 @@ int ac_stream_run(ac_stream* s, const ac_psy_plan* psy, int nchunks, int k, cons
     AC_REQUIRE(p->N == psy->N, "mdct filters_n (%d) != psychoacoustic filter_bands_n (%d)", p->N, psy->N);
     AC_REQUIRE(p->device == psy->device, "plans live on different devices");
   }
+  float* const prev0 = s->d_prev_block;   // where the state lives on entry (and again on exit: settle_state)
+  float* const tail0 = s->d_tail;
   int st = AC_OK;
   bool duplex = xhat_chunks && nchunks >= 2 && wave_level(p, s->C, 0, k) && fast_duplex_serves(p, psy, s->B, s->C, k, k);
   if (duplex) {
@@ -716,14 +734,14 @@ int ac_stream_run(ac_stream* s, const ac_psy_plan* psy, int nchunks, int k, cons
       }
     }
     if (!st) st = ac_stream_inverse(s, X_chunks[nchunks - 1], xhat_chunks[nchunks - 1], k, stream);
-    return st;
+    return st ? st : settle_state(s, prev0, tail0, hs);
   }
   for (int i = 0; i < nchunks && !st; ++i) {
     st = stream_analysis(s, psy, x_chunks[i], X_chunks[i], psy ? t_chunks[i] : nullptr, psy ? thr_chunks[i] : nullptr,
                          drown, k, stream);
     if (!st && xhat_chunks) st = ac_stream_inverse(s, X_chunks[i], xhat_chunks[i], k, stream);
   }
-  return st;
+  return st ? st : settle_state(s, prev0, tail0, hs);
 }
 
 // ---- element-wise utilities ------------------------------------------------------------------------

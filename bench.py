@@ -428,9 +428,14 @@ def other_configs(torch, np, audiocodec_amd, dev, steps, warmup, settle_ms):
             st.reset()
             st.run(chunks if Bs > 1 else xs[:, :len(chunks) * k * N], k, masking=fused)
 
+        def one_call_graph():    # the same call captured once into a HIP graph and replayed (StreamingMDCT.run(graph=True))
+            st.reset()
+            st.run(chunks if Bs > 1 else xs[:, :len(chunks) * k * N], k, masking=fused, graph=True)
+
         fr = Bs * 2 * k * len(chunks)
         row = {"chunks": len(chunks)}
-        for name, fn in (("chain_one_stream", chain), ("pipelined_two_streams", pipelined), ("ac_stream_run", one_call)):
+        for name, fn in (("chain_one_stream", chain), ("pipelined_two_streams", pipelined), ("ac_stream_run", one_call),
+                         ("ac_stream_run_graph_replay", one_call_graph)):
             dt = wall(fn)
             row[name] = {"ms": dt * 1e3, "frames_per_s": fr / dt, "us_per_chunk": dt / len(chunks) * 1e6,
                          "x_real_time": (k * len(chunks) * N / 48000.0) / dt,

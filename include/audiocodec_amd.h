@@ -204,7 +204,11 @@ int ac_stream_inverse(ac_stream* s, const float* X_chunk, float* x, int k, void*
  * binding overhead).  With synthesis, chunks small enough to be latency-bound (one or a few clips) and distinct buffers
  * per chunk, the analysis of chunk i + 1 and the synthesis of chunk i share ONE launch (float32, mono / stereo,
  * filters_n 1024 / 2048): nchunks + 1 launches instead of 2 nchunks, same results bit for bit.  A caller that reuses
- * one buffer for consecutive chunks gets the dependent chain.  The pointer lists are host arrays. */
+ * one buffer for consecutive chunks gets the dependent chain.  The stream's state ends up at the addresses where the call
+ * found it, and nothing synchronises or allocates: a call is capturable into a HIP graph (hipStreamBeginCapture on
+ * `stream`), and replaying the graph repeats it on new contents of the same buffers -- 7.9 us per chunk of one stereo
+ * clip against 11.9 us for the plain launches (the gaps between dependent launches go).  The pointer lists are host
+ * arrays. */
 int ac_stream_run(ac_stream* s, const ac_psy_plan* psy, int nchunks, int k, const float* const* x_chunks,
                   float* const* X_chunks, float* const* t_chunks, float* const* thr_chunks, float* const* xhat_chunks,
                   float drown, void* stream);

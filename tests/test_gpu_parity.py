@@ -494,6 +494,33 @@ def test_stream_run_duplex_equals_the_chain(N, C, k, K, masking):
     st.close(), ref.close(), st2.close()
 
 
+@pytest.mark.parametrize("N,C,k,K,masking", [(1024, 2, 16, 83, True), (1024, 1, 8, 40, False), (2048, 2, 8, 24, False),
+                                              (256, 2, 32, 96, True)])
+def test_stream_run_as_a_replayed_graph(N, C, k, K, masking):
+    """StreamingMDCT.run(graph=True): the call is captured once (odd chunk counts included: ac_stream_run leaves the
+    state buffers where it found them) and replayed on new contents of the same input buffer; results equal the plain
+    calls bit for bit, the stream state carries over from call to call, reset() still works"""
+    g = torch.Generator(device="cuda").manual_seed(N + K)
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    xbuf = torch.empty(1, K * N, C, device="cuda")
+    sg, sp = codec.stream(1, C), codec.stream(1, C)
+    for call in range(3):
+        xbuf.uniform_(-1, 1, generator=g)
+        got = sg.run(xbuf, k, masking=masking, drown=0.1, graph=True)
+        ref = sp.run(xbuf.clone(), k, masking=masking, drown=0.1)       # continues its own stream the same way
+        torch.cuda.synchronize()
+        for a, b in zip(got, ref):
+            assert (a is None and b is None) or torch.equal(a, b), call
+    assert len(sg._graphs) == 1
+    sg.reset(), sp.reset()
+    xbuf.uniform_(-1, 1, generator=g)
+    got, ref = sg.run(xbuf, k, masking=masking, drown=0.1, graph=True), sp.run(xbuf.clone(), k, masking=masking, drown=0.1)
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[3], ref[3])
+    X_full = codec.encode(xbuf, drown=0.1)[0] if masking else codec.mdct.transform(xbuf)   # (the fused kernel's own rounding)
+    assert torch.equal(got[0], X_full[:, :K])
+    sg.close(), sp.close()
+
+
 def test_encode_decode_under_graph_capture():
     """The entry points only enqueue kernels on the caller's stream (no allocation, no synchronisation once the plans
     exist), so an encode + decode pair is capturable into a HIP graph; a replay on new input gives the eager result."""
