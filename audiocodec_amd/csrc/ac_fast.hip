@@ -1375,7 +1375,7 @@ __device__ __forceinline__ void inv_fast_body(const InvArgs& a, char* lds, const
 }
 
 template <int R, int CMODE, int NW, int IOF = 0>
-__global__ __launch_bounds__(NW * 64, (IOF != 0 ? 2 : wpe<R, CMODE>())) void k_inv_fast(InvArgs a) {
+__global__ __launch_bounds__(NW * 64, ((IOF == 2 || (IOF == 1 && !(R == 8 && CMODE != 1))) ? 2 : wpe<R, CMODE>())) void k_inv_fast(InvArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS + Geo<R>::TAB_LDS];
   inv_fast_body<R, CMODE, NW, IOF>(a, lds, (int)blockIdx.x, (int)gridDim.x);
 }
@@ -1887,8 +1887,60 @@ __device__ __forceinline__ void store_half(float* r0, float* r1, bool has1, int 
   }
 }
 
+// the same movers for 16-bit PCM rows (x = pcm / 32768 on the way in, clamp(round(32768 x)) on the way out)
+template <int CMODE, int LB>
+__device__ __forceinline__ void load_rowm(const int16_t* r0, const int16_t* r1, bool has1, int l, v4f (&v)[8]) {
+  if (CMODE == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const s4 p = reinterpret_cast<const s4*>(r0)[LB * i + l];
+      v[i] = v4f{Pcm16Fmt::dec(p.x), Pcm16Fmt::dec(p.y), Pcm16Fmt::dec(p.z), Pcm16Fmt::dec(p.w)};
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const s2 u = reinterpret_cast<const s2*>(r0)[LB * i + l];
+      const s2 w = has1 ? reinterpret_cast<const s2*>(r1)[LB * i + l] : s2{0, 0};
+      v[i] = v4f{Pcm16Fmt::dec(u.x), Pcm16Fmt::dec(w.x), Pcm16Fmt::dec(u.y), Pcm16Fmt::dec(w.y)};
+    }
+  }
+}
+template <int CMODE, int LB>
+__device__ __forceinline__ void store_rowm(int16_t* r0, int16_t* r1, bool has1, int l, const v4f (&v)[8]) {
+  if (CMODE == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const s2 lo = Pcm16Fmt::enc2(v[i].x, v[i].y), hi = Pcm16Fmt::enc2(v[i].z, v[i].w);
+      reinterpret_cast<s4*>(r0)[LB * i + l] = s4{lo.x, lo.y, hi.x, hi.y};
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      reinterpret_cast<s2*>(r0)[LB * i + l] = Pcm16Fmt::enc2(v[i].x, v[i].z);
+      if (has1) reinterpret_cast<s2*>(r1)[LB * i + l] = Pcm16Fmt::enc2(v[i].y, v[i].w);
+    }
+  }
+}
+template <int CMODE>
+__device__ __forceinline__ void load_half(const int16_t* r0, const int16_t* r1, bool has1, int l8, v4f* v) {
+  if (CMODE == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const s4 p = reinterpret_cast<const s4*>(r0)[8 * i + l8];
+      v[i] = v4f{Pcm16Fmt::dec(p.x), Pcm16Fmt::dec(p.y), Pcm16Fmt::dec(p.z), Pcm16Fmt::dec(p.w)};
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const s2 u = reinterpret_cast<const s2*>(r0)[8 * i + l8];
+      const s2 w = has1 ? reinterpret_cast<const s2*>(r1)[8 * i + l8] : s2{0, 0};
+      v[i] = v4f{Pcm16Fmt::dec(u.x), Pcm16Fmt::dec(w.x), Pcm16Fmt::dec(u.y), Pcm16Fmt::dec(w.y)};
+    }
+  }
+}
+
 struct FwdMArgs {
-  const float* x;    // [B, Kin*N, C]
+  const void* x;     // [B, Kin*N, C]  float32, or 16-bit PCM (IOF 1)
   float* X;          // [B, F, N, C]
   const float* prev_block;   // [B, N, C] or null: block -1 of every signal (streaming analysis state)
   float* state_out;          // [B, N, C] or null: receives block Kin-1 (another buffer than prev_block)
@@ -1901,8 +1953,9 @@ struct FwdMArgs {
 
 // analysis: the lanes of group f transform frame NFR c + f of the wave's signal pair (a group whose frame index is past
 // the last frame idles); fold and twiddles as in k_fwd_fast with LB in the place of 64
-template <int NFR, int CMODE, int NW>
+template <int NFR, int CMODE, int NW, int IOF = 0>
 __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
+  using pcm_t = typename std::conditional<IOF == 1, int16_t, float>::type;   // (streaming state: float32 only, IOF 0)
   using G = Geo<8>;
   constexpr int LB = 64 / NFR;
   __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS + G::TAB_LDS];
@@ -1926,15 +1979,15 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
     const Pair pq = make_pair<CMODE>(pair, C, a.nsig);
     const int n = c * NFR + f;
     const bool frame_ok = n < a.F;
-    const float* x0 = a.x + row_off(pq.b0, a.Kin, 0, blk, pq.c0);
-    const float* x1 = a.x + row_off(pq.b1, a.Kin, 0, blk, pq.c1);
+    const pcm_t* x0 = static_cast<const pcm_t*>(a.x) + row_off(pq.b0, a.Kin, 0, blk, pq.c0);
+    const pcm_t* x1 = static_cast<const pcm_t*>(a.x) + row_off(pq.b1, a.Kin, 0, blk, pq.c1);
     const v4f zero = {0.f, 0.f, 0.f, 0.f};
     v4f cb[8], pb[8];
     // rows of frame m: the current block m and the block before it (streaming: block -1 is the stored state); a missing
     // block (before the first / after the last) is read from a neighbouring valid row and zeroed afterwards
-    auto rows_of = [&](int m, const float*& c0p, const float*& c1p, const float*& p0p, const float*& p1p, bool& cur_ok,
+    auto rows_of = [&](int m, const pcm_t*& c0p, const pcm_t*& c1p, const pcm_t*& p0p, const pcm_t*& p1p, bool& cur_ok,
                        bool& prv_ok) {
-      const bool from_state = a.prev_block != nullptr && m == 0;
+      const bool from_state = IOF == 0 && a.prev_block != nullptr && m == 0;
       cur_ok = m < a.Kin;
       prv_ok = (m >= 1 && m <= a.Kin) || from_state;
       const int bc = cur_ok ? m : a.Kin - 1, bp = (m >= 1 && m <= a.Kin) ? m - 1 : 0;
@@ -1942,9 +1995,11 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
       c1p = x1 + (size_t)bc * blk;
       p0p = x0 + (size_t)bp * blk;
       p1p = x1 + (size_t)bp * blk;
-      if (from_state) {
-        p0p = a.prev_block + row_off(pq.b0, 1, 0, blk, pq.c0);
-        p1p = a.prev_block + row_off(pq.b1, 1, 0, blk, pq.c1);
+      if constexpr (IOF == 0) {
+        if (from_state) {
+          p0p = a.prev_block + row_off(pq.b0, 1, 0, blk, pq.c0);
+          p1p = a.prev_block + row_off(pq.b1, 1, 0, blk, pq.c1);
+        }
       }
     };
     C2 z[8];
@@ -1953,14 +2008,16 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
 #pragma unroll
       for (int fb = 0; fb < 2; ++fb) {
         const int m = c * NFR + 2 * g + fb;
-        const float *c0p, *c1p, *p0p, *p1p;
+        const pcm_t *c0p, *c1p, *p0p, *p1p;
         bool cur_ok, prv_ok;
         rows_of(m, c0p, c1p, p0p, p1p, cur_ok, prv_ok);
         load_half<CMODE>(c0p, c1p, pq.has1, l8, cb + 4 * fb);
         load_half<CMODE>(p0p, p1p, pq.has1, l8, pb + 4 * fb);
-        if (a.state_out && m == a.Kin - 1)   // streaming: the chunk's last block is the next chunk's block -1
-          store_half<CMODE>(a.state_out + row_off(pq.b0, 1, 0, blk, pq.c0), a.state_out + row_off(pq.b1, 1, 0, blk, pq.c1),
-                            pq.has1, l8, cb + 4 * fb);
+        if constexpr (IOF == 0) {
+          if (a.state_out && m == a.Kin - 1)   // streaming: the chunk's last block is the next chunk's block -1
+            store_half<CMODE>(a.state_out + row_off(pq.b0, 1, 0, blk, pq.c0), a.state_out + row_off(pq.b1, 1, 0, blk, pq.c1),
+                              pq.has1, l8, cb + 4 * fb);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           cb[4 * fb + i] = cur_ok ? cb[4 * fb + i] : zero;
@@ -1983,14 +2040,16 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
         z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + G::I_PRE)[r * 64 + lane]);
       }
     } else {
-      const float *c0p, *c1p, *p0p, *p1p;
+      const pcm_t *c0p, *c1p, *p0p, *p1p;
       bool cur_ok, prv_ok;
       rows_of(n, c0p, c1p, p0p, p1p, cur_ok, prv_ok);
       load_rowm<CMODE, LB>(c0p, c1p, pq.has1, l, cb);
       load_rowm<CMODE, LB>(p0p, p1p, pq.has1, l, pb);
-      if (a.state_out && n == a.Kin - 1)   // streaming: the chunk's last block is the next chunk's block -1
-        store_rowm<CMODE, LB>(a.state_out + row_off(pq.b0, 1, 0, blk, pq.c0), a.state_out + row_off(pq.b1, 1, 0, blk, pq.c1),
-                              pq.has1, l, cb);
+      if constexpr (IOF == 0) {
+        if (a.state_out && n == a.Kin - 1)   // streaming: the chunk's last block is the next chunk's block -1
+          store_rowm<CMODE, LB>(a.state_out + row_off(pq.b0, 1, 0, blk, pq.c0), a.state_out + row_off(pq.b1, 1, 0, blk, pq.c1),
+                                pq.has1, l, cb);
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         cb[i] = cur_ok ? cb[i] : zero;
@@ -2034,7 +2093,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
 
 struct InvMArgs {
   const float* X;    // [B, Kp, N, C]
-  float* x;          // [B, nblk*N, C]
+  void* x;           // [B, nblk*N, C]  float32, or 16-bit PCM (IOF 1)
   const float* tail_in;   // [B, C, N/2] or null: aliased half of the frame before frame 0 (streaming synthesis state)
   float* tail_out;        // [B, C, N/2] or null: receives the aliased half of frame nblk - 1
   const float* tab;  // analysis image; the synthesis image follows at Geo<8>::I_TOTAL floats
@@ -2049,8 +2108,9 @@ struct InvMArgs {
 // output block n from it and the aliased half of frame n - 1, which the group below has (one shift by LB lanes through
 // LDS); group 0 takes it from the chunk before (kept in registers), and a strip that does not start a signal begins with
 // the DCT-IV of the chunk before it.  Unfold as in k_inv_fast.
-template <int NFR, int CMODE, int NW>
+template <int NFR, int CMODE, int NW, int IOF = 0>
 __global__ __launch_bounds__(NW * 64, AC_WPE) void k_inv_multi(InvMArgs a) {
+  using pcm_t = typename std::conditional<IOF == 1, int16_t, float>::type;
   using G = Geo<8>;
   constexpr int LB = 64 / NFR;
   __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS + G::TAB_LDS];
@@ -2192,7 +2252,8 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_inv_multi(InvMArgs a) {
       }
     }
     if (n < a.nblk)
-      store_rowm<CMODE, LB>(a.x + row_off(pq.b0, a.nblk, n, blk, pq.c0), a.x + row_off(pq.b1, a.nblk, n, blk, pq.c1), pq.has1, l, row);
+      store_rowm<CMODE, LB>(static_cast<pcm_t*>(a.x) + row_off(pq.b0, a.nblk, n, blk, pq.c0),
+                            static_cast<pcm_t*>(a.x) + row_off(pq.b1, a.nblk, n, blk, pq.c1), pq.has1, l, row);
   }
 }
 
@@ -2357,9 +2418,10 @@ static bool build_mdct_fast(int N, int window, std::vector<float>* out) {
 
 // frames per wave of the plan's kernels: 1 (filters_n 1024 / 2048), 2 (512), 4 (256), 8 (128) or 16 (64)
 int fast_mdct_frames_per_wave(int N) { return N == 512 ? 2 : N == 256 ? 4 : N == 128 ? 8 : N == 64 ? 16 : 1; }
-// what the several-frames-per-wave kernels serve: float32 tensors, mono or stereo, at least one block
+// what the several-frames-per-wave kernels serve: float32 tensors or 16-bit PCM on the PCM side, mono or stereo, at
+// least one block
 bool fast_multi_serves(const ac_mdct_plan* p, int C, int iof, int blocks) {
-  return fast_mdct_frames_per_wave(p->N) > 1 && (C == 1 || C == 2) && iof == 0 && blocks >= 1;
+  return fast_mdct_frames_per_wave(p->N) > 1 && (C == 1 || C == 2) && (iof == 0 || iof == 1) && blocks >= 1;
 }
 
 bool fast_mdct_supported(int N, int window) { return build_mdct_fast(N, window, nullptr); }
@@ -2532,13 +2594,18 @@ static unsigned persistent_grid(int cus, int wg_per_cu, long long ntasks, int nw
 }
 
 template <int NFR>
-static void launch_fwd_multi_N(const FwdMArgs& a, int C, unsigned grid, hipStream_t s) {
+static void launch_fwd_multi_N(const FwdMArgs& a, int iof, int C, unsigned grid, hipStream_t s) {
   const dim3 blk(AC_WAVES * 64);
+  if (iof == 1) {
+    if (C == 2) hipLaunchKernelGGL((k_fwd_multi<NFR, 0, AC_WAVES, 1>), dim3(grid), blk, 0, s, a);
+    else hipLaunchKernelGGL((k_fwd_multi<NFR, 2, AC_WAVES, 1>), dim3(grid), blk, 0, s, a);
+    return;
+  }
   if (C == 2) hipLaunchKernelGGL((k_fwd_multi<NFR, 0, AC_WAVES>), dim3(grid), blk, 0, s, a);
   else hipLaunchKernelGGL((k_fwd_multi<NFR, 2, AC_WAVES>), dim3(grid), blk, 0, s, a);
 }
-static int launch_fwd_multi(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, float* state_out, int B,
-                            int Kin, int F, int C, hipStream_t s) {
+static int launch_fwd_multi(const ac_mdct_plan* p, const void* x, int iof, float* X, const float* prev_block, float* state_out,
+                            int B, int Kin, int F, int C, hipStream_t s) {
   const int nfr = fast_mdct_frames_per_wave(p->N);
   FwdMArgs a;
   a.x = x;
@@ -2560,22 +2627,27 @@ static int launch_fwd_multi(const ac_mdct_plan* p, const float* x, float* X, con
   unsigned grid;
   const int st = grid_for(a.ntasks, AC_WAVES * T, &grid);
   if (st) return st;
-  if (nfr == 2) launch_fwd_multi_N<2>(a, C, grid, s);
-  else if (nfr == 4) launch_fwd_multi_N<4>(a, C, grid, s);
-  else if (nfr == 8) launch_fwd_multi_N<8>(a, C, grid, s);
-  else launch_fwd_multi_N<16>(a, C, grid, s);
+  if (nfr == 2) launch_fwd_multi_N<2>(a, iof, C, grid, s);
+  else if (nfr == 4) launch_fwd_multi_N<4>(a, iof, C, grid, s);
+  else if (nfr == 8) launch_fwd_multi_N<8>(a, iof, C, grid, s);
+  else launch_fwd_multi_N<16>(a, iof, C, grid, s);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }
 
 template <int NFR>
-static void launch_inv_multi_N(const InvMArgs& a, int C, unsigned grid, hipStream_t s) {
+static void launch_inv_multi_N(const InvMArgs& a, int iof, int C, unsigned grid, hipStream_t s) {
   const dim3 blk(AC_WAVES * 64);
+  if (iof == 1) {
+    if (C == 2) hipLaunchKernelGGL((k_inv_multi<NFR, 0, AC_WAVES, 1>), dim3(grid), blk, 0, s, a);
+    else hipLaunchKernelGGL((k_inv_multi<NFR, 2, AC_WAVES, 1>), dim3(grid), blk, 0, s, a);
+    return;
+  }
   if (C == 2) hipLaunchKernelGGL((k_inv_multi<NFR, 0, AC_WAVES>), dim3(grid), blk, 0, s, a);
   else hipLaunchKernelGGL((k_inv_multi<NFR, 2, AC_WAVES>), dim3(grid), blk, 0, s, a);
 }
-static int launch_inv_multi(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out, int B,
-                            int Kp, int nblk, int C, hipStream_t s) {
+static int launch_inv_multi(const ac_mdct_plan* p, const float* X, void* x, int iof, const float* tail_in, float* tail_out,
+                            int B, int Kp, int nblk, int C, hipStream_t s) {
   const int nfr = fast_mdct_frames_per_wave(p->N);
   InvMArgs a;
   a.X = X;
@@ -2599,10 +2671,10 @@ static int launch_inv_multi(const ac_mdct_plan* p, const float* X, float* x, con
   unsigned grid;
   const int st = grid_for(a.ntasks, AC_WAVES, &grid);
   if (st) return st;
-  if (nfr == 2) launch_inv_multi_N<2>(a, C, grid, s);
-  else if (nfr == 4) launch_inv_multi_N<4>(a, C, grid, s);
-  else if (nfr == 8) launch_inv_multi_N<8>(a, C, grid, s);
-  else launch_inv_multi_N<16>(a, C, grid, s);
+  if (nfr == 2) launch_inv_multi_N<2>(a, iof, C, grid, s);
+  else if (nfr == 4) launch_inv_multi_N<4>(a, iof, C, grid, s);
+  else if (nfr == 8) launch_inv_multi_N<8>(a, iof, C, grid, s);
+  else launch_inv_multi_N<16>(a, iof, C, grid, s);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }
@@ -2734,7 +2806,7 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x
       set_error("internal: no wave-level analysis kernel for filters_n = %d, %d channels, io format %d here", p->N, C, iof);
       return AC_EUNSUPPORTED;
     }
-    return launch_fwd_multi(p, static_cast<const float*>(x), X, prev_block, state_out, B, Kin, F, C, s);
+    return launch_fwd_multi(p, x, iof, X, prev_block, state_out, B, Kin, F, C, s);
   }
   FwdArgs a;
   unsigned grid;
@@ -2809,7 +2881,7 @@ int launch_inv_fast(const ac_mdct_plan* p, const float* X, void* x, int iof, con
       set_error("internal: no wave-level synthesis kernel for filters_n = %d, %d channels, io format %d here", p->N, C, iof);
       return AC_EUNSUPPORTED;
     }
-    return launch_inv_multi(p, X, static_cast<float*>(x), tail_in, tail_out, B, Kp, nblk, C, s);
+    return launch_inv_multi(p, X, x, iof, tail_in, tail_out, B, Kp, nblk, C, s);
   }
   InvArgs a;
   unsigned grid;

@@ -904,10 +904,12 @@ def test_autograd_of_the_masking_model(path, sr, N, M, C, drown):
     assert float(torch.linalg.vector_norm(X2.grad.double() - Xd2.grad) / torch.linalg.vector_norm(Xd2.grad)) <= 1e-3
 
 
-@pytest.mark.parametrize("N,C", [(1024, 2), (1024, 1), (2048, 2), (1024, 3), (2048, 1), (2048, 3)])
+@pytest.mark.parametrize("N,C", [(1024, 2), (1024, 1), (2048, 2), (1024, 3), (2048, 1), (2048, 3),
+                                 (512, 2), (512, 1), (256, 2), (256, 1), (128, 2), (128, 1), (64, 2), (64, 1)])
 def test_pcm16_at_the_boundary(N, C):
-    """int16 PCM in / out: bit-identical to the float path fed pcm / 32768, and the round trip returns the PCM exactly."""
-    B, K = 3, 5
+    """int16 PCM in / out: bit-identical to the float path fed pcm / 32768, and the round trip returns the PCM exactly
+    (filters_n below 1024: the several-frames-per-wave kernels, block counts that leave lane groups idle)."""
+    B, K = 3, (5 if N >= 1024 else 21)
     pcm = torch.randint(-32768, 32768, (B, K * N, C), device="cuda", dtype=torch.int16)
     pcm[0, :7, 0] = torch.tensor([-32768, 32767, 0, 1, -1, 12345, -12345], dtype=torch.int16)
     codec = audiocodec_amd.AudioCodec(48000, N)
@@ -925,8 +927,10 @@ def test_pcm16_at_the_boundary(N, C):
     assert torch.equal(out[:, N:-N], pcm)
     ref = torch.clamp(torch.round(codec.decode(X) * 32768.0), -32768, 32767).to(torch.int16)
     assert torch.equal(out, ref)
-    with pytest.raises(_lib.AudioCodecError):      # the generic kernels do not take 16-bit PCM
-        audiocodec_amd.AudioCodec(48000, 256).encode(pcm[:, : 4 * 256])
+    with pytest.raises(_lib.AudioCodecError):      # the LDS-FFT / generic kernels do not take 16-bit PCM
+        audiocodec_amd.AudioCodec(48000, 960).encode(torch.zeros(1, 4 * 960, 2, device="cuda", dtype=torch.int16))
+    with pytest.raises(_lib.AudioCodecError):      # ... nor do the short-frame kernels for other channel counts
+        audiocodec_amd.AudioCodec(48000, 256).encode(torch.zeros(1, 4 * 256, 3, device="cuda", dtype=torch.int16))
 
 
 def test_plan_and_stream_lifecycle():
