@@ -36,7 +36,9 @@
 extern "C" {
 #endif
 
-#define AC_VERSION 150 /* 0.1.5: + ac_stream_encode, analysis state written by the kernels, AC_TESTING gate of the test hook */
+#define AC_VERSION 160 /* 0.1.6: ac_stream_run replayable as a HIP graph (state left in place), duplex launches; filters_n 64 / 128 and
+                          * 16-bit PCM on the several-frames-per-wave kernels; mixed-radix FFT tier; masking model for any even
+                          * filter_bands_n <= 1024.  (0.1.5: + ac_stream_encode, analysis state written by the kernels, AC_TESTING gate) */
 
 enum {
   AC_OK = 0,

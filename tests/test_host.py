@@ -31,7 +31,7 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(lib, s), "libaudiocodec_amd.so does not export %s" % s
     assert sorted(_lib.PROTOTYPES) == syms, "ctypes prototypes and header disagree"
-    assert lib.ac_version() == 150
+    assert lib.ac_version() == 160
 
 
 def test_library_contains_gfx950_code_object():
