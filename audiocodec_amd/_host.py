@@ -59,7 +59,10 @@ def check_device_tensor(t, name, dtype, ndim):
     if not t.is_cuda:
         raise RuntimeError("%s lives on %s: this package only runs on a ROCm device tensor (device='cuda'); "
                            "there is no CPU fallback" % (name, t.device))
-    return t.contiguous()
+    t = t.contiguous()
+    if t.data_ptr() % 16 != 0:      # a view that starts inside an allocation: the kernels want 16-byte aligned rows
+        t = t.clone()
+    return t
 
 
 class _NoSwitch:

@@ -91,6 +91,9 @@ class AudioCodec:
             raise ValueError("%s must have shape %s, got %s" % (name, tuple(shape), tuple(t.shape)))
         if not t.is_contiguous():
             raise ValueError("%s must be contiguous (got strides %s for shape %s)" % (name, t.stride(), tuple(t.shape)))
+        if t.data_ptr() % 16 != 0:
+            raise ValueError("%s starts at an address that is not 16-byte aligned (a view into the middle of an "
+                             "allocation?)" % name)
         return t
 
     def encode_into(self, x, X, t, thr, drown=0.0):
@@ -226,8 +229,9 @@ class StreamingMDCT:
         if out is None:
             return torch.empty(shape, dtype=like.dtype, device=like.device)
         if not isinstance(out, torch.Tensor) or tuple(out.shape) != tuple(shape) or out.dtype != like.dtype \
-                or out.device != like.device or not out.is_contiguous():
-            raise ValueError("%s must be a contiguous %s tensor of shape %s on %s" % (name, like.dtype, tuple(shape), like.device))
+                or out.device != like.device or not out.is_contiguous() or out.data_ptr() % 16 != 0:
+            raise ValueError("%s must be a contiguous, 16-byte aligned %s tensor of shape %s on %s"
+                             % (name, like.dtype, tuple(shape), like.device))
         return out
 
     def _stream(self, stream):

@@ -370,6 +370,7 @@ static int mdct_forward(const ac_mdct_plan* p, const void* x, bool pcm16, float*
   if (st) return st;
   if (B == 0 || C == 0) return AC_OK;
   AC_REQUIRE(X != nullptr && (x != nullptr || K == 0), "NULL tensor pointer");
+  AC_REQUIRE_ALIGNED(x, X);
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
   if (wave_level(p, C, pcm16 ? 1 : 0, K))
@@ -388,6 +389,7 @@ static int mdct_inverse(const ac_mdct_plan* p, const float* X, void* x, bool pcm
   if (st) return st;
   if (B == 0 || C == 0) return AC_OK;
   AC_REQUIRE(x != nullptr && (X != nullptr || Kp == 0), "NULL tensor pointer");
+  AC_REQUIRE_ALIGNED(x, X);
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
   if (wave_level(p, C, pcm16 ? 1 : 0, Kp)) return launch_inv_fast(p, X, x, pcm16, nullptr, nullptr, B, Kp, Kp + 1, C, s);
@@ -418,6 +420,7 @@ int ac_tonality(const ac_psy_plan* p, const float* X, float* t, int B, int F, in
   if (st) return st;
   if (B == 0 || C == 0 || F == 0) return AC_OK;
   AC_REQUIRE(X != nullptr && t != nullptr, "NULL tensor pointer");
+  AC_REQUIRE_ALIGNED(X);
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
   if (p->fast && !g_force_generic) return launch_psy_fast(p, X, nullptr, t, nullptr, 0.f, B, F, C, s);
@@ -432,6 +435,7 @@ int ac_mask_threshold(const ac_psy_plan* p, const float* X, const float* t, floa
   if (st) return st;
   if (B == 0 || C == 0 || F == 0) return AC_OK;
   AC_REQUIRE(X != nullptr && t != nullptr && thr != nullptr, "NULL tensor pointer");
+  AC_REQUIRE_ALIGNED(X, thr);
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
   if (p->fast && !g_force_generic) return launch_psy_fast(p, X, t, nullptr, thr, drown, B, F, C, s);
@@ -446,6 +450,7 @@ int ac_tonality_backward(const ac_psy_plan* p, const float* X, const float* grad
   if (st) return st;
   if (B == 0 || C == 0 || F == 0) return AC_OK;
   AC_REQUIRE(X != nullptr && grad_t != nullptr && grad_X != nullptr, "NULL tensor pointer");
+  AC_REQUIRE_ALIGNED(X, grad_X);
   DeviceGuard guard(p->device);
   if (p->fast && !g_force_generic)
     return launch_psy_bwd_fast(p, X, nullptr, 0.f, nullptr, grad_t, grad_X, nullptr, accumulate, B, F, C,
@@ -461,6 +466,7 @@ int ac_mask_threshold_backward(const ac_psy_plan* p, const float* X, const float
   if (B == 0 || C == 0 || F == 0) return AC_OK;
   AC_REQUIRE(X != nullptr && t != nullptr && grad_thr != nullptr && grad_X != nullptr && grad_t != nullptr,
              "NULL tensor pointer");
+  AC_REQUIRE_ALIGNED(X, grad_thr, grad_X);
   DeviceGuard guard(p->device);
   if (p->fast && !g_force_generic)
     return launch_psy_bwd_fast(p, X, t, drown, grad_thr, nullptr, grad_X, grad_t, 0, B, F, C, (hipStream_t)stream);
@@ -476,6 +482,7 @@ static int encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const 
   if (st) return st;
   if (B == 0 || C == 0) return AC_OK;
   AC_REQUIRE(X != nullptr && t != nullptr && thr != nullptr && (x != nullptr || K == 0), "NULL tensor pointer");
+  AC_REQUIRE_ALIGNED(x, X, thr);
   DeviceGuard guard(mdct->device);
   hipStream_t s = (hipStream_t)stream;
   if (mdct->fast && psy->fast && !g_force_generic) {
@@ -517,6 +524,7 @@ int ac_encode_fused_ex(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const f
   if (st) return st;
   if (B == 0 || C == 0) return AC_OK;
   AC_REQUIRE(X != nullptr && t != nullptr && thr != nullptr && (x != nullptr || K == 0), "NULL tensor pointer");
+  AC_REQUIRE_ALIGNED(x, X, thr, o_noisy, o_dbn);
   if (mdct->fast && psy->fast && !g_force_generic && fast_epilogue_supported(mdct, psy, 0, C)) {
     DeviceGuard guard(mdct->device);
     return launch_fwd_fast(mdct, psy, x, 0, X, t, thr, drown, nullptr, B, K, K + 1, C, (hipStream_t)stream, nullptr, o_noisy,
@@ -601,6 +609,7 @@ static int stream_analysis(ac_stream* s, const ac_psy_plan* psy, const float* x_
   AC_REQUIRE(k >= 0, "negative chunk length %d", k);
   if (k == 0) return AC_OK;
   AC_REQUIRE(x_chunk != nullptr && X != nullptr, "NULL tensor pointer");
+  AC_REQUIRE_ALIGNED(x_chunk, X, thr);
   const ac_mdct_plan* p = s->plan;
   if (psy) {
     AC_REQUIRE(t != nullptr && thr != nullptr, "NULL tensor pointer");
@@ -652,6 +661,7 @@ int ac_stream_inverse(ac_stream* s, const float* X_chunk, float* x, int k, void*
   AC_REQUIRE(k >= 0, "negative chunk length %d", k);
   if (k == 0) return AC_OK;
   AC_REQUIRE(X_chunk != nullptr && x != nullptr, "NULL tensor pointer");
+  AC_REQUIRE_ALIGNED(X_chunk, x);
   const ac_mdct_plan* p = s->plan;
   DeviceGuard guard(s->device);
   hipStream_t hs = (hipStream_t)stream;
@@ -693,6 +703,7 @@ int ac_stream_run(ac_stream* s, const ac_psy_plan* psy, int nchunks, int k, cons
     AC_REQUIRE(x_chunks[i] != nullptr && X_chunks[i] != nullptr, "chunk %d: NULL tensor pointer", i);
     AC_REQUIRE(psy == nullptr || (t_chunks[i] != nullptr && thr_chunks[i] != nullptr), "chunk %d: NULL tensor pointer", i);
     AC_REQUIRE(xhat_chunks == nullptr || xhat_chunks[i] != nullptr, "chunk %d: NULL tensor pointer", i);
+    AC_REQUIRE_ALIGNED(x_chunks[i], X_chunks[i], psy ? thr_chunks[i] : nullptr, xhat_chunks ? xhat_chunks[i] : nullptr);
   }
   // Small chunks with synthesis (one clip, a few hundred frames per chunk): the analysis of chunk i + 1 rides in the same
   // launch as the synthesis of chunk i (k_duplex_fast) -- the two are independent, and a chunk's two dependent launches
@@ -817,6 +828,7 @@ int ac_mdct_forward_typed(const ac_mdct_plan* p, const void* x, void* X, int dty
   if (st) return st;
   if (B == 0 || C == 0) return AC_OK;
   AC_REQUIRE(X != nullptr && (x != nullptr || K == 0), "NULL tensor pointer");
+  AC_REQUIRE_ALIGNED(x, X);
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == AC_F64) return launch_fwd_f64(p, static_cast<const double*>(x), static_cast<double*>(X), B, K, K + 1, C, s);
@@ -833,6 +845,7 @@ int ac_mdct_inverse_typed(const ac_mdct_plan* p, const void* X, void* x, int dty
   if (st) return st;
   if (B == 0 || C == 0) return AC_OK;
   AC_REQUIRE(x != nullptr && (X != nullptr || Kp == 0), "NULL tensor pointer");
+  AC_REQUIRE_ALIGNED(x, X);
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == AC_F64) return launch_inv_f64(p, static_cast<const double*>(X), static_cast<double*>(x), B, Kp, Kp + 1, C, s);
@@ -849,6 +862,7 @@ int ac_tonality_typed(const ac_psy_plan* p, const void* X, void* t, int dtype, i
   if (st) return st;
   if (B == 0 || C == 0 || F == 0) return AC_OK;
   AC_REQUIRE(X != nullptr && t != nullptr, "NULL tensor pointer");
+  AC_REQUIRE_ALIGNED(X);
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == AC_F64) return launch_tonality_f64(p, static_cast<const double*>(X), static_cast<double*>(t), B, F, C, s);
@@ -868,6 +882,7 @@ int ac_mask_threshold_typed(const ac_psy_plan* p, const void* X, const void* t, 
   if (st) return st;
   if (B == 0 || C == 0 || F == 0) return AC_OK;
   AC_REQUIRE(X != nullptr && t != nullptr && thr != nullptr, "NULL tensor pointer");
+  AC_REQUIRE_ALIGNED(X, thr);
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == AC_F64)

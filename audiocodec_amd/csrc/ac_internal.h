@@ -1,5 +1,6 @@
 // Internal declarations shared by the translation units of libaudiocodec_amd.so.
 #pragma once
+#include <cstdint>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -28,6 +29,18 @@ void set_error(const char* fmt, ...);
       ac::set_error(__VA_ARGS__);  \
       return AC_EINVAL;            \
     }                              \
+  } while (0)
+
+// The kernels move rows with 16-byte (8-byte: mono, 16-bit PCM) vector accesses: tensor base addresses must be 16-byte
+// aligned (any allocation is; a view that starts inside one may not be).
+#define AC_REQUIRE_ALIGNED(...)                                                                                  \
+  do {                                                                                                           \
+    const void* ac_ptrs_[] = {__VA_ARGS__};                                                                      \
+    for (const void* ac_p_ : ac_ptrs_)                                                                           \
+      if ((reinterpret_cast<uintptr_t>(ac_p_) & 15) != 0) {                                                      \
+        ac::set_error("tensor address %p is not 16-byte aligned (pass the start of an allocation or an aligned view)", ac_p_); \
+        return AC_EINVAL;                                                                                        \
+      }                                                                                                          \
   } while (0)
 
 // Makes `device` current for the lifetime of the guard (no-op when it already is).

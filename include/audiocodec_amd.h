@@ -14,6 +14,8 @@
  *        spectrum   X   [B, F, N, C]     F frames of N filters    (mdctransformer.py:105-107)
  *        tonality   t   [B, F, 1, C]                              (psychoacoustic.py:110)
  *        threshold  thr [B, F, N, C]                              (psychoacoustic.py:134-135)
+ *    PCM, spectrum and threshold tensors start at 16-byte aligned addresses (any allocation does; a view that starts
+ *    inside one may not): the kernels move rows with 16- and 8-byte vector accesses.  AC_EINVAL otherwise;
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream); every call only
  *    enqueues work and returns without synchronising; the library never allocates, frees or
  *    synchronises caller memory and never changes the current device outside *_create;

@@ -521,6 +521,30 @@ def test_stream_run_as_a_replayed_graph(N, C, k, K, masking):
     sg.close(), sp.close()
 
 
+def test_misaligned_tensors_are_copied_or_refused():
+    """The kernels move rows with 16-byte accesses.  An input view that starts inside an allocation is copied by the Python
+    layer (same results); a caller-owned OUTPUT at such an address is refused (ValueError), and the C ABI itself refuses
+    any misaligned tensor (AC_EINVAL) instead of launching on it."""
+    N, B, K, C = 1024, 2, 3, 2
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    buf = torch.rand(B * K * N * C + 8, device="cuda") * 2 - 1
+    x_off = buf[1:1 + B * K * N * C].view(B, K * N, C)
+    assert x_off.is_contiguous() and x_off.data_ptr() % 16 == 4
+    X, t, thr = codec.encode(x_off)
+    Xa, ta, thra = codec.encode(x_off.clone())
+    assert torch.equal(X, Xa) and torch.equal(t, ta) and torch.equal(thr, thra)
+    assert torch.equal(codec.mdct.transform(x_off), codec.mdct.transform(x_off.clone()))
+    Xbuf = torch.empty(B * (K + 1) * N * C + 8, device="cuda")
+    X_off = Xbuf[1:1 + B * (K + 1) * N * C].view(B, K + 1, N, C)
+    with pytest.raises(ValueError):
+        codec.encode_into(x_off.clone(), X_off, ta, thra)
+    lib = _lib.load()
+    from audiocodec_amd import _host
+    st = lib.ac_mdct_forward(codec.mdct._plan(buf.device), _host.ptr(x_off), _host.ptr(Xa), B, K, C, _host.stream_ptr(buf.device))
+    assert st == -1 and b"aligned" in lib.ac_last_error()
+    torch.cuda.synchronize()
+
+
 def test_encode_decode_under_graph_capture():
     """The entry points only enqueue kernels on the caller's stream (no allocation, no synchronisation once the plans
     exist), so an encode + decode pair is capturable into a HIP graph; a replay on new input gives the eager result."""
