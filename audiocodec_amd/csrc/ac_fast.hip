@@ -2913,7 +2913,8 @@ bool fast_duplex_serves(const ac_mdct_plan* p, const ac_psy_plan* psy, int B, in
   if (psy && !(p->N == Geo<8>::FN && C == 2 && psy->fast && psy->spread != 1)) return false;
   const long long pairs = (C == 2) ? B : (B + 1) / 2;
   static const long long max_tasks = [] { const char* e = getenv("AC_DUPLEX_MAX_TASKS"); return e ? atoll(e) : 0ll; }();
-  return pairs * ((long long)k_fwd + k_inv) <= (max_tasks > 0 ? max_tasks : (long long)p->cus * 256);
+  // (the mono instantiations are compiled for two waves per SIMD: beyond latency-bound sizes the chain's kernels win)
+  return pairs * ((long long)k_fwd + k_inv) <= (max_tasks > 0 ? max_tasks : (long long)p->cus * (C == 2 ? 256 : 8));
 }
 
 template <int R>
