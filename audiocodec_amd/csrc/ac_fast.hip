@@ -2718,7 +2718,11 @@ static void launch_fwd_R(const FwdArgs& a, bool psy, int spread, int C, unsigned
     else if (C == 2) hipLaunchKernelGGL((k_fwd_fast<R, 0, true, AC_WAVES_PSY, IOF>), dim3(grid), blk, 0, s, a);
     else if (C == 1) {
       // (R = 16: the caller runs transform and masking model as two launches, see encode_fused in ac_api.hip)
-      if constexpr (R == 8) hipLaunchKernelGGL((k_fwd_fast<R, 2, true, AC_WAVES_PSY, IOF>), dim3(grid), blk, 0, s, a);
+      if constexpr (R == 8) {
+        if (spread == 1) hipLaunchKernelGGL((k_fwd_fast<R, 2, true, AC_WAVES_PSY, IOF, 1>), dim3(grid), blk, 0, s, a);
+        else if (spread == 2) hipLaunchKernelGGL((k_fwd_fast<R, 2, true, AC_WAVES_PSY, IOF, 2>), dim3(grid), blk, 0, s, a);
+        else hipLaunchKernelGGL((k_fwd_fast<R, 2, true, AC_WAVES_PSY, IOF>), dim3(grid), blk, 0, s, a);
+      }
     } else {
       if constexpr (R == 8 || !PCM16) hipLaunchKernelGGL((k_fwd_fast<R, 1, true, AC_WAVES_PSY, IOF>), dim3(grid), blk, 0, s, a);
     }
@@ -2974,6 +2978,10 @@ static void launch_psy_R(const PsyArgs& a, bool want_t, bool want_thr, int sprea
   const dim3 blk(AC_WAVES * 64);
   if (CMODE == 0 && want_thr && spread == 1) return launch_psy_thr<R, 0, 1>(a, want_t, grid, s);
   if (CMODE == 0 && want_thr && spread == 2) return launch_psy_thr<R, 0, 2>(a, want_t, grid, s);
+  if constexpr (R == 8 && CMODE == 2) {   // mono at 8 points per lane: the same two forms (two clips ride in the pair)
+    if (want_thr && spread == 1) return launch_psy_thr<8, 2, 1>(a, want_t, grid, s);
+    if (want_thr && spread == 2) return launch_psy_thr<8, 2, 2>(a, want_t, grid, s);
+  }
   if (want_t && !want_thr) hipLaunchKernelGGL((k_psy_fast<R, CMODE, true, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
   else if (!want_t && want_thr) hipLaunchKernelGGL((k_psy_fast<R, CMODE, false, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
   else if (want_t && want_thr) hipLaunchKernelGGL((k_psy_fast<R, CMODE, true, true, AC_WAVES>), dim3(grid), blk, 0, s, a);

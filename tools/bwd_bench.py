@@ -10,8 +10,11 @@ X = codec.mdct.transform(x)
 t = codec.psy.tonality(X)
 g = torch.rand_like(X)
 gt = torch.rand_like(t)
-def timeit(fn, n=5):
-    fn(); torch.cuda.synchronize()
+def timeit(fn, n=10):
+    import time
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.1:      # settle the device
+        fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): fn()

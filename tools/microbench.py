@@ -14,9 +14,13 @@ X = torch.empty((B, K + 1, N, C), device=dev); t = torch.empty((B, K + 1, 1, C),
 thr = torch.empty_like(X); xh = torch.empty((B, (K + 2) * N, C), device=dev)
 frames = B * C * K
 
-def timeit(fn, n=10):
-    for _ in range(2): fn()
-    torch.cuda.synchronize()
+def timeit(fn, n=20):
+    # (an MI355X that has idled for a few ms runs the first ~30 ms of any load up to 25 % slower, DESIGN.md 5a: keep it
+    # busy for ~100 ms before the timed launches, as bench.py does)
+    t_end = time.perf_counter() + 0.1
+    while time.perf_counter() < t_end:
+        for _ in range(8): fn()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): fn()
