@@ -363,6 +363,8 @@ class StreamingMDCT:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     outs = self.run(x, blocks_per_chunk, masking=masking, synthesis=synthesis, drown=drown)
+            while len(self._graphs) >= 8:                         # a graph keeps its outputs alive: a handful at most
+                self._graphs.pop(next(iter(self._graphs)))
             hit = self._graphs[key] = (g, outs, chunks)            # (the inputs stay alive with their graph)
         hit[0].replay()
         return hit[1]
