@@ -45,6 +45,12 @@ typedef const float* gtab_t;   // LDS-resident table image
 #ifndef AC_WAVES
 #define AC_WAVES 4                  // waves per workgroup, plain transform / inverse / stand-alone psycho
 #endif
+#ifndef AC_NT_X
+#define AC_NT_X AC_NT_STORE         // the fused encode's two write streams separately (experiments: one temporal, one streaming)
+#endif
+#ifndef AC_NT_THR
+#define AC_NT_THR AC_NT_STORE
+#endif
 #ifndef AC_WPE
 #define AC_WPE 3                    // waves per SIMD the register allocator must leave room for
 #endif
@@ -403,18 +409,15 @@ __device__ __forceinline__ void load_row(const float* __restrict__ r0, const flo
   }
 }
 
-template <int CMODE, int R = 8>
+template <int CMODE, int R = 8, bool NTS = (AC_NT_STORE != 0)>
 __device__ __forceinline__ void store_row(float* __restrict__ r0, float* __restrict__ r1, int C, bool has1, int lane,
                                           const v4f (&v)[R]) {
   if (CMODE == 0) {
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       const int q = 64 * i + lane;
-#if AC_NT_STORE
-      __builtin_nontemporal_store(v[i], reinterpret_cast<v4f*>(r0) + q);
-#else
-      reinterpret_cast<v4f*>(r0)[q] = v[i];
-#endif
+      if (NTS) __builtin_nontemporal_store(v[i], reinterpret_cast<v4f*>(r0) + q);
+      else reinterpret_cast<v4f*>(r0)[q] = v[i];
     }
   } else if (CMODE == 2) {
 #pragma unroll
@@ -1109,7 +1112,7 @@ __device__ __forceinline__ void fwd_fast_body(const FwdArgs& a, char* lds, const
       int16_t* Xh = reinterpret_cast<int16_t*>(a.X);
       store_row_h<Bf16Fmt, CMODE, R>(Xh + o0, Xh + o1, C, pq.has1, lane, row);
     } else {
-      store_row<CMODE, R>(a.X + o0, a.X + o1, C, pq.has1, lane, row);
+      store_row<CMODE, R, (AC_NT_X != 0)>(a.X + o0, a.X + o1, C, pq.has1, lane, row);
     }
     if constexpr (EPI) {
       if (a.dbn) {   // amplitude_to_dB_norm of the coefficients (psychoacoustic.py:87-100), from the registers
@@ -1167,7 +1170,7 @@ __device__ __forceinline__ void fwd_fast_body(const FwdArgs& a, char* lds, const
           if (pq.has1) t_h[t1] = e.y;
         }
       } else {
-        if (!emitted) store_row<CMODE, R>(a.thr + o0, a.thr + o1, C, pq.has1, lane, th);
+        if (!emitted) store_row<CMODE, R, (AC_NT_THR != 0)>(a.thr + o0, a.thr + o1, C, pq.has1, lane, th);
         if (lane == 0) {
           a.t[t0] = tt.x;
           if (pq.has1) a.t[t1] = tt.y;
