@@ -2981,9 +2981,9 @@ static void launch_psy_R(const PsyArgs& a, bool want_t, bool want_thr, int sprea
   const dim3 blk(AC_WAVES * 64);
   if (CMODE == 0 && want_thr && spread == 1) return launch_psy_thr<R, 0, 1>(a, want_t, grid, s);
   if (CMODE == 0 && want_thr && spread == 2) return launch_psy_thr<R, 0, 2>(a, want_t, grid, s);
-  if constexpr (R == 8 && CMODE == 2) {   // mono at 8 points per lane: the same two forms (two clips ride in the pair)
-    if (want_thr && spread == 1) return launch_psy_thr<8, 2, 1>(a, want_t, grid, s);
-    if (want_thr && spread == 2) return launch_psy_thr<8, 2, 2>(a, want_t, grid, s);
+  if constexpr (CMODE == 2) {   // mono: the same two forms (two clips ride in the pair)
+    if (want_thr && spread == 1) return launch_psy_thr<R, 2, 1>(a, want_t, grid, s);
+    if (want_thr && spread == 2) return launch_psy_thr<R, 2, 2>(a, want_t, grid, s);
   }
   if (want_t && !want_thr) hipLaunchKernelGGL((k_psy_fast<R, CMODE, true, false, AC_WAVES>), dim3(grid), blk, 0, s, a);
   else if (!want_t && want_thr) hipLaunchKernelGGL((k_psy_fast<R, CMODE, false, true, AC_WAVES>), dim3(grid), blk, 0, s, a);
