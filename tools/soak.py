@@ -1,0 +1,61 @@
+"""Randomised soak of the wave-level / LDS-FFT / masking tiers against the O(N^2) kernels (AC_TESTING=1): shapes, sizes,
+windows, channel counts, streaming chunkings, 16-bit PCM.  Not part of the test suite (minutes, not seconds); prints the
+first mismatch and exits non-zero.   AC_TESTING=1 python tools/soak.py [seconds] [seed]"""
+import os, sys, time
+os.environ.setdefault("AC_TESTING", "1")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch, audiocodec_amd
+from audiocodec_amd import _lib
+lib = _lib.load()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+SIZES = [64, 128, 256, 512, 1024, 2048, 960, 480, 240, 120, 576, 192, 96, 48, 32, 16, 1536, 3072, 4096]
+TOL, LSB = 1e-4, 1.0 / 32768
+t_end, cases = time.time() + budget, 0
+def fail(msg):
+    print("MISMATCH:", msg); sys.exit(1)
+while time.time() < t_end:
+    N = int(rng.choice(SIZES)); wt = str(rng.choice(["vorbis", "sine"]))
+    B, C = int(rng.integers(1, 5)), int(rng.integers(1, 4))
+    K = int(rng.integers(0, max(2, min(60, 40000 // N))))
+    M = int(rng.choice([64, 48, 20])) if N >= 128 else int(rng.choice([16, 8]))
+    drown = float(rng.choice([0.0, 0.3, 1.0]))
+    tag = "N=%d %s B=%d K=%d C=%d M=%d" % (N, wt, B, K, C, M)
+    x = torch.from_numpy(rng.uniform(-1, 1, (B, K * N, C)).astype(np.float32)).cuda()
+    codec = audiocodec_amd.AudioCodec(48000, N, bark_bands_n=M, window_type=wt)
+    lib.ac_set_force_generic(0)
+    X, t, thr = codec.encode(x, drown=drown)
+    xh = codec.decode(X)
+    lib.ac_set_force_generic(1)
+    try:
+        Xg = codec.mdct.transform(x); tg = codec.psy.tonality(X); thrg = codec.psy.global_masking_threshold(X, t, drown)
+        xg = codec.decode(X)
+    finally:
+        lib.ac_set_force_generic(0)
+    peak = Xg.abs().amax(dim=2, keepdim=True).clamp_min(1e-20)
+    if float(((X - Xg).abs() / peak).max()) > TOL: fail(tag + " transform")
+    if float(((t - tg).abs() - 1e-4 * tg.abs()).max()) > 1e-6: fail(tag + " tonality")
+    if float(((thr - thrg).abs() / thrg).max()) > TOL: fail(tag + " threshold")
+    if float((xh - xg).abs().max()) > 2e-6: fail(tag + " inverse")
+    if K > 0 and float((xh[:, N:-N] - x).abs().max()) > LSB: fail(tag + " round trip")
+    # streaming in random chunks = one shot, bit for bit (float32 path of the same tier)
+    if K >= 2:
+        st = codec.stream(B, C)
+        cuts = sorted(set([0, K] + [int(v) for v in rng.integers(1, K, size=int(rng.integers(1, 4)))]))
+        outs = [st.transform_chunk(x[:, a * N:b * N].contiguous()) for a, b in zip(cuts[:-1], cuts[1:])]
+        outs.append(st.transform_chunk(torch.zeros(B, N, C, device="cuda")))
+        Xs = torch.cat(outs, dim=1)
+        if not torch.equal(Xs, codec.mdct.transform(x)): fail(tag + " streaming transform, cuts %s" % cuts)
+        st.reset()
+        outs = [st.inverse_chunk(X[:, a:b].contiguous()) for a, b in zip(cuts[:-1] , cuts[1:])] + [st.inverse_chunk(X[:, K:].contiguous())]
+        if float((torch.cat(outs, dim=1) - xh[:, :(K + 1) * N]).abs().max()) > 1e-6: fail(tag + " streaming inverse")
+        st.close()
+    # 16-bit PCM where the wave-level kernels take it
+    if codec.mdct.is_fast() and (N >= 1024 or C <= 2) and K > 0:
+        pcm = torch.from_numpy(rng.integers(-32768, 32768, (B, K * N, C)).astype(np.int16)).cuda()
+        Xp = codec.encode(pcm)[0]
+        if not torch.equal(Xp, codec.encode(pcm.float() / 32768.0)[0]): fail(tag + " pcm16 encode")
+        if not torch.equal(codec.decode(Xp, pcm16=True)[:, N:-N], pcm): fail(tag + " pcm16 round trip")
+    cases += 1
+print("soak: %d random cases in %.0f s, no mismatch" % (cases, budget))
