@@ -1,6 +1,6 @@
 """Randomised soak of the wave-level / LDS-FFT / masking tiers against the O(N^2) kernels (AC_TESTING=1): shapes, sizes,
 windows, channel counts, streaming chunkings, 16-bit PCM.  Not part of the test suite (minutes, not seconds); prints the
-first mismatch and exits non-zero.   AC_TESTING=1 python tools/soak.py [seconds] [seed]"""
+first mismatch and exits non-zero.   AC_TESTING=1 python tools/soak.py [seconds] [seed]   (BIG=1: fewer, larger cases)"""
 import os, sys, time
 os.environ.setdefault("AC_TESTING", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,6 +9,7 @@ import numpy as np, torch, audiocodec_amd
 from audiocodec_amd import _lib
 lib = _lib.load()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+BIG = os.environ.get("BIG", "0") == "1"   # BIG=1: fewer, larger cases
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 SIZES = [64, 128, 256, 512, 1024, 2048, 960, 480, 240, 120, 576, 192, 96, 48, 32, 16, 1536, 3072, 4096]
 TOL, LSB = 1e-4, 1.0 / 32768
@@ -19,6 +20,10 @@ while time.time() < t_end:
     N = int(rng.choice(SIZES)); wt = str(rng.choice(["vorbis", "sine"]))
     B, C = int(rng.integers(1, 5)), int(rng.integers(1, 4))
     K = int(rng.integers(0, max(2, min(60, 40000 // N))))
+    if BIG:   # launches of many workgroups: frames per wave > 1, strips, persistent rounds (the O(N^2) check bounds the size)
+        N = int(rng.choice([64, 128, 256, 512, 1024, 2048, 960, 480]))
+        B, C = int(rng.integers(1, 48)), int(rng.integers(1, 3))
+        K = int(rng.integers(1, max(2, (6000 if N >= 1024 else 20000) // (B * C))))
     M = int(rng.choice([64, 48, 20])) if N >= 128 else int(rng.choice([16, 8]))
     drown = float(rng.choice([0.0, 0.3, 1.0]))
     tag = "N=%d %s B=%d K=%d C=%d M=%d" % (N, wt, B, K, C, M)
