@@ -56,6 +56,26 @@ while time.time() < t_end:
         outs = [st.inverse_chunk(X[:, a:b].contiguous()) for a, b in zip(cuts[:-1] , cuts[1:])] + [st.inverse_chunk(X[:, K:].contiguous())]
         if float((torch.cat(outs, dim=1) - xh[:, :(K + 1) * N]).abs().max()) > 1e-6: fail(tag + " streaming inverse")
         st.close()
+    # ac_stream_run (duplex launches where they apply) = the chunk-by-chunk calls, bit for bit; once more as a replayed graph
+    if K >= 2 and C <= 2 and N in (1024, 2048) and cases % 3 == 0:
+        k = int(rng.integers(1, K + 1)); n = K // k
+        masking = bool(rng.integers(0, 2))
+        chunks = [x[:, i * k * N:(i + 1) * k * N].contiguous() for i in range(n)]
+        sa, sb = codec.stream(B, C), codec.stream(B, C)
+        Xl, tl, thl, xl = sa.run(chunks, k, masking=masking, drown=drown)
+        for i, c in enumerate(chunks):
+            if masking:
+                Xc, tc, thc = sb.encode_chunk(c, drown=drown)
+                if not (torch.equal(tc, tl[i]) and torch.equal(thc, thl[i])): fail(tag + " stream run masking, k=%d chunk %d" % (k, i))
+            else:
+                Xc = sb.transform_chunk(c)
+            if not torch.equal(Xc, Xl[i]): fail(tag + " stream run spectrum, k=%d chunk %d" % (k, i))
+            if not torch.equal(sb.inverse_chunk(Xc), xl[i]): fail(tag + " stream run synthesis, k=%d chunk %d" % (k, i))
+        sa.reset()
+        g1 = sa.run(chunks, k, masking=masking, drown=drown, graph=True)
+        if not all(torch.equal(a, b) for a, b in zip(g1[0], Xl)) or not all(torch.equal(a, b) for a, b in zip(g1[3], xl)):
+            fail(tag + " stream run as a graph, k=%d" % k)
+        sa.close(), sb.close()
     # 16-bit PCM where the wave-level kernels take it
     if codec.mdct.is_fast() and (N >= 1024 or C <= 2) and K > 0:
         pcm = torch.from_numpy(rng.integers(-32768, 32768, (B, K * N, C)).astype(np.int16)).cuda()
