@@ -819,6 +819,10 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[R], char* lds0, char* 
 // copies the table image (and the psy image) into the workgroup's LDS behind the wave buffers; every thread takes part
 template <int NW, int WSTRIDE, int TABF, int PSYW, int PSY_TOTAL = 0, int MFB = 0>
 __device__ __forceinline__ void load_tables(char* lds, const float* __restrict__ image, const uint32_t* psy_tab) {
+#ifdef AC_EXP_NOTABLES   // timing experiment only (wrong results): what the table copy costs a latency-bound launch
+  __syncthreads();
+  return;
+#endif
   if (image) {
     v4f* dst = reinterpret_cast<v4f*>(lds + NW * WSTRIDE);
     const v4f* src = reinterpret_cast<const v4f*>(image);
