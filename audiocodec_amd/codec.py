@@ -34,7 +34,13 @@ class AudioCodec:
         """x [B, K*N, C] -> (X [B,K+1,N,C], tonality [B,K+1,1,C], threshold [B,K+1,N,C]).
 
         ``x`` is float PCM in [-1, 1] (the reference's convention) or ``torch.int16`` PCM (extension: x = pcm / 32768
-        is applied inside the kernel's loads, half the PCM bytes)."""
+        is applied inside the kernel's loads, half the PCM bytes).  When ``x`` requires a gradient the same three results
+        come from the differentiable entry points in sequence (transform, tonality, threshold: each carries its backward
+        pass), as the reference's op chain is differentiable in a training graph; otherwise one fused launch."""
+        if isinstance(x, torch.Tensor) and x.requires_grad and torch.is_grad_enabled():
+            X = self.mdct.transform(x)
+            t = self.psy.tonality(X)
+            return X, t, self.psy.global_masking_threshold(X, t, drown)
         pcm16 = isinstance(x, torch.Tensor) and x.dtype == torch.int16
         x = _host.check_device_tensor(x, "x", torch.int16 if pcm16 else self.compute_dtype, 3)
         B, S, C = x.shape
@@ -57,6 +63,10 @@ class AudioCodec:
         :return: ``(X, tonality, threshold, noisy or None, db_norm or None)``
         """
         _host.require_float32(self.compute_dtype, "encode_ex")
+        if isinstance(x, torch.Tensor) and x.requires_grad and torch.is_grad_enabled():   # the differentiable composition
+            X, t, thr = self.encode(x, drown)
+            return (X, t, thr, self.psy.add_noise(X, thr, seed=noise_seed) if noise_seed is not None else None,
+                    self.psy.amplitude_to_dB_norm(X) if db_norm else None)
         x = _host.check_device_tensor(x, "x", self.compute_dtype, 3)
         B, S, C = x.shape
         N = self.filters_n
@@ -94,6 +104,9 @@ class AudioCodec:
         if t.data_ptr() % 16 != 0:
             raise ValueError("%s starts at an address that is not 16-byte aligned (a view into the middle of an "
                              "allocation?)" % name)
+        if t.requires_grad and torch.is_grad_enabled():
+            raise ValueError("%s requires a gradient: results written into caller-owned tensors carry none -- use "
+                             "encode() / decode(), which are differentiable" % name)
         return t
 
     def encode_into(self, x, X, t, thr, drown=0.0):

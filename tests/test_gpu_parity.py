@@ -521,6 +521,38 @@ def test_stream_run_as_a_replayed_graph(N, C, k, K, masking):
     sg.close(), sp.close()
 
 
+def test_codec_encode_decode_are_differentiable():
+    """AudioCodec.encode / encode_ex / decode on an input that requires a gradient: the differentiable composition (the
+    reference's op chain is differentiable), same values as the fused launch within the tolerance of the un-fused path,
+    gradients equal those of the explicit composition; the *_into forms refuse such tensors instead of dropping the graph"""
+    N, B, K, C = 1024, 2, 3, 2
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.empty(B, K * N, C, device="cuda").uniform_(-1, 1, generator=g)
+    w = torch.rand(B, K + 1, N, C, device="cuda", generator=g)
+    xa = x.clone().requires_grad_(True)
+    X, t, thr = codec.encode(xa, drown=0.2)
+    assert X.requires_grad and t.requires_grad and thr.requires_grad
+    Xf, tf, thrf = codec.encode(x, drown=0.2)
+    assert float((X.detach() - Xf).abs().max()) <= 1e-6 and float(((thr.detach() - thrf).abs() / thrf).max()) <= 1e-5
+    xh = codec.decode(X)
+    assert xh.requires_grad
+    ((thr * w).sum() + (xh ** 2).sum()).backward()
+    xb = x.clone().requires_grad_(True)
+    Xb = codec.mdct.transform(xb)
+    tb = codec.psy.tonality(Xb)
+    thrb = codec.psy.global_masking_threshold(Xb, tb, 0.2)
+    ((thrb * w).sum() + (codec.mdct.inverse_transform(Xb) ** 2).sum()).backward()
+    assert torch.equal(xa.grad, xb.grad) and float(xa.grad.abs().max()) > 0
+    ex = codec.encode_ex(x.clone().requires_grad_(True), drown=0.2, noise_seed=5, db_norm=True)
+    assert all(v.requires_grad for v in ex)
+    assert torch.equal(ex[3].detach(), codec.psy.add_noise(ex[0].detach(), ex[2].detach(), seed=5))
+    with pytest.raises(ValueError, match="gradient"):
+        codec.encode_into(xa, Xf, tf, thrf)
+    with torch.no_grad():
+        codec.encode_into(xa, Xf, tf, thrf)          # explicit no_grad: fine
+
+
 def test_misaligned_tensors_are_copied_or_refused():
     """The kernels move rows with 16-byte accesses.  An input view that starts inside an allocation is copied by the Python
     layer (same results); a caller-owned OUTPUT at such an address is refused (ValueError), and the C ABI itself refuses
