@@ -233,6 +233,9 @@ class StreamingMDCT:
             _lib.check(self._lib.ac_stream_reset(self._handle, _host.stream_ptr(self.device)))
 
     def _check_chunk(self, x, name, ndim):
+        if isinstance(x, torch.Tensor) and x.requires_grad and torch.is_grad_enabled():
+            raise ValueError("%s requires a gradient: the streaming calls keep state on the device and are not "
+                             "differentiable -- use MDCTransformer.transform / inverse_transform" % name)
         x = _host.check_device_tensor(x, name, self.mdct.compute_dtype, ndim)
         if x.device != self.device:
             raise ValueError("%s lives on %s but the stream's state lives on %s" % (name, x.device, self.device))

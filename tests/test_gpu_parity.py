@@ -551,6 +551,10 @@ def test_codec_encode_decode_are_differentiable():
         codec.encode_into(xa, Xf, tf, thrf)
     with torch.no_grad():
         codec.encode_into(xa, Xf, tf, thrf)          # explicit no_grad: fine
+    st = codec.stream(B, C)
+    with pytest.raises(ValueError, match="gradient"):
+        st.transform_chunk(xa[:, :N])
+    st.close()
 
 
 def test_misaligned_tensors_are_copied_or_refused():
