@@ -218,18 +218,51 @@ static inline __host__ __device__ int next_radix(int rem) { return rem % 4 == 0 
 // workgroup-wide).  Stockham autosort, decimation in time: a pass of radix r joins r transforms of length L into one of
 // length r L -- butterfly j = (p, q), q < L: x_s = src[q + L (p + s m)] W_{rL}^{q s}, m = H / (r L);
 // dst[q + L (r p + t)] = sum_s x_s w_r^{s t}.
+// B may BE v (the analysis kernel at filters_n > 2048, where a third buffer would leave one workgroup per CU): the
+// pre-twiddled input then goes through registers into the buffer from which the passes end in A, so that the last step
+// reads A and writes v.
+// (ALIAS is a template parameter, not a run-time test: the staging registers of the aliased form cost the other one
+// a third of its speed when both share a body)
+constexpr int kAliasPerThread = 8;   // N/2 values over 256 threads, N <= 4096
+template <bool ALIAS = false>
 __device__ void dct4_lds(float2* v, cpair* A, cpair* B, const float* __restrict__ ctab, const float2* __restrict__ tw,
                          int N, int tid, int nt) {
   const int H = N >> 1;
-  for (int n = tid; n < H; n += nt) {
-    cpair t;
-    t.re = v[2 * n];
-    t.im = v[N - 1 - 2 * n];
-    A[n] = cmulw(t, cis_neg(ctab, 4 * n + 1, N));   // exp(-i pi (n + 1/4) / N)
-  }
-  __syncthreads();
   cpair* src = A;
   cpair* dst = B;
+  if constexpr (ALIAS) {
+    int passes = 0;
+    for (int rem0 = H; rem0 > 1; rem0 /= next_radix(rem0)) ++passes;
+    if (passes & 1) {   // an odd number of passes starts in B (= v) and ends in A
+      src = B;
+      dst = A;
+    }
+    cpair held[kAliasPerThread];
+#pragma unroll
+    for (int i = 0; i < kAliasPerThread; ++i) {
+      const int n = tid + i * nt;
+      if (n < H) {
+        cpair t;
+        t.re = v[2 * n];
+        t.im = v[N - 1 - 2 * n];
+        held[i] = cmulw(t, cis_neg(ctab, 4 * n + 1, N));
+      }
+    }
+    __syncthreads();   // every value of v has been read: its bytes may now serve as B
+#pragma unroll
+    for (int i = 0; i < kAliasPerThread; ++i) {
+      const int n = tid + i * nt;
+      if (n < H) src[n] = held[i];
+    }
+  } else {
+    for (int n = tid; n < H; n += nt) {
+      cpair t;
+      t.re = v[2 * n];
+      t.im = v[N - 1 - 2 * n];
+      A[n] = cmulw(t, cis_neg(ctab, 4 * n + 1, N));   // exp(-i pi (n + 1/4) / N)
+    }
+  }
+  __syncthreads();
   int rem = H;
   for (int L = 1; L < H;) {
     const int r = next_radix(rem);
@@ -302,8 +335,15 @@ static inline __host__ __device__ int lds_group_threads(int N) {
   return nt;
 }
 
-// one group per (clip, channel pair, frame)
-template <typename TIO>
+// LDS floats per group of the analysis kernel: v [N float2] + A + B; beyond filters_n 2048 B shares v's bytes (measured:
+// N = 4096 0.679 -> 0.495 ms, two workgroups per CU instead of one; at smaller sizes the third buffer is faster)
+#ifndef AC_LDS_ALIAS_ABOVE
+#define AC_LDS_ALIAS_ABOVE 2048
+#endif
+static inline __host__ __device__ int lds_fwd_floats_per_group(int N) { return N > AC_LDS_ALIAS_ABOVE ? 4 * N : 6 * N; }
+
+// one group per (clip, channel pair, frame); ALIAS: the form for filters_n > 2048 (a kernel of its own: see dct4_lds)
+template <typename TIO, bool ALIAS = false>
 __global__ __launch_bounds__(kThreads) void k_fwd_lds(const TIO* __restrict__ x, TIO* __restrict__ X,
                                                       const TIO* __restrict__ prev_block,
                                                       const float* __restrict__ coef,
@@ -311,12 +351,13 @@ __global__ __launch_bounds__(kThreads) void k_fwd_lds(const TIO* __restrict__ x,
                                                       int N, long long ntasks) {
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int nt = lds_group_threads(N), grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
-  float2* tw = reinterpret_cast<float2*>(smem + (size_t)(kThreads / nt) * 6 * N);   // [N/2] behind the groups' buffers
+  const int per = ALIAS ? 4 * N : 6 * N;                   // (= lds_fwd_floats_per_group(N)) second FFT buffer aliased to v or not
+  float2* tw = reinterpret_cast<float2*>(smem + (size_t)(kThreads / nt) * per);   // [N/2] behind the groups' buffers
   fill_twiddles(tw, ctab, N);
-  float* base = smem + (size_t)grp * 6 * N;
+  float* base = smem + (size_t)grp * per;
   float2* v = reinterpret_cast<float2*>(base);             // [N]
   cpair* A = reinterpret_cast<cpair*>(base + 2 * N);       // [N/2]
-  cpair* Bf = reinterpret_cast<cpair*>(base + 4 * N);      // [N/2]
+  cpair* Bf = ALIAS ? reinterpret_cast<cpair*>(base) : reinterpret_cast<cpair*>(base + 4 * N);   // [N/2]
   const int h = N >> 1;
   const long long task_raw = (long long)blockIdx.x * (kThreads / nt) + grp;
   const bool valid = task_raw < ntasks;
@@ -349,7 +390,7 @@ __global__ __launch_bounds__(kThreads) void k_fwd_lds(const TIO* __restrict__ x,
     v[j] = vp;
   }
   __syncthreads();
-  dct4_lds(v, A, Bf, ctab, tw, N, tid, nt);
+  dct4_lds<ALIAS>(v, A, Bf, ctab, tw, N, tid, nt);
   if (!valid) return;
   const float scale = (float)(1.0 / ((double)N * 1.4142135623730951));   // 1/sqrt(4N) * sqrt(2/N)
   TIO* Xo = X + (((size_t)b * F + (size_t)n) * N) * C + c;
@@ -803,11 +844,17 @@ int launch_fwd_generic(const ac_mdct_plan* p, const float* x, float* X, const fl
   if (lds_fft_ok(p->N) && !g_force_generic) {
     const int CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const long long ntasks = (long long)B * CP * F;
-    const size_t lds2 = ((size_t)gpw * 6 * p->N + p->N) * sizeof(float);
-    const int st2 = allow_lds(k_fwd_lds<float>, lds2);
+    const size_t lds2 = ((size_t)gpw * lds_fwd_floats_per_group(p->N) + p->N) * sizeof(float);
+    const bool alias = lds_fwd_floats_per_group(p->N) == 4 * p->N;
+    const int st2 = alias ? allow_lds(k_fwd_lds<float, true>, lds2) : allow_lds(k_fwd_lds<float, false>, lds2);
     if (st2) return st2;
-    hipLaunchKernelGGL(k_fwd_lds<float>, dim3((unsigned)((ntasks + gpw - 1) / gpw)), dim3(kThreads), lds2, s, x, X, prev_block,
-                       p->d_coef, p->d_ctab, Kin, F, C, CP, p->N, ntasks);
+    const dim3 grid((unsigned)((ntasks + gpw - 1) / gpw));
+    if (alias)
+      hipLaunchKernelGGL((k_fwd_lds<float, true>), grid, dim3(kThreads), lds2, s, x, X, prev_block, p->d_coef, p->d_ctab, Kin, F,
+                         C, CP, p->N, ntasks);
+    else
+      hipLaunchKernelGGL((k_fwd_lds<float, false>), grid, dim3(kThreads), lds2, s, x, X, prev_block, p->d_coef, p->d_ctab, Kin, F,
+                         C, CP, p->N, ntasks);
     AC_HIP_CHECK(hipGetLastError());
     return AC_OK;
   }
@@ -967,11 +1014,17 @@ int launch_fwd_bf16(const ac_mdct_plan* p, const bf16_t* x, bf16_t* X, int B, in
   if (lds_fft_ok(p->N) && !g_force_generic) {
     const int CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const long long ntasks = (long long)B * CP * F;
-    const size_t lds2 = ((size_t)gpw * 6 * p->N + p->N) * sizeof(float);
-    const int st2 = allow_lds(k_fwd_lds<bf16_t>, lds2);
+    const size_t lds2 = ((size_t)gpw * lds_fwd_floats_per_group(p->N) + p->N) * sizeof(float);
+    const bool alias = lds_fwd_floats_per_group(p->N) == 4 * p->N;
+    const int st2 = alias ? allow_lds(k_fwd_lds<bf16_t, true>, lds2) : allow_lds(k_fwd_lds<bf16_t, false>, lds2);
     if (st2) return st2;
-    hipLaunchKernelGGL(k_fwd_lds<bf16_t>, dim3((unsigned)((ntasks + gpw - 1) / gpw)), dim3(kThreads), lds2, s, x, X,
-                       (const bf16_t*)nullptr, p->d_coef, p->d_ctab, Kin, F, C, CP, p->N, ntasks);
+    const dim3 grid((unsigned)((ntasks + gpw - 1) / gpw));
+    if (alias)
+      hipLaunchKernelGGL((k_fwd_lds<bf16_t, true>), grid, dim3(kThreads), lds2, s, x, X, (const bf16_t*)nullptr, p->d_coef,
+                         p->d_ctab, Kin, F, C, CP, p->N, ntasks);
+    else
+      hipLaunchKernelGGL((k_fwd_lds<bf16_t, false>), grid, dim3(kThreads), lds2, s, x, X, (const bf16_t*)nullptr, p->d_coef,
+                         p->d_ctab, Kin, F, C, CP, p->N, ntasks);
     AC_HIP_CHECK(hipGetLastError());
     return AC_OK;
   }
