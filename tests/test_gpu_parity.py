@@ -222,10 +222,15 @@ def test_tonality_like_reference(path):
     p = audiocodec_amd.PsychoacousticModel(sample_rate=N, filter_bands_n=N)
     X = m.transform(dev(sine_wav(0.8, 4, sample_rate=64, duration_sec=5.0)))
     assert float(p.tonality(X)[0, 1]) == 1.0
-    x = torch.rand(10, 10 * N, 2, device="cuda") * 2 - 1
-    t = p.tonality(m.transform(x))
+    # (the reference draws unseeded noise and asserts a mean below 0.1, which white noise at 64 bins only just keeps:
+    # the same seeded draw as the oracle's test, and the oracle's values beside the bound)
+    xn = np.random.default_rng(3).uniform(-1, 1, (10, 10 * N, 2)).astype(np.float32)
+    X = m.transform(dev(xn))
+    t = p.tonality(X)
     assert tuple(t.shape) == (10, 11, 1, 2)
     assert float(t[0, 1:-1].mean()) < 0.1
+    to = PsychoOracle(N, N, compute_dtype=np.float64).tonality(host(X).astype(np.float64))
+    assert tonality_err(host(t), to) <= 1.0
 
 
 @pytest.mark.parametrize("sr,N,M,B,F,C", [(48000, 1024, 64, 3, 4, 2), (48000, 1024, 64, 2, 3, 1), (48000, 1024, 64, 1, 2, 3),
