@@ -29,10 +29,12 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init_process_group(backend=None):
-    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+def init_process_group(backend=None, force=False):
+    """Initialise torch.distributed from the torchrun environment.  A single process gets no group unless ``force``:
+    a one-rank group sends the same barrier / all-reduce calls through the backend (RCCL on the device for "nccl") as
+    an N-rank run does, which is how the multi-GPU code path is exercised on a one-GPU box."""
     rank, world, local_rank = env_rank_world()
-    if world == 1:
+    if world == 1 and not force:
         return rank, world, local_rank
     if not dist.is_initialized():
         if backend is None:
@@ -40,6 +42,9 @@ def init_process_group(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
+            if torch.cuda.device_count() < world:
+                raise RuntimeError("%d ranks over RCCL need %d devices, this box has %d"
+                                   % (world, world, torch.cuda.device_count()))
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
@@ -47,7 +52,7 @@ def init_process_group(backend=None):
 
 def reduce_scalars(values, op="sum", device=None):
     """All-reduce a short list of Python floats (float64 on the wire).  Also serves as a barrier."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return [float(v) for v in values]
     if device is None or dist.get_backend() != "nccl":
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
@@ -58,5 +63,8 @@ def reduce_scalars(values, op="sum", device=None):
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+    if dist.is_available() and dist.is_initialized():
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()

@@ -216,3 +216,63 @@ def test_host_table_builders_under_sanitizers(tmp_path):
     assert build.returncode == 0, build.stderr
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and run.stdout.strip() == "ok", run.stdout + run.stderr
+
+
+# ---- bench.py's rank launching (the data path has no collective: mdctransformer.py:292-295) ----------------
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ac_bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_launch_plan_backend_by_device_count():
+    """`python bench.py --gpus N` starts N ranks under torch.distributed.run: RCCL ("nccl") when the box has a device per
+    rank, gloo (ranks share devices; rehearsal) otherwise; an explicit --dist / AC_BENCH_BACKEND is passed through."""
+    b = _bench_module()
+    for gpus, have, want in ((8, 8, "nccl"), (2, 8, "nccl"), (1, 1, "nccl"), (2, 1, "gloo"), (8, 1, "gloo")):
+        p = b.plan_launch(gpus, have, "auto", {}, ["--gpus", str(gpus)], 12345)
+        assert p["backend"] == want and p["env"]["AC_BENCH_BACKEND"] == want
+        cmd = p["cmd"]
+        assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+        assert cmd[cmd.index("--nproc-per-node") + 1] == str(gpus)
+        assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "12345"
+        assert cmd[-2:] == ["--gpus", str(gpus)] and cmd[-3].endswith("bench.py")
+    assert b.plan_launch(2, 1, "nccl", {}, [], 1)["backend"] == "nccl"            # asked for: the ranks refuse, not the planner
+    assert b.plan_launch(2, 8, "auto", {"AC_BENCH_BACKEND": "gloo"}, [], 1)["backend"] == "gloo"
+
+
+def test_bench_dry_run_launch_prints_the_plan():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-launch"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stdout + out.stderr
+    import json
+    plan = json.loads(out.stdout.strip().splitlines()[-1])
+    assert plan["ranks"] == 2 and plan["backend"] == ("nccl" if plan["devices"] >= 2 else "gloo")
+    assert "--dry-run-launch" not in plan["cmd"]
+
+
+def test_bench_rank_without_a_device_refuses_nccl():
+    """A rank of an RCCL run whose box has fewer devices than ranks exits non-zero before any process group exists."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", AC_BENCH_BACKEND="nccl", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--no-smi"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has a device per rank")
+    assert out.returncode != 0
+    assert "MI355X" in (out.stdout + out.stderr) or "devices" in (out.stdout + out.stderr)
+
+
+def test_one_rank_process_group_goes_through_the_backend(tmp_path):
+    """init_process_group(force=True) gives ONE rank a real group: the same barrier / all-reduce calls an N-rank run issues
+    (gloo here; `-m gpu` runs the RCCL form on the device)."""
+    script = tmp_path / "one.py"
+    script.write_text("import sys\nsys.path.insert(0, %r)\nimport torch.distributed as d\nfrom audiocodec_amd import dist as acd\n"
+                      "r, w, _ = acd.init_process_group('gloo', force=True)\nassert d.is_initialized() and d.get_world_size() == 1\n"
+                      "assert acd.reduce_scalars([2.5, 4.0], 'sum') == [2.5, 4.0]\nassert acd.reduce_scalars([7.0], 'max') == [7.0]\n"
+                      "acd.barrier()\nd.destroy_process_group()\nprint('OK', r, w)\n" % ROOT)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and "OK 0 1" in out.stdout, out.stdout + out.stderr
