@@ -18,7 +18,7 @@ AC_EINVAL, AC_EHIP, AC_ENOMEM, AC_ENODEV, AC_EUNSUPPORTED = -1, -2, -3, -4, -5
 WINDOW_IDS = {"vorbis": 0, "sine": 1}   # anything else -> 2 (rectangular), mdctransformer.py:199-211
 WINDOW_RECT = 2
 
-# name -> (restype, argtypes); mirrors include/audiocodec_amd.h one to one
+# name -> (restype, argtypes); mirrors include/audiocodec_amd.h (+ the test hook of audiocodec_amd_testing.h) one to one
 PROTOTYPES = {
     "ac_version": (c_int, []),
     "ac_last_error": (c_char_p, []),
@@ -70,6 +70,7 @@ PROTOTYPES = {
     "ac_stream_destroy": (c_int, [c_void_p]),
     "ac_stream_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ac_stream_inverse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ac_stream_settle": (c_int, [c_void_p, c_void_p]),
     "ac_stream_run": (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                               POINTER(c_void_p), POINTER(c_void_p), c_float, c_void_p]),
     "ac_stream_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p]),
@@ -109,7 +110,7 @@ def load():
             fn = getattr(lib, name)          # AttributeError here = header/library mismatch
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.ac_version() < 100:
+        if lib.ac_version() < 170:
             raise ImportError("libaudiocodec_amd too old: %d" % lib.ac_version())
         _lib = lib
     return _lib
@@ -128,6 +129,13 @@ def _build_in_tree():
     import shutil
     import subprocess
     import tempfile
+    # under a profiler (rocprofv3 preloads a library that initialises the GPU in every child) the make / hipcc / clang
+    # children would exec from GPU-initialised processes, which this pool forbids: refuse, do not build
+    preload = [k for k in os.environ if k.startswith(("ROCP", "ROCPROFILER", "ROCTRACER"))]
+    if preload or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        _build_log = ("not building under a profiler (%s set): run `make -C audiocodec_amd/csrc` (or __graft_entry__.build()) "
+                      "before the profiled command" % ", ".join(preload or ["LD_PRELOAD"]))
+        return
     libdir = os.path.join(_HERE, "lib")
     os.makedirs(libdir, exist_ok=True)
     with open(os.path.join(libdir, ".build.lock"), "w") as lock:

@@ -324,6 +324,17 @@ class StreamingMDCT:
             K = S // N
             full, rest = K // k, K % k
             like = xt
+            if (k * N * C * 4) % 16 != 0 and K > k:
+                # chunk boundaries inside one tensor would not be 16-byte aligned (filters_n * channels_n odd multiples of
+                # 2): per-chunk tensors through the list form, concatenated afterwards
+                parts = [xt[:, i * k * N:(i + 1) * k * N].clone() for i in range(full)]
+                o = self.run(parts, k, masking=masking, synthesis=synthesis, drown=drown) if full else ([], [], [], [])
+                if rest:
+                    r = self.run([xt[:, full * k * N:].clone()], rest, masking=masking, synthesis=synthesis, drown=drown)
+                    o = tuple((a or []) + (b or []) if (a is not None or b is not None) else None for a, b in zip(o, r))
+                cat = lambda ts: torch.cat(ts, dim=1) if ts else None   # noqa: E731
+                return cat(o[0]), cat(o[1]) if masking else None, cat(o[2]) if masking else None, \
+                    cat(o[3]) if synthesis else None
             Xall = torch.empty((1, K, N, C), dtype=xt.dtype, device=xt.device)
             tall = torch.empty((1, K, 1, C), dtype=xt.dtype, device=xt.device) if masking else None
             thrall = torch.empty_like(Xall) if masking else None
@@ -369,6 +380,10 @@ class StreamingMDCT:
         key = (tuple((c.data_ptr(), tuple(c.shape)) for c in chunks), isinstance(x, (list, tuple)), int(blocks_per_chunk),
                bool(masking), bool(synthesis), float(drown))
         hit = self._graphs.get(key)
+        # a captured call addresses the stream's HOME state buffers; chunk calls (and reset) since the last run() may have
+        # left the current state in the other buffer of the pair: move it home first (no device work when it is there)
+        with _host.on_device(self.device):
+            _lib.check(self._lib.ac_stream_settle(self._handle, _host.stream_ptr(self.device)))
         if hit is None:
             with _host.on_device(self.device):
                 self.mdct._plan(self.device)                       # plans are built outside the capture

@@ -249,6 +249,7 @@ int ac_psy_plan_create_ex(int N, int M, double sample_rate, double alpha, int de
   p->device = device;
   p->sample_rate = sample_rate;
   p->alpha = alpha;
+  if (hipDeviceGetAttribute(&p->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || p->cus <= 0) p->cus = 256;
   psy_tables(N, M, sample_rate, alpha, p->host);
   SparseRows wb, wi, wf, vb;
   w_by_band(p->host, wb);
@@ -576,6 +577,8 @@ int ac_stream_create(const ac_mdct_plan* plan, int B, int C, ac_stream** out) {
     ac_stream_destroy(s);
     return e == hipErrorOutOfMemory ? AC_ENOMEM : AC_EHIP;
   }
+  s->d_prev_home = s->d_prev_block;
+  s->d_tail_home = s->d_tail;
   *out = s;
   return AC_OK;
 }
@@ -583,6 +586,8 @@ int ac_stream_create(const ac_mdct_plan* plan, int B, int C, ac_stream** out) {
 int ac_stream_reset(ac_stream* s, void* stream) {
   AC_REQUIRE(s != nullptr, "stream is NULL");
   DeviceGuard guard(s->device);
+  if (s->d_prev_block != s->d_prev_home) std::swap(s->d_prev_block, s->d_prev_tmp);   // the zero state lives at home
+  if (s->d_tail != s->d_tail_home) std::swap(s->d_tail, s->d_tail_tmp);
   const size_t nb = (size_t)s->B * s->N * s->C * sizeof(float);
   const size_t nt = (size_t)s->B * s->C * (s->N / 2) * sizeof(float);
   AC_HIP_CHECK(hipMemsetAsync(s->d_prev_block, 0, nb, (hipStream_t)stream));
@@ -676,19 +681,26 @@ int ac_stream_inverse(ac_stream* s, const float* X_chunk, float* x, int k, void*
 }
 
 // The state buffers swap roles with every chunk; after an odd number of chunks the current state sits in the other
-// buffer.  ac_stream_run leaves the state where it found it (one small device copy), so that the launches of a call
-// captured into a HIP graph can be replayed: a replay reads and writes the same addresses as the captured call.
-static int settle_state(ac_stream* s, float* prev0, float* tail0, hipStream_t hs) {
+// buffer.  ac_stream_settle moves it back to the stream's home buffers (one small device copy per state, none when it is
+// already there).  ac_stream_run settles on entry and on exit, so the launches of a call captured into a HIP graph
+// address the home buffers, and a replay reads and writes the same addresses as the captured call -- provided the state is
+// at home when the replay starts: after chunk calls (ac_stream_forward / _encode / _inverse), call ac_stream_settle first.
+static int settle_state(ac_stream* s, hipStream_t hs) {
   DeviceGuard guard(s->device);
-  if (s->d_prev_block != prev0) {
-    AC_HIP_CHECK(hipMemcpyAsync(prev0, s->d_prev_block, (size_t)s->B * s->N * s->C * sizeof(float), hipMemcpyDeviceToDevice, hs));
+  if (s->d_prev_block != s->d_prev_home) {
+    AC_HIP_CHECK(hipMemcpyAsync(s->d_prev_home, s->d_prev_block, (size_t)s->B * s->N * s->C * sizeof(float), hipMemcpyDeviceToDevice, hs));
     std::swap(s->d_prev_block, s->d_prev_tmp);
   }
-  if (s->d_tail != tail0) {
-    AC_HIP_CHECK(hipMemcpyAsync(tail0, s->d_tail, (size_t)s->B * s->C * (s->N / 2) * sizeof(float), hipMemcpyDeviceToDevice, hs));
+  if (s->d_tail != s->d_tail_home) {
+    AC_HIP_CHECK(hipMemcpyAsync(s->d_tail_home, s->d_tail, (size_t)s->B * s->C * (s->N / 2) * sizeof(float), hipMemcpyDeviceToDevice, hs));
     std::swap(s->d_tail, s->d_tail_tmp);
   }
   return AC_OK;
+}
+
+int ac_stream_settle(ac_stream* s, void* stream) {
+  AC_REQUIRE(s != nullptr, "stream is NULL");
+  return settle_state(s, (hipStream_t)stream);
 }
 
 int ac_stream_run(ac_stream* s, const ac_psy_plan* psy, int nchunks, int k, const float* const* x_chunks,
@@ -716,9 +728,8 @@ int ac_stream_run(ac_stream* s, const ac_psy_plan* psy, int nchunks, int k, cons
     AC_REQUIRE(p->N == psy->N, "mdct filters_n (%d) != psychoacoustic filter_bands_n (%d)", p->N, psy->N);
     AC_REQUIRE(p->device == psy->device, "plans live on different devices");
   }
-  float* const prev0 = s->d_prev_block;   // where the state lives on entry (and again on exit: settle_state)
-  float* const tail0 = s->d_tail;
-  int st = AC_OK;
+  int st = settle_state(s, hs);   // the state at its home buffers on entry and again on exit
+  if (st) return st;
   bool duplex = xhat_chunks && nchunks >= 2 && wave_level(p, s->C, 0, k) && fast_duplex_serves(p, psy, s->B, s->C, k, k);
   if (duplex) {
     // the two halves of a launch must not touch each other's tensors: a caller that reuses one X (or PCM) buffer for
@@ -747,14 +758,14 @@ int ac_stream_run(ac_stream* s, const ac_psy_plan* psy, int nchunks, int k, cons
       }
     }
     if (!st) st = ac_stream_inverse(s, X_chunks[nchunks - 1], xhat_chunks[nchunks - 1], k, stream);
-    return st ? st : settle_state(s, prev0, tail0, hs);
+    return st ? st : settle_state(s, hs);
   }
   for (int i = 0; i < nchunks && !st; ++i) {
     st = stream_analysis(s, psy, x_chunks[i], X_chunks[i], psy ? t_chunks[i] : nullptr, psy ? thr_chunks[i] : nullptr,
                          drown, k, stream);
     if (!st && xhat_chunks) st = ac_stream_inverse(s, X_chunks[i], xhat_chunks[i], k, stream);
   }
-  return st ? st : settle_state(s, prev0, tail0, hs);
+  return st ? st : settle_state(s, hs);
 }
 
 // ---- element-wise utilities ------------------------------------------------------------------------

@@ -819,10 +819,6 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[R], char* lds0, char* 
 // copies the table image (and the psy image) into the workgroup's LDS behind the wave buffers; every thread takes part
 template <int NW, int WSTRIDE, int TABF, int PSYW, int PSY_TOTAL = 0, int MFB = 0>
 __device__ __forceinline__ void load_tables(char* lds, const float* __restrict__ image, const uint32_t* psy_tab) {
-#ifdef AC_EXP_NOTABLES   // timing experiment only (wrong results): what the table copy costs a latency-bound launch
-  __syncthreads();
-  return;
-#endif
   if (image) {
     v4f* dst = reinterpret_cast<v4f*>(lds + NW * WSTRIDE);
     const v4f* src = reinterpret_cast<const v4f*>(image);
@@ -998,13 +994,7 @@ __device__ __forceinline__ void fwd_fast_body(const FwdArgs& a, char* lds, const
       v4f cb[R], pb[R];
       const bool cur_ok = issue_loads(kCur, pair, n, cb);
       if constexpr (EPI) load_p1<R>(a.tab, lane, p1);
-#ifdef AC_EXP_NOHALO   // timing experiment only (wrong results): what the second read of every block costs
-      const bool prv_ok = true;
-#pragma unroll
-      for (int i = 0; i < R; ++i) pb[i] = cb[i] * 0.5f;
-#else
       const bool prv_ok = issue_loads(kPrv, pair, n, pb);
-#endif
       if (!cur_ok) zero_row(cb);   // edge frames only (wave-uniform)
       if (!prv_ok) zero_row(pb);
       if constexpr (IOF == 0) {

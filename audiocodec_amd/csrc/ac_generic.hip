@@ -26,7 +26,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 // one workgroup per (signal = b*C + c, frame n)
 // ------------------------------------------------------------------------------------------------
 template <typename TIO, typename TC = typename Compute<TIO>::type>
-__global__ __launch_bounds__(kThreads) void k_fwd_generic(const TIO* __restrict__ x, TIO* __restrict__ X,
+static __global__ __launch_bounds__(kThreads) void k_fwd_generic(const TIO* __restrict__ x, TIO* __restrict__ X,
                                                           const TIO* __restrict__ prev_block,
                                                           const TC* __restrict__ coef,
                                                           const TC* __restrict__ ctab, int Kin, int F, int C,
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kThreads) void k_fwd_generic(const TIO* __restrict_
 // one workgroup per (signal, output block n); block n = nblk only writes the new stream state
 // ------------------------------------------------------------------------------------------------
 template <typename TIO, typename TC = typename Compute<TIO>::type>
-__global__ __launch_bounds__(kThreads) void k_inv_generic(const TIO* __restrict__ X, TIO* __restrict__ x,
+static __global__ __launch_bounds__(kThreads) void k_inv_generic(const TIO* __restrict__ X, TIO* __restrict__ x,
                                                           const TC* __restrict__ tail_in,
                                                           TC* __restrict__ tail_out,
                                                           const TC* __restrict__ coef,
@@ -344,7 +344,7 @@ static inline __host__ __device__ int lds_fwd_floats_per_group(int N) { return N
 
 // one group per (clip, channel pair, frame); ALIAS: the form for filters_n > 2048 (a kernel of its own: see dct4_lds)
 template <typename TIO, bool ALIAS = false>
-__global__ __launch_bounds__(kThreads) void k_fwd_lds(const TIO* __restrict__ x, TIO* __restrict__ X,
+static __global__ __launch_bounds__(kThreads) void k_fwd_lds(const TIO* __restrict__ x, TIO* __restrict__ X,
                                                       const TIO* __restrict__ prev_block,
                                                       const float* __restrict__ coef,
                                                       const float* __restrict__ ctab, int Kin, int F, int C, int CP,
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(kThreads) void k_fwd_lds(const TIO* __restrict__ x,
 // stays in LDS along the strip, so a strip of T blocks costs T + 1 transforms; the block index nblk (one past the
 // last) only writes the new stream state.  Every group runs the same number of transforms (barriers are workgroup-wide).
 template <typename TIO>
-__global__ __launch_bounds__(kThreads) void k_inv_lds(const TIO* __restrict__ X, TIO* __restrict__ x,
+static __global__ __launch_bounds__(kThreads) void k_inv_lds(const TIO* __restrict__ X, TIO* __restrict__ x,
                                                       const float* __restrict__ tail_in, float* __restrict__ tail_out,
                                                       const float* __restrict__ coef, const float* __restrict__ ctab,
                                                       int Kp, int nblk, int seg, int nseg, int C, int CP, int N,
@@ -504,7 +504,7 @@ __device__ __forceinline__ float m_min(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ double m_min(double a, double b) { return fmin(a, b); }
 
 template <typename TIO, typename TC = typename Compute<TIO>::type>
-__global__ __launch_bounds__(kThreads) void k_tonality_generic(const TIO* __restrict__ X, TIO* __restrict__ t,
+static __global__ __launch_bounds__(kThreads) void k_tonality_generic(const TIO* __restrict__ X, TIO* __restrict__ t,
                                                                int C, int N) {
   __shared__ TC red[kThreads / 64];
   const TC eps = (TC)1e-14;
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(kThreads) void k_tonality_generic(const TIO* __rest
 // one workgroup per (b, frame, c)
 // ------------------------------------------------------------------------------------------------
 template <typename TIO, typename TC = typename Compute<TIO>::type>
-__global__ __launch_bounds__(kThreads) void k_threshold_generic(
+static __global__ __launch_bounds__(kThreads) void k_threshold_generic(
     const TIO* __restrict__ X, const TIO* __restrict__ t, TIO* __restrict__ thr, TC drown, TC alpha,
     const int32_t* __restrict__ wb_ptr, const int32_t* __restrict__ wb_idx, const TC* __restrict__ wb_val,
     const int32_t* __restrict__ wi_ptr, const int32_t* __restrict__ wi_idx, const TC* __restrict__ wi_val,
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(kThreads) void k_threshold_generic(
 // ------------------------------------------------------------------------------------------------
 // t = min(c' [mean_f ln max(eps, I_f) - ln(mean_f I_f + eps)], 1), c' = (10 / ln 10) / (-60), I_f = X_f^2:
 // d t / d X_f = c' (1/N) ([I_f > eps] / I_f - 1 / (mean I + eps)) 2 X_f   where the clamp is inactive
-__global__ __launch_bounds__(kThreads) void k_tonality_bwd_generic(const float* __restrict__ X,
+static __global__ __launch_bounds__(kThreads) void k_tonality_bwd_generic(const float* __restrict__ X,
                                                                    const float* __restrict__ gt,
                                                                    float* __restrict__ gX, int accumulate, int C,
                                                                    int N) {
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(kThreads) void k_tonality_bwd_generic(const float* 
 // Y_j = fac_j A_j, A_j = sum_i Q_i S[i,j], Q_i = max(eps, P_i)^alpha, P_i = sum_f X_f^2 W[f,i],
 // fac_j = 10^(-alpha O_j / 10), O_j = (1 - drown)(t beta_j + 9 t + 5.5).  The adjoint walks the chain backwards;
 // every max() passes the gradient to its active branch.
-__global__ __launch_bounds__(kThreads) void k_threshold_bwd_generic(
+static __global__ __launch_bounds__(kThreads) void k_threshold_bwd_generic(
     const float* __restrict__ X, const float* __restrict__ t, const float* __restrict__ gthr, float* __restrict__ gX,
     float* __restrict__ gt, float drown, float alpha,
     const int32_t* __restrict__ wb_ptr, const int32_t* __restrict__ wb_idx, const float* __restrict__ wb_val,
@@ -736,7 +736,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // (db_of, normal_pair, noisy_of: ac_internal.h, shared with the fused encode epilogue)
 // 16-byte vectors (n4 of them), one per thread, workgroups in address order (4 KB per workgroup: the store pattern the
 // memory system rewards most, tools/ubench_write_pattern.hip) + a scalar tail; a, out 16-byte aligned when n4 > 0
-__global__ __launch_bounds__(256) void k_db(const float* __restrict__ a, float* __restrict__ out, size_t n, size_t n4,
+static __global__ __launch_bounds__(256) void k_db(const float* __restrict__ a, float* __restrict__ out, size_t n, size_t n4,
                                             int norm) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n4) {
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(256) void k_db(const float* __restrict__ a, float* 
 }
 
 // d amplitude_to_dB / d a = (20 / ln 10) / a where a^2 > eps, else 0 (the clamp); the normalised form scales by 1 / 140
-__global__ __launch_bounds__(256) void k_db_bwd(const float* __restrict__ a, const float* __restrict__ g,
+static __global__ __launch_bounds__(256) void k_db_bwd(const float* __restrict__ a, const float* __restrict__ g,
                                                 float* __restrict__ ga, size_t n, int norm) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const float c = norm ? (8.685889638065035f / 140.f) : 8.685889638065035f;
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(256) void k_db_bwd(const float* __restrict__ a, con
 
 // add_noise (psychoacoustic.py:150-167): out = X + thr * Normal(0, 1/6); X == nullptr stands for zeros (the gradient of
 // add_noise with respect to the threshold is add_noise(0, grad_out) under the same seed)
-__global__ __launch_bounds__(256) void k_add_noise(const float* __restrict__ X, const float* __restrict__ thr,
+static __global__ __launch_bounds__(256) void k_add_noise(const float* __restrict__ X, const float* __restrict__ thr,
                                                    float* __restrict__ out, size_t n, size_t n4, uint64_t seed) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t key = mix64(seed);
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(256) void k_add_noise(const float* __restrict__ X, 
 // the same two utilities for the other storage types (double: fp64 arithmetic; bfloat16: float32 arithmetic), one
 // element per thread and iteration; the noise stream is the float32 one (same seed, same normals)
 template <typename TIO, typename TC = typename Compute<TIO>::type>
-__global__ __launch_bounds__(256) void k_db_typed(const TIO* __restrict__ a, TIO* __restrict__ out, size_t n, int norm) {
+static __global__ __launch_bounds__(256) void k_db_typed(const TIO* __restrict__ a, TIO* __restrict__ out, size_t n, int norm) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const TC v = ldv(a + i);
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(256) void k_db_typed(const TIO* __restrict__ a, TIO
   }
 }
 template <typename TIO, typename TC = typename Compute<TIO>::type>
-__global__ __launch_bounds__(256) void k_add_noise_typed(const TIO* __restrict__ X, const TIO* __restrict__ thr,
+static __global__ __launch_bounds__(256) void k_add_noise_typed(const TIO* __restrict__ X, const TIO* __restrict__ thr,
                                                          TIO* __restrict__ out, size_t n, uint64_t seed) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const uint64_t key = mix64(seed);

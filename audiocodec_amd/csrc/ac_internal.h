@@ -8,6 +8,7 @@
 #include <string>
 
 #include "../../include/audiocodec_amd.h"
+#include "../../include/audiocodec_amd_testing.h"
 #include "ac_tables.h"
 
 namespace ac {
@@ -133,6 +134,8 @@ struct ac_psy_plan {
   int mid = 0;
   uint32_t* d_mid = nullptr;
   int mid_words = 0;
+  int mid_wi_w = 0, mid_off_S = 0, mid_off_band = 0, mid_off_wbe = 0, mid_off_wi = 0;   // layout of the image (build_mid)
+  int cus = 0;                 // compute units of the device (sizes the launches)
 };
 
 struct ac_stream {
@@ -143,6 +146,11 @@ struct ac_stream {
   float* d_prev_tmp = nullptr;     // double buffer for the analysis state (written by the kernel that reads the other)
   float* d_tail = nullptr;         // synthesis state [B, C, N/2]  (u_last[h .. N-1])
   float* d_tail_tmp = nullptr;     // double buffer for the synthesis state
+  // the buffers swap roles with every chunk; "home" = the pair the state is moved back to by ac_stream_settle (and by
+  // ac_stream_run on entry and exit, and by ac_stream_reset), so that launches captured into a HIP graph address the
+  // state where a later replay will find it
+  float* d_prev_home = nullptr;
+  float* d_tail_home = nullptr;
 };
 
 // ---- kernel launchers (each returns an AC_* status) -----------------------------------------

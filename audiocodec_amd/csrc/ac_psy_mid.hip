@@ -337,6 +337,11 @@ int mid_psy_plan_init(ac_psy_plan* p) {
     return AC_EUNSUPPORTED;
   }
   p->mid_words = L.words;
+  p->mid_wi_w = L.wi_w;
+  p->mid_off_S = L.off_S;
+  p->mid_off_band = L.off_band;
+  p->mid_off_wbe = L.off_wbe;
+  p->mid_off_wi = L.off_wi;
   AC_HIP_CHECK(hipMalloc((void**)&p->d_mid, w.size() * sizeof(uint32_t)));
   AC_HIP_CHECK(hipMemcpy(p->d_mid, w.data(), w.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   return AC_OK;
@@ -350,8 +355,14 @@ int launch_psy_mid(const ac_psy_plan* p, const float* X, const float* t_in, floa
     set_error("internal: the wave-level masking model serves mono and stereo tensors");
     return AC_EUNSUPPORTED;
   }
+  // (the layout of the image was fixed when the plan was built: a launch only fills in arguments)
   MidLayout L;
-  build_mid(p, nullptr, &L);
+  L.words = p->mid_words;
+  L.wi_w = p->mid_wi_w;
+  L.off_S = p->mid_off_S;
+  L.off_band = p->mid_off_band;
+  L.off_wbe = p->mid_off_wbe;
+  L.off_wi = p->mid_off_wi;
   MidArgs a;
   a.X = X;
   a.t_in = t_in;
@@ -384,13 +395,7 @@ int launch_psy_mid(const ac_psy_plan* p, const float* X, const float* t_in, floa
     return AC_EUNSUPPORTED;
   }
   // frames per wave: as many as keep every CU supplied with a few workgroups (the image copy is paid per workgroup)
-  int cus = 256;
-  {
-    hipDeviceProp_t prop;
-    static int cached = 0;
-    if (!cached && hipGetDeviceProperties(&prop, p->device) == hipSuccess) cached = prop.multiProcessorCount;
-    if (cached) cus = cached;
-  }
+  const int cus = p->cus > 0 ? p->cus : 256;
   int T = want_thr ? 8 : 1;
   while (T > 1 && a.ntasks < (long long)nw * T * cus * 6) T >>= 1;
   a.T = T;

@@ -187,10 +187,13 @@ class PsychoacousticModel:
         return out
 
     def _db_backward(self, a, g, norm):
-        ga = torch.empty_like(a)
+        # the kernel walks three flat arrays in the logical (row-major) order: one contiguous copy of each input, held until
+        # the launch has been enqueued, and a contiguous result (a permuted view would otherwise get a scrambled gradient)
+        a_c, g_c = a.contiguous(), g.contiguous()
+        ga = torch.empty(a.shape, dtype=a.dtype, device=a.device)
         with _host.on_device(a.device):
-            _lib.check(self._lib.ac_amplitude_to_db_backward(_host.ptr(a.contiguous()), _host.ptr(g), _host.ptr(ga),
-                                                             a.numel(), int(norm), _host.stream_ptr(a.device)))
+            _lib.check(self._lib.ac_amplitude_to_db_backward(_host.ptr(a_c), _host.ptr(g_c), _host.ptr(ga),
+                                                             a_c.numel(), int(norm), _host.stream_ptr(a.device)))
         return ga
 
     def _db(self, mdct_amplitude, norm):

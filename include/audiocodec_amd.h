@@ -38,9 +38,16 @@
 extern "C" {
 #endif
 
-#define AC_VERSION 160 /* 0.1.6: ac_stream_run replayable as a HIP graph (state left in place), duplex launches; filters_n 64 / 128 and
-                          * 16-bit PCM on the several-frames-per-wave kernels; mixed-radix FFT tier; masking model for any even
-                          * filter_bands_n <= 1024.  (0.1.5: + ac_stream_encode, analysis state written by the kernels, AC_TESTING gate) */
+/* The library is built with -fvisibility=hidden: the entry points declared in this header (and the test hook of
+ * audiocodec_amd_testing.h) are its only dynamic symbols. */
+#ifndef AC_API
+#define AC_API __attribute__((visibility("default")))
+#endif
+
+#define AC_VERSION 170 /* 0.1.7: only the ac_* entry points are exported; ac_stream_settle (home buffers for the streaming state);
+                          * float32 precompute (ac_*_create_pre, ac_*_host_pre); fused encode at filters_n 64 ... 512; ac_workspace_*.
+                          * (0.1.6: ac_stream_run replayable as a HIP graph, duplex launches; filters_n 64 / 128 and 16-bit PCM on the
+                          * several-frames-per-wave kernels; mixed-radix FFT tier; masking model for any even filter_bands_n <= 1024) */
 
 enum {
   AC_OK = 0,
@@ -58,8 +65,8 @@ typedef struct ac_mdct_plan ac_mdct_plan;
 typedef struct ac_psy_plan ac_psy_plan;
 typedef struct ac_stream ac_stream;
 
-int ac_version(void);
-const char* ac_last_error(void);
+AC_API int ac_version(void);
+AC_API const char* ac_last_error(void);
 
 /* ------------------------------------------------------------------------------------------
  * Host-only constant builders (fp64 precompute, no GPU needed).
@@ -70,19 +77,19 @@ const char* ac_last_error(void);
  * written to coef[8*N/2] in the order a1 a2 a3 a4 s1 s2 s3 s4:
  *   analysis   v[h+j] = a1[j] xc[j] + a2[j] xc[N-1-j],   v[j]       = a3[j] xp[h-1-j] + a4[j] xp[h+j]
  *   synthesis  out[j] = s1[j] u_n[h-1-j] + s2[j] u_{n-1}[h+j],   out[N-1-j] = s3[j] u_n[h-1-j] + s4[j] u_{n-1}[h+j] */
-int ac_mdct_fold_coefficients_host(int N, int window, double* coef);
+AC_API int ac_mdct_fold_coefficients_host(int N, int window, double* coef);
 
 /* Dense polyphase matrices exactly as the reference stores them: H, H_inv [2,N,N] float32
  * (mdctransformer.py:58-59).  Never used by the kernels; for the Python attributes only. */
-int ac_mdct_dense_matrices_host(int N, int window, float* H, float* H_inv);
+AC_API int ac_mdct_dense_matrices_host(int N, int window, float* H, float* H_inv);
 
 /* Constants of PsychoacousticModel.__init__ (psychoacoustic.py:52-69): W [N,M], W_inv [M,N],
  * spreading_matrix [M,M], quiet_threshold_intensity [M] as float32 (any pointer may be NULL) and
  * scalars[4] = {max_frequency, max_bark, bark_band_width, dB_MIN} as double. */
-int ac_psy_tables_host(int N, int M, double sample_rate, double alpha,
+AC_API int ac_psy_tables_host(int N, int M, double sample_rate, double alpha,
                        float* W, float* W_inv, float* S, float* quiet, double* scalars);
 /* the same constants unrounded, as PsychoacousticModel holds them with compute_dtype = float64 */
-int ac_psy_tables_host_f64(int N, int M, double sample_rate, double alpha,
+AC_API int ac_psy_tables_host_f64(int N, int M, double sample_rate, double alpha,
                            double* W, double* W_inv, double* S, double* quiet, double* scalars);
 
 /* ------------------------------------------------------------------------------------------
@@ -90,12 +97,12 @@ int ac_psy_tables_host_f64(int N, int M, double sample_rate, double alpha,
  * ---------------------------------------------------------------------------------------- */
 
 /* MDCTransformer.__init__ (mdctransformer.py:13-59).  N even, >= 2. */
-int ac_mdct_plan_create(int N, int window, int device, ac_mdct_plan** out);
-int ac_mdct_plan_destroy(ac_mdct_plan* plan);
+AC_API int ac_mdct_plan_create(int N, int window, int device, ac_mdct_plan** out);
+AC_API int ac_mdct_plan_destroy(ac_mdct_plan* plan);
 
 /* PsychoacousticModel.__init__ (psychoacoustic.py:14-69). */
-int ac_psy_plan_create(int N, int M, double sample_rate, double alpha, int device, ac_psy_plan** out);
-int ac_psy_plan_destroy(ac_psy_plan* plan);
+AC_API int ac_psy_plan_create(int N, int M, double sample_rate, double alpha, int device, ac_psy_plan** out);
+AC_API int ac_psy_plan_destroy(ac_psy_plan* plan);
 
 /* Form of the band x band product with the spreading matrix (psychoacoustic.py:205-207: sum_i max(eps, P_i)^alpha S[i,j])
  * in the wave-level kernels -- BASELINE configs[3] "Bark spreading cast as band x band MFMA contraction, bf16":
@@ -109,39 +116,37 @@ int ac_psy_plan_destroy(ac_psy_plan* plan);
  * Served for stereo input (float32 or 16-bit PCM) by ac_encode_fused* and ac_mask_threshold; other channel counts and
  * the bfloat16 tensors of the *_typed entry points keep the float32 product.  AC_EUNSUPPORTED unless the plan runs the wave-level kernels. */
 enum { AC_SPREAD_F32 = 0, AC_SPREAD_BF16_MFMA = 1, AC_SPREAD_BF16X2_MFMA = 2 };
-int ac_psy_plan_create_ex(int N, int M, double sample_rate, double alpha, int device, int spreading, ac_psy_plan** out);
-int ac_psy_plan_spreading(const ac_psy_plan* plan);
+AC_API int ac_psy_plan_create_ex(int N, int M, double sample_rate, double alpha, int device, int spreading, ac_psy_plan** out);
+AC_API int ac_psy_plan_spreading(const ac_psy_plan* plan);
 
 /* 1 when the plan runs the wave-level kernels (filters_n 1024 / 2048, Princen-Bradley window; 64 Bark bands), 0 when it
  * runs the LDS-FFT middle tier (filters_n from 16 to 4096 with a 5-smooth half: 2^a 3^b 5^c) or the generic O(N^2) kernels. */
-int ac_mdct_plan_is_fast(const ac_mdct_plan* plan);
-int ac_psy_plan_is_fast(const ac_psy_plan* plan);
+AC_API int ac_mdct_plan_is_fast(const ac_mdct_plan* plan);
+AC_API int ac_psy_plan_is_fast(const ac_psy_plan* plan);
 /* Which kernels serve the masking model of a plan: 2 = the wave-level kernels fused into the encode (filter_bands_n 1024 /
  * 2048, 64 Bark bands, every bin in at most two adjacent bands); 1 = the wave-level kernels for general band layouts
  * (any even filter_bands_n up to 1024, up to 64 bands; mono / stereo tensors, other channel counts take the generic ones);
  * 0 = the generic kernels (one workgroup per channel-frame). */
-int ac_psy_plan_tier(const ac_psy_plan* plan);
+AC_API int ac_psy_plan_tier(const ac_psy_plan* plan);
 
-/* Test hook (process-global): force the generic kernels (1) or restore automatic selection (0).  Honoured only in a
- * process started with AC_TESTING=1 in its environment; AC_EUNSUPPORTED otherwise. */
-int ac_set_force_generic(int on);
+/* (The test hook that forces the generic kernels is declared in audiocodec_amd_testing.h, not here.) */
 
 /* ------------------------------------------------------------------------------------------
  * Hot path.
  * ---------------------------------------------------------------------------------------- */
 
 /* MDCTransformer.transform (mdctransformer.py:62-125):  x [B, K*N, C] -> X [B, K+1, N, C]. */
-int ac_mdct_forward(const ac_mdct_plan* plan, const float* x, float* X, int B, int K, int C, void* stream);
+AC_API int ac_mdct_forward(const ac_mdct_plan* plan, const float* x, float* X, int B, int K, int C, void* stream);
 
 /* MDCTransformer.inverse_transform (mdctransformer.py:128-153):  X [B, Kp, N, C] -> x [B, (Kp+1)*N, C]. */
-int ac_mdct_inverse(const ac_mdct_plan* plan, const float* X, float* x, int B, int Kp, int C, void* stream);
+AC_API int ac_mdct_inverse(const ac_mdct_plan* plan, const float* X, float* x, int B, int Kp, int C, void* stream);
 
 /* PsychoacousticModel.tonality (psychoacoustic.py:102-120):  X [B, F, N, C] -> t [B, F, 1, C]. */
-int ac_tonality(const ac_psy_plan* plan, const float* X, float* t, int B, int F, int C, void* stream);
+AC_API int ac_tonality(const ac_psy_plan* plan, const float* X, float* t, int B, int F, int C, void* stream);
 
 /* PsychoacousticModel.global_masking_threshold (psychoacoustic.py:122-148, with 169-210, 301-331):
  * X [B,F,N,C], t [B,F,1,C], drown in [0,1] -> thr [B,F,N,C]. */
-int ac_mask_threshold(const ac_psy_plan* plan, const float* X, const float* t, float drown, float* thr,
+AC_API int ac_mask_threshold(const ac_psy_plan* plan, const float* X, const float* t, float drown, float* thr,
                       int B, int F, int C, void* stream);
 
 /* Backward passes of the masking model (the reference is differentiated by TensorFlow when it is used inside a
@@ -150,15 +155,15 @@ int ac_mask_threshold(const ac_psy_plan* plan, const float* X, const float* t, f
  *   accumulate != 0 adds into grad_X instead of overwriting it.
  * ac_mask_threshold_backward: grad_thr [B,F,N,C] -> grad_X [B,F,N,C] and grad_t [B,F,1,C]
  *   (d threshold / d X and d threshold / d tonality, psychoacoustic.py:122-148 with 169-210, 301-331). */
-int ac_tonality_backward(const ac_psy_plan* plan, const float* X, const float* grad_t, float* grad_X, int accumulate,
+AC_API int ac_tonality_backward(const ac_psy_plan* plan, const float* X, const float* grad_t, float* grad_X, int accumulate,
                          int B, int F, int C, void* stream);
-int ac_mask_threshold_backward(const ac_psy_plan* plan, const float* X, const float* t, float drown,
+AC_API int ac_mask_threshold_backward(const ac_psy_plan* plan, const float* X, const float* t, float drown,
                                const float* grad_thr, float* grad_X, float* grad_t, int B, int F, int C, void* stream);
 
 /* Fused encode = transform -> tonality -> global_masking_threshold in one pass over the PCM
  * (the composition of tests/test_psychoacoustic.py:38-41 + psychoacoustic.py:130-131).
  * x [B,K*N,C] -> X [B,K+1,N,C], t [B,K+1,1,C], thr [B,K+1,N,C].  mdct N must equal psy N. */
-int ac_encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t,
+AC_API int ac_encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t,
                     float* thr, float drown, int B, int K, int C, void* stream);
 
 /* The fused encode with its element-wise tail (psychoacoustic.py:150-167 and :87-100 on the frames just computed), so
@@ -168,7 +173,7 @@ int ac_encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const floa
  * One launch for stereo float32 input on the wave-level kernels at filters_n = 1024; elsewhere the encode followed by
  * the two element-wise kernels.  flags = 0 is ac_encode_fused. */
 enum { AC_EMIT_NOISY = 1, AC_EMIT_DB_NORM = 2 };
-int ac_encode_fused_ex(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr,
+AC_API int ac_encode_fused_ex(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr,
                        float drown, int flags, float* noisy, float* db_norm, uint64_t seed, int B, int K, int C,
                        void* stream);
 
@@ -176,9 +181,9 @@ int ac_encode_fused_ex(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const f
  * x = pcm / 32768 on the way in, pcm = clamp(round(32768 x), -32768, 32767) on the way out, fused into the kernels'
  * loads / stores, so a frame moves 2 bytes per sample instead of 4.  Served by the wave-level kernels (filters_n 1024
  * or 2048, 'vorbis' / 'sine' window); AC_EUNSUPPORTED otherwise.  Shapes as the float32 entry points. */
-int ac_mdct_forward_pcm16(const ac_mdct_plan* plan, const int16_t* x, float* X, int B, int K, int C, void* stream);
-int ac_mdct_inverse_pcm16(const ac_mdct_plan* plan, const float* X, int16_t* x, int B, int Kp, int C, void* stream);
-int ac_encode_fused_pcm16(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const int16_t* x, float* X, float* t,
+AC_API int ac_mdct_forward_pcm16(const ac_mdct_plan* plan, const int16_t* x, float* X, int B, int K, int C, void* stream);
+AC_API int ac_mdct_inverse_pcm16(const ac_mdct_plan* plan, const float* X, int16_t* x, int B, int Kp, int C, void* stream);
+AC_API int ac_encode_fused_pcm16(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const int16_t* x, float* X, float* t,
                           float* thr, float drown, int B, int K, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -187,18 +192,23 @@ int ac_encode_fused_pcm16(const ac_mdct_plan* mdct, const ac_psy_plan* psy, cons
  * the last DCT-IV output per (b,c) [B,C,N/2].  A fresh/reset stream starts from zero state, so the
  * concatenation of chunk outputs equals the one-shot transform frame for frame.
  * ---------------------------------------------------------------------------------------- */
-int ac_stream_create(const ac_mdct_plan* plan, int B, int C, ac_stream** out);
-int ac_stream_reset(ac_stream* s, void* stream);
-int ac_stream_destroy(ac_stream* s);
+AC_API int ac_stream_create(const ac_mdct_plan* plan, int B, int C, ac_stream** out);
+AC_API int ac_stream_reset(ac_stream* s, void* stream);
+AC_API int ac_stream_destroy(ac_stream* s);
 /* x_chunk [B, k*N, C] -> X [B, k, N, C]  (frame i = blocks i-1, i; block -1 = state) */
-int ac_stream_forward(ac_stream* s, const float* x_chunk, float* X, int k, void* stream);
+AC_API int ac_stream_forward(ac_stream* s, const float* x_chunk, float* X, int k, void* stream);
 /* the same with the masking model on the chunk's frames: X, t [B, k, 1, C], thr [B, k, N, C] equal, frame for frame and bit
  * for bit, what ac_encode_fused returns for the whole signal (one fused launch where the wave-level kernels serve both
  * plans; psychoacoustic.py:102-148 on mdctransformer.py:62-125) */
-int ac_stream_encode(ac_stream* s, const ac_psy_plan* psy, const float* x_chunk, float* X, float* t, float* thr,
+AC_API int ac_stream_encode(ac_stream* s, const ac_psy_plan* psy, const float* x_chunk, float* X, float* t, float* thr,
                      float drown, int k, void* stream);
 /* X_chunk [B, k, N, C] -> x [B, k*N, C]  (block i = frames i, i-1; frame -1 = state) */
-int ac_stream_inverse(ac_stream* s, const float* X_chunk, float* x, int k, void* stream);
+AC_API int ac_stream_inverse(ac_stream* s, const float* X_chunk, float* x, int k, void* stream);
+/* The two state buffers of a stream are double-buffered (a kernel reads one while it writes the other), so the current
+ * state changes address with every chunk call.  ac_stream_settle moves it back to the stream's home buffers: at most two
+ * small device-to-device copies on `stream` (B*N*C and B*C*N/2 floats), nothing when it is already there.  Needed only by
+ * callers that replay a captured ac_stream_run (below) after chunk calls: settle before capturing and before each such replay. */
+AC_API int ac_stream_settle(ac_stream* s, void* stream);
 
 /* Feeds nchunks consecutive chunks of k blocks through the stream in one call (a long device-resident signal, a ring
  * buffer that has filled up): chunk i is analysed -- with the masking model when psy is not NULL, else t_chunks /
@@ -208,12 +218,14 @@ int ac_stream_inverse(ac_stream* s, const float* X_chunk, float* x, int k, void*
  * binding overhead).  With synthesis, chunks small enough to be latency-bound (one or a few clips) and distinct buffers
  * per chunk, the analysis of chunk i + 1 and the synthesis of chunk i share ONE launch (float32, mono / stereo,
  * filters_n 1024 / 2048): nchunks + 1 launches instead of 2 nchunks, same results bit for bit.  A caller that reuses
- * one buffer for consecutive chunks gets the dependent chain.  The stream's state ends up at the addresses where the call
- * found it, and nothing synchronises or allocates: a call is capturable into a HIP graph (hipStreamBeginCapture on
- * `stream`), and replaying the graph repeats it on new contents of the same buffers -- 7.9 us per chunk of one stereo
- * clip against 11.9 us for the plain launches (the gaps between dependent launches go).  The pointer lists are host
- * arrays. */
-int ac_stream_run(ac_stream* s, const ac_psy_plan* psy, int nchunks, int k, const float* const* x_chunks,
+ * one buffer for consecutive chunks gets the dependent chain.  The call settles the stream's state at its home buffers on
+ * entry and on exit (ac_stream_settle) and nothing synchronises or allocates: a call is capturable into a HIP graph
+ * (hipStreamBeginCapture on `stream`; call ac_stream_settle BEFORE the capture so that no state copy is recorded), and
+ * replaying the graph repeats it on new contents of the same buffers -- 7.9 us per chunk of one stereo clip against
+ * 11.9 us for the plain launches (the gaps between dependent launches go).  A replay addresses the home buffers: if chunk
+ * calls (ac_stream_forward / _encode / _inverse) or ac_stream_reset ran since the last ac_stream_run, call
+ * ac_stream_settle before replaying.  The pointer lists are host arrays. */
+AC_API int ac_stream_run(ac_stream* s, const ac_psy_plan* psy, int nchunks, int k, const float* const* x_chunks,
                   float* const* X_chunks, float* const* t_chunks, float* const* thr_chunks, float* const* xhat_chunks,
                   float drown, void* stream);
 
@@ -221,14 +233,14 @@ int ac_stream_run(ac_stream* s, const ac_psy_plan* psy, int nchunks, int k, cons
  * Element-wise utilities of PsychoacousticModel (psychoacoustic.py:71-100, 150-167).
  * ---------------------------------------------------------------------------------------- */
 /* amplitude_to_dB (norm = 0) / amplitude_to_dB_norm (norm = 1) on n floats. */
-int ac_amplitude_to_db(const float* a, float* out, size_t n, int norm, void* stream);
+AC_API int ac_amplitude_to_db(const float* a, float* out, size_t n, int norm, void* stream);
 /* d amplitude_to_dB(_norm) / d a: grad_a = grad_out * (20 / ln 10) / a where a^2 > 1e-14 (0 inside the clamp), / 140 for
  * the normalised form. */
-int ac_amplitude_to_db_backward(const float* a, const float* grad_out, float* grad_a, size_t n, int norm, void* stream);
+AC_API int ac_amplitude_to_db_backward(const float* a, const float* grad_out, float* grad_a, size_t n, int norm, void* stream);
 /* add_noise: out = X + thr * Normal(0, 1/6), counter-based generator keyed by (seed, element-pair index).  X == NULL
  * stands for zeros: ac_add_noise(NULL, g, out, n, seed) is the gradient of add_noise with respect to the threshold
  * (the gradient with respect to X is g itself). */
-int ac_add_noise(const float* X, const float* thr, float* out, size_t n, uint64_t seed, void* stream);
+AC_API int ac_add_noise(const float* X, const float* thr, float* out, size_t n, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Buffer placement probe (see the performance note at the top).  Runs ac_encode_fused with each of
@@ -236,7 +248,7 @@ int ac_add_noise(const float* X, const float* thr, float* out, size_t n, uint64_
  * candidate with HIP events (median of three launches after one warm-up) and returns the index of the fastest in *best and,
  * when ms is not NULL, the n times in milliseconds.  The one entry point that synchronises (on its own events).
  * ---------------------------------------------------------------------------------------- */
-int ac_probe_placement(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t,
+AC_API int ac_probe_placement(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t,
                        float* const* thr_candidates, int n_candidates, int B, int K, int C, void* stream, int* best,
                        float* ms);
 
@@ -255,15 +267,15 @@ int ac_probe_placement(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const f
  * No streaming state and no backward passes for AC_F64 / AC_BF16.
  * ---------------------------------------------------------------------------------------- */
 enum { AC_F32 = 0, AC_F64 = 1, AC_BF16 = 2 };
-int ac_mdct_forward_typed(const ac_mdct_plan* plan, const void* x, void* X, int dtype, int B, int K, int C, void* stream);
-int ac_mdct_inverse_typed(const ac_mdct_plan* plan, const void* X, void* x, int dtype, int B, int Kp, int C, void* stream);
-int ac_tonality_typed(const ac_psy_plan* plan, const void* X, void* t, int dtype, int B, int F, int C, void* stream);
-int ac_mask_threshold_typed(const ac_psy_plan* plan, const void* X, const void* t, double drown, void* thr, int dtype,
+AC_API int ac_mdct_forward_typed(const ac_mdct_plan* plan, const void* x, void* X, int dtype, int B, int K, int C, void* stream);
+AC_API int ac_mdct_inverse_typed(const ac_mdct_plan* plan, const void* X, void* x, int dtype, int B, int Kp, int C, void* stream);
+AC_API int ac_tonality_typed(const ac_psy_plan* plan, const void* X, void* t, int dtype, int B, int F, int C, void* stream);
+AC_API int ac_mask_threshold_typed(const ac_psy_plan* plan, const void* X, const void* t, double drown, void* thr, int dtype,
                             int B, int F, int C, void* stream);
-int ac_encode_fused_typed(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const void* x, void* X, void* t, void* thr,
+AC_API int ac_encode_fused_typed(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const void* x, void* X, void* t, void* thr,
                           double drown, int dtype, int B, int K, int C, void* stream);
-int ac_amplitude_to_db_typed(const void* a, void* out, size_t n, int norm, int dtype, void* stream);
-int ac_add_noise_typed(const void* X, const void* thr, void* out, size_t n, uint64_t seed, int dtype, void* stream);
+AC_API int ac_amplitude_to_db_typed(const void* a, void* out, size_t n, int norm, int dtype, void* stream);
+AC_API int ac_add_noise_typed(const void* X, const void* thr, void* out, size_t n, uint64_t seed, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1400,7 +1400,7 @@ def test_bench_contract_line_on_a_small_workload():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["traffic"] is None and r["traffic_source"] is None   # measured traffic is on file for the full-size workload only
-    assert d["value"] > 1e6 and d["round_trip_max_abs_err"] <= LSB
+    assert d["value"] > 1e6 and d["reduced_over_ranks"]["round_trip_max_abs_err"] <= LSB
     assert d["reduced_over_ranks"]["frames_per_step"] == 16 * 2 * 32
 
 
@@ -1425,20 +1425,21 @@ def test_bench_one_rank_over_rccl():
     """The RCCL branch on the hardware there is: `python bench.py --gpus 1 --dist nccl` starts ONE rank under
     torch.distributed.run; its barrier, max-over-ranks time, checksum reductions and the closing barrier(device_ids=...) /
     destroy_process_group go through RCCL on the device -- the code the 1 / 2 / 4 / 8 curve depends on
-    (no data-path collective: clips are independent, mdctransformer.py:292-295).  Same results bit for bit and the same value
-    as the plain run within 5 % (two processes: where the allocator puts X and thr moves the step by a few per cent on its
-    own) on a workload large enough to time: 64 clips x 234 blocks."""
-    common = ("--clips", 64, "--blocks", 234, "--steps", 20, "--warmup", 5, "--no-cpu-baseline", "--no-other-configs",
-              "--no-workspace", "--no-encode-api", "--no-smi")
+    (no data-path collective: clips are independent, mdctransformer.py:292-295).  Same results bit for bit, and the same value
+    as the plain run within 8 % on BASELINE configs[1] itself (two processes: where the allocator puts X and thr moves the
+    step by up to 7 % on its own, DESIGN.md section 5, and RCCL's own buffers shift every later allocation)."""
+    common = ("--steps", 60, "--warmup", 5, "--no-cpu-baseline", "--no-other-configs", "--no-workspace", "--no-encode-api",
+              "--no-smi")
     nccl = _run_bench("--gpus", 1, "--dist", "nccl", *common)
     plain = _run_bench("--gpus", 1, *common)
     assert nccl["config"]["backend"] == "nccl" and plain["config"]["backend"] is None
     assert nccl["n_gpus"] == 1 and nccl["config"]["devices"] == 1
     a, b = nccl["reduced_over_ranks"], plain["reduced_over_ranks"]
-    assert a["frames_per_step"] == b["frames_per_step"] == 64 * 2 * 234
+    assert a["frames_per_step"] == b["frames_per_step"] == 256 * 2 * 468
     for k in ("checksum_X", "checksum_thr", "checksum_pcm", "checksum_tonality", "round_trip_max_abs_err"):
         assert a[k] == b[k], (k, a[k], b[k])
-    assert abs(nccl["value"] / plain["value"] - 1.0) < 0.05, (nccl["value"], plain["value"])
+    print("one rank over RCCL %.1f M frames/s, plain %.1f M frames/s" % (nccl["value"] / 1e6, plain["value"] / 1e6))
+    assert abs(nccl["value"] / plain["value"] - 1.0) < 0.08, (nccl["value"], plain["value"])
     # the driver's own form of the same thing: torch.distributed.run --nproc-per-node 1 bench.py --gpus 1
     import json
     import os
@@ -1446,8 +1447,8 @@ def test_bench_one_rank_over_rccl():
     import sys
     from conftest import ROOT
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-                          "127.0.0.1", "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "1"]
-                         + [str(v) for v in common], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                          "127.0.0.1", "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--clips", "16",
+                          "--blocks", "32"] + [str(v) for v in common], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stdout + out.stderr
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["config"]["backend"] == "nccl" and d["n_gpus"] == 1

@@ -18,10 +18,13 @@ from audiocodec_amd import _lib
 from audiocodec_amd.dist import clip_range
 
 
-def _header_symbols():
-    text = open(os.path.join(ROOT, "include", "audiocodec_amd.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(ac_[a-z0-9_]+)\s*\(", text)))
+def _header_symbols(names=("audiocodec_amd.h", "audiocodec_amd_testing.h")):
+    syms = set()
+    for name in names:
+        text = open(os.path.join(ROOT, "include", name)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        syms |= set(re.findall(r"\b(ac_[a-z0-9_]+)\s*\(", text))
+    return sorted(syms)
 
 
 def test_library_exports_every_header_symbol():
@@ -31,7 +34,18 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(lib, s), "libaudiocodec_amd.so does not export %s" % s
     assert sorted(_lib.PROTOTYPES) == syms, "ctypes prototypes and header disagree"
-    assert lib.ac_version() == 160
+    assert lib.ac_version() == 170
+    assert _header_symbols(("audiocodec_amd_testing.h",)) == ["ac_set_force_generic"]
+    assert "ac_set_force_generic" not in _header_symbols(("audiocodec_amd.h",))
+
+
+def test_library_exports_nothing_but_the_c_abi():
+    """-fvisibility=hidden: the dynamic symbol table of the library defines the ac_* entry points of include/*.h and
+    nothing else -- no mangled C++ internals for another library to collide with or a caller to depend on."""
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    defined = sorted(ln.split()[-1] for ln in out.stdout.splitlines() if ln.strip())
+    assert defined == _header_symbols(), sorted(set(defined) ^ set(_header_symbols()))
 
 
 def test_library_contains_gfx950_code_object():

@@ -2,6 +2,7 @@
 # usage: tools/pmc.sh <encode|transform|inverse|psy> <tag>   (run on the GPU box; writes gpurun_out/pmc_<tag>.txt)
 what=$1; tag=$2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+make -s -C audiocodec_amd/csrc || exit 1   # never build under the profiler (the import-time fallback refuses to)
 sets=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY" \
       "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU" \
       "FETCH_SIZE" "WRITE_SIZE")

@@ -2,6 +2,7 @@
 # usage: tools/pmc2.sh <encode|inverse> <tag>: memory-pipeline back-pressure counters (run on the GPU box)
 what=$1; tag=$2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+make -s -C audiocodec_amd/csrc || exit 1   # never build under the profiler (the import-time fallback refuses to)
 sets=("SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INST_LEVEL_VMEM" \
       "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum" "TA_DATA_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum" \
       "TCC_EA0_WRREQ_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum" "TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum" \

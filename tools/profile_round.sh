@@ -38,7 +38,7 @@ with open(out + "/bench_kernel_stats_timed_region.csv", "w") as fh:
         timed = d[-steps:]      # nothing launches these kernels after the timed loop (side measurements switched off)
         fh.write("%s,%d,%.1f,%d,%d,timed region of bench.py (the last %d of %d dispatches; events in the same run: encode %.4f ms decode %.4f ms)\n"
                  % (name, len(timed), sum(timed) / len(timed), min(timed), max(timed), steps, len(d),
-                    line["kernels"]["encode_ms"], line["kernels"]["decode_ms"]))
+                    line["encode_ms"], line["decode_ms"]))
 print(open(out + "/bench_kernel_stats_timed_region.csv").read())
 PY
 tools/pmc.sh encode ${r}_enc > /dev/null 2>&1 && cp gpurun_out/pmc_${r}_enc.txt $out/pmc_encode.txt || exit 1

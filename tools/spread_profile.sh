@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (GPU box): tools/spread_profile.sh   -- kernel stats + instruction-mix counters of the three spreading forms
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+make -s -C audiocodec_amd/csrc || exit 1   # never build under the profiler
 out=gpurun_out/spread
 mkdir -p $out
 for n in 1024 2048; do

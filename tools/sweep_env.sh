@@ -10,8 +10,8 @@ for r in $(seq $rounds); do
 import json,sys
 for line in sys.stdin:
     if line.startswith('{'):
-        d=json.loads(line); k=d['kernels']
-        print('$v', k['encode_ms'], k['decode_ms'], d['value']/1e6)
+        d=json.loads(line)
+        if 'value' in d: print('$v', d['encode_ms'], d['decode_ms'], d['value']/1e6)
 " >> $tmp
   done
 done
