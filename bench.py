@@ -782,6 +782,7 @@ def main():
                 return {k: (v if k.startswith("checksum") else trim(v)) for k, v in o.items()}
             return float("%.7g" % o) if isinstance(o, float) else o
         out = trim(out)
+        out["roofline"]["frac"] = out["roofline"]["achieved"] / out["roofline"]["peak"]   # (consistent after the rounding)
         side_line = json.dumps({"bench_side": side})
         if args.side_json:
             with open(args.side_json, "w") as f:
