@@ -43,6 +43,16 @@ def require_hip_compute_dtype(compute_dtype, who):
     return DTYPE_IDS[compute_dtype]
 
 
+def precompute_id(precompute_dtype, who):
+    """AC_F64 / AC_F32 for the reference's ``precompute_dtype`` keyword (mdctransformer.py:13-14,31-35;
+    psychoacoustic.py:14-15,61-69): the arithmetic type the constant tables are computed in on the host."""
+    dt = as_torch_dtype(precompute_dtype)
+    if dt not in (torch.float64, torch.float32):
+        raise NotImplementedError("%s: constants are pre-computed in float64 (the reference's default) or float32, got %s"
+                                  % (who, dt))
+    return dt, DTYPE_IDS[dt]
+
+
 def require_float32(compute_dtype, what):
     if compute_dtype != torch.float32:
         raise NotImplementedError("%s is implemented for compute_dtype float32 only (got %s)" % (what, compute_dtype))

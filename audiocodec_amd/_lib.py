@@ -29,6 +29,12 @@ PROTOTYPES = {
                                    POINTER(c_float), POINTER(c_float), POINTER(c_double)]),
     "ac_psy_tables_host_f64": (c_int, [c_int, c_int, c_double, c_double, POINTER(c_double), POINTER(c_double),
                                        POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+    "ac_mdct_fold_coefficients_host_pre": (c_int, [c_int, c_int, c_int, POINTER(c_double)]),
+    "ac_mdct_dense_matrices_host_pre": (c_int, [c_int, c_int, c_int, POINTER(c_float), POINTER(c_float)]),
+    "ac_psy_tables_host_pre": (c_int, [c_int, c_int, c_double, c_double, c_int, POINTER(c_double), POINTER(c_double),
+                                       POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+    "ac_mdct_plan_create_pre": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
+    "ac_psy_plan_create_pre": (c_int, [c_int, c_int, c_double, c_double, c_int, c_int, c_int, POINTER(c_void_p)]),
     "ac_mdct_plan_create": (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
     "ac_mdct_plan_destroy": (c_int, [c_void_p]),
     "ac_psy_plan_create": (c_int, [c_int, c_int, c_double, c_double, c_int, POINTER(c_void_p)]),

@@ -22,10 +22,12 @@ class AudioCodec:
     """MDCT analysis + psychoacoustic masking (encode) and MDCT synthesis (decode)."""
 
     def __init__(self, sample_rate=48000, filters_n=1024, bark_bands_n=64, alpha=0.6, window_type="vorbis",
-                 compute_dtype=torch.float32, spreading=None):
-        self.mdct = MDCTransformer(filters_n, window_type=window_type, compute_dtype=compute_dtype)
+                 compute_dtype=torch.float32, spreading=None, precompute_dtype=torch.float64):
+        self.mdct = MDCTransformer(filters_n, window_type=window_type, compute_dtype=compute_dtype,
+                                   precompute_dtype=precompute_dtype)
         self.psy = PsychoacousticModel(sample_rate, filter_bands_n=filters_n, bark_bands_n=bark_bands_n,
-                                       alpha=alpha, compute_dtype=compute_dtype, spreading=spreading)
+                                       alpha=alpha, compute_dtype=compute_dtype, precompute_dtype=precompute_dtype,
+                                       spreading=spreading)
         self.filters_n = int(filters_n)
         self.compute_dtype = self.mdct.compute_dtype
         self._lib = _lib.load()

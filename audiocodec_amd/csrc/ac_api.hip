@@ -69,12 +69,19 @@ int ac_set_force_generic(int on) {
 
 // ---- host-only builders ------------------------------------------------------------------------
 
+#define AC_REQUIRE_PRE(d) AC_REQUIRE((d) == AC_F32 || (d) == AC_F64, "precompute = %d is not AC_F32 or AC_F64", (d))
+
 int ac_mdct_fold_coefficients_host(int N, int window, double* coef) {
+  return ac_mdct_fold_coefficients_host_pre(N, window, AC_F64, coef);
+}
+
+int ac_mdct_fold_coefficients_host_pre(int N, int window, int precompute, double* coef) {
   AC_REQUIRE(N >= 2 && (N % 2) == 0, "number of filters used in mdct transformation needs to be even (got %d)", N);
   AC_REQUIRE(valid_window(window), "unknown window id %d", window);
+  AC_REQUIRE_PRE(precompute);
   AC_REQUIRE(coef != nullptr, "coef is NULL");
   FoldCoef c;
-  fold_coefficients(N, window, c);
+  fold_coefficients(N, window, c, precompute);
   const int h = N / 2;
   const std::vector<double>* v[8] = {&c.a1, &c.a2, &c.a3, &c.a4, &c.s1, &c.s2, &c.s3, &c.s4};
   for (int i = 0; i < 8; ++i) std::memcpy(coef + (size_t)i * h, v[i]->data(), h * sizeof(double));
@@ -82,12 +89,15 @@ int ac_mdct_fold_coefficients_host(int N, int window, double* coef) {
 }
 
 int ac_mdct_dense_matrices_host(int N, int window, float* H, float* H_inv) {
+  return ac_mdct_dense_matrices_host_pre(N, window, AC_F64, H, H_inv);
+}
+
+int ac_mdct_dense_matrices_host_pre(int N, int window, int precompute, float* H, float* H_inv) {
   AC_REQUIRE(N >= 2 && (N % 2) == 0, "number of filters used in mdct transformation needs to be even (got %d)", N);
   AC_REQUIRE(valid_window(window), "unknown window id %d", window);
+  AC_REQUIRE_PRE(precompute);
   FoldCoef c;
-  fold_coefficients(N, window, c);
-  std::vector<double> w;
-  window_samples(N, window, w);
+  fold_coefficients(N, window, c, precompute);
   const int h = N / 2;
   const size_t NN = (size_t)N * N;
   if (H) {
@@ -134,10 +144,16 @@ int ac_psy_tables_host(int N, int M, double sample_rate, double alpha, float* W,
 
 int ac_psy_tables_host_f64(int N, int M, double sample_rate, double alpha, double* W, double* W_inv, double* S,
                            double* quiet, double* scalars) {
+  return ac_psy_tables_host_pre(N, M, sample_rate, alpha, AC_F64, W, W_inv, S, quiet, scalars);
+}
+
+int ac_psy_tables_host_pre(int N, int M, double sample_rate, double alpha, int precompute, double* W, double* W_inv,
+                           double* S, double* quiet, double* scalars) {
   AC_REQUIRE(N >= 1 && M >= 1, "filter_bands_n (%d) and bark_bands_n (%d) must be positive", N, M);
   AC_REQUIRE(sample_rate > 0 && alpha > 0, "sample_rate and alpha must be positive");
+  AC_REQUIRE_PRE(precompute);
   PsyTables t;
-  psy_tables(N, M, sample_rate, alpha, t);
+  psy_tables(N, M, sample_rate, alpha, t, precompute);
   if (W) std::copy(t.W.begin(), t.W.end(), W);
   if (W_inv) std::copy(t.W_inv.begin(), t.W_inv.end(), W_inv);
   if (S) std::copy(t.S.begin(), t.S.end(), S);
@@ -154,8 +170,13 @@ int ac_psy_tables_host_f64(int N, int M, double sample_rate, double alpha, doubl
 // ---- plans --------------------------------------------------------------------------------------
 
 int ac_mdct_plan_create(int N, int window, int device, ac_mdct_plan** out) {
+  return ac_mdct_plan_create_pre(N, window, AC_F64, device, out);
+}
+
+int ac_mdct_plan_create_pre(int N, int window, int precompute, int device, ac_mdct_plan** out) {
   AC_REQUIRE(out != nullptr, "out is NULL");
   *out = nullptr;
+  AC_REQUIRE_PRE(precompute);
   AC_REQUIRE(N >= 2 && (N % 2) == 0, "number of filters used in mdct transformation needs to be even (got %d)", N);
   AC_REQUIRE(N <= 8192, "filters_n = %d not supported (max 8192)", N);
   AC_REQUIRE(valid_window(window), "unknown window id %d", window);
@@ -170,10 +191,11 @@ int ac_mdct_plan_create(int N, int window, int device, ac_mdct_plan** out) {
   p->N = N;
   p->window = window;
   p->device = device;
+  p->pre = precompute;
   if (hipDeviceGetAttribute(&p->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || p->cus <= 0)
     p->cus = 256;
   FoldCoef c;
-  fold_coefficients(N, window, c);
+  fold_coefficients(N, window, c, precompute);
   const int h = N / 2;
   std::vector<float> coef(8 * (size_t)h);
   const std::vector<double>* v[8] = {&c.a1, &c.a2, &c.a3, &c.a4, &c.s1, &c.s2, &c.s3, &c.s4};
@@ -189,7 +211,7 @@ int ac_mdct_plan_create(int N, int window, int device, ac_mdct_plan** out) {
   if (!st) st = upload(ctab, &p->d_ctab);
   if (!st) st = upload(coef64, &p->d_coef64);
   if (!st) st = upload(ctab64, &p->d_ctab64);
-  if (!st && fast_mdct_supported(N, window)) {
+  if (!st && fast_mdct_supported(N, window, precompute)) {
     st = fast_mdct_plan_init(p);
     if (!st) p->fast = 1;
   }
@@ -213,7 +235,7 @@ int ac_mdct_plan_destroy(ac_mdct_plan* p) {
   return AC_OK;
 }
 
-int ac_psy_plan_create(int N, int M, double sample_rate, double alpha, int device, ac_psy_plan** out) {
+static int default_spreading() {
   // The spreading product of a plan created without an explicit choice: the split-bfloat16 matrix-core form where the
   // wave-level kernels serve the plan (measured 2 % faster on the fused encode, thresholds within 1e-5 of the float32
   // form), the float32 form everywhere else.  AC_SPREAD (0 / 1 / 2) overrides: tuning hook, read once.
@@ -222,14 +244,36 @@ int ac_psy_plan_create(int N, int M, double sample_rate, double alpha, int devic
     const int v = e ? atoi(e) : AC_SPREAD_BF16X2_MFMA;
     return v >= 0 && v <= 2 ? v : AC_SPREAD_BF16X2_MFMA;
   }();
-  ac_psy_plan* p = nullptr;
-  int st = ac_psy_plan_create_ex(N, M, sample_rate, alpha, device, dflt, &p);
-  if (st == AC_EUNSUPPORTED && dflt != 0) st = ac_psy_plan_create_ex(N, M, sample_rate, alpha, device, 0, &p);
-  if (out) *out = p;
-  return st;
+  return dflt;
+}
+
+int ac_psy_plan_create(int N, int M, double sample_rate, double alpha, int device, ac_psy_plan** out) {
+  return ac_psy_plan_create_pre(N, M, sample_rate, alpha, device, -1, AC_F64, out);
 }
 
 int ac_psy_plan_create_ex(int N, int M, double sample_rate, double alpha, int device, int spreading, ac_psy_plan** out) {
+  AC_REQUIRE(spreading >= AC_SPREAD_F32 && spreading <= AC_SPREAD_BF16X2_MFMA, "spreading = %d is not one of AC_SPREAD_*", spreading);
+  return ac_psy_plan_create_pre(N, M, sample_rate, alpha, device, spreading, AC_F64, out);
+}
+
+static int psy_plan_build(int N, int M, double sample_rate, double alpha, int device, int spreading, int precompute,
+                          ac_psy_plan** out);
+
+int ac_psy_plan_create_pre(int N, int M, double sample_rate, double alpha, int device, int spreading, int precompute,
+                           ac_psy_plan** out) {
+  AC_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  AC_REQUIRE_PRE(precompute);
+  AC_REQUIRE(spreading >= -1 && spreading <= AC_SPREAD_BF16X2_MFMA, "spreading = %d is not one of AC_SPREAD_* (or -1: default)", spreading);
+  if (spreading >= 0) return psy_plan_build(N, M, sample_rate, alpha, device, spreading, precompute, out);
+  const int dflt = default_spreading();
+  int st = psy_plan_build(N, M, sample_rate, alpha, device, dflt, precompute, out);
+  if (st == AC_EUNSUPPORTED && dflt != 0) st = psy_plan_build(N, M, sample_rate, alpha, device, 0, precompute, out);
+  return st;
+}
+
+static int psy_plan_build(int N, int M, double sample_rate, double alpha, int device, int spreading, int precompute,
+                          ac_psy_plan** out) {
   AC_REQUIRE(out != nullptr, "out is NULL");
   *out = nullptr;
   AC_REQUIRE(spreading >= AC_SPREAD_F32 && spreading <= AC_SPREAD_BF16X2_MFMA, "spreading = %d is not one of AC_SPREAD_*", spreading);
@@ -249,8 +293,9 @@ int ac_psy_plan_create_ex(int N, int M, double sample_rate, double alpha, int de
   p->device = device;
   p->sample_rate = sample_rate;
   p->alpha = alpha;
+  p->pre = precompute;
   if (hipDeviceGetAttribute(&p->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || p->cus <= 0) p->cus = 256;
-  psy_tables(N, M, sample_rate, alpha, p->host);
+  psy_tables(N, M, sample_rate, alpha, p->host, precompute);
   SparseRows wb, wi, wf, vb;
   w_by_band(p->host, wb);
   winv_by_bin(p->host, wi);

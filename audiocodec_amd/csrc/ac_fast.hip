@@ -83,11 +83,14 @@ struct Geo {
   static constexpr int I_COEF = I_POST + 128 * R;   // [R][64] float2  fold (A, B)(e) | unfold (a, b)(k)
   static constexpr int I_PRE = I_COEF + 128 * R;    // [R][64] float2  exp(-i pi (e + 1/4) / N), e = lane + 64 r
   static constexpr int I_P1 = I_PRE + 128 * R;      // [R][64] float2  W_{64R}^(lane k0), pass-1 twiddles
-  static constexpr int I_TOTAL = I_P1 + 128 * R;    // floats per image in global memory
+  // the other two coefficients of a fold block that is not a rotation (float32-precomputed or rectangular windows; FOLD4
+  // kernels read them from global memory: the image is L2-resident): analysis (cE, cO)(e) | synthesis (s3, s4)(k)
+  static constexpr int I_COEF2 = I_P1 + 128 * R;    // [R][64] float2
+  static constexpr int I_TOTAL = I_COEF2 + 128 * R; // floats per image in global memory
   // R = 8 holds the seven pass-1 twiddles of a lane in registers (LDS is the scarcer resource: 3 workgroups per CU);
   // R = 16 reads its fifteen from LDS (registers are: 64 for the frame alone)
   static constexpr bool P1_IN_REGS = (R == 8);
-  static constexpr int I_LDS = P1_IN_REGS ? I_P1 : I_TOTAL;   // floats that live in LDS (R = 8: 12 800 bytes)
+  static constexpr int I_LDS = P1_IN_REGS ? I_P1 : I_COEF2;   // floats that live in LDS (R = 8: 12 800 bytes)
   // a kernel short of LDS leaves the pre-twiddles out as well (I_LDS_NOPRE floats) and forms them as
   // PRE[e] = POST[e] * (exp(-i pi / (4 N)) / scale): four more packed multiply-adds per element
   static constexpr int I_LDS_NOPRE = I_PRE;
@@ -1950,7 +1953,7 @@ struct FwdMArgs {
 
 // analysis: the lanes of group f transform frame NFR c + f of the wave's signal pair (a group whose frame index is past
 // the last frame idles); fold and twiddles as in k_fwd_fast with LB in the place of 64
-template <int NFR, int CMODE, int NW, int IOF = 0>
+template <int NFR, int CMODE, int NW, int IOF = 0, bool FOLD4 = false>
 __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
   using pcm_t = typename std::conditional<IOF == 1, int16_t, float>::type;   // (streaming state: float32 only, IOF 0)
   using G = Geo<8>;
@@ -2032,7 +2035,13 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
         const v2f xep = v2f{gp.x, gp.y}, xec = v2f{gc.x, gc.y};
         const v2f ab = reinterpret_cast<const v2f*>(tab + G::I_COEF)[r * 64 + lane];
         const v2f carry = ab.y * xep + ab.x * xop;
-        const v2f cur = (r4 < 2) ? (ab.y * xoc - ab.x * xec) : (ab.x * xec - ab.y * xoc);
+        v2f cur;
+        if constexpr (FOLD4) {   // a fold block that is not a rotation: its own two coefficients for the current block
+          const v2f ce = reinterpret_cast<const v2f*>(a.tab + G::I_COEF2)[r * 64 + lane];
+          cur = ce.x * xec + ce.y * xoc;
+        } else {
+          cur = (r4 < 2) ? (ab.y * xoc - ab.x * xec) : (ab.x * xec - ab.y * xoc);
+        }
         const C2 v = (r4 < 2) ? C2{carry, cur} : C2{cur, carry};
         z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + G::I_PRE)[r * 64 + lane]);
       }
@@ -2062,7 +2071,13 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
         const v2f xep = v2f{gp.x, gp.y}, xec = v2f{gc.x, gc.y};
         const v2f ab = reinterpret_cast<const v2f*>(tab + G::I_COEF)[r * 64 + lane];
         const v2f carry = ab.y * xep + ab.x * xop;
-        const v2f cur = (r < 4) ? (ab.y * xoc - ab.x * xec) : (ab.x * xec - ab.y * xoc);
+        v2f cur;
+        if constexpr (FOLD4) {
+          const v2f ce = reinterpret_cast<const v2f*>(a.tab + G::I_COEF2)[r * 64 + lane];
+          cur = ce.x * xec + ce.y * xoc;
+        } else {
+          cur = (r < 4) ? (ab.y * xoc - ab.x * xec) : (ab.x * xec - ab.y * xoc);
+        }
         const C2 v = (r < 4) ? C2{carry, cur} : C2{cur, carry};
         z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + G::I_PRE)[r * 64 + lane]);
       }
@@ -2105,7 +2120,7 @@ struct InvMArgs {
 // output block n from it and the aliased half of frame n - 1, which the group below has (one shift by LB lanes through
 // LDS); group 0 takes it from the chunk before (kept in registers), and a strip that does not start a signal begins with
 // the DCT-IV of the chunk before it.  Unfold as in k_inv_fast.
-template <int NFR, int CMODE, int NW, int IOF = 0>
+template <int NFR, int CMODE, int NW, int IOF = 0, bool FOLD4 = false>
 __global__ __launch_bounds__(NW * 64, AC_WPE) void k_inv_multi(InvMArgs a) {
   using pcm_t = typename std::conditional<IOF == 1, int16_t, float>::type;
   using G = Geo<8>;
@@ -2229,7 +2244,13 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_inv_multi(InvMArgs a) {
         const v2f cin = (f == 0) ? pend[j2] : sh[j2];
         const v2f ab = reinterpret_cast<const v2f*>(tab + G::I_COEF)[j2 * 64 + lane];
         const v2f o1 = ab.x * now[j2] + ab.y * cin;
-        const v2f o2 = ab.y * now[j2] - ab.x * cin;
+        v2f o2;
+        if constexpr (FOLD4) {   // F^-1 of a block that is not a rotation: (s3, s4) on their own
+          const v2f cd = reinterpret_cast<const v2f*>(a.tab + G::I_TOTAL + G::I_COEF2)[j2 * 64 + lane];
+          o2 = cd.x * now[j2] + cd.y * cin;
+        } else {
+          o2 = ab.y * now[j2] - ab.x * cin;
+        }
         xe[(j2 + 4) & 7] = (j2 < 4) ? o2 : o1;
         xo_in[j2] = (j2 < 4) ? o1 : o2;
       }
@@ -2285,12 +2306,12 @@ PsyParams psy_params(const ac_psy_plan* p, float drown) {
 // host side
 // ------------------------------------------------------------------------------------------------------
 template <int R>
-static bool build_mdct_fast_R(int N, int window, std::vector<float>* out) {
+static bool build_mdct_fast_R(int N, int window, int pre, std::vector<float>* out) {
   using G = Geo<R>;
   if (N != G::FN) return false;
   const int h = N / 2;
   FoldCoef c;
-  fold_coefficients(N, window, c);
+  fold_coefficients(N, window, c, pre);
   std::vector<float> t(2 * G::I_TOTAL, 0.f);
   float* tf = t.data();                 // analysis image
   float* ti = t.data() + G::I_TOTAL;    // synthesis image
@@ -2346,13 +2367,17 @@ static bool build_mdct_fast_R(int N, int window, std::vector<float>* out) {
 
 // Table images of the several-frames-per-wave kernels (filters_n = 16 LB, LB = 32 or 16 lanes per frame): the Geo<8>
 // layout with every entry replicated to the 64 lanes, l = lane mod LB taking the place of the lane.
-static bool build_mdct_multi(int N, int window, std::vector<float>* out) {
+// *fold4 (may be null): set when some fold block is not a rotation (float32-precomputed constants, mdctransformer.py:218-221
+// in float32; the rectangular window, :209-211): the kernels then take the FOLD4 form, which reads the block's other two
+// coefficients from I_COEF2.  A caller that passes no fold4 gets false for such tables.
+static bool build_mdct_multi(int N, int window, int pre, std::vector<float>* out, bool* fold4) {
   using G = Geo<8>;
   if (N != 512 && N != 256 && N != 128 && N != 64) return false;
   const int LB = N / 16, Q2 = LB >= 8 ? LB / 8 : 1, h = N / 2, FH = 8 * LB;
   const bool two_halves = N == 64;   // input side on 8 lanes x 4 registers (see load_half), output side on LB = 4 lanes
   FoldCoef c;
-  fold_coefficients(N, window, c);
+  fold_coefficients(N, window, c, pre);
+  bool general = false;
   std::vector<float> t(2 * G::I_TOTAL, 0.f);
   float* tf = t.data();
   float* ti = t.data() + G::I_TOTAL;
@@ -2386,19 +2411,23 @@ static bool build_mdct_multi(int N, int window, std::vector<float>* out) {
       if (e < h / 2) {
         const int jc = h - 1 - 2 * e, jk = 2 * e;
         cE = c.a2[jc]; cO = c.a1[jc]; kE = c.a4[jk]; kO = c.a3[jk];
-        if (!same(cE, -kO) || !same(cO, kE)) return false;
+        if (!same(cE, -kO) || !same(cO, kE)) general = true;
       } else {
         const int pidx = e - h / 2;
         const int jc = 2 * pidx, jk = h - 1 - 2 * pidx;
         cE = c.a1[jc]; cO = c.a2[jc]; kE = c.a3[jk]; kO = c.a4[jk];
-        if (!same(cE, kO) || !same(cO, -kE)) return false;
+        if (!same(cE, kO) || !same(cO, -kE)) general = true;
       }
       put2(tf + G::I_COEF, i, kO, kE);
+      put2(tf + G::I_COEF2, i, cE, cO);
       const int j = (k < h / 2) ? (h - 1 - 2 * k) : (2 * k - h);
-      if (!same(c.s3[j], c.s2[j]) || !same(c.s4[j], -c.s1[j])) return false;
+      if (!same(c.s3[j], c.s2[j]) || !same(c.s4[j], -c.s1[j])) general = true;
       put2(ti + G::I_COEF, i, c.s1[j], c.s2[j]);
+      put2(ti + G::I_COEF2, i, c.s3[j], c.s4[j]);
     }
   }
+  if (general && !fold4) return false;
+  if (fold4) *fold4 = general;
   if (out) *out = t;
   return true;
 }
@@ -2406,10 +2435,11 @@ static bool build_mdct_multi(int N, int window, std::vector<float>* out) {
 // Builds the two table images; false when the size is not served (filters_n 1024 and 2048 are) or the window's fold
 // blocks are not rotations (the rectangular "window", mdctransformer.py:209-211), which the two-coefficient fold
 // cannot express.
-static bool build_mdct_fast(int N, int window, std::vector<float>* out) {
-  if (N == Geo<8>::FN) return build_mdct_fast_R<8>(N, window, out);
-  if (N == Geo<16>::FN) return build_mdct_fast_R<16>(N, window, out);
-  if (N == 512 || N == 256 || N == 128 || N == 64) return build_mdct_multi(N, window, out);
+static bool build_mdct_fast(int N, int window, int pre, std::vector<float>* out, bool* fold4) {
+  if (fold4) *fold4 = false;
+  if (N == Geo<8>::FN) return build_mdct_fast_R<8>(N, window, pre, out);
+  if (N == Geo<16>::FN) return build_mdct_fast_R<16>(N, window, pre, out);
+  if (N == 512 || N == 256 || N == 128 || N == 64) return build_mdct_multi(N, window, pre, out, fold4);
   return false;
 }
 
@@ -2418,17 +2448,23 @@ int fast_mdct_frames_per_wave(int N) { return N == 512 ? 2 : N == 256 ? 4 : N ==
 // what the several-frames-per-wave kernels serve: float32 tensors or 16-bit PCM on the PCM side, mono or stereo, at
 // least one block
 bool fast_multi_serves(const ac_mdct_plan* p, int C, int iof, int blocks) {
-  return fast_mdct_frames_per_wave(p->N) > 1 && (C == 1 || C == 2) && (iof == 0 || iof == 1) && blocks >= 1;
+  // (the FOLD4 kernels -- fold blocks that are not rotations -- are instantiated for float32 tensors only)
+  return fast_mdct_frames_per_wave(p->N) > 1 && (C == 1 || C == 2) && (iof == 0 || (iof == 1 && !p->fold4)) && blocks >= 1;
 }
 
-bool fast_mdct_supported(int N, int window) { return build_mdct_fast(N, window, nullptr); }
+bool fast_mdct_supported(int N, int window, int pre) {
+  bool fold4;
+  return build_mdct_fast(N, window, pre, nullptr, &fold4);
+}
 
 int fast_mdct_plan_init(ac_mdct_plan* p) {
   std::vector<float> t;
-  if (!build_mdct_fast(p->N, p->window, &t)) {
+  bool fold4 = false;
+  if (!build_mdct_fast(p->N, p->window, p->pre, &t, &fold4)) {
     set_error("internal: wave-level kernels not supported for this configuration");
     return AC_EUNSUPPORTED;
   }
+  p->fold4 = fold4 ? 1 : 0;
   p->fast_bytes = t.size() * sizeof(float);
   AC_HIP_CHECK(hipMalloc((void**)&p->d_fast, p->fast_bytes));
   AC_HIP_CHECK(hipMemcpy(p->d_fast, t.data(), p->fast_bytes, hipMemcpyHostToDevice));
@@ -2591,8 +2627,13 @@ static unsigned persistent_grid(int cus, int wg_per_cu, long long ntasks, int nw
 }
 
 template <int NFR>
-static void launch_fwd_multi_N(const FwdMArgs& a, int iof, int C, unsigned grid, hipStream_t s) {
+static void launch_fwd_multi_N(const FwdMArgs& a, int iof, bool fold4, int C, unsigned grid, hipStream_t s) {
   const dim3 blk(AC_WAVES * 64);
+  if (fold4) {
+    if (C == 2) hipLaunchKernelGGL((k_fwd_multi<NFR, 0, AC_WAVES, 0, true>), dim3(grid), blk, 0, s, a);
+    else hipLaunchKernelGGL((k_fwd_multi<NFR, 2, AC_WAVES, 0, true>), dim3(grid), blk, 0, s, a);
+    return;
+  }
   if (iof == 1) {
     if (C == 2) hipLaunchKernelGGL((k_fwd_multi<NFR, 0, AC_WAVES, 1>), dim3(grid), blk, 0, s, a);
     else hipLaunchKernelGGL((k_fwd_multi<NFR, 2, AC_WAVES, 1>), dim3(grid), blk, 0, s, a);
@@ -2624,17 +2665,23 @@ static int launch_fwd_multi(const ac_mdct_plan* p, const void* x, int iof, float
   unsigned grid;
   const int st = grid_for(a.ntasks, AC_WAVES * T, &grid);
   if (st) return st;
-  if (nfr == 2) launch_fwd_multi_N<2>(a, iof, C, grid, s);
-  else if (nfr == 4) launch_fwd_multi_N<4>(a, iof, C, grid, s);
-  else if (nfr == 8) launch_fwd_multi_N<8>(a, iof, C, grid, s);
-  else launch_fwd_multi_N<16>(a, iof, C, grid, s);
+  const bool f4 = p->fold4 != 0;
+  if (nfr == 2) launch_fwd_multi_N<2>(a, iof, f4, C, grid, s);
+  else if (nfr == 4) launch_fwd_multi_N<4>(a, iof, f4, C, grid, s);
+  else if (nfr == 8) launch_fwd_multi_N<8>(a, iof, f4, C, grid, s);
+  else launch_fwd_multi_N<16>(a, iof, f4, C, grid, s);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }
 
 template <int NFR>
-static void launch_inv_multi_N(const InvMArgs& a, int iof, int C, unsigned grid, hipStream_t s) {
+static void launch_inv_multi_N(const InvMArgs& a, int iof, bool fold4, int C, unsigned grid, hipStream_t s) {
   const dim3 blk(AC_WAVES * 64);
+  if (fold4) {
+    if (C == 2) hipLaunchKernelGGL((k_inv_multi<NFR, 0, AC_WAVES, 0, true>), dim3(grid), blk, 0, s, a);
+    else hipLaunchKernelGGL((k_inv_multi<NFR, 2, AC_WAVES, 0, true>), dim3(grid), blk, 0, s, a);
+    return;
+  }
   if (iof == 1) {
     if (C == 2) hipLaunchKernelGGL((k_inv_multi<NFR, 0, AC_WAVES, 1>), dim3(grid), blk, 0, s, a);
     else hipLaunchKernelGGL((k_inv_multi<NFR, 2, AC_WAVES, 1>), dim3(grid), blk, 0, s, a);
@@ -2668,10 +2715,11 @@ static int launch_inv_multi(const ac_mdct_plan* p, const float* X, void* x, int 
   unsigned grid;
   const int st = grid_for(a.ntasks, AC_WAVES, &grid);
   if (st) return st;
-  if (nfr == 2) launch_inv_multi_N<2>(a, iof, C, grid, s);
-  else if (nfr == 4) launch_inv_multi_N<4>(a, iof, C, grid, s);
-  else if (nfr == 8) launch_inv_multi_N<8>(a, iof, C, grid, s);
-  else launch_inv_multi_N<16>(a, iof, C, grid, s);
+  const bool f4 = p->fold4 != 0;
+  if (nfr == 2) launch_inv_multi_N<2>(a, iof, f4, C, grid, s);
+  else if (nfr == 4) launch_inv_multi_N<4>(a, iof, f4, C, grid, s);
+  else if (nfr == 8) launch_inv_multi_N<8>(a, iof, f4, C, grid, s);
+  else launch_inv_multi_N<16>(a, iof, f4, C, grid, s);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }

@@ -101,6 +101,8 @@ struct ac_mdct_plan {
   int N = 0, window = 0, device = 0;
   int cus = 0;                 // compute units of the device (sizes the persistent launches)
   int fast = 0;                // 1: wave-level FFT kernels available for this N
+  int pre = AC_F64;            // arithmetic type the constants were computed in (the reference's precompute_dtype)
+  int fold4 = 0;               // 1: the wave-level kernels run their FOLD4 form (fold blocks that are not rotations)
   float* d_coef = nullptr;     // [8][N/2]  a1 a2 a3 a4 s1 s2 s3 s4
   float* d_ctab = nullptr;     // [8N]      cos(pi i / (4N)), generic kernels
   double* d_coef64 = nullptr;  // the same two tables in float64 (AC_F64 entry points)
@@ -114,6 +116,7 @@ struct ac_psy_plan {
   int N = 0, M = 0, device = 0;
   double sample_rate = 0, alpha = 0;
   int fast = 0;                // 1: the fused wave-level epilogue supports this (N, M, table shape)
+  int pre = AC_F64;            // arithmetic type the constants were computed in (the reference's precompute_dtype)
   int spread = 0;              // AC_SPREAD_*: form of the band x band spreading product in the wave-level kernels
   ac::PsyTables host;
   int32_t* d_wb_ptr = nullptr; int32_t* d_wb_idx = nullptr; float* d_wb_val = nullptr; int wb_max = 0;
@@ -166,7 +169,7 @@ int launch_threshold_generic(const ac_psy_plan* p, const float* X, const float* 
                              int F, int C, hipStream_t s);
 
 // wave-level FFT kernels (ac_fast.hip)
-bool fast_mdct_supported(int N, int window);
+bool fast_mdct_supported(int N, int window, int pre);
 // filters_n 512 / 256 run several frames per wave (2 / 4); those kernels serve float32 mono / stereo tensors with at least
 // one block (streaming state included) -- everything else at these sizes takes the LDS-FFT tier
 int fast_mdct_frames_per_wave(int N);

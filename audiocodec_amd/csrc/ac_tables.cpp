@@ -1,4 +1,5 @@
-// Host-side constant builders.  Everything here runs once per plan, in fp64, on the CPU.
+// Host-side constant builders.  Everything here runs once per plan on the CPU, in the plan's precompute dtype (fp64 by
+// default, as the reference's precompute_dtype).
 #include "ac_tables.h"
 
 #include <algorithm>
@@ -10,49 +11,69 @@ namespace ac {
 
 static const double kPi = 3.14159265358979323846;
 
-void window_samples(int N, int window, std::vector<double>& w) {
+// The builders are templates over the arithmetic type T of the reference's `precompute_dtype` (mdctransformer.py:13-14,
+// 31-35; psychoacoustic.py:14-15, 61-69): double (the default) or float.  TensorFlow converts a Python scalar that meets a
+// tensor to the tensor's dtype, so every literal below is rounded to T first and every operation runs in T, in the
+// reference's order; results are stored as doubles (exact for both).
+template <typename T>
+static void window_samples_t(int N, int window, std::vector<double>& w) {
   const int L = N + N / 2;
   w.resize(L);
   for (int n = 0; n < L; ++n) {
-    const double p = n + 0.5;
+    const T p = (T)n + (T)0.5;                                               // tf.range(0.5, ...): k + 1/2, exact
     if (window == AC_WINDOW_SINE) {
-      w[n] = std::sin(kPi / (2 * N) * p);                                   // :199-203
+      w[n] = (double)std::sin((T)(kPi / (2 * N)) * p);                       // :199-203
     } else if (window == AC_WINDOW_VORBIS) {
-      const double s = std::sin(kPi / (2.0 * N) * p);                        // :204-208
-      w[n] = std::sin(kPi / 2.0 * s * s);
+      const T s = std::sin((T)(kPi / (2.0 * N)) * p);                        // :204-208
+      const T s2 = s * s;
+      w[n] = (double)std::sin((T)(kPi / 2.0) * s2);
     } else {
       w[n] = 1.0;                                                            // :209-211
     }
   }
 }
 
-void fold_coefficients(int N, int window, FoldCoef& c) {
+void window_samples(int N, int window, std::vector<double>& w, int pre) {
+  if (pre == AC_F32) window_samples_t<float>(N, window, w);
+  else window_samples_t<double>(N, window, w);
+}
+
+template <typename T>
+static void fold_coefficients_t(int N, int window, FoldCoef& c) {
   const int h = N / 2;
-  std::vector<double> w;
-  window_samples(N, window, w);
+  std::vector<double> wd;
+  window_samples_t<T>(N, window, wd);
   for (auto* v : {&c.a1, &c.a2, &c.a3, &c.a4, &c.s1, &c.s2, &c.s3, &c.s4}) v->resize(h);
   for (int j = 0; j < h; ++j) {
     // 2x2 block of F coupling rows {j, N-1-j} with columns {h-1-j, h+j}  (:214-229)
-    const double p = w[j];                                                   // upper-left
-    const double q = w[N + j];                                               // upper-right
-    const double r = w[N - 1 - j];                                           // lower-left
-    const double s = -(1.0 - w[N + j] * w[N - 1 - j]) / w[j];                // lower-right (:218-226)
-    const double det = p * s - q * r;
-    c.a1[j] = q;
-    c.a2[j] = s;
-    c.a3[j] = w[h - 1 - j];
-    c.a4[j] = w[h + j];
-    c.s1[j] = s / det;
-    c.s2[j] = -r / det;
-    c.s3[j] = -q / det;
-    c.s4[j] = p / det;
+    const T p = (T)wd[j];                                                    // upper-left
+    const T q = (T)wd[N + j];                                                // upper-right
+    const T r = (T)wd[N - 1 - j];                                            // lower-left
+    const T s = -(((T)1 - q * r) / p);                                       // lower-right (:218-226): cancels for small j
+    // (in float this is exactly 0 for j = 0 at N = 64 -- the reference's float32-precompute behaviour, reproduced)
+    // F^-1 (tf.linalg.inv, :185): the 2x2 block inverted in closed form, in T
+    const T det = p * s - q * r;
+    c.a1[j] = (double)q;
+    c.a2[j] = (double)s;
+    c.a3[j] = wd[h - 1 - j];
+    c.a4[j] = wd[h + j];
+    c.s1[j] = (double)(s / det);
+    c.s2[j] = (double)(-r / det);
+    c.s3[j] = (double)(-q / det);
+    c.s4[j] = (double)(p / det);
   }
 }
 
-static inline double bark2freq(double z) { return 600.0 * std::sinh(z / 6.0); }   // :337-339
-static inline double freq2bark(double f) { return 6.0 * std::asinh(f / 600.0); }  // :333-335
+void fold_coefficients(int N, int window, FoldCoef& c, int pre) {
+  if (pre == AC_F32) fold_coefficients_t<float>(N, window, c);
+  else fold_coefficients_t<double>(N, window, c);
+}
 
-void psy_tables(int N, int M, double sample_rate, double alpha, PsyTables& t) {
+template <typename T> static inline T bark2freq_t(T z) { return (T)600 * std::sinh(z / (T)6); }   // :337-339
+template <typename T> static inline T freq2bark_t(T f) { return (T)6 * std::asinh(f / (T)600); }  // :333-335
+
+template <typename T>
+static void psy_tables_t(int N, int M, double sample_rate, double alpha, PsyTables& t) {
   t.N = N;
   t.M = M;
   t.sample_rate = sample_rate;
@@ -63,54 +84,56 @@ void psy_tables(int N, int M, double sample_rate, double alpha, PsyTables& t) {
     const float a2 = eps * eps;
     t.dB_MIN = 10.f * std::log(std::max(eps, a2)) / std::log(10.f) + 120.f;
   }
-  const double dB_MAX = 120.0;
-  t.max_frequency = sample_rate / 2.0;                                       // :61
-  t.max_bark = freq2bark(t.max_frequency);                                   // :62
-  t.bark_band_width = t.max_bark / M;                                        // :63
-  const double bw = t.bark_band_width;
+  const T dB_MAX = (T)120, dB_MIN = (T)t.dB_MIN;
+  const T max_frequency = (T)sample_rate / (T)2;                             // :61
+  const T max_bark = freq2bark_t<T>(max_frequency);                          // :62
+  const T bw = max_bark / (T)M;                                              // :63
+  t.max_frequency = (double)max_frequency;
+  t.max_bark = (double)max_bark;
+  t.bark_band_width = (double)bw;
 
   // _bark_freq_mapping  :257-299
   t.W.assign((size_t)N * M, 0.0);
   t.W_inv.assign((size_t)M * N, 0.0);
-  const double fbw = t.max_frequency / N;                                    // :282
+  const T fbw = max_frequency / (T)N;                                        // :282
   for (int j = 0; j < M; ++j) {
-    const double bark_low = bw * j;                                          // :285
-    const double lo = bark2freq(bark_low);
-    const double hi = bark2freq(bark_low + bw);
+    const T bark_low = bw * (T)j;                                            // :285
+    const T lo = bark2freq_t<T>(bark_low);
+    const T hi = bark2freq_t<T>(bark_low + bw);
     for (int f = 0; f < N; ++f) {
-      const double f_lo = fbw * f;                                           // :289
-      const double f_hi = f_lo + fbw;
-      const double lo_c = std::min(std::max(lo, f_lo), f_hi);
-      const double hi_c = std::min(std::max(hi, f_lo), f_hi);
-      const double overlap = hi_c - lo_c;
-      t.W[(size_t)f * M + j] = overlap / fbw;                                // :294
-      t.W_inv[(size_t)j * N + f] = overlap / (hi - lo);
+      const T f_lo = fbw * (T)f;                                             // :289
+      const T f_hi = f_lo + fbw;
+      const T lo_c = std::min(std::max(lo, f_lo), f_hi);
+      const T hi_c = std::min(std::max(hi, f_lo), f_hi);
+      const T overlap = hi_c - lo_c;
+      t.W[(size_t)f * M + j] = (double)(overlap / fbw);                      // :294
+      t.W_inv[(size_t)j * N + f] = (double)(overlap / (hi - lo));
     }
   }
 
   // _quiet_threshold_intensity_in_bark  :232-255
   t.quiet.resize(M);
   for (int j = 0; j < M; ++j) {
-    const double mid = bw * j + bw / 2.0;
-    const double kHz = bark2freq(mid) / 1000.0;
-    double dB = 3.64 * std::pow(kHz, -0.8) - 6.5 * std::exp(-0.6 * std::pow(kHz - 3.3, 2.0)) +
-                1e-3 * std::pow(kHz, 4.0);
-    dB = std::min(std::max(dB, t.dB_MIN), dB_MAX);
-    t.quiet[j] = std::pow(10.0, (dB - dB_MAX) / 10.0);
+    const T mid = bw * (T)j + bw / (T)2;
+    const T kHz = bark2freq_t<T>(mid) / (T)1000;
+    T dB = (T)3.64 * std::pow(kHz, (T)-0.8) - (T)6.5 * std::exp((T)-0.6 * std::pow(kHz - (T)3.3, (T)2)) +
+           (T)1e-3 * std::pow(kHz, (T)4);
+    dB = std::min(std::max(dB, dB_MIN), dB_MAX);
+    t.quiet[j] = (double)std::pow((T)10, (dB - dB_MAX) / (T)10);
   }
 
-  // _spreading_matrix_in_bark  :212-230   (z = linspace(-max_bark, max_bark, 2M))
+  // _spreading_matrix_in_bark  :212-230   (z = linspace(-max_bark, max_bark, 2M), in max_bark's dtype)
   std::vector<double> g(2 * (size_t)M);
   for (int i = 0; i < 2 * M; ++i) {
-    double z;
+    T z;
     if (2 * M == 1) {
-      z = -t.max_bark;
+      z = -max_bark;
     } else {
-      const double step = (t.max_bark - (-t.max_bark)) / (2 * M - 1);
-      z = (i == 2 * M - 1) ? t.max_bark : (-t.max_bark + step * i);
+      const T step = (max_bark - (-max_bark)) / (T)(2 * M - 1);
+      z = (i == 2 * M - 1) ? max_bark : (-max_bark + step * (T)i);
     }
-    const double f = 15.81 + 7.5 * (z + 0.474) - 17.5 * std::sqrt(1.0 + std::pow(z + 0.474, 2.0));
-    g[i] = std::pow(10.0, alpha * f / 10.0);                                 // :223
+    const T f = (T)15.81 + (T)7.5 * (z + (T)0.474) - (T)17.5 * std::sqrt((T)1 + std::pow(z + (T)0.474, (T)2));
+    g[i] = (double)std::pow((T)10, (T)alpha * f / (T)10);                    // :223
   }
   t.g = g;
   t.S.resize((size_t)M * M);
@@ -125,6 +148,11 @@ void psy_tables(int N, int M, double sample_rate, double alpha, PsyTables& t) {
     for (int j = 0; j < M; ++j) t.beta[j] = step * (float)j;
     if (M > 1) t.beta[M - 1] = stop;
   }
+}
+
+void psy_tables(int N, int M, double sample_rate, double alpha, PsyTables& t, int pre) {
+  if (pre == AC_F32) psy_tables_t<float>(N, M, sample_rate, alpha, t);
+  else psy_tables_t<double>(N, M, sample_rate, alpha, t);
 }
 
 void w_by_band(const PsyTables& t, SparseRows& out) {

@@ -63,23 +63,24 @@ class MDCTransformer:
         :param compute_dtype:    dtype of inputs and outputs: float32 (the wave-level kernels), float64 (everything in
                                  float64, constants included: the on-device float64 cross-check) or bfloat16 (bfloat16 tensors,
                                  float32 arithmetic inside); autograd and streaming are float32 only
-        :param precompute_dtype: constants are always pre-computed in float64 on the host (the
-                                 reference's default, ``:14,31-35``); other values are rejected
+        :param precompute_dtype: arithmetic type the window / fold constants are computed in on the host before they are
+                                 cast to float32 tables (``:14,31-35,58-59``): float64 (default) or float32 -- the latter
+                                 reproduces the reference's float32 rounding, including the cancellation at ``:218-221``
+                                 (the reference's TensorFlow known-answer vector stems from such a revision); the fold
+                                 blocks are then no rotations and the kernels carry all four coefficients per block
         """
         assert (filters_n % 2) == 0, "number of filters used in mdct transformation needs to be even"
         self.filters_n = int(filters_n)
         self.window_type = window_type
         self.compute_dtype = _host.as_torch_dtype(compute_dtype)
-        self.precompute_dtype = _host.as_torch_dtype(precompute_dtype)
+        self.precompute_dtype, self._pre_id = _host.precompute_id(precompute_dtype, "MDCTransformer")
         self._dtype_id = _host.require_hip_compute_dtype(self.compute_dtype, "MDCTransformer")
-        if self.precompute_dtype != torch.float64:
-            raise NotImplementedError("constants are pre-computed in float64 only")
         self._window = _lib.window_id(window_type)
         self._lib = _lib.load()
         self._H = None
         self._H_inv = None
-        n, w, lib = self.filters_n, self._window, self._lib
-        self._plans = _host.PlanCache(self, lambda dev, out: lib.ac_mdct_plan_create(n, w, dev, out),
+        n, w, pre, lib = self.filters_n, self._window, self._pre_id, self._lib
+        self._plans = _host.PlanCache(self, lambda dev, out: lib.ac_mdct_plan_create_pre(n, w, pre, dev, out),
                                       lib.ac_mdct_plan_destroy)
 
     # ---- dense polyphase matrices, for attribute parity only (mdctransformer.py:58-59) -------------
@@ -89,8 +90,8 @@ class MDCTransformer:
             H = np.empty((2, n, n), dtype=np.float32)
             Hi = np.empty((2, n, n), dtype=np.float32)
             fp = ctypes.POINTER(ctypes.c_float)
-            _lib.check(self._lib.ac_mdct_dense_matrices_host(n, self._window, H.ctypes.data_as(fp),
-                                                             Hi.ctypes.data_as(fp)))
+            _lib.check(self._lib.ac_mdct_dense_matrices_host_pre(n, self._window, self._pre_id, H.ctypes.data_as(fp),
+                                                                 Hi.ctypes.data_as(fp)))
             self._H, self._H_inv = torch.from_numpy(H), torch.from_numpy(Hi)
         return self._H, self._H_inv
 
@@ -108,8 +109,8 @@ class MDCTransformer:
         """The 8 x N/2 non-zeros of F and F^-1 in float64 (a1..a4, s1..s4; see include/audiocodec_amd.h)."""
         h = self.filters_n // 2
         coef = np.empty((8, h), dtype=np.float64)
-        _lib.check(self._lib.ac_mdct_fold_coefficients_host(
-            self.filters_n, self._window, coef.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+        _lib.check(self._lib.ac_mdct_fold_coefficients_host_pre(
+            self.filters_n, self._window, self._pre_id, coef.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
         return coef
 
     def is_fast(self, device=None):
@@ -131,6 +132,9 @@ class MDCTransformer:
         return self._transform(x)
 
     def _require_adjoint(self):
+        if self._pre_id != _host.DTYPE_IDS[torch.float64]:
+            raise NotImplementedError("backward needs float64-precomputed constants: with float32 ones the synthesis bank "
+                                      "is the transpose of the analysis bank only to float32 rounding")
         if self._window == _lib.WINDOW_RECT:
             raise NotImplementedError("backward needs a Princen-Bradley window ('vorbis' or 'sine'): the rectangular "
                                       "window's synthesis bank is not the transpose of its analysis bank")

@@ -111,44 +111,40 @@ class PsychoacousticModel:
             raise TypeError("compute_dtype of PsychoacousticModel should be float64, float32 or bfloat16")
         self.compute_dtype = compute_dtype
         self._dtype_id = _host.require_hip_compute_dtype(compute_dtype, "PsychoacousticModel")
-        if _host.as_torch_dtype(precompute_dtype) != torch.float64:
-            raise NotImplementedError("constants are pre-computed in float64 only")
+        self.precompute_dtype, self._pre_id = _host.precompute_id(precompute_dtype, "PsychoacousticModel")
         self._lib = _lib.load()
 
         N, M = self.filter_bands_n, self.bark_bands_n
-        # constants in the compute dtype, as the reference holds them (float64: unrounded; bfloat16: float32 here, the
-        # kernels' arithmetic type)
-        np_t, c_t = (np.float64, ctypes.c_double) if compute_dtype == torch.float64 else (np.float32, ctypes.c_float)
-        W = np.empty((N, M), dtype=np_t)
-        W_inv = np.empty((M, N), dtype=np_t)
-        S = np.empty((M, M), dtype=np_t)
-        quiet = np.empty((M,), dtype=np_t)
+        # constants computed in the precompute dtype (``:61-69``), then held in the compute dtype, as the reference holds
+        # them (float64: unrounded; bfloat16: float32 here, the kernels' arithmetic type)
+        np_t = np.float64 if compute_dtype == torch.float64 else np.float32
+        W = np.empty((N, M), dtype=np.float64)
+        W_inv = np.empty((M, N), dtype=np.float64)
+        S = np.empty((M, M), dtype=np.float64)
+        quiet = np.empty((M,), dtype=np.float64)
         scalars = np.empty((4,), dtype=np.float64)
-        fp = ctypes.POINTER(c_t)
-        tables = self._lib.ac_psy_tables_host_f64 if compute_dtype == torch.float64 else self._lib.ac_psy_tables_host
-        _lib.check(tables(
-            N, M, float(sample_rate), float(alpha), W.ctypes.data_as(fp), W_inv.ctypes.data_as(fp),
-            S.ctypes.data_as(fp), quiet.ctypes.data_as(fp), scalars.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+        fp = ctypes.POINTER(ctypes.c_double)
+        _lib.check(self._lib.ac_psy_tables_host_pre(
+            N, M, float(sample_rate), float(alpha), self._pre_id, W.ctypes.data_as(fp), W_inv.ctypes.data_as(fp),
+            S.ctypes.data_as(fp), quiet.ctypes.data_as(fp), scalars.ctypes.data_as(fp)))
+        W, W_inv, S, quiet = (v.astype(np_t) for v in (W, W_inv, S, quiet))
         self._dB_MAX = torch.tensor(120.0, dtype=compute_dtype)                 # :52
         self._INTENSITY_EPS = torch.tensor(1e-14, dtype=compute_dtype)          # :56
         self._dB_MIN = torch.tensor(scalars[3], dtype=compute_dtype)            # :58  (= -20 dB)
-        self.max_frequency = torch.tensor(scalars[0], dtype=torch.float64)      # :61
-        self.max_bark = torch.tensor(scalars[1], dtype=torch.float64)           # :62
-        self.bark_band_width = torch.tensor(scalars[2], dtype=torch.float64)    # :63
+        self.max_frequency = torch.tensor(scalars[0], dtype=self.precompute_dtype)      # :61
+        self.max_bark = torch.tensor(scalars[1], dtype=self.precompute_dtype)           # :62
+        self.bark_band_width = torch.tensor(scalars[2], dtype=self.precompute_dtype)    # :63
         self.W = torch.from_numpy(W)                                            # :66
         self.W_inv = torch.from_numpy(W_inv)                                    # :67
         self.quiet_threshold_intensity = torch.from_numpy(quiet).reshape(1, 1, M, 1)   # :68
         self.spreading_matrix = torch.from_numpy(S)                             # :69
 
-        sr, al, lib = float(sample_rate), float(alpha), self._lib
+        sr, al, lib, pre = float(sample_rate), float(alpha), self._lib, self._pre_id
         if spreading is not None and spreading not in self.SPREADING:
             raise ValueError("spreading must be one of %s" % sorted(self.SPREADING))
         self.spreading = spreading
-        if spreading is None:
-            create = lambda dev, out: lib.ac_psy_plan_create(N, M, sr, al, dev, out)   # noqa: E731
-        else:
-            mode = self.SPREADING[spreading]
-            create = lambda dev, out: lib.ac_psy_plan_create_ex(N, M, sr, al, dev, mode, out)   # noqa: E731
+        mode = -1 if spreading is None else self.SPREADING[spreading]   # -1: the library's default for the plan
+        create = lambda dev, out: lib.ac_psy_plan_create_pre(N, M, sr, al, dev, mode, pre, out)   # noqa: E731
         self._plans = _host.PlanCache(self, create, lib.ac_psy_plan_destroy)
 
     def _plan(self, device):

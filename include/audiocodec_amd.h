@@ -61,6 +61,9 @@ enum {
 /* window_type of MDCTransformer.__init__ (mdctransformer.py:13,199-211) */
 enum { AC_WINDOW_VORBIS = 0, AC_WINDOW_SINE = 1, AC_WINDOW_RECT = 2 };
 
+/* element types: `dtype` of the *_typed entry points (compute_dtype) and `precompute` of the *_pre ones (precompute_dtype) */
+enum { AC_F32 = 0, AC_F64 = 1, AC_BF16 = 2 };
+
 typedef struct ac_mdct_plan ac_mdct_plan;
 typedef struct ac_psy_plan ac_psy_plan;
 typedef struct ac_stream ac_stream;
@@ -92,6 +95,17 @@ AC_API int ac_psy_tables_host(int N, int M, double sample_rate, double alpha,
 AC_API int ac_psy_tables_host_f64(int N, int M, double sample_rate, double alpha,
                            double* W, double* W_inv, double* S, double* quiet, double* scalars);
 
+/* The same builders in the arithmetic type of the reference's `precompute_dtype` (mdctransformer.py:13-14,31-35,58-59;
+ * psychoacoustic.py:14-15,61-69): precompute = AC_F64 (what the functions above compute: the reference's default) or AC_F32
+ * -- every constant and operation rounded to float32, in the reference's order, including the cancellation
+ * (1 - w[N+j] w[N-1-j]) / w[j] of mdctransformer.py:218-221 (exactly 0 for j = 0 at filters_n = 64 in float32) and the
+ * float32 Bark mapping.  The reference's one TensorFlow-generated known-answer vector (tests/test_mdctransformer.py:51-52)
+ * stems from a float32-precompute revision.  Values are returned as doubles (exact) / float32 matrices. */
+AC_API int ac_mdct_fold_coefficients_host_pre(int N, int window, int precompute, double* coef);
+AC_API int ac_mdct_dense_matrices_host_pre(int N, int window, int precompute, float* H, float* H_inv);
+AC_API int ac_psy_tables_host_pre(int N, int M, double sample_rate, double alpha, int precompute,
+                                  double* W, double* W_inv, double* S, double* quiet, double* scalars);
+
 /* ------------------------------------------------------------------------------------------
  * Plans (own the device copies of the constant tables).
  * ---------------------------------------------------------------------------------------- */
@@ -103,6 +117,15 @@ AC_API int ac_mdct_plan_destroy(ac_mdct_plan* plan);
 /* PsychoacousticModel.__init__ (psychoacoustic.py:14-69). */
 AC_API int ac_psy_plan_create(int N, int M, double sample_rate, double alpha, int device, ac_psy_plan** out);
 AC_API int ac_psy_plan_destroy(ac_psy_plan* plan);
+
+/* Plans whose constants are computed in `precompute` = AC_F64 (as the plain *_create) or AC_F32 (see the *_host_pre
+ * builders).  With float32 constants the 2x2 fold blocks of F are no longer exact rotations, so the MDCT runs kernels
+ * that carry all four coefficients per block: the several-frames-per-wave kernels at filters_n 64 ... 512 (mono / stereo,
+ * float32), the LDS-FFT / O(N^2) tiers elsewhere.  ac_psy_plan_create_pre: spreading = AC_SPREAD_* or -1 for the default
+ * of ac_psy_plan_create. */
+AC_API int ac_mdct_plan_create_pre(int N, int window, int precompute, int device, ac_mdct_plan** out);
+AC_API int ac_psy_plan_create_pre(int N, int M, double sample_rate, double alpha, int device, int spreading, int precompute,
+                                  ac_psy_plan** out);
 
 /* Form of the band x band product with the spreading matrix (psychoacoustic.py:205-207: sum_i max(eps, P_i)^alpha S[i,j])
  * in the wave-level kernels -- BASELINE configs[3] "Bark spreading cast as band x band MFMA contraction, bf16":
@@ -266,7 +289,6 @@ AC_API int ac_probe_placement(const ac_mdct_plan* mdct, const ac_psy_plan* psy, 
  *            bfloat16's output rounding (2^-9 relative) -- more accurate than the reference's all-bfloat16 op sequence.
  * No streaming state and no backward passes for AC_F64 / AC_BF16.
  * ---------------------------------------------------------------------------------------- */
-enum { AC_F32 = 0, AC_F64 = 1, AC_BF16 = 2 };
 AC_API int ac_mdct_forward_typed(const ac_mdct_plan* plan, const void* x, void* X, int dtype, int B, int K, int C, void* stream);
 AC_API int ac_mdct_inverse_typed(const ac_mdct_plan* plan, const void* X, void* x, int dtype, int B, int Kp, int C, void* stream);
 AC_API int ac_tonality_typed(const ac_psy_plan* plan, const void* X, void* t, int dtype, int B, int F, int C, void* stream);

@@ -218,6 +218,46 @@ def main():
     a = np.array([0.0, 1e-7, 1e-3, 0.5, 1.0, -0.25], dtype=f32)
     save("db_utils", a=a, dB_ref32=p32.amplitude_to_dB(a), dBn_ref32=p32.amplitude_to_dB_norm(a),
          dB_ref64=p64.amplitude_to_dB(a.astype(f64)), dBn_ref64=p64.amplitude_to_dB_norm(a.astype(f64)))
+    # 7. precompute_dtype = float32 (mdctransformer.py:13-14,31-35,58-59; psychoacoustic.py:14-15,61-69): the constants built in
+    #    float32 arithmetic.  The reference's TensorFlow known-answer vector (fixture 1) stems from such a revision.  A file of
+    #    its own: the fixtures above keep their bytes.
+    def mdct32(N, wt, dt):
+        return MDCT(N, window_type=wt, compute_dtype=np.dtype(dt), precompute_dtype=tf.float32)
+
+    def psy32(sr, N, M, dt, alpha=0.6):
+        return Psy(sr, filter_bands_n=N, bark_bands_n=M, alpha=alpha, compute_dtype=np.dtype(dt), precompute_dtype=tf.float32)
+
+    arrs = {}
+    g1 = np.load(os.path.join(OUT, "mdct_n64_sine.npz"))
+    m = mdct32(64, "vorbis", f32)
+    arrs["n64_x"] = g1["x"]
+    arrs["n64_X_ref32pre"] = m.transform(g1["x"])                       # float32 compute, float32 precompute
+    arrs["n64_H"], arrs["n64_H_inv"] = np.asarray(m.H), np.asarray(m.H_inv)
+    arrs["n64_H_dtype"] = np.array(str(np.asarray(m.H).dtype))
+    g2 = np.load(os.path.join(OUT, "mdct_n256_roundtrip.npz"))
+    m = mdct32(256, "vorbis", f32)
+    X = m.transform(g2["x"])
+    arrs["n256_x"], arrs["n256_X_ref32pre"], arrs["n256_xhat_ref32pre"] = g2["x"], X, m.inverse_transform(X)
+    for wt in ("sine", "rect"):
+        m = mdct32(16, wt, f32)
+        arrs["n16_%s_H" % wt], arrs["n16_%s_H_inv" % wt] = np.asarray(m.H), np.asarray(m.H_inv)
+    for sr, N, M in ((48000, 1024, 64), (32768, 64, 64)):
+        p = psy32(sr, N, M, f32)
+        tag = "psy_%d_%d_%d_" % (sr, N, M)
+        wi, wv = _triplets(np.asarray(p.W))
+        vi, vv = _triplets(np.asarray(p.W_inv))
+        arrs.update({tag + "W_idx": wi, tag + "W_val": wv, tag + "W_inv_idx": vi, tag + "W_inv_val": vv,
+                     tag + "S": np.asarray(p.spreading_matrix), tag + "quiet": np.asarray(p.quiet_threshold_intensity).reshape(-1),
+                     tag + "max_bark": np.asarray(p.max_bark), tag + "bark_band_width": np.asarray(p.bark_band_width)})
+    gp = np.load(os.path.join(OUT, "psy_48000_1024_64_cases.npz"))
+    p = psy32(48000, 1024, 64, f32)
+    for name in ("rand", "envelope"):
+        Xc = gp["X_" + name]
+        t = p.tonality(Xc)
+        arrs["psy_X_" + name], arrs["psy_t_" + name] = Xc, t
+        arrs["psy_thr_%s_d00" % name] = p.global_masking_threshold(Xc, t, 0.0)
+    arrs["psy_thr_rand_d05"] = p.global_masking_threshold(gp["X_rand"], p.tonality(gp["X_rand"]), 0.5)
+    save("precompute_float32_cases", **arrs)
     return 0
 
 

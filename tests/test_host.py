@@ -290,3 +290,44 @@ def test_one_rank_process_group_goes_through_the_backend(tmp_path):
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0 and "OK 0 1" in out.stdout, out.stdout + out.stderr
+
+
+# ---- precompute_dtype (mdctransformer.py:13-14,31-35; psychoacoustic.py:14-15) ---------------------------------------
+def test_precompute_dtype_float32_host_tables(golden):
+    """The constructors take the reference's precompute_dtype keyword: float64 (default) or float32.  In float32 the
+    host builders round every constant and operation to float32 in the reference's order: the cancellation of
+    mdctransformer.py:218-221 yields exactly 0 for j = 0 at N = 64, the dense H / H_inv meet the reference's own
+    float32-precompute matrices to 2 ulp (glibc's sinf against numpy's), the Bark tables to what one ulp of max_bark
+    moves them (the float32 Bark mapping is that coarse: its own distance to the float64 tables is 4e-4 in W)."""
+    g = golden("precompute_float32_cases")
+    m = audiocodec_amd.MDCTransformer(64, precompute_dtype=torch.float32)
+    assert m.precompute_dtype == torch.float32
+    c = m.fold_coefficients()
+    assert c[1][0] == 0.0 and audiocodec_amd.MDCTransformer(64).fold_coefficients()[1][0] < -2e-4      # a2[0]
+    np.testing.assert_allclose(m.H.numpy(), g["n64_H"], rtol=0, atol=3e-7)
+    np.testing.assert_allclose(m.H_inv.numpy(), g["n64_H_inv"], rtol=0, atol=5e-7)
+    from oracle.audiocodec_oracle import fold_coefficients
+    o = fold_coefficients(64, "vorbis", np.float32)
+    for i, k in enumerate(["a1", "a2", "a3", "a4", "s1", "s2", "s3", "s4"]):
+        np.testing.assert_allclose(c[i], o[k].astype(np.float64), rtol=0, atol=5e-7)
+    for wt in ("sine", "rect"):
+        mw = audiocodec_amd.MDCTransformer(16, window_type=wt, precompute_dtype="float32")
+        np.testing.assert_allclose(mw.H.numpy(), g["n16_%s_H" % wt], rtol=0, atol=3e-7)
+        np.testing.assert_allclose(mw.H_inv.numpy(), g["n16_%s_H_inv" % wt], rtol=0, atol=5e-7)
+    for sr, N, M in ((48000, 1024, 64), (32768, 64, 64)):
+        tag = "psy_%d_%d_%d_" % (sr, N, M)
+        p = audiocodec_amd.PsychoacousticModel(sr, N, M, precompute_dtype=torch.float32)
+        assert p.max_bark.dtype == torch.float32 and abs(float(p.max_bark) - float(g[tag + "max_bark"])) <= 4e-6
+        np.testing.assert_allclose(p.W.numpy(), _dense(g[tag + "W_idx"], g[tag + "W_val"], (N, M)), rtol=0, atol=2e-3)
+        np.testing.assert_allclose(p.W_inv.numpy(), _dense(g[tag + "W_inv_idx"], g[tag + "W_inv_val"], (M, N)), rtol=0, atol=1e-4)
+        np.testing.assert_allclose(p.spreading_matrix.numpy(), g[tag + "S"], rtol=1e-4)
+        np.testing.assert_allclose(p.quiet_threshold_intensity.numpy().reshape(-1), g[tag + "quiet"], rtol=2e-4)
+        assert float(torch.sum(torch.abs(torch.sum(p.W, dim=1) - 1.0))) < 1e-3          # rows still sum to one
+    with pytest.raises(NotImplementedError):
+        audiocodec_amd.MDCTransformer(64, precompute_dtype=torch.bfloat16)
+    with pytest.raises(NotImplementedError):
+        audiocodec_amd.PsychoacousticModel(48000, precompute_dtype=torch.float16)
+    lib = _lib.load()
+    out = ctypes.c_void_p()
+    assert lib.ac_mdct_plan_create_pre(64, 0, 7, 0, ctypes.byref(out)) == _lib.AC_EINVAL and b"precompute" in lib.ac_last_error()
+    assert lib.ac_psy_plan_create_pre(64, 64, 48000.0, 0.6, 0, -2, 1, ctypes.byref(out)) == _lib.AC_EINVAL

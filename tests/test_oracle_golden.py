@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from conftest import rel_elem, rel_l2, rel_peak
-from oracle.audiocodec_oracle import MDCTOracle, PsychoOracle, sine_wav
+from oracle.audiocodec_oracle import MDCTOracle, PsychoOracle, fold_coefficients, sine_wav
 
 # the reference multiplies the DCT by a float32-rounded sqrt(2) (mdctransformer.py:347): a 1.7e-8
 # relative scale offset between its fp64 evaluation and exact arithmetic
@@ -206,3 +206,72 @@ def test_db_utils(golden):
     np.testing.assert_allclose(p.amplitude_to_dB(g["a"]), g["dB_ref32"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(p.amplitude_to_dB_norm(g["a"]), g["dBn_ref32"], rtol=0, atol=1e-6)
     assert p.amplitude_to_dB(np.float32(0.0)) == -20.0 and p.amplitude_to_dB(np.float32(1.0)) == 120.0
+
+
+# ---- precompute_dtype = float32 (mdctransformer.py:13-14,31-35,58-59; psychoacoustic.py:14-15,61-69) -------------------
+def _dense_from_triplets(idx, val, shape):
+    m = np.zeros(shape, dtype=val.dtype)
+    m[idx[:, 0], idx[:, 1]] = val
+    return m
+
+
+def test_known_answer_vector_with_float32_precompute(golden):
+    """The reference's one TensorFlow-generated vector (tests/test_mdctransformer.py:51-52) stems from a revision that
+    pre-computed the window in float32: evaluated that way -- the reference's own source with precompute_dtype=tf.float32
+    (fixture X_ref32pre) and the oracle's restatement of it -- it is met to 1e-7 TWO-SIDED (measured 1.1e-8 / 4.5e-8),
+    where the float64-precompute default only reaches 6e-7.  This is the tightest statement the reference's tests allow
+    about real-TensorFlow numbers."""
+    g, g1 = golden("precompute_float32_cases"), golden("mdct_n64_sine")
+    a = g1["known_answer_frame1_first10"]
+    np.testing.assert_array_equal(g["n64_x"], g1["x"])
+    assert np.max(np.abs(g["n64_X_ref32pre"][0, 1, :10, 0] - a)) <= 1e-7          # reference source, float32 precompute
+    assert np.max(np.abs(g1["X_ref32"][0, 1, :10, 0] - a)) > 3e-7                  # (the float64-precompute default is not that close)
+    for dt in (np.float32, np.float64):
+        o = MDCTOracle(64, "vorbis", dt, precompute_dtype=np.float32)
+        for dense in (False, True):
+            X = o.transform(g["n64_x"].astype(dt), dense=dense)
+            assert np.max(np.abs(X[0, 1, :10, 0] - a)) <= 1e-7, (dt, dense)
+            assert np.max(np.abs(X - g["n64_X_ref32pre"])) <= 1e-7
+
+
+def test_float32_precompute_reproduces_the_cancellation(golden):
+    """(1 - w[N+j] w[N-1-j]) / w[j] (mdctransformer.py:218-221) in float32 is exactly 0 for j = 0 at N = 64 (SURVEY 0.8);
+    the oracle's float32 tables equal the reference's dense H / H_inv bit for bit (same numpy arithmetic)."""
+    g = golden("precompute_float32_cases")
+    c = fold_coefficients(64, "vorbis", np.float32)
+    assert c["a2"].dtype == np.float32 and c["a2"][0] == 0.0 and c["w"][0] > 2e-4
+    assert abs(fold_coefficients(64, "vorbis")["a2"][0] + c["w"][0]) < 1e-7          # float64: -w[0], as the identity says
+    o = MDCTOracle(64, "vorbis", np.float32, precompute_dtype=np.float32)
+    np.testing.assert_array_equal(o.dense_H().astype(np.float32), g["n64_H"])
+    np.testing.assert_allclose(o.dense_H_inv().astype(np.float32), g["n64_H_inv"], rtol=0, atol=2e-7)
+    for wt in ("sine", "rect"):
+        o = MDCTOracle(16, wt, np.float32, precompute_dtype=np.float32)
+        np.testing.assert_array_equal(o.dense_H().astype(np.float32), g["n16_%s_H" % wt])
+        np.testing.assert_allclose(o.dense_H_inv().astype(np.float32), g["n16_%s_H_inv" % wt], rtol=0, atol=2e-7)
+    o = MDCTOracle(256, "vorbis", np.float32, precompute_dtype=np.float32)
+    X = o.transform(g["n256_x"])
+    assert np.max(np.abs(X - g["n256_X_ref32pre"])) <= 2e-7
+    assert np.max(np.abs(o.inverse_transform(X) - g["n256_xhat_ref32pre"])) <= 2e-6
+
+
+@pytest.mark.parametrize("sr,N,M", [(48000, 1024, 64), (32768, 64, 64)])
+def test_psy_tables_with_float32_precompute(golden, sr, N, M):
+    """The masking model's constants in float32 arithmetic: the oracle (numpy, the reference's op order) equals the
+    reference's own float32-precompute tables; they sit up to 4e-4 (W) away from the float64-precompute ones -- the
+    float32 Bark mapping is that coarse (band edges near 24 kHz carry 2e-3 Hz of rounding against 23 Hz bins)."""
+    g = golden("precompute_float32_cases")
+    tag = "psy_%d_%d_%d_" % (sr, N, M)
+    p = PsychoOracle(sr, N, M, compute_dtype=np.float32, precompute_dtype=np.float32)
+    np.testing.assert_array_equal(p.W, _dense_from_triplets(g[tag + "W_idx"], g[tag + "W_val"], (N, M)))
+    np.testing.assert_array_equal(p.W_inv, _dense_from_triplets(g[tag + "W_inv_idx"], g[tag + "W_inv_val"], (M, N)))
+    np.testing.assert_allclose(p.spreading_matrix, g[tag + "S"], rtol=1e-6)
+    np.testing.assert_allclose(p.quiet_threshold_intensity.reshape(-1), g[tag + "quiet"], rtol=1e-6)
+    assert p.max_bark.dtype == np.float32 and float(p.max_bark) == float(g[tag + "max_bark"])
+    p64 = PsychoOracle(sr, N, M, compute_dtype=np.float32)
+    assert 0 < np.max(np.abs(p64.W - p.W)) < 1e-3
+    if N == 1024:
+        t = p.tonality(g["psy_X_rand"])
+        np.testing.assert_allclose(t, g["psy_t_rand"], rtol=1e-5, atol=1e-7)
+        for key, drown in (("psy_thr_rand_d00", 0.0), ("psy_thr_rand_d05", 0.5)):
+            thr = p.global_masking_threshold(g["psy_X_rand"], t, drown)
+            assert rel_elem(thr, g[key]) <= 1e-5
