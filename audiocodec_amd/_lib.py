@@ -62,6 +62,7 @@ PROTOTYPES = {
     "ac_tonality_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ac_mask_threshold_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int,
                                            c_int, c_int, c_void_p]),
+    "ac_encode_launches": (c_int, [c_void_p, c_void_p, c_int]),
     "ac_encode_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int,
                                 c_int, c_void_p]),
     "ac_encode_fused_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p,

@@ -32,6 +32,13 @@ class AudioCodec:
         self.compute_dtype = self.mdct.compute_dtype
         self._lib = _lib.load()
 
+    def encode_launches(self, channels_n=2, device=None):
+        """How many kernel launches :meth:`encode` takes for float32 tensors of ``channels_n`` channels on ``device``
+        (``ac_encode_launches``): 1 = the fused kernels (filters_n 64 ... 2048 in powers of two, mono / stereo), 2 = transform +
+        one masking-model pass, 3 = the generic kernels."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        return int(self._lib.ac_encode_launches(self.mdct._plan(dev), self.psy._plan(dev), int(channels_n)))
+
     def encode(self, x, drown=0.0):
         """x [B, K*N, C] -> (X [B,K+1,N,C], tonality [B,K+1,1,C], threshold [B,K+1,N,C]).
 

@@ -541,6 +541,9 @@ static int encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const 
     if (!st) st = launch_psy_fast(psy, X, nullptr, t, thr, drown, B, K + 1, C, s);
     return st;
   }
+  // filters_n 64 ... 512: the several-frames-per-wave kernels with the general-layout masking model in the same launch
+  if (!g_force_generic && mdct->fast && fast_multi_fuses(mdct, psy, C, pcm16 ? 1 : 0, K))
+    return launch_fwd_fast(mdct, psy, x, 0, X, t, thr, drown, nullptr, B, K, K + 1, C, s);
   // un-fused composition for configurations the fused kernel does not cover: the transform, then tonality + threshold in
   // one wave-level pass over X where the general-layout masking kernels serve the plan, else the two generic kernels
   st = mdct_forward(mdct, x, pcm16, X, B, K, C, stream);
@@ -548,6 +551,14 @@ static int encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const 
   if (!st) st = ac_tonality(psy, X, t, B, K + 1, C, stream);
   if (!st) st = ac_mask_threshold(psy, X, t, drown, thr, B, K + 1, C, stream);
   return st;
+}
+
+int ac_encode_launches(const ac_mdct_plan* mdct, const ac_psy_plan* psy, int C) {
+  if (!mdct || !psy || mdct->N != psy->N || mdct->device != psy->device || C < 1) return 0;
+  if (g_force_generic) return 3;
+  if (mdct->fast && psy->fast) return (mdct->N == 2048 && C == 1) ? 2 : 1;   // (see encode_fused)
+  if (mdct->fast && fast_multi_fuses(mdct, psy, C, 0, 1)) return 1;
+  return (psy->mid && C <= 2) ? 2 : 3;
 }
 
 int ac_encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr,
@@ -670,8 +681,10 @@ static int stream_analysis(ac_stream* s, const ac_psy_plan* psy, const float* x_
   hipStream_t hs = (hipStream_t)stream;
   int st;
   const bool fast = wave_level(p, s->C, 0, k);
-  // (filters_n = 2048 mono: the fused kernel is not instantiated, see encode_fused)
-  const bool fused = psy && fast && psy->fast && !(p->N == 2048 && s->C == 1);
+  // (filters_n = 2048 mono: the fused kernel is not instantiated, see encode_fused; filters_n 64 ... 512: the masking model
+  // for general band layouts rides in the several-frames-per-wave kernels)
+  const bool fused = psy && fast && ((psy->fast && fast_mdct_frames_per_wave(p->N) == 1 && !(p->N == 2048 && s->C == 1)) ||
+                                     fast_multi_fuses(p, psy, s->C, 0, k));
   if (fast) {
     st = launch_fwd_fast(p, fused ? psy : nullptr, x_chunk, false, X, fused ? t : nullptr, fused ? thr : nullptr, drown,
                          s->d_prev_block, s->B, k, k, s->C, hs, s->d_prev_tmp);

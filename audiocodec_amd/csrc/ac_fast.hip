@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "ac_internal.h"
+#include "ac_psy_mid_dev.h"
 
 namespace ac {
 namespace {
@@ -1949,20 +1950,61 @@ struct FwdMArgs {
   int cpp;           // chunks of NFR consecutive frames per signal pair: ceil(F / NFR)
   int T;             // chunks per wave: workgroup g owns chunks [g NW T, (g+1) NW T), wave w takes g NW T + w + NW t
   long long nsig, ntasks;   // B * C and npairs * cpp
+  // fused masking model (PSY kernels): tonality [B, F, 1, C], threshold [B, F, N, C], the image of ac_psy_plan::d_mid
+  float* t;
+  float* thr;
+  const uint32_t* psy_img;
+  mid::MidParams mp;
 };
+
+// LDS of the several-frames-per-wave analysis kernels: [NW wave buffers | table image | masking-model image (PSY)].
+// The table images in global memory carry every entry replicated to the 64 lanes (index r * 64 + lane); the PSY kernels,
+// short of LDS, keep one period of each row only -- TS = max(LB, 8) entries (8: the 64-filter kernels read their input-side
+// tables by lane mod 8) -- and, at two frames per wave, read the pre-twiddles from the (L2-resident) global image.
+template <int NFR, bool PSY> constexpr int multi_ts() { return PSY ? ((64 / NFR) > 8 ? (64 / NFR) : 8) : 64; }
+template <int NFR, bool PSY> constexpr bool multi_pre_global() { return PSY && NFR == 2; }
+template <int NFR, bool PSY> constexpr int multi_tab_bytes() {
+  return PSY ? (128 + (multi_pre_global<NFR, PSY>() ? 2 : 3) * 16 * multi_ts<NFR, PSY>()) * 4 : Geo<8>::TAB_LDS;
+}
 
 // analysis: the lanes of group f transform frame NFR c + f of the wave's signal pair (a group whose frame index is past
 // the last frame idles); fold and twiddles as in k_fwd_fast with LB in the place of 64
-template <int NFR, int CMODE, int NW, int IOF = 0, bool FOLD4 = false>
+// PSY: the masking model of ac_psy_mid_dev.h on the frames just transformed (the fused encode at filters_n 64 ... 512): the
+// wave lays its NFR spectra out in natural order in its LDS buffer (8 KB: NFR frames x N bins x two signals), then walks
+// them one frame at a time with all 64 lanes exactly as k_psy_mid does on a row loaded from HBM -- same device function on
+// the same values, so X, tonality and threshold equal transform -> k_psy_mid bit for bit, and X is not read back from HBM.
+// The frame's intensities overwrite its own slot; Q and G live in the last KB of the buffer.
+template <int NFR, int CMODE, int NW, int IOF = 0, bool FOLD4 = false, bool PSY = false>
 __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
   using pcm_t = typename std::conditional<IOF == 1, int16_t, float>::type;   // (streaming state: float32 only, IOF 0)
   using G = Geo<8>;
   constexpr int LB = 64 / NFR;
-  __shared__ __attribute__((aligned(16))) char lds[NW * WAVE_LDS + G::TAB_LDS];
+  constexpr int TS = multi_ts<NFR, PSY>();                  // entries per register row of the LDS tables
+  constexpr bool PRE_GLOBAL = multi_pre_global<NFR, PSY>();
+  constexpr int TABB = multi_tab_bytes<NFR, PSY>();
+  // (LDS offsets of the tables in floats: the global image's own when it is copied whole)
+  constexpr int L_POST = PSY ? 128 : G::I_POST, L_COEF = PSY ? 128 + 16 * TS : G::I_COEF, L_PRE = PSY ? 128 + 32 * TS : G::I_PRE;
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // NW * WAVE_LDS + TABB (+ the masking-model image)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  load_tables<NW, WAVE_LDS, G::I_LDS, 0>(lds, a.tab, nullptr);
+  if constexpr (PSY) {
+    float* dst = reinterpret_cast<float*>(lds + NW * WAVE_LDS);
+    for (int i = threadIdx.x; i < 128; i += NW * 64) dst[G::I_P2 + i] = a.tab[G::I_P2 + i];
+    for (int i = threadIdx.x; i < 8 * TS; i += NW * 64) {     // one period of every row of POST / COEF / PRE
+      const int src = (i / TS) * 64 + (i % TS);
+      reinterpret_cast<v2f*>(dst + L_POST)[i] = reinterpret_cast<const v2f*>(a.tab + G::I_POST)[src];
+      reinterpret_cast<v2f*>(dst + L_COEF)[i] = reinterpret_cast<const v2f*>(a.tab + G::I_COEF)[src];
+      if (!PRE_GLOBAL) reinterpret_cast<v2f*>(dst + L_PRE)[i] = reinterpret_cast<const v2f*>(a.tab + G::I_PRE)[src];
+    }
+    uint4* pd = reinterpret_cast<uint4*>(lds + NW * WAVE_LDS + TABB);
+    for (int i = threadIdx.x; i < a.mp.img_words / 4; i += NW * 64) pd[i] = reinterpret_cast<const uint4*>(a.psy_img)[i];
+    __syncthreads();
+  } else {
+    load_tables<NW, WAVE_LDS, G::I_LDS, 0>(lds, a.tab, nullptr);
+  }
   char* buf = lds + wave * WAVE_LDS;
   gtab_t tab = reinterpret_cast<const float*>(lds + NW * WAVE_LDS);
+  const uint32_t* pimg = reinterpret_cast<const uint32_t*>(lds + NW * WAVE_LDS + TABB);
+  const int tl = lane & (TS - 1);   // column of the lane in a table row
   v2f p1[8];
   load_p1<8>(a.tab, lane, p1);
   const int f = lane / LB, l = lane & (LB - 1);
@@ -2033,7 +2075,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
         const v4f& gp = pb[fb4 + ((r4 + 2) & 3)];
         const v4f& gc = cb[fb4 + ((r4 + 2) & 3)];
         const v2f xep = v2f{gp.x, gp.y}, xec = v2f{gc.x, gc.y};
-        const v2f ab = reinterpret_cast<const v2f*>(tab + G::I_COEF)[r * 64 + lane];
+        const v2f ab = reinterpret_cast<const v2f*>(tab + L_COEF)[r * TS + tl];
         const v2f carry = ab.y * xep + ab.x * xop;
         v2f cur;
         if constexpr (FOLD4) {   // a fold block that is not a rotation: its own two coefficients for the current block
@@ -2043,7 +2085,8 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
           cur = (r4 < 2) ? (ab.y * xoc - ab.x * xec) : (ab.x * xec - ab.y * xoc);
         }
         const C2 v = (r4 < 2) ? C2{carry, cur} : C2{cur, carry};
-        z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + G::I_PRE)[r * 64 + lane]);
+        z[r] = cmul(v, PRE_GLOBAL ? reinterpret_cast<const v2f*>(a.tab + G::I_PRE)[r * 64 + lane]
+                                   : reinterpret_cast<const v2f*>(tab + L_PRE)[r * TS + tl]);
       }
     } else {
       const pcm_t *c0p, *c1p, *p0p, *p1p;
@@ -2069,7 +2112,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
         const v4f& gp = pb[(r + 4) & 7];
         const v4f& gc = cb[(r + 4) & 7];
         const v2f xep = v2f{gp.x, gp.y}, xec = v2f{gc.x, gc.y};
-        const v2f ab = reinterpret_cast<const v2f*>(tab + G::I_COEF)[r * 64 + lane];
+        const v2f ab = reinterpret_cast<const v2f*>(tab + L_COEF)[r * TS + tl];
         const v2f carry = ab.y * xep + ab.x * xop;
         v2f cur;
         if constexpr (FOLD4) {
@@ -2079,7 +2122,8 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
           cur = (r < 4) ? (ab.y * xoc - ab.x * xec) : (ab.x * xec - ab.y * xoc);
         }
         const C2 v = (r < 4) ? C2{carry, cur} : C2{cur, carry};
-        z[r] = cmul(v, reinterpret_cast<const v2f*>(tab + G::I_PRE)[r * 64 + lane]);
+        z[r] = cmul(v, PRE_GLOBAL ? reinterpret_cast<const v2f*>(a.tab + G::I_PRE)[r * 64 + lane]
+                                   : reinterpret_cast<const v2f*>(tab + L_PRE)[r * TS + tl]);
       }
     }
     fft_wave_multi<NFR>(z, buf, tab, p1, lane);
@@ -2088,7 +2132,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
       v2f xe[8], xo_in[8], xo[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const C2 r = cmul_negim(z[j], reinterpret_cast<const v2f*>(tab + G::I_POST)[j * 64 + lane]);
+        const C2 r = cmul_negim(z[j], reinterpret_cast<const v2f*>(tab + L_POST)[j * TS + tl]);
         xe[j] = r.re;
         xo_in[j] = r.im;
       }
@@ -2099,6 +2143,53 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
     if (frame_ok) {
       const int nn = n;
       store_rowm<CMODE, LB>(a.X + row_off(pq.b0, a.F, nn, blk, pq.c0), a.X + row_off(pq.b1, a.F, nn, blk, pq.c1), pq.has1, l, row);
+    }
+    if constexpr (PSY) {
+      constexpr int FN = 16 * LB;                      // filters_n
+      constexpr int RP = FN >= 128 ? FN / 128 : 1;     // granule registers per lane when 64 lanes share one frame
+      wave_sync();
+      {
+        char* fb = buf + f * (8 * FN) + 16 * l;        // granule q = l + LB i of the group's frame at byte 16 q of its slot
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<v4f*>(fb + 16 * LB * i) = row[i];
+      }
+      wave_sync();
+      v2f* Qb = reinterpret_cast<v2f*>(buf + 8192);
+      v2f Scol[32];
+      mid::load_scol(pimg, a.mp, lane, Scol);          // (per chunk: the column does not sit in registers through the FFT)
+#pragma unroll 1
+      for (int ff = 0; ff < NFR; ++ff) {
+        const int nn = c * NFR + ff;
+        if (nn >= a.F) break;
+        char* ib = buf + ff * (8 * FN);
+        v4f xq[RP];
+#pragma unroll
+        for (int i = 0; i < RP; ++i)
+          xq[i] = mid::in_frame<RP>(a.mp, i, lane) ? *reinterpret_cast<const v4f*>(ib + 16 * (64 * i + lane)) : v4f{0.f, 0.f, 0.f, 0.f};
+        const v2f t = mid::tonality_frame<RP>(xq, a.mp, lane);
+        const size_t o0 = row_off(pq.b0, a.F, nn, blk, pq.c0), o1 = row_off(pq.b1, a.F, nn, blk, pq.c1);
+        if (lane == 0) {
+          a.t[((size_t)pq.b0 * a.F + (size_t)nn) * C + pq.c0] = t.x;
+          if (pq.has1) a.t[((size_t)pq.b1 * a.F + (size_t)nn) * C + pq.c1] = t.y;
+        }
+        v4f th[RP];
+        mid::threshold_frame<RP>(xq, t, a.mp, pimg, ib, Qb, Qb + 64, Scol, lane, th);
+        if (CMODE == 0) {
+#pragma unroll
+          for (int i = 0; i < RP; ++i)
+            if (mid::in_frame<RP>(a.mp, i, lane)) __builtin_nontemporal_store(th[i], reinterpret_cast<v4f*>(a.thr + o0) + 64 * i + lane);
+        } else {
+#pragma unroll
+          for (int i = 0; i < RP; ++i)
+            if (mid::in_frame<RP>(a.mp, i, lane)) reinterpret_cast<v2f*>(a.thr + o0)[64 * i + lane] = v2f{th[i].x, th[i].z};
+          if (pq.has1) {
+#pragma unroll
+            for (int i = 0; i < RP; ++i)
+              if (mid::in_frame<RP>(a.mp, i, lane)) reinterpret_cast<v2f*>(a.thr + o1)[64 * i + lane] = v2f{th[i].y, th[i].w};
+          }
+        }
+        wave_sync();   // the frame's reads of Q / G are done before the next frame writes them
+      }
     }
   }
 }
@@ -2452,6 +2543,13 @@ bool fast_multi_serves(const ac_mdct_plan* p, int C, int iof, int blocks) {
   return fast_mdct_frames_per_wave(p->N) > 1 && (C == 1 || C == 2) && (iof == 0 || (iof == 1 && !p->fold4)) && blocks >= 1;
 }
 
+// the fused encode of the several-frames-per-wave kernels: float32 mono / stereo tensors, rotation fold blocks, and a
+// masking model the general-layout wave-level code serves at this size
+bool fast_multi_fuses(const ac_mdct_plan* p, const ac_psy_plan* psy, int C, int iof, int blocks) {
+  return psy != nullptr && psy->mid && !p->fold4 && iof == 0 && psy->N == p->N && fast_multi_serves(p, C, iof, blocks) &&
+         (size_t)AC_WAVES * WAVE_LDS + 12800 + (size_t)psy->mid_words * 4 <= 160 * 1024;
+}
+
 bool fast_mdct_supported(int N, int window, int pre) {
   bool fold4;
   return build_mdct_fast(N, window, pre, nullptr, &fold4);
@@ -2627,23 +2725,34 @@ static unsigned persistent_grid(int cus, int wg_per_cu, long long ntasks, int nw
 }
 
 template <int NFR>
-static void launch_fwd_multi_N(const FwdMArgs& a, int iof, bool fold4, int C, unsigned grid, hipStream_t s) {
+static int launch_fwd_multi_N(const FwdMArgs& a, int iof, bool fold4, bool psy, int C, unsigned grid, hipStream_t s) {
   const dim3 blk(AC_WAVES * 64);
+  auto go = [&](auto kernel, size_t lds) -> int {
+    if (lds > 64 * 1024)
+      AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3(grid), blk, lds, s, a);
+    return AC_OK;
+  };
+  if (psy) {   // fused masking model: float32 tensors, rotation fold blocks (the caller checked)
+    const size_t lds = (size_t)AC_WAVES * WAVE_LDS + multi_tab_bytes<NFR, true>() + (size_t)a.mp.img_words * 4;
+    if (C == 2) return go(k_fwd_multi<NFR, 0, AC_WAVES, 0, false, true>, lds);
+    return go(k_fwd_multi<NFR, 2, AC_WAVES, 0, false, true>, lds);
+  }
+  const size_t lds = (size_t)AC_WAVES * WAVE_LDS + Geo<8>::TAB_LDS;
   if (fold4) {
-    if (C == 2) hipLaunchKernelGGL((k_fwd_multi<NFR, 0, AC_WAVES, 0, true>), dim3(grid), blk, 0, s, a);
-    else hipLaunchKernelGGL((k_fwd_multi<NFR, 2, AC_WAVES, 0, true>), dim3(grid), blk, 0, s, a);
-    return;
+    if (C == 2) return go(k_fwd_multi<NFR, 0, AC_WAVES, 0, true>, lds);
+    return go(k_fwd_multi<NFR, 2, AC_WAVES, 0, true>, lds);
   }
   if (iof == 1) {
-    if (C == 2) hipLaunchKernelGGL((k_fwd_multi<NFR, 0, AC_WAVES, 1>), dim3(grid), blk, 0, s, a);
-    else hipLaunchKernelGGL((k_fwd_multi<NFR, 2, AC_WAVES, 1>), dim3(grid), blk, 0, s, a);
-    return;
+    if (C == 2) return go(k_fwd_multi<NFR, 0, AC_WAVES, 1>, lds);
+    return go(k_fwd_multi<NFR, 2, AC_WAVES, 1>, lds);
   }
-  if (C == 2) hipLaunchKernelGGL((k_fwd_multi<NFR, 0, AC_WAVES>), dim3(grid), blk, 0, s, a);
-  else hipLaunchKernelGGL((k_fwd_multi<NFR, 2, AC_WAVES>), dim3(grid), blk, 0, s, a);
+  if (C == 2) return go(k_fwd_multi<NFR, 0, AC_WAVES>, lds);
+  return go(k_fwd_multi<NFR, 2, AC_WAVES>, lds);
 }
-static int launch_fwd_multi(const ac_mdct_plan* p, const void* x, int iof, float* X, const float* prev_block, float* state_out,
-                            int B, int Kin, int F, int C, hipStream_t s) {
+// psy (may be null): the plan of the masking model for general band layouts, fused into the launch (fast_multi_fuses())
+static int launch_fwd_multi(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x, int iof, float* X, float* t, float* thr,
+                            float drown, const float* prev_block, float* state_out, int B, int Kin, int F, int C, hipStream_t s) {
   const int nfr = fast_mdct_frames_per_wave(p->N);
   FwdMArgs a;
   a.x = x;
@@ -2656,20 +2765,28 @@ static int launch_fwd_multi(const ac_mdct_plan* p, const void* x, int iof, float
   a.C = C;
   a.cpp = (F + nfr - 1) / nfr;
   a.nsig = (long long)B * C;
+  a.t = t;
+  a.thr = thr;
+  a.psy_img = psy ? psy->d_mid : nullptr;
+  if (psy) a.mp = mid_params(psy, drown);
+  else a.mp = mid::MidParams{};
   const long long npairs = (C == 2) ? (long long)B : (a.nsig + 1) / 2;
   a.ntasks = npairs * a.cpp;
+  // chunks per wave: the table copy (and the masking model's image) is paid once per workgroup
   static const int tper = [] { const char* e = getenv("AC_FWD_T"); return e ? atoi(e) : 4; }();
-  int T = tper > 0 ? tper : 4;
+  static const int tper_psy = [] { const char* e = getenv("AC_FWD_T_PSY"); return e ? atoi(e) : 8; }();
+  int T = psy ? (tper_psy > 0 ? tper_psy : 8) : (tper > 0 ? tper : 4);
   while (T > 1 && a.ntasks < (long long)AC_WAVES * T * p->cus * 2) T >>= 1;
   a.T = T;
   unsigned grid;
-  const int st = grid_for(a.ntasks, AC_WAVES * T, &grid);
+  int st = grid_for(a.ntasks, AC_WAVES * T, &grid);
   if (st) return st;
   const bool f4 = p->fold4 != 0;
-  if (nfr == 2) launch_fwd_multi_N<2>(a, iof, f4, C, grid, s);
-  else if (nfr == 4) launch_fwd_multi_N<4>(a, iof, f4, C, grid, s);
-  else if (nfr == 8) launch_fwd_multi_N<8>(a, iof, f4, C, grid, s);
-  else launch_fwd_multi_N<16>(a, iof, f4, C, grid, s);
+  if (nfr == 2) st = launch_fwd_multi_N<2>(a, iof, f4, psy != nullptr, C, grid, s);
+  else if (nfr == 4) st = launch_fwd_multi_N<4>(a, iof, f4, psy != nullptr, C, grid, s);
+  else if (nfr == 8) st = launch_fwd_multi_N<8>(a, iof, f4, psy != nullptr, C, grid, s);
+  else st = launch_fwd_multi_N<16>(a, iof, f4, psy != nullptr, C, grid, s);
+  if (st) return st;
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }
@@ -2851,11 +2968,11 @@ int launch_fwd_fast(const ac_mdct_plan* p, const ac_psy_plan* psy, const void* x
                     float* state_out, float* noisy, float* dbn, uint64_t seed) {
   if (B <= 0 || C <= 0 || F <= 0) return AC_OK;
   if (fast_mdct_frames_per_wave(p->N) > 1) {
-    if (psy || thr || t || noisy || dbn || !fast_multi_serves(p, C, iof, Kin)) {
+    if (noisy || dbn || !fast_multi_serves(p, C, iof, Kin) || (psy && !(fast_multi_fuses(p, psy, C, iof, Kin) && t && thr))) {
       set_error("internal: no wave-level analysis kernel for filters_n = %d, %d channels, io format %d here", p->N, C, iof);
       return AC_EUNSUPPORTED;
     }
-    return launch_fwd_multi(p, x, iof, X, prev_block, state_out, B, Kin, F, C, s);
+    return launch_fwd_multi(p, psy, x, iof, X, psy ? t : nullptr, psy ? thr : nullptr, drown, prev_block, state_out, B, Kin, F, C, s);
   }
   FwdArgs a;
   unsigned grid;

@@ -174,6 +174,8 @@ bool fast_mdct_supported(int N, int window, int pre);
 // one block (streaming state included) -- everything else at these sizes takes the LDS-FFT tier
 int fast_mdct_frames_per_wave(int N);
 bool fast_multi_serves(const ac_mdct_plan* p, int C, int iof, int blocks);
+// ... and whether the masking model of `psy` (general band layouts, ac_psy_mid_dev.h) rides in the same launch
+bool fast_multi_fuses(const ac_mdct_plan* p, const ac_psy_plan* psy, int C, int iof, int blocks);
 bool fast_psy_supported(const ac_psy_plan* p);
 int fast_mdct_plan_init(ac_mdct_plan* p);
 int fast_psy_plan_init(ac_psy_plan* p);

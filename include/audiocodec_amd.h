@@ -189,6 +189,12 @@ AC_API int ac_mask_threshold_backward(const ac_psy_plan* plan, const float* X, c
 AC_API int ac_encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t,
                     float* thr, float drown, int B, int K, int C, void* stream);
 
+/* How ac_encode_fused serves (mdct, psy) on tensors of C channels: 1 = ONE launch (filters_n 1024 / 2048 with the fused
+ * wave-level epilogue; filters_n 64 ... 512, mono / stereo, with the masking model for general band layouts in the
+ * several-frames-per-wave kernels), 2 = the transform, then tonality + threshold in one pass over X, 3 = three launches
+ * (generic kernels).  0 for inconsistent plans. */
+AC_API int ac_encode_launches(const ac_mdct_plan* mdct, const ac_psy_plan* psy, int C);
+
 /* The fused encode with its element-wise tail (psychoacoustic.py:150-167 and :87-100 on the frames just computed), so
  * that a caller who wants them does not pay another pass over X and thr:
  *   AC_EMIT_NOISY    noisy   [B,K+1,N,C] = X + thr * Normal(0, 1/6): the values ac_add_noise(X, thr, seed) gives, bit for bit;

@@ -266,9 +266,58 @@ def test_codec_golden_beside_the_powers_of_two(golden, path, N):
         for drown in (0.0, 0.5):
             thr = host(codec.psy.global_masking_threshold(Xp, dev(t_ref.astype(np.float32)), drown))
             assert rel_elem(thr, g["thr_%s_d%02d_ref64" % (name, int(drown * 10))]) <= TOL
-    # the codec's encode on the fixture's PCM: same spectrum, thresholds of its own spectrum within the bar of the model
+    # the codec's encode on the fixture's PCM: same spectrum, thresholds of its own spectrum within the bar of the model.
+    # At 512 / 128 that is ONE launch (the masking model rides in the several-frames-per-wave kernels), at 960 two
     Xe, te, thre = codec.encode(dev(g["x"]))
     assert rel_peak(host(Xe), g["X_ref64"]) <= TOL
+    if path == "auto":
+        assert codec.encode_launches(2) == (2 if N == 960 else 1)
+    # the fixture's interior frames are frames 1..3 of that spectrum (Xp_rand = X_ref32[:, 1:4]): reference-produced
+    # tonality / thresholds of the reference's float32 spectrum against the fused kernel's own spectrum -- the spectra
+    # agree to 1e-6 of the frame peak, which the thresholds feel at a few 1e-5
+    assert tonality_err(host(te[:, 1:4]), g["t_rand_ref64"]) <= 1.0
+    assert rel_elem(host(thre[:, 1:4]), g["thr_rand_d00_ref64"]) <= 3e-4
+    o = PsychoOracle(48000, N, 64, compute_dtype=np.float64)
+    X64 = host(Xe).astype(np.float64)
+    t64 = o.tonality(X64)
+    assert tonality_err(host(te), t64) <= 1.0 and rel_elem(host(thre), o.global_masking_threshold(X64, t64)) <= TOL
+
+
+@pytest.mark.parametrize("N,C,sr", [(512, 2, 48000), (512, 1, 48000), (256, 2, 48000), (256, 1, 44100), (128, 2, 48000), (128, 1, 48000),
+                                    (64, 2, 48000), (64, 1, 32768), (64, 2, 64)])
+def test_fused_encode_below_1024_equals_the_unfused_calls(N, C, sr):
+    """filters_n 512 / 256 / 128 / 64 -- the reference's own test sizes (tests/test_mdctransformer.py:23,42, composition at
+    N = 64 in tests/test_psychoacoustic.py:36-41): encode() is ONE launch, k_fwd_multi with the masking model for general
+    band layouts on the frames it has just transformed, and returns bit for bit what transform -> tonality ->
+    global_masking_threshold return (the same device function on the same values; X is not read back from HBM).  Ragged
+    frame counts (F not a multiple of the frames per wave), an odd number of mono signals, drown; the streaming form
+    (ac_stream_encode: state included) chunk by chunk; and the float64 oracle at the stated bar."""
+    _lib.load().ac_set_force_generic(0)
+    B, K = (5 if C == 1 else 3), 11
+    g = torch.Generator(device="cuda").manual_seed(N + C)
+    x = torch.empty(B, K * N, C, device="cuda").uniform_(-1, 1, generator=g)
+    x[0, : 3 * N] *= 1e-3                                     # a quiet stretch
+    x[-1, 2 * N: 5 * N, 0] = 0.0                              # and a silent one
+    codec = audiocodec_amd.AudioCodec(sr, N)
+    assert codec.encode_launches(C) == 1 and codec.psy.tier() == 1
+    for drown in (0.0, 0.3):
+        X, t, thr = codec.encode(x, drown)
+        Xu = codec.mdct.transform(x)
+        tu = codec.psy.tonality(Xu)
+        thru = codec.psy.global_masking_threshold(Xu, tu, drown)
+        assert torch.equal(X, Xu) and torch.equal(t, tu) and torch.equal(thr, thru)
+    o, om = PsychoOracle(sr, N, 64, compute_dtype=np.float64), MDCTOracle(N, "vorbis", np.float64)
+    Xo = om.transform(host(x).astype(np.float64))
+    assert rel_peak(host(X), Xo) <= TOL
+    X64 = host(X).astype(np.float64)
+    t64 = o.tonality(X64)
+    assert tonality_err(host(t), t64) <= 1.0
+    assert rel_elem(host(thr), o.global_masking_threshold(X64, t64, 0.3)) <= TOL
+    st = codec.stream(B, C)
+    parts = [st.encode_chunk(x[:, a * N:b * N].contiguous(), drown=0.3) for a, b in ((0, 1), (1, 6), (6, 11))]
+    for i, ref in enumerate((X, t, thr)):
+        assert torch.equal(torch.cat([p_[i] for p_ in parts], dim=1), ref[:, :K])
+    st.close()
 
 
 def test_tonality_like_reference(path):
