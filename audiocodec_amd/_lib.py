@@ -49,6 +49,14 @@ PROTOTYPES = {
     "ac_tonality_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ac_mask_threshold_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_int, c_int, c_int, c_int,
                                         c_void_p]),
+    "ac_workspace_create": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_void_p, POINTER(c_void_p)]),
+    "ac_workspace_buffers": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                     POINTER(c_void_p)]),
+    "ac_workspace_regions": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_void_p), POINTER(c_size_t)]),
+    "ac_workspace_report": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_float), POINTER(c_double)]),
+    "ac_workspace_destroy": (c_int, [c_void_p]),
+    "ac_workspace_alloc_dlpack": (c_void_p, [c_void_p, c_int, c_int, POINTER(ctypes.c_int64), c_void_p]),
+    "ac_workspace_live": (ctypes.c_long, [c_void_p]),
     "ac_probe_placement": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p), c_int, c_int, c_int,
                                    c_int, c_void_p, POINTER(c_int), POINTER(c_float)]),
     "ac_encode_fused_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_int,

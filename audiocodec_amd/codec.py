@@ -13,7 +13,7 @@ import ctypes
 
 import torch
 
-from . import _host, _lib
+from . import _host, _lib, placement
 from .mdctransformer import MDCTransformer
 from .psychoacoustic import PsychoacousticModel
 
@@ -57,11 +57,18 @@ class AudioCodec:
         if S % N != 0:
             raise ValueError("samples_n (%d) is not a multiple of filters_n (%d)" % (S, N))
         K = S // N
-        X = torch.empty((B, K + 1, N, C), dtype=self.compute_dtype, device=x.device)
+        # the library allocates what it returns, and decides where: spectra and thresholds in different classes of VRAM
+        # (audiocodec_amd/placement.py; plain torch.empty for small batches, other dtypes, AC_NO_PLACEMENT=1)
+        placement.ensure(self, (B, S, C), x.device)
+        X = placement.empty(placement.REGION_SPECTRA, (B, K + 1, N, C), self.compute_dtype, x.device)
         t = torch.empty((B, K + 1, 1, C), dtype=self.compute_dtype, device=x.device)
-        thr = torch.empty((B, K + 1, N, C), dtype=self.compute_dtype, device=x.device)
+        thr = placement.empty(placement.REGION_OTHER, (B, K + 1, N, C), self.compute_dtype, x.device)
         self.encode_into(x, X, t, thr, drown)
         return X, t, thr
+
+    def placement_report(self, device=None):
+        """How the tensors :meth:`encode` / :meth:`decode` return are placed on ``device`` (``placement.report``)."""
+        return placement.report(device)
 
     def encode_ex(self, x, drown=0.0, noise_seed=None, db_norm=False):
         """:meth:`encode` with its element-wise tail computed in the same pass (``ac_encode_fused_ex``):

@@ -1973,7 +1973,7 @@ template <int NFR, bool PSY> constexpr int multi_tab_bytes() {
 // wave lays its NFR spectra out in natural order in its LDS buffer (8 KB: NFR frames x N bins x two signals), then walks
 // them one frame at a time with all 64 lanes exactly as k_psy_mid does on a row loaded from HBM -- same device function on
 // the same values, so X, tonality and threshold equal transform -> k_psy_mid bit for bit, and X is not read back from HBM.
-// The frame's intensities overwrite its own slot; Q and G live in the last KB of the buffer.
+// A frame's intensities overwrite its own slot, and so do its 64 G_j after them.
 template <int NFR, int CMODE, int NW, int IOF = 0, bool FOLD4 = false, bool PSY = false>
 __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
   using pcm_t = typename std::conditional<IOF == 1, int16_t, float>::type;   // (streaming state: float32 only, IOF 0)
@@ -2154,42 +2154,45 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
         for (int i = 0; i < 8; ++i) *reinterpret_cast<v4f*>(fb + 16 * LB * i) = row[i];
       }
       wave_sync();
-      v2f* Qb = reinterpret_cast<v2f*>(buf + 8192);
-      v2f Scol[32];
-      mid::load_scol(pimg, a.mp, lane, Scol);          // (per chunk: the column does not sit in registers through the FFT)
+      constexpr int FB = RP >= 4 ? 2 : 4;              // frames side by side (ac_psy_mid_dev.h)
 #pragma unroll 1
-      for (int ff = 0; ff < NFR; ++ff) {
-        const int nn = c * NFR + ff;
-        if (nn >= a.F) break;
-        char* ib = buf + ff * (8 * FN);
-        v4f xq[RP];
+      for (int g0 = 0; g0 < NFR; g0 += FB) {
+        if (c * NFR + g0 >= a.F) break;
+        char* ib = buf + g0 * (8 * FN);
+        v4f xq[FB][RP];
+        bool ok[FB];
+        size_t o0[FB], o1[FB];
 #pragma unroll
-        for (int i = 0; i < RP; ++i)
-          xq[i] = mid::in_frame<RP>(a.mp, i, lane) ? *reinterpret_cast<const v4f*>(ib + 16 * (64 * i + lane)) : v4f{0.f, 0.f, 0.f, 0.f};
-        const v2f t = mid::tonality_frame<RP>(xq, a.mp, lane);
-        const size_t o0 = row_off(pq.b0, a.F, nn, blk, pq.c0), o1 = row_off(pq.b1, a.F, nn, blk, pq.c1);
-        if (lane == 0) {
-          a.t[((size_t)pq.b0 * a.F + (size_t)nn) * C + pq.c0] = t.x;
-          if (pq.has1) a.t[((size_t)pq.b1 * a.F + (size_t)nn) * C + pq.c1] = t.y;
+        for (int fb = 0; fb < FB; ++fb) {
+          const int nn = c * NFR + g0 + fb;
+          ok[fb] = nn < a.F;   // (a slot past the last frame holds the zero spectrum of an idle group of lanes: computed, not stored)
+          o0[fb] = row_off(pq.b0, a.F, ok[fb] ? nn : 0, blk, pq.c0);
+          o1[fb] = row_off(pq.b1, a.F, ok[fb] ? nn : 0, blk, pq.c1);
+#pragma unroll
+          for (int i = 0; i < RP; ++i)
+            xq[fb][i] = mid::in_frame<RP>(a.mp, i, lane) ? *reinterpret_cast<const v4f*>(ib + fb * (8 * FN) + 16 * (64 * i + lane))
+                                                         : v4f{0.f, 0.f, 0.f, 0.f};
         }
-        v4f th[RP];
-        mid::threshold_frame<RP>(xq, t, a.mp, pimg, ib, Qb, Qb + 64, Scol, lane, th);
-        if (CMODE == 0) {
+        v2f t[FB];
+        mid::tonality_frames<RP, FB>(xq, a.mp, lane, t);
 #pragma unroll
-          for (int i = 0; i < RP; ++i)
-            if (mid::in_frame<RP>(a.mp, i, lane)) __builtin_nontemporal_store(th[i], reinterpret_cast<v4f*>(a.thr + o0) + 64 * i + lane);
-        } else {
-#pragma unroll
-          for (int i = 0; i < RP; ++i)
-            if (mid::in_frame<RP>(a.mp, i, lane)) reinterpret_cast<v2f*>(a.thr + o0)[64 * i + lane] = v2f{th[i].x, th[i].z};
-          if (pq.has1) {
-#pragma unroll
-            for (int i = 0; i < RP; ++i)
-              if (mid::in_frame<RP>(a.mp, i, lane)) reinterpret_cast<v2f*>(a.thr + o1)[64 * i + lane] = v2f{th[i].y, th[i].w};
+        for (int fb = 0; fb < FB; ++fb)
+          if (ok[fb] && lane == 0) {
+            const int nn = c * NFR + g0 + fb;
+            a.t[((size_t)pq.b0 * a.F + (size_t)nn) * C + pq.c0] = t[fb].x;
+            if (pq.has1) a.t[((size_t)pq.b1 * a.F + (size_t)nn) * C + pq.c1] = t[fb].y;
           }
-        }
-        wave_sync();   // the frame's reads of Q / G are done before the next frame writes them
+        mid::threshold_frames<RP, FB>(xq, t, a.mp, pimg, ib, 8 * FN, lane, [&](int fb, int i, const v4f& th) {
+          if (!ok[fb]) return;
+          if (CMODE == 0) {
+            __builtin_nontemporal_store(th, reinterpret_cast<v4f*>(a.thr + o0[fb]) + 64 * i + lane);
+          } else {
+            reinterpret_cast<v2f*>(a.thr + o0[fb])[64 * i + lane] = v2f{th.x, th.z};
+            if (pq.has1) reinterpret_cast<v2f*>(a.thr + o1[fb])[64 * i + lane] = v2f{th.y, th.w};
+          }
+        });
       }
+      wave_sync();   // the last group's reads of its slots are done before the next chunk's FFT writes the buffer
     }
   }
 }

@@ -4,14 +4,8 @@
 // bins freely) -- e.g. the models beside the several-frames-per-wave MDCT kernels (filters_n 256 / 512), where the
 // O(N)-per-workgroup generic kernels ran at 0.5-0.8 TB/s.  gfx950 only.
 //
-// One 64-lane wave per (frame, channel pair) as in k_psy_fast: the row is loaded with coalesced 16-byte (stereo) or
-// 8-byte (mono, two signals side by side) accesses, tonality comes from DPP wave sums, the intensities go through an LDS
-// image, lane j < M owns Bark band j and walks its list of (bin, weight) entries (W "by band": psychoacoustic.py:301-315),
-// the band x band spreading product reads S from LDS with the Q_i broadcast (psychoacoustic.py:205-207, tonality offset
-// pulled out of the sum: SURVEY App. A.3; S is Toeplitz, S[i][j] = g[M - i + j] (:223-228), so the image holds the 2 M
-// prototype values instead of M x M), and every bin gathers its <= WI (band, weight) entries of W_inv from a fixed-width
-// table stored entry-major (psychoacoustic.py:317-331).  All constant tables sit in one image copied to LDS per
-// workgroup; a wave walks T frames so that the copy is paid once per 4 T frames.
+// The per-frame arithmetic lives in ac_psy_mid_dev.h (shared with the fused encode of the several-frames-per-wave MDCT
+// kernels); this file holds the stand-alone kernel, the host-side image builder and the launcher.
 #include <algorithm>
 #include <cstring>
 #include <vector>
@@ -36,15 +30,16 @@ struct MidArgs {
   long long nsig, ntasks;
 };
 
-// One 64-lane wave per (frame, channel pair) as in k_psy_fast: the row is loaded with coalesced 16-byte (stereo) or
-// 8-byte (mono, two signals side by side) accesses; the per-frame arithmetic is ac_psy_mid_dev.h.  All constant tables
-// sit in one image copied to LDS per workgroup; a wave walks T frames so that the copy is paid once per 4 T frames.
-// wave buffer: [N] v2f intensities (c0, c1) | [64] v2f Q | [64] v2f G
-template <int R, int CMODE, bool WANT_T, bool WANT_THR>
-__global__ __launch_bounds__(256, (R == 8 ? 3 : 4)) void k_psy_mid(MidArgs a) {
+// One 64-lane wave per (frame, channel pair) as in k_psy_fast, FB frames at a time (their rows are loaded together: FB
+// times the bytes in flight per wave, and the per-frame arithmetic of ac_psy_mid_dev.h interleaves the frames' dependent
+// chains): rows move with coalesced 16-byte (stereo) or 8-byte (mono, two signals side by side) accesses.  All constant
+// tables sit in one image copied to LDS per workgroup; a wave walks T frames so that the copy is paid once per 4 T frames.
+// wave buffer: FB slots of [N] v2f intensities (c0, c1), the head of a slot reused for the frame's 64 G_j
+template <int R, int CMODE, bool WANT_T, bool WANT_THR, int FB>
+__global__ __launch_bounds__(256, ((WANT_THR && (FB > 1 || R >= 8)) ? 3 : 4)) void k_psy_mid(MidArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int N = a.p.N;
-  const int WAVE_BYTES = 8 * N + 1024;
+  const int SLOT = 8 * N, WAVE_BYTES = FB * SLOT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   uint32_t* img = reinterpret_cast<uint32_t*>(smem);
   if (WANT_THR) {
@@ -54,72 +49,70 @@ __global__ __launch_bounds__(256, (R == 8 ? 3 : 4)) void k_psy_mid(MidArgs a) {
   }
   char* buf = smem + (size_t)a.p.img_words * 4 + (size_t)wave * WAVE_BYTES;
   const int C = a.C;
-  v2f Scol[32];
-  if (WANT_THR) load_scol(img, a.p, lane, Scol);
-  long long task = (long long)blockIdx.x * nw * a.T + wave;
-  for (int tt = 0; tt < a.T && task < a.ntasks; ++tt, task += nw) {   // (no workgroup barrier inside)
-  wave_sync();   // the previous frame's reads of the wave's buffers are done
-  const int f = (int)(task % a.F);
-  const long long p = task / a.F;
-  // the two signals of the wave: stereo = the two channels of clip p; mono = clips 2 p and 2 p + 1
-  const bool has1 = CMODE == 0 ? true : (2 * p + 1 < a.nsig);
-  const long long b0 = CMODE == 0 ? p : 2 * p, b1 = CMODE == 0 ? p : (has1 ? 2 * p + 1 : 2 * p);
-  const size_t blk = (size_t)N * C;
-  const size_t o0 = ((size_t)b0 * a.F + (size_t)f) * blk, o1 = ((size_t)b1 * a.F + (size_t)f) * blk;
-  const size_t t0 = ((size_t)b0 * a.F + (size_t)f) * C, t1 = CMODE == 0 ? t0 + 1 : ((size_t)b1 * a.F + (size_t)f) * C;
-
-  // granule q = lane + 64 i: (X[2q], X[2q+1]) x (s0, s1); granules past the frame (q >= N/2) read as zero
-  auto in = [&](int i) { return in_frame<R>(a.p, i, lane); };
-  v4f xq[R];
-  if (CMODE == 0) {
+  const long long task0 = (long long)blockIdx.x * nw * a.T + wave;
+  for (int tt = 0; tt < a.T && task0 + (long long)tt * nw < a.ntasks; tt += FB) {   // (no workgroup barrier inside)
+    wave_sync();   // the previous group's reads of the wave's buffers are done
+    auto in = [&](int i) { return in_frame<R>(a.p, i, lane); };
+    bool ok[FB], has1[FB];
+    size_t o0[FB], o1[FB], t0[FB], t1[FB];
+    v4f xq[FB][R];
 #pragma unroll
-    for (int i = 0; i < R; ++i) xq[i] = in(i) ? reinterpret_cast<const v4f*>(a.X + o0)[64 * i + lane] : v4f{0.f, 0.f, 0.f, 0.f};
-  } else {
+    for (int fb = 0; fb < FB; ++fb) {
+      const long long task = task0 + (long long)(tt + fb) * nw;
+      ok[fb] = tt + fb < a.T && task < a.ntasks;
+      const long long tk = ok[fb] ? task : task0 + (long long)tt * nw;   // (a frame past the end re-reads the group's first row)
+      const int f = (int)(tk % a.F);
+      const long long p = tk / a.F;
+      // the two signals of the wave: stereo = the two channels of clip p; mono = clips 2 p and 2 p + 1
+      has1[fb] = CMODE == 0 ? true : (2 * p + 1 < a.nsig);
+      const long long b0 = CMODE == 0 ? p : 2 * p, b1 = CMODE == 0 ? p : (has1[fb] ? 2 * p + 1 : 2 * p);
+      const size_t blk = (size_t)N * C;
+      o0[fb] = ((size_t)b0 * a.F + (size_t)f) * blk;
+      o1[fb] = ((size_t)b1 * a.F + (size_t)f) * blk;
+      t0[fb] = ((size_t)b0 * a.F + (size_t)f) * C;
+      t1[fb] = CMODE == 0 ? t0[fb] + 1 : ((size_t)b1 * a.F + (size_t)f) * C;
+      // granule q = lane + 64 i: (X[2q], X[2q+1]) x (s0, s1); granules past the frame (q >= N/2) read as zero
+      if (CMODE == 0) {
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-      const v2f u = in(i) ? reinterpret_cast<const v2f*>(a.X + o0)[64 * i + lane] : v2f{0.f, 0.f};
-      xq[i] = v4f{u.x, 0.f, u.y, 0.f};
-    }
-    if (has1) {
+        for (int i = 0; i < R; ++i)
+          xq[fb][i] = in(i) ? reinterpret_cast<const v4f*>(a.X + o0[fb])[64 * i + lane] : v4f{0.f, 0.f, 0.f, 0.f};
+      } else {
 #pragma unroll
-      for (int i = 0; i < R; ++i) {
-        const v2f w = in(i) ? reinterpret_cast<const v2f*>(a.X + o1)[64 * i + lane] : v2f{0.f, 0.f};
-        xq[i].y = w.x;
-        xq[i].w = w.y;
+        for (int i = 0; i < R; ++i) {
+          const v2f u = in(i) ? reinterpret_cast<const v2f*>(a.X + o0[fb])[64 * i + lane] : v2f{0.f, 0.f};
+          const v2f w = (in(i) && has1[fb]) ? reinterpret_cast<const v2f*>(a.X + o1[fb])[64 * i + lane] : v2f{0.f, 0.f};
+          xq[fb][i] = v4f{u.x, w.x, u.y, w.y};
+        }
       }
     }
-  }
-  v2f t = {0.f, 0.f};
-  if (WANT_T) {
-    t = tonality_frame<R>(xq, a.p, lane);
-    if (lane == 0) {
-      a.t_out[t0] = t.x;
-      if (has1) a.t_out[t1] = t.y;
+    v2f t[FB];
+    if (WANT_T) {
+      tonality_frames<R, FB>(xq, a.p, lane, t);
+#pragma unroll
+      for (int fb = 0; fb < FB; ++fb)
+        if (ok[fb] && lane == 0) {
+          a.t_out[t0[fb]] = t[fb].x;
+          if (has1[fb]) a.t_out[t1[fb]] = t[fb].y;
+        }
+    } else {
+#pragma unroll
+      for (int fb = 0; fb < FB; ++fb) t[fb] = v2f{a.t_in[t0[fb]], has1[fb] ? a.t_in[t1[fb]] : 0.f};
     }
-  } else {
-    t.x = a.t_in[t0];
-    t.y = has1 ? a.t_in[t1] : 0.f;
-  }
-  if (!WANT_THR) continue;
-  v4f th[R];
-  v2f* Qb = reinterpret_cast<v2f*>(buf + 8 * N);
-  threshold_frame<R>(xq, t, a.p, img, buf, Qb, Qb + 64, Scol, lane, th);
-  if (CMODE == 0) {
-#pragma unroll
-    for (int i = 0; i < R; ++i)
-      if (in(i)) __builtin_nontemporal_store(th[i], reinterpret_cast<v4f*>(a.thr + o0) + 64 * i + lane);
-  } else {
-#pragma unroll
-    for (int i = 0; i < R; ++i)
-      if (in(i)) reinterpret_cast<v2f*>(a.thr + o0)[64 * i + lane] = v2f{th[i].x, th[i].z};
-    if (has1) {
-#pragma unroll
-      for (int i = 0; i < R; ++i)
-        if (in(i)) reinterpret_cast<v2f*>(a.thr + o1)[64 * i + lane] = v2f{th[i].y, th[i].w};
-    }
-  }
-  }   // frames of the wave
+    if (!WANT_THR) continue;
+    threshold_frames<R, FB>(xq, t, a.p, img, buf, SLOT, lane, [&](int fb, int i, const v4f& th) {
+      if (!ok[fb]) return;
+      if (CMODE == 0) {
+        __builtin_nontemporal_store(th, reinterpret_cast<v4f*>(a.thr + o0[fb]) + 64 * i + lane);
+      } else {
+        reinterpret_cast<v2f*>(a.thr + o0[fb])[64 * i + lane] = v2f{th.x, th.z};
+        if (has1[fb]) reinterpret_cast<v2f*>(a.thr + o1[fb])[64 * i + lane] = v2f{th.y, th.w};
+      }
+    });
+  }   // groups of frames of the wave
 }
+
+// frames a wave handles side by side: as many as keep the frames' registers (4 R each) within the budget
+constexpr int mid_fb(int R) { return R >= 8 ? 1 : R == 4 ? 2 : 4; }
 
 struct MidLayout {
   int wi_w = 0, off_S = 0, off_band = 0, off_wbe = 0, off_wi = 0, words = 0;
@@ -136,7 +129,7 @@ bool build_mid(const ac_psy_plan* p, std::vector<uint32_t>* out, MidLayout* lay)
   MidLayout L;
   L.wi_w = wi.max_row;
   L.off_S = 0;
-  L.off_band = L.off_S + 128;
+  L.off_band = L.off_S + 2 * (MF_TAB_BYTES / 4);
   L.off_band = (L.off_band + 3) / 4 * 4;                  // 16-byte aligned rows of four words
   L.off_wbe = L.off_band + 4 * 64;
   // a band's weights cover the run of bins from its first to its last non-zero (zeros in between, if any, stay zeros)
@@ -167,7 +160,23 @@ bool build_mid(const ac_psy_plan* p, std::vector<uint32_t>* out, MidLayout* lay)
   for (int i = 0; i < M; ++i)
     for (int j = 0; j < M; ++j)
       if ((float)t.S[(size_t)i * M + j] != (float)t.g[(size_t)(M - i + j)]) return false;
-  for (int d = -(M - 1); d <= M - 1; ++d) putf(L.off_S + 64 + d, (float)t.g[(size_t)(M + d)]);
+  {
+    // bf16 tiles for spread_tiles: copy c, entry y = rev[y - c], rev[m] = gp[128 - m] (m = 1 .. 127), with
+    // gp[64 + d] = g[M + d] where |d| < M, else 0; hi parts, then lo parts (the layout of spread_mfma in ac_fast.hip)
+    auto gp = [&](int k) { const int d = k - 64; return (d > -M && d < M) ? (float)t.g[(size_t)(M + d)] : 0.f; };
+    auto bf16_rne = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+    auto bf16_val = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+    uint16_t* tb = reinterpret_cast<uint16_t*>(w.data() + L.off_S);
+    for (int c = 0; c < 4; ++c)
+      for (int y = 0; y < 132; ++y) {
+        const int m = y - c;
+        if (m < 1 || m > 127) continue;
+        const float v = gp(128 - m);
+        const uint16_t hi = bf16_rne(v);
+        tb[(c * MF_COPY_STRIDE) / 2 + y] = hi;
+        tb[(MF_TAB_BYTES + c * MF_COPY_STRIDE) / 2 + y] = bf16_rne(v - bf16_val(hi));
+      }
+  }
   for (int j = 0; j < M; ++j) {
     w[(size_t)L.off_band + 4 * j + 0] = (uint32_t)start[j];
     w[(size_t)L.off_band + 4 * j + 1] = (uint32_t)count[j] | ((uint32_t)first[j] << 16);
@@ -187,7 +196,7 @@ bool build_mid(const ac_psy_plan* p, std::vector<uint32_t>* out, MidLayout* lay)
   return true;
 }
 
-size_t mid_lds_bytes(int N, int words, int nw) { return (size_t)words * 4 + (size_t)nw * (8 * (size_t)N + 1024); }
+size_t mid_lds_bytes(int N, int words, int nw, int fb) { return (size_t)words * 4 + (size_t)nw * fb * 8 * (size_t)N; }
 
 template <int R, int CMODE>
 int launch_mid_R(const MidArgs& a, bool want_t, bool want_thr, unsigned grid, int nw, size_t lds, hipStream_t s) {
@@ -198,9 +207,9 @@ int launch_mid_R(const MidArgs& a, bool want_t, bool want_thr, unsigned grid, in
     hipLaunchKernelGGL(kernel, dim3(grid), blk, lds, s, a);
     return AC_OK;
   };
-  if (want_t && want_thr) return go(k_psy_mid<R, CMODE, true, true>);
-  if (want_thr) return go(k_psy_mid<R, CMODE, false, true>);
-  return go(k_psy_mid<R, CMODE, true, false>);
+  if (want_t && want_thr) return go(k_psy_mid<R, CMODE, true, true, mid_fb(R)>);
+  if (want_thr) return go(k_psy_mid<R, CMODE, false, true, mid_fb(R)>);
+  return go(k_psy_mid<R, CMODE, true, false, mid_fb(R)>);
 }
 
 }  // namespace
@@ -265,18 +274,20 @@ int launch_psy_mid(const ac_psy_plan* p, const float* X, const float* t_in, floa
   a.nsig = (long long)B * C;
   a.ntasks = ((C == 2) ? (long long)B : (a.nsig + 1) / 2) * F;
   const bool want_t = t_out != nullptr, want_thr = thr != nullptr;
+  const int R = p->N <= 128 ? 1 : p->N <= 256 ? 2 : p->N <= 512 ? 4 : 8;   // granule registers per lane
+  const int fb = mid_fb(R);
   // four waves per workgroup when the image and the wave buffers fit three workgroups to a CU, else two
   int nw = 4;
-  if (mid_lds_bytes(p->N, L.words, nw) > 53 * 1024) nw = 2;
-  const size_t lds = want_thr ? mid_lds_bytes(p->N, L.words, nw) : 0;
+  if (mid_lds_bytes(p->N, L.words, nw, fb) > 53 * 1024) nw = 2;
+  const size_t lds = want_thr ? mid_lds_bytes(p->N, L.words, nw, fb) : 0;
   if (lds > 160 * 1024) {
     set_error("internal: masking-model tables too large for LDS (%zu bytes)", lds);
     return AC_EUNSUPPORTED;
   }
   // frames per wave: as many as keep every CU supplied with a few workgroups (the image copy is paid per workgroup)
   const int cus = p->cus > 0 ? p->cus : 256;
-  int T = want_thr ? 8 : 1;
-  while (T > 1 && a.ntasks < (long long)nw * T * cus * 6) T >>= 1;
+  int T = want_thr ? 8 : fb;
+  while (T > fb && a.ntasks < (long long)nw * T * cus * 6) T >>= 1;
   a.T = T;
   const long long per = (long long)nw * T;
   const long long g = (a.ntasks + per - 1) / per;
@@ -286,7 +297,6 @@ int launch_psy_mid(const ac_psy_plan* p, const float* X, const float* t_in, floa
   }
   const unsigned grid = (unsigned)g;
   int st;
-  const int R = p->N <= 128 ? 1 : p->N <= 256 ? 2 : p->N <= 512 ? 4 : 8;   // granule registers per lane
   if (C == 2) st = R == 1 ? launch_mid_R<1, 0>(a, want_t, want_thr, grid, nw, lds, s)
                  : R == 2 ? launch_mid_R<2, 0>(a, want_t, want_thr, grid, nw, lds, s)
                  : R == 4 ? launch_mid_R<4, 0>(a, want_t, want_thr, grid, nw, lds, s)

@@ -14,7 +14,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import _host, _lib
+from . import _host, _lib, placement
 
 
 class _TransformFn(torch.autograd.Function):
@@ -146,7 +146,7 @@ class MDCTransformer:
         if S % N != 0:
             raise ValueError("samples_n (%d) is not a multiple of filters_n (%d)" % (S, N))
         K = S // N
-        X = torch.empty((B, K + 1, N, C), dtype=x.dtype, device=x.device)
+        X = placement.empty(placement.REGION_SPECTRA, (B, K + 1, N, C), x.dtype, x.device)   # (see placement.py)
         with _host.on_device(x.device):
             _lib.check(self._lib.ac_mdct_forward_typed(self._plans.get(x.device), _host.ptr(x), _host.ptr(X),
                                                        self._dtype_id, B, K, C, _host.stream_ptr(x.device)))
@@ -169,7 +169,7 @@ class MDCTransformer:
         B, Kp, N, C = X.shape
         if N != self.filters_n:
             raise ValueError("axis 2 of mdct_amplitudes (%d) != filters_n (%d)" % (N, self.filters_n))
-        x = torch.empty((B, (Kp + 1) * N, C), dtype=X.dtype, device=X.device)
+        x = placement.empty(placement.REGION_OTHER, (B, (Kp + 1) * N, C), X.dtype, X.device)
         with _host.on_device(X.device):
             _lib.check(self._lib.ac_mdct_inverse_typed(self._plans.get(X.device), _host.ptr(X), _host.ptr(x),
                                                        self._dtype_id, B, Kp, C, _host.stream_ptr(X.device)))

@@ -13,7 +13,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import _host, _lib
+from . import _host, _lib, placement
 
 
 class _TonalityFn(torch.autograd.Function):
@@ -269,7 +269,7 @@ class PsychoacousticModel:
             raise ValueError("tonality_per_block must have shape %s, got %s" % ((B, F, 1, C), tuple(t.shape)))
         if t.device != X.device:
             raise ValueError("mdct_amplitudes and tonality_per_block live on different devices")
-        thr = torch.empty_like(X)
+        thr = placement.empty(placement.REGION_OTHER, tuple(X.shape), X.dtype, X.device)   # (see placement.py)
         with _host.on_device(X.device):
             _lib.check(self._lib.ac_mask_threshold_typed(self._plans.get(X.device), _host.ptr(X), _host.ptr(t),
                                                          float(drown), _host.ptr(thr), self._dtype_id, B, F, C,

@@ -1,154 +1,73 @@
-"""Caller-owned buffers for one encode / decode batch, placed for the MI355X's HBM.
+"""Caller-owned buffers for one encode / decode batch shape, placed for the MI355X's HBM (the Python face of the C ABI's
+``ac_workspace_*``; see ``include/audiocodec_amd.h`` and DESIGN.md, "placement").
 
-Measured on MI355X (tools/placement_*.py): the fused encode kernel writes two streams of the same
-length side by side (spectrum ``X`` and threshold ``thr``), the decode kernel reads ``X`` and writes the PCM.  The 288 GB
-of VRAM fall into stretches of 8 ... 64 GiB that belong to a few classes (three show in a map taken by moving ``thr``
-across a 224 GiB allocation); when the two tensors a kernel streams side by side lie in stretches of the same class, the
-kernel runs slower -- encode 0.55-0.57 ms against 0.49 ms on the bench workload, decode 0.355 against 0.345 -- and
-offsets inside a stretch (2 MiB ... several GiB) make no difference.  Which stretch an allocation lands in is the
-driver's business, so a :class:`Workspace` keeps ``x``, ``X`` and the tonality in one allocation and tries a few
-allocations for ``thr`` and the decoded PCM, one after the other, timing the encode kernel on each (the C entry point
-``ac_probe_placement``), until two of them differ by the gap between the classes; it keeps the fastest and drops the
-others.  Consecutive allocations come from the same stretch, so between two tries a spacer is allocated straight from
-the HIP runtime (never touched, returned to the driver before the constructor ends; at most ``span_gib`` in all).
-Nothing about the kernels or their results changes; only where the caller's tensors live.
+The fused encode writes the spectrum ``X`` and the threshold ``thr`` side by side, the decode reads ``X`` and writes the
+PCM; when the two tensors a kernel streams side by side lie in stretches of VRAM of the same class the kernel runs 10-15 %
+slower.  ``ac_workspace_create`` keeps ``X``, the tonality and ``x`` in one allocation and tries a few allocations for
+(``thr``, decoded PCM), timing the encode kernel on each, with untouched spacers between the tries; it keeps the fastest
+and returns everything else to the driver.  Nothing about the kernels or their results changes; only where the tensors live.
 
-Opt-in: plain ``torch`` allocations work with every entry point; this class only removes the luck from where they land.
+Opt-in, for callers of ``encode_into`` / ``decode_into``.  The tensors ``AudioCodec.encode`` / ``decode`` allocate
+themselves are placed by the same mechanism without any of this (``audiocodec_amd/placement.py``).
 """
 
 from __future__ import annotations
 
 import ctypes
-import time
 
-import numpy as np
 import torch
 
-from . import _host, _lib
-
-_GIB = 1 << 30
+from . import _host, _lib, placement
 
 
 class Workspace:
     """``x [B, K*N, C]``, ``X [B, K+1, N, C]``, ``t [B, K+1, 1, C]``, ``thr`` like ``X``, ``xh [B, (K+2)*N, C]`` (float32).
 
-    :param max_tries: allocations tried for (``thr``, ``xh``); each is the size of those two tensors, all but the chosen
-                      one are released again (to torch's caching allocator) when the constructor returns.  The search
-                      stops early once the timings show both classes (fastest <= 0.93 x slowest)
+    :param max_tries: allocations tried for (``thr``, ``xh``), at most 16; all but the chosen one are back with the driver
+                      when the constructor returns.  The search stops early at the first candidate that reaches the
+                      two-class rate, or once two candidates differ by the gap between the classes
     :param span_gib:  upper bound on the untouched spacer memory held for a moment between the tries (0: no spacers)
-    :param tune:      False: one allocation each, no timing
+    :param tune:      False: one allocation each (``max_tries = 1``)
     """
-
-    CLASS_GAP = 0.93
-    SPACER_GIB = 12.0
-    GOOD_RATE = 5.7e12        # algorithmic bytes / s of the fused encode that only a two-class placement reaches (stereo,
-                              # filters_n 1024: 5.9-6.0e12 against 5.1-5.4e12 in one class)
 
     def __init__(self, codec, batches_n, blocks_n, channels_n, max_tries=8, span_gib=96.0, tune=True, device=None):
         _host.require_float32(codec.compute_dtype, "Workspace")
         self.codec = codec
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         B, K, C, N = int(batches_n), int(blocks_n), int(channels_n), codec.filters_n
-        self.shapes = {"x": (B, K * N, C), "X": (B, K + 1, N, C), "t": (B, K + 1, 1, C), "thr": (B, K + 1, N, C),
-                       "xh": (B, (K + 2) * N, C)}
-        words = {k: max(int(np.prod(s)), 1) for k, s in self.shapes.items()}
-        pad = (1 << 21) // 4                                     # every tensor starts on a 2 MiB boundary of its chunk
-        self._words = {k: (w + pad - 1) // pad * pad for k, w in words.items()}
-        need_a = self._words["x"] + self._words["X"] + self._words["t"]
-        need_b = self._words["thr"] + self._words["xh"]
-        self._a = torch.empty(need_a, dtype=torch.float32, device=self.device)
-        self._carve(self._a, ("X", "t", "x"))
-        tries = max(1, int(max_tries)) if (tune and B * K > 0) else 1
-        self.report = {"bytes_a": need_a * 4, "bytes_b": need_b * 4, "tries": 0, "tuned": False}
-        cands, times, spacers = [], [], _Spacers(self.device, span_gib)
-        if tries > 1:
-            lib = _lib.load()
-            gen = torch.Generator(device=self.device).manual_seed(0)
-            self.x.uniform_(-1.0, 1.0, generator=gen)            # timing on zeros would flatter every candidate alike
-            plans = (codec.mdct._plan(self.device), codec.psy._plan(self.device))
-            for i in range(tries):
-                try:
-                    c = torch.empty(need_b, dtype=torch.float32, device=self.device)
-                except torch.cuda.OutOfMemoryError:
-                    if not cands:
-                        raise
-                    break
-                cands.append(c)
-                if i == 0:                                       # an idle device runs its first ~30 ms of load slower
-                    self._carve(c, ("thr", "xh"))
-                    t0 = time.perf_counter()
-                    while time.perf_counter() - t0 < 0.06:
-                        codec.encode_into(self.x, self.X, self.t, self.thr)
-                        torch.cuda.synchronize(self.device)
-                ptrs = (ctypes.c_void_p * 1)(c.data_ptr())
-                ms = (ctypes.c_float * 1)()
-                arg = ctypes.c_int(0)
-                with torch.cuda.device(self.device):
-                    _lib.check(lib.ac_probe_placement(plans[0], plans[1], _host.ptr(self.x), _host.ptr(self.X),
-                                                      _host.ptr(self.t), ptrs, 1, B, K, C, _host.stream_ptr(self.device),
-                                                      ctypes.byref(arg), ms))
-                times.append(float(ms[0]))
-                if len(times) >= 2 and min(times) <= self.CLASS_GAP * max(times):
-                    break
-                enc_bytes = 4.0 * (words["x"] + words["X"] + words["thr"] + words["t"])
-                if enc_bytes / (times[-1] * 1e-3) >= self.GOOD_RATE:     # already a two-class placement
-                    break
-                spacers.add(self.SPACER_GIB)                     # the next try comes from further along the VRAM
-            best = int(np.argmin(times))
-            self.report.update({"tuned": True, "tries": len(times), "encode_ms_by_try": times, "chosen_try": best,
-                                "addresses": ["%#x" % c.data_ptr() for c in cands], "spacer_GiB": spacers.held_gib})
-            spacers.release()
-        else:
-            cands.append(torch.empty(need_b, dtype=torch.float32, device=self.device))
-            best = 0
-        self._b = cands[best]
-        self._carve(self._b, ("thr", "xh"))
+        lib = self._lib = _lib.load()
+        tries = max(1, min(16, int(max_tries))) if tune else 1
+        handle = ctypes.c_void_p()
+        with _host.on_device(self.device):
+            _lib.check(lib.ac_workspace_create(codec.mdct._plan(self.device), codec.psy._plan(self.device), B, K, C, 1, tries,
+                                               float(span_gib), _host.stream_ptr(self.device), ctypes.byref(handle)))
+        self._handle = handle
+        pool = placement._Pool(handle, self.device, (B, K, C, N), None)
+        # carved in the layout of ac_workspace_buffers: region A = [X | t | x], region B = [thr | xh]; each tensor owns its
+        # extent, and the regions are freed when the workspace AND every tensor are gone
+        self.X = pool.alloc(placement.REGION_SPECTRA, (B, K + 1, N, C))
+        self.t = pool.alloc(placement.REGION_SPECTRA, (B, K + 1, 1, C))
+        self.x = pool.alloc(placement.REGION_SPECTRA, (B, K * N, C))
+        self.thr = pool.alloc(placement.REGION_OTHER, (B, K + 1, N, C))
+        self.xh = pool.alloc(placement.REGION_OTHER, (B, (K + 2) * N, C))
+        if any(v is None for v in (self.X, self.t, self.x, self.thr, self.xh)):
+            raise RuntimeError("internal: workspace regions too small for their tensors")
+        n, chosen, spacer = ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
+        ms = (ctypes.c_float * 16)()
+        a, b, na, nb = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_size_t()
+        lib.ac_workspace_report(handle, ctypes.byref(n), ctypes.byref(chosen), ms, ctypes.byref(spacer))
+        lib.ac_workspace_regions(handle, ctypes.byref(a), ctypes.byref(na), ctypes.byref(b), ctypes.byref(nb))
+        self.report = {"bytes_a": int(na.value), "bytes_b": int(nb.value), "tries": n.value, "tuned": tries > 1,
+                       "encode_ms_by_try": [float(ms[i]) for i in range(n.value)], "chosen_try": chosen.value,
+                       "spacer_GiB": spacer.value}
 
-    def _carve(self, chunk, names):
-        o = 0
-        for k in names:
-            setattr(self, k, chunk[o: o + int(np.prod(self.shapes[k]))].view(self.shapes[k]))
-            o += self._words[k]
-
-
-class _Spacers:
-    """Untouched device allocations straight from the HIP runtime (not torch's caching allocator, so releasing them gives
-    the memory back to the driver without flushing anybody's cache)."""
-
-    def __init__(self, device, budget_gib):
-        self.device, self.budget, self.held_gib, self.ptrs = device, float(budget_gib), 0.0, []
-        try:
-            self.hip = ctypes.CDLL("libamdhip64.so")
-            self.hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
-            self.hip.hipMalloc.restype = ctypes.c_int
-            self.hip.hipFree.argtypes = [ctypes.c_void_p]
-            self.hip.hipFree.restype = ctypes.c_int
-        except OSError:
-            self.hip = None
-
-    def add(self, gib):
-        if self.hip is None or self.held_gib + gib > self.budget:
-            return False
-        free = torch.cuda.mem_get_info(self.device)[0] / _GIB
-        if gib > 0.5 * free:
-            return False
-        p = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
-            if self.hip.hipMalloc(ctypes.byref(p), int(gib * _GIB)) != 0 or not p.value:
-                return False
-        self.ptrs.append(p)
-        self.held_gib += gib
-        return True
-
-    def release(self):
-        with torch.cuda.device(self.device):
-            for p in self.ptrs:
-                self.hip.hipFree(p)
-        self.ptrs = []
+    def close(self):
+        if getattr(self, "_handle", None) is not None:
+            self._lib.ac_workspace_destroy(self._handle)   # (the regions go when the last tensor carved out of them does)
+            self._handle = None
 
     def __del__(self):
         try:
-            if self.ptrs:
-                self.release()
+            self.close()
         except Exception:
             pass

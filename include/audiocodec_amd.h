@@ -24,9 +24,9 @@
  *
  * Performance note (MI355X): the kernels stream their tensors at the device's copy rate, and that rate depends on where
  * the caller's buffers live -- when the two tensors a kernel streams side by side (X and thr for ac_encode_fused, X
- * and x for ac_mdct_inverse) sit in stretches of VRAM of the same class, the kernel runs up to 15 % slower.  The Python
- * package's audiocodec_amd.Workspace finds a good pair of allocations by timing the encode kernel; a C caller can do
- * the same with a few candidate allocations.
+ * and x for ac_mdct_inverse) sit in stretches of VRAM of the same class, the kernel runs up to 15 % slower.
+ * ac_workspace_create (below) hands out buffers placed by timing the encode kernel on a few candidate allocations; the
+ * Python package draws the tensors its encode() / decode() return from such a workspace (audiocodec_amd/placement.py).
  */
 #ifndef AUDIOCODEC_AMD_H
 #define AUDIOCODEC_AMD_H
@@ -272,11 +272,40 @@ AC_API int ac_amplitude_to_db_backward(const float* a, const float* grad_out, fl
 AC_API int ac_add_noise(const float* X, const float* thr, float* out, size_t n, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Buffer placement probe (see the performance note at the top).  Runs ac_encode_fused with each of
- * the n candidate threshold buffers (x, X, t fixed; contents of X, t and the candidates are overwritten), times every
- * candidate with HIP events (median of three launches after one warm-up) and returns the index of the fastest in *best and,
- * when ms is not NULL, the n times in milliseconds.  The one entry point that synchronises (on its own events).
+ * Placed buffers (see the performance note at the top; DESIGN.md "placement").  ac_workspace_create allocates, straight
+ * from the HIP runtime, device buffers for batches of B clips x K blocks x C channels of this (mdct, psy) pair:
+ *   region A = [copies x (X [B,K+1,N,C] | t [B,K+1,1,C]) | x [B,K*N,C]],   region B = [copies x (thr like X | xhat [B,(K+2)*N,C])]
+ * and places region B for the MI355X's HBM: up to max_tries candidate allocations are timed with the fused encode itself
+ * (median of three launches on noise, device warmed first), untouched spacers of 12 GiB (at most span_gib in all) move
+ * each next candidate along the VRAM, the search stops at the first candidate that reaches the two-class rate or once two
+ * candidates differ by the gap between the classes; the fastest stays, every other allocation and every spacer is back
+ * with the driver before the call returns.  The one entry point (with ac_probe_placement) that synchronises.  Memory
+ * held afterwards: exactly the two regions (ac_workspace_regions).  copies > 1 gives double-buffered outputs.
+ * ac_workspace_buffers returns the tensors of copy `copy` (any pointer argument may be NULL); x is filled with
+ * uniform(-1, 1) noise by the probe.  Results of the kernels do not depend on where their buffers live.
  * ---------------------------------------------------------------------------------------- */
+typedef struct ac_workspace ac_workspace;
+AC_API int ac_workspace_create(const ac_mdct_plan* mdct, const ac_psy_plan* psy, int B, int K, int C, int copies, int max_tries,
+                               double span_gib, void* stream, ac_workspace** out);
+AC_API int ac_workspace_buffers(const ac_workspace* ws, int copy, float** x, float** X, float** t, float** thr, float** xhat);
+AC_API int ac_workspace_regions(const ac_workspace* ws, void** a, size_t* bytes_a, void** b, size_t* bytes_b);
+/* tries made, index of the chosen one, encode time of every try in ms (encode_ms: room for 16 floats), spacer memory
+ * held for a moment during the search in GiB */
+AC_API int ac_workspace_report(const ac_workspace* ws, int* tries, int* chosen, float* encode_ms, double* spacer_gib);
+AC_API int ac_workspace_destroy(ac_workspace* ws);
+/* The two regions as a pool: a float32 tensor of `shape` (ndim <= 8, compact row-major) carved out of region 0 (A: spectra)
+ * or 1 (B: thresholds, PCM), returned as a DLManagedTensor* (dlpack.h) whose deleter gives the memory back -- what
+ * torch.from_dlpack / any DLPack consumer turns into a tensor that owns its storage.  A released extent is handed out again
+ * only for work on the stream its last tenant was allocated for (same-stream order is execution order).  NULL when the
+ * region has no room: the caller then allocates elsewhere.  Once used, the fixed tensors of ac_workspace_buffers overlap
+ * the pool's and must not be used; ac_workspace_destroy defers freeing the regions until the last tensor is released.
+ * ac_workspace_live: tensors handed out and not yet released. */
+AC_API void* ac_workspace_alloc_dlpack(ac_workspace* ws, int region, int ndim, const int64_t* shape, void* stream);
+AC_API long ac_workspace_live(ac_workspace* ws);
+
+/* The probe on its own: runs ac_encode_fused with each of the n caller-owned candidate threshold buffers (x, X, t fixed;
+ * contents of X, t and the candidates are overwritten), times every candidate with HIP events (median of three launches
+ * after one warm-up) and returns the index of the fastest in *best and, when ms is not NULL, the n times in milliseconds. */
 AC_API int ac_probe_placement(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t,
                        float* const* thr_candidates, int n_candidates, int B, int K, int C, void* stream, int* best,
                        float* ms);

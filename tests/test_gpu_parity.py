@@ -1542,7 +1542,7 @@ def test_workspace_places_buffers_without_changing_results():
         assert tuple(ws.t.shape) == (B, K + 1, 1, C) and tuple(ws.thr.shape) == tuple(ws.X.shape)
         assert tuple(ws.xh.shape) == (B, (K + 2) * N, C)
         assert all(v.is_contiguous() and v.data_ptr() % (1 << 21) == 0 for v in (ws.x, ws.X, ws.thr, ws.xh))
-        assert ws.report["tuned"] == tune and (not tune or 2 <= ws.report["tries"] <= 3)
+        assert ws.report["tuned"] == tune and 1 <= ws.report["tries"] <= (3 if tune else 1)
         ws.x.copy_(x)
         codec.encode_into(ws.x, ws.X, ws.t, ws.thr)
         codec.decode_into(ws.X, ws.xh)
@@ -1550,6 +1550,94 @@ def test_workspace_places_buffers_without_changing_results():
         assert float((ws.xh[:, N:-N] - x).abs().max()) <= LSB
     with pytest.raises(NotImplementedError):
         audiocodec_amd.Workspace(audiocodec_amd.AudioCodec(48000, N, compute_dtype=torch.float64), B, K, C)
+
+
+def test_library_allocated_results_are_placed_without_changing_them():
+    """AudioCodec.encode / decode allocate what they return (the reference's API shape), so the LIBRARY decides where it
+    lives: the first encode too large for the Infinity Cache builds the device's pool (ac_workspace_create: <= 8 timed
+    candidates, spacers and losers back with the driver), later results are carved out of its two regions
+    (ac_workspace_alloc_dlpack) and give their extent back when they die.  Same values as caller-owned plain tensors, bit
+    for bit; spectra and thresholds in different regions; extents recycled; fallback to torch.empty when the regions are
+    full; AC_NO_PLACEMENT semantics via placement.release."""
+    from audiocodec_amd import placement
+    placement.release()
+    N, B, K, C = 1024, 64, 234, 2                       # X = 245 MB: beyond the cache-resident sizes
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.empty(B, K * N, C, device="cuda").uniform_(-1, 1, generator=g)
+    Xr, tr, thrr = (torch.empty(B, K + 1, N, C, device="cuda"), torch.empty(B, K + 1, 1, C, device="cuda"),
+                    torch.empty(B, K + 1, N, C, device="cuda"))
+    codec.encode_into(x, Xr, tr, thrr)
+    assert placement.report() is None
+    X, t, thr = codec.encode(x)
+    rep = codec.placement_report()
+    assert rep is not None and 1 <= rep["tries"] <= 8 and rep["sized_for"]["batches_n"] == B and rep["live_tensors"] == 2
+    assert rep["bytes_held"] == rep["region_spectra_bytes"] + rep["region_other_bytes"] <= 16 * 2 ** 30
+    assert torch.equal(X, Xr) and torch.equal(t, tr) and torch.equal(thr, thrr)
+    import ctypes
+    a, b, na, nb = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_size_t()
+    _lib.load().ac_workspace_regions(placement.pool(x.device).handle, ctypes.byref(a), ctypes.byref(na), ctypes.byref(b), ctypes.byref(nb))
+    assert a.value <= X.data_ptr() < a.value + na.value and b.value <= thr.data_ptr() < b.value + nb.value
+    xh = codec.decode(X)
+    assert b.value <= xh.data_ptr() < b.value + nb.value and float((xh[:, N:-N] - x).abs().max()) <= LSB
+    # views keep their extent alive; the extent comes back when the last one dies
+    view = thr[:, 1:3]
+    p_thr = thr.data_ptr()
+    del thr
+    assert codec.placement_report()["live_tensors"] == 3
+    keep = view.clone()
+    del view
+    assert codec.placement_report()["live_tensors"] == 2
+    X2, t2, thr2 = codec.encode(x)                       # second generation while the first is alive
+    assert torch.equal(X2, Xr) and torch.equal(thr2, thrr) and torch.equal(thr2[:, 1:3], keep)
+    assert X2.data_ptr() != X.data_ptr() and thr2.data_ptr() == p_thr           # (first fit: the freed extent)
+    X3, t3, thr3 = codec.encode(x)                       # a third generation does not fit: plain allocations, same values
+    assert torch.equal(X3, Xr) and torch.equal(thr3, thrr)
+    assert not (a.value <= X3.data_ptr() < a.value + na.value)
+    # the other entry points of the reference's API draw from the same pool
+    Xt = codec.mdct.transform(x[:8])
+    thrt = codec.psy.global_masking_threshold(Xt, codec.psy.tonality(Xt))
+    assert torch.equal(Xt, Xr[:8]) and torch.equal(thrt, thrr[:8])
+    del X, X2, X3, thr2, thr3, xh, Xt, thrt, t, t2, t3
+    assert codec.placement_report()["live_tensors"] == 0
+    placement.release()
+    assert placement.report() is None
+
+
+def test_workspace_c_abi():
+    """ac_workspace_* through ctypes alone (what a C caller has): placed buffers, fixed tensors of two copies, report."""
+    import ctypes
+    lib = _lib.load()
+    N, B, K, C = 1024, 8, 16, 2
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    dev_ = torch.device("cuda", torch.cuda.current_device())
+    ws = ctypes.c_void_p()
+    _lib.check(lib.ac_workspace_create(codec.mdct._plan(dev_), codec.psy._plan(dev_), B, K, C, 2, 3, 24.0, None, ctypes.byref(ws)))
+    ptrs = [[ctypes.c_void_p() for _ in range(5)] for _ in range(2)]
+    for cpy in range(2):
+        _lib.check(lib.ac_workspace_buffers(ws, cpy, *[ctypes.byref(p_) for p_ in ptrs[cpy]]))
+    assert lib.ac_workspace_buffers(ws, 2, None, None, None, None, None) == _lib.AC_EINVAL
+    assert ptrs[0][0].value == ptrs[1][0].value and ptrs[0][1].value != ptrs[1][1].value      # one x, two X
+    assert all(p_.value % (1 << 21) == 0 for row in ptrs for p_ in row)
+    tries, chosen, spacer = ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
+    ms = (ctypes.c_float * 16)()
+    _lib.check(lib.ac_workspace_report(ws, ctypes.byref(tries), ctypes.byref(chosen), ms, ctypes.byref(spacer)))
+    assert 1 <= tries.value <= 3 and 0 <= chosen.value < tries.value and ms[chosen.value] > 0 and spacer.value <= 24.0
+    # run the codec on raw pointers of copy 1 and compare with plain tensors (the probe left uniform noise in x)
+    x_, X_, t_, thr_, xh_ = ptrs[1]
+    _lib.check(lib.ac_encode_fused(codec.mdct._plan(dev_), codec.psy._plan(dev_), x_, X_, t_, thr_, 0.0, B, K, C, None))
+    _lib.check(lib.ac_mdct_inverse(codec.mdct._plan(dev_), X_, xh_, B, K + 1, C, None))
+    torch.cuda.synchronize()
+    xs = torch.empty(B, K * N, C, device="cuda")
+    import ctypes as ct
+    hip = ct.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(ct.c_void_p(xs.data_ptr()), x_, ct.c_size_t(xs.numel() * 4), 3) == 0
+    assert float(xs.abs().max()) <= 1.0 and float(xs.std()) > 0.5
+    Xp, tp, thrp = codec.encode(xs)
+    Xw = torch.empty_like(Xp)
+    assert hip.hipMemcpy(ct.c_void_p(Xw.data_ptr()), X_, ct.c_size_t(Xw.numel() * 4), 3) == 0
+    assert torch.equal(Xw, Xp)
+    assert lib.ac_workspace_destroy(ws) == 0
 
 
 def _run_bench(*args):
