@@ -1960,11 +1960,12 @@ struct FwdMArgs {
 // LDS of the several-frames-per-wave analysis kernels: [NW wave buffers | table image | masking-model image (PSY)].
 // The table images in global memory carry every entry replicated to the 64 lanes (index r * 64 + lane); the PSY kernels,
 // short of LDS, keep one period of each row only -- TS = max(LB, 8) entries (8: the 64-filter kernels read their input-side
-// tables by lane mod 8) -- and, at two frames per wave, read the pre-twiddles from the (L2-resident) global image.
+// tables by lane mod 8) -- and, at two frames per wave (filters_n = 512, where the masking model's image is largest), read
+// the fold coefficients and the pre-twiddles from the (L2-resident) global image: 53.6 KB per workgroup, three to a CU.
 template <int NFR, bool PSY> constexpr int multi_ts() { return PSY ? ((64 / NFR) > 8 ? (64 / NFR) : 8) : 64; }
 template <int NFR, bool PSY> constexpr bool multi_pre_global() { return PSY && NFR == 2; }
-template <int NFR, bool PSY> constexpr int multi_tab_bytes() {
-  return PSY ? (128 + (multi_pre_global<NFR, PSY>() ? 2 : 3) * 16 * multi_ts<NFR, PSY>()) * 4 : Geo<8>::TAB_LDS;
+template <int NFR, bool PSY> constexpr int multi_tab_bytes() {   // (PRE_GLOBAL: fold coefficients and pre-twiddles both stay in global memory)
+  return PSY ? (128 + (multi_pre_global<NFR, PSY>() ? 1 : 3) * 16 * multi_ts<NFR, PSY>()) * 4 : Geo<8>::TAB_LDS;
 }
 
 // analysis: the lanes of group f transform frame NFR c + f of the wave's signal pair (a group whose frame index is past
@@ -1992,8 +1993,10 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
     for (int i = threadIdx.x; i < 8 * TS; i += NW * 64) {     // one period of every row of POST / COEF / PRE
       const int src = (i / TS) * 64 + (i % TS);
       reinterpret_cast<v2f*>(dst + L_POST)[i] = reinterpret_cast<const v2f*>(a.tab + G::I_POST)[src];
-      reinterpret_cast<v2f*>(dst + L_COEF)[i] = reinterpret_cast<const v2f*>(a.tab + G::I_COEF)[src];
-      if (!PRE_GLOBAL) reinterpret_cast<v2f*>(dst + L_PRE)[i] = reinterpret_cast<const v2f*>(a.tab + G::I_PRE)[src];
+      if (!PRE_GLOBAL) {
+        reinterpret_cast<v2f*>(dst + L_COEF)[i] = reinterpret_cast<const v2f*>(a.tab + G::I_COEF)[src];
+        reinterpret_cast<v2f*>(dst + L_PRE)[i] = reinterpret_cast<const v2f*>(a.tab + G::I_PRE)[src];
+      }
     }
     uint4* pd = reinterpret_cast<uint4*>(lds + NW * WAVE_LDS + TABB);
     for (int i = threadIdx.x; i < a.mp.img_words / 4; i += NW * 64) pd[i] = reinterpret_cast<const uint4*>(a.psy_img)[i];
@@ -2019,6 +2022,8 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
       ++pair;
     }
     const Pair pq = make_pair<CMODE>(pair, C, a.nsig);
+    // (tables read from global memory are fetched per chunk: hoisted out of the loop they would hold 32 registers)
+    const uint32_t glane = PRE_GLOBAL ? in_loop((uint32_t)lane) : (uint32_t)lane;
     const int n = c * NFR + f;
     const bool frame_ok = n < a.F;
     const pcm_t* x0 = static_cast<const pcm_t*>(a.x) + row_off(pq.b0, a.Kin, 0, blk, pq.c0);
@@ -2075,7 +2080,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
         const v4f& gp = pb[fb4 + ((r4 + 2) & 3)];
         const v4f& gc = cb[fb4 + ((r4 + 2) & 3)];
         const v2f xep = v2f{gp.x, gp.y}, xec = v2f{gc.x, gc.y};
-        const v2f ab = reinterpret_cast<const v2f*>(tab + L_COEF)[r * TS + tl];
+        const v2f ab = (PRE_GLOBAL ? reinterpret_cast<const v2f*>(a.tab + G::I_COEF)[r * 64 + glane] : reinterpret_cast<const v2f*>(tab + L_COEF)[r * TS + tl]);
         const v2f carry = ab.y * xep + ab.x * xop;
         v2f cur;
         if constexpr (FOLD4) {   // a fold block that is not a rotation: its own two coefficients for the current block
@@ -2085,7 +2090,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
           cur = (r4 < 2) ? (ab.y * xoc - ab.x * xec) : (ab.x * xec - ab.y * xoc);
         }
         const C2 v = (r4 < 2) ? C2{carry, cur} : C2{cur, carry};
-        z[r] = cmul(v, PRE_GLOBAL ? reinterpret_cast<const v2f*>(a.tab + G::I_PRE)[r * 64 + lane]
+        z[r] = cmul(v, PRE_GLOBAL ? reinterpret_cast<const v2f*>(a.tab + G::I_PRE)[r * 64 + glane]
                                    : reinterpret_cast<const v2f*>(tab + L_PRE)[r * TS + tl]);
       }
     } else {
@@ -2112,7 +2117,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
         const v4f& gp = pb[(r + 4) & 7];
         const v4f& gc = cb[(r + 4) & 7];
         const v2f xep = v2f{gp.x, gp.y}, xec = v2f{gc.x, gc.y};
-        const v2f ab = reinterpret_cast<const v2f*>(tab + L_COEF)[r * TS + tl];
+        const v2f ab = (PRE_GLOBAL ? reinterpret_cast<const v2f*>(a.tab + G::I_COEF)[r * 64 + glane] : reinterpret_cast<const v2f*>(tab + L_COEF)[r * TS + tl]);
         const v2f carry = ab.y * xep + ab.x * xop;
         v2f cur;
         if constexpr (FOLD4) {
@@ -2122,7 +2127,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
           cur = (r < 4) ? (ab.y * xoc - ab.x * xec) : (ab.x * xec - ab.y * xoc);
         }
         const C2 v = (r < 4) ? C2{carry, cur} : C2{cur, carry};
-        z[r] = cmul(v, PRE_GLOBAL ? reinterpret_cast<const v2f*>(a.tab + G::I_PRE)[r * 64 + lane]
+        z[r] = cmul(v, PRE_GLOBAL ? reinterpret_cast<const v2f*>(a.tab + G::I_PRE)[r * 64 + glane]
                                    : reinterpret_cast<const v2f*>(tab + L_PRE)[r * TS + tl]);
       }
     }

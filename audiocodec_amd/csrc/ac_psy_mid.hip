@@ -39,7 +39,7 @@ template <int R, int CMODE, bool WANT_T, bool WANT_THR, int FB>
 __global__ __launch_bounds__(256, ((WANT_THR && (FB > 1 || R >= 8)) ? 3 : 4)) void k_psy_mid(MidArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int N = a.p.N;
-  const int SLOT = 8 * N, WAVE_BYTES = FB * SLOT;
+  const int SLOT = N >= 64 ? 8 * N : 512, WAVE_BYTES = FB * SLOT;   // (a slot also takes the frame's 64 G_j: 512 bytes)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   uint32_t* img = reinterpret_cast<uint32_t*>(smem);
   if (WANT_THR) {
@@ -131,7 +131,7 @@ bool build_mid(const ac_psy_plan* p, std::vector<uint32_t>* out, MidLayout* lay)
   L.off_S = 0;
   L.off_band = L.off_S + 2 * (MF_TAB_BYTES / 4);
   L.off_band = (L.off_band + 3) / 4 * 4;                  // 16-byte aligned rows of four words
-  L.off_wbe = L.off_band + 4 * 64;
+  L.off_wbe = L.off_band + 4 * 64;                        // (16-byte aligned: off_band is, and so is every band's start)
   // a band's weights cover the run of bins from its first to its last non-zero (zeros in between, if any, stay zeros)
   std::vector<int> first(M, 0), count(M, 0), start(M, 0);
   int total = 0;
@@ -146,9 +146,9 @@ bool build_mid(const ac_psy_plan* p, std::vector<uint32_t>* out, MidLayout* lay)
       count[j] = hi - lo + 1;
     }
     start[j] = total;
-    total += count[j];
+    total += (count[j] + 3) / 4 * 4;   // (a band's weights: a multiple of four, zero-padded)
   }
-  if (total > 4 * N) return false;   // (bands that each span most of the spectrum: not a Bark mapping; other tiers)
+  if (total > 4 * N + 4 * M) return false;   // (bands that each span most of the spectrum: not a Bark mapping; other tiers)
   L.off_wi = L.off_wbe + total;
   L.off_wi = (L.off_wi + 3) / 4 * 4;                      // 16-byte reads: the entries of two adjacent bins
   L.words = L.off_wi + 2 * N * L.wi_w;
@@ -196,7 +196,7 @@ bool build_mid(const ac_psy_plan* p, std::vector<uint32_t>* out, MidLayout* lay)
   return true;
 }
 
-size_t mid_lds_bytes(int N, int words, int nw, int fb) { return (size_t)words * 4 + (size_t)nw * fb * 8 * (size_t)N; }
+size_t mid_lds_bytes(int N, int words, int nw, int fb) { return (size_t)words * 4 + (size_t)nw * fb * (N >= 64 ? 8 * (size_t)N : 512); }
 
 template <int R, int CMODE>
 int launch_mid_R(const MidArgs& a, bool want_t, bool want_thr, unsigned grid, int nw, size_t lds, hipStream_t s) {

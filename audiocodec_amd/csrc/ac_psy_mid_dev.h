@@ -122,8 +122,9 @@ __device__ __forceinline__ void spread_tiles(const v2f (&Q)[FB], const char* mf,
 //             rev[m] = gp[128 - m], gp[64 + d] = g[M + d] (0 where |d| >= M: S[i][j] = gp[64 + j - i], psychoacoustic.py:
 //             223-228), hi parts (MF_TAB_BYTES) then lo parts
 //   off_band: per band j: {first entry, count | first bin << 16, quiet, beta}   4 words
-//   off_wbe:  W by band: the weights of the band's bins first bin, first bin + 1, ...  (a band's bins are contiguous: both
-//             loads of a step have addresses that depend on nothing loaded before)
+//   off_wbe:  W by band: the weights of the band's bins first bin, first bin + 1, ..., padded with zeros to a multiple of
+//             four and 16-byte aligned (a band's bins are contiguous: the loads of a step have addresses that depend on
+//             nothing loaded before)
 //   off_wi:   entry-major: [e < wi_w][bin f] {byte offset of G[band] in the wave's G area, weight}  (weight 0 pads)
 struct MidParams {
   int img_words;
@@ -211,21 +212,20 @@ __device__ __forceinline__ void threshold_frames(const v4f (&xq)[FB][R], const v
       P0[fb] = v2f{0.f, 0.f};
       P1[fb] = v2f{0.f, 0.f};
     }
-    const int cnt = (int)(bw.y & 0xffffu);
-    int k = 0;
-#pragma unroll 2
-    for (; k + 1 < cnt; k += 2) {
-      const float w0 = wt[k], w1 = wt[k + 1];
+    // four bins per step (the host pads a band's weights to a multiple of four with zeros, 16-byte aligned; a padded step
+    // re-reads the band's last bin, so nothing outside the frame's intensities is touched): even bins into P0, odd into P1
+    const int cnt = (int)(bw.y & 0xffffu), last = cnt - 1;
+    for (int k = 0; k < cnt; k += 4) {
+      const v4f w4 = *reinterpret_cast<const v4f*>(wt + k);
+      const int k1 = min(k + 1, last), k2 = min(k + 2, last), k3 = min(k + 3, last);
 #pragma unroll
       for (int fb = 0; fb < FB; ++fb) {
-        P0[fb] += reinterpret_cast<const v2f*>(Ib + fb * istride)[k] * w0;
-        P1[fb] += reinterpret_cast<const v2f*>(Ib + fb * istride)[k + 1] * w1;
+        const v2f* I = reinterpret_cast<const v2f*>(Ib + fb * istride);
+        P0[fb] += I[k] * w4.x;
+        P1[fb] += I[k1] * w4.y;
+        P0[fb] += I[k2] * w4.z;
+        P1[fb] += I[k3] * w4.w;
       }
-    }
-    if (k < cnt) {
-      const float w0 = wt[k];
-#pragma unroll
-      for (int fb = 0; fb < FB; ++fb) P0[fb] += reinterpret_cast<const v2f*>(Ib + fb * istride)[k] * w0;
     }
 #pragma unroll
     for (int fb = 0; fb < FB; ++fb) Q[fb] = exp2v(a.alpha * log2v(maxv(P0[fb] + P1[fb], kEps)));   // max(eps, P)^alpha  (:206)

@@ -32,7 +32,7 @@ import torch
 from . import _host, _lib
 
 REGION_SPECTRA, REGION_OTHER = 0, 1
-MIN_BYTES = 192 << 20            # spectra smaller than this stay in the Infinity Cache: placement does not matter for them
+MIN_BYTES = 128 << 20            # X and thr smaller than this fit the 256 MiB Infinity Cache together: placement does not matter for them
 _lock = threading.Lock()
 _pools = {}                      # device index -> _Pool, or False when creation failed / was declined
 

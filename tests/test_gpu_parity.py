@@ -1561,7 +1561,7 @@ def test_library_allocated_results_are_placed_without_changing_them():
     full; AC_NO_PLACEMENT semantics via placement.release."""
     from audiocodec_amd import placement
     placement.release()
-    N, B, K, C = 1024, 64, 234, 2                       # X = 245 MB: beyond the cache-resident sizes
+    N, B, K, C = 1024, 80, 234, 2                       # X = 154 MB: X and thr together exceed the 256 MiB Infinity Cache
     codec = audiocodec_amd.AudioCodec(48000, N)
     g = torch.Generator(device="cuda").manual_seed(9)
     x = torch.empty(B, K * N, C, device="cuda").uniform_(-1, 1, generator=g)
