@@ -2782,8 +2782,8 @@ static int launch_fwd_multi(const ac_mdct_plan* p, const ac_psy_plan* psy, const
   a.ntasks = npairs * a.cpp;
   // chunks per wave: the table copy (and the masking model's image) is paid once per workgroup
   static const int tper = [] { const char* e = getenv("AC_FWD_T"); return e ? atoi(e) : 4; }();
-  static const int tper_psy = [] { const char* e = getenv("AC_FWD_T_PSY"); return e ? atoi(e) : 8; }();
-  int T = psy ? (tper_psy > 0 ? tper_psy : 8) : (tper > 0 ? tper : 4);
+  static const int tper_psy = [] { const char* e = getenv("AC_FWD_T_PSY"); return e ? atoi(e) : 4; }();   // (2 ... 8 measure alike)
+  int T = psy ? (tper_psy > 0 ? tper_psy : 4) : (tper > 0 ? tper : 4);
   while (T > 1 && a.ntasks < (long long)AC_WAVES * T * p->cus * 2) T >>= 1;
   a.T = T;
   unsigned grid;
