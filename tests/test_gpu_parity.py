@@ -1568,6 +1568,8 @@ def test_library_allocated_results_are_placed_without_changing_them():
     Xr, tr, thrr = (torch.empty(B, K + 1, N, C, device="cuda"), torch.empty(B, K + 1, 1, C, device="cuda"),
                     torch.empty(B, K + 1, N, C, device="cuda"))
     codec.encode_into(x, Xr, tr, thrr)
+    Xt_ref = codec.mdct.transform(x[:8])                 # (no pool yet: plain allocations)
+    thrt_ref = codec.psy.global_masking_threshold(Xt_ref, codec.psy.tonality(Xt_ref))
     assert placement.report() is None
     X, t, thr = codec.encode(x)
     rep = codec.placement_report()
@@ -1602,7 +1604,8 @@ def test_library_allocated_results_are_placed_without_changing_them():
     # the other entry points of the reference's API draw from the same pool
     Xt = codec.mdct.transform(x[:8])
     thrt = codec.psy.global_masking_threshold(Xt, codec.psy.tonality(Xt))
-    assert torch.equal(Xt, Xr[:8]) and torch.equal(thrt, thrr[:8])
+    assert torch.equal(Xt, Xt_ref) and torch.equal(thrt, thrt_ref)
+    assert a.value <= Xt.data_ptr() < a.value + na.value and b.value <= thrt.data_ptr() < b.value + nb.value
     del X, X2, X3, thr2, thr3, xh, Xt, thrt, t, t2
     assert codec.placement_report()["live_tensors"] == 0
     placement.release()
