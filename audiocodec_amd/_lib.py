@@ -35,6 +35,7 @@ PROTOTYPES = {
                                        POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     "ac_mdct_plan_create_pre": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
     "ac_psy_plan_create_pre": (c_int, [c_int, c_int, c_double, c_double, c_int, c_int, c_int, POINTER(c_void_p)]),
+    "ac_mdct_plan_adjoint": (c_int, [c_void_p, POINTER(c_void_p)]),
     "ac_mdct_plan_create": (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
     "ac_mdct_plan_destroy": (c_int, [c_void_p]),
     "ac_psy_plan_create": (c_int, [c_int, c_int, c_double, c_double, c_int, POINTER(c_void_p)]),
@@ -61,6 +62,8 @@ PROTOTYPES = {
                                    c_int, c_void_p, POINTER(c_int), POINTER(c_float)]),
     "ac_encode_fused_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_int,
                                       c_int, c_int, c_void_p]),
+    "ac_stream_encode_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_int, c_void_p]),
+    "ac_stream_inverse_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ac_amplitude_to_db_typed": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "ac_add_noise_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_uint64, c_int, c_void_p]),
     "ac_mdct_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -215,9 +215,12 @@ class StreamingMDCT:
     """
 
     def __init__(self, mdct: MDCTransformer, batches_n, channels_n, device=None, psy: PsychoacousticModel = None):
-        _host.require_float32(mdct.compute_dtype, "streaming overlap-add")
+        if mdct.compute_dtype not in (torch.float32, torch.bfloat16):
+            raise NotImplementedError("streaming overlap-add serves compute_dtype float32 (every size) and bfloat16 (the "
+                                      "wave-level kernels: filters_n 1024 / 2048, mono / stereo); got %s" % mdct.compute_dtype)
         if psy is not None:
-            _host.require_float32(psy.compute_dtype, "streaming masking model")
+            if psy.compute_dtype != mdct.compute_dtype:
+                raise ValueError("psy.compute_dtype (%s) != mdct.compute_dtype (%s)" % (psy.compute_dtype, mdct.compute_dtype))
             if psy.filter_bands_n != mdct.filters_n:
                 raise ValueError("psy.filter_bands_n (%d) != mdct.filters_n (%d)" % (psy.filter_bands_n, mdct.filters_n))
         self.mdct, self.psy = mdct, psy
@@ -280,7 +283,8 @@ class StreamingMDCT:
         k = S // N
         X = self._out(out, "out", (B, k, N, C), x)
         with _host.on_device(x.device):
-            _lib.check(self._lib.ac_stream_forward(self._handle, _host.ptr(x), _host.ptr(X), k, self._stream(stream)))
+            _lib.check(self._lib.ac_stream_encode_typed(self._handle, None, _host.ptr(x), _host.ptr(X), None, None, 0.0,
+                                                        self.mdct._dtype_id, k, self._stream(stream)))
         return X
 
     def encode_chunk(self, x_chunk, drown=0.0, out=None, stream=None):
@@ -300,8 +304,9 @@ class StreamingMDCT:
         t = self._out(o[1], "out[1]", (B, k, 1, C), x)
         thr = self._out(o[2], "out[2]", (B, k, N, C), x)
         with _host.on_device(x.device):
-            _lib.check(self._lib.ac_stream_encode(self._handle, self.psy._plan(x.device), _host.ptr(x), _host.ptr(X),
-                                                  _host.ptr(t), _host.ptr(thr), float(drown), k, self._stream(stream)))
+            _lib.check(self._lib.ac_stream_encode_typed(self._handle, self.psy._plan(x.device), _host.ptr(x), _host.ptr(X),
+                                                        _host.ptr(t), _host.ptr(thr), float(drown), self.mdct._dtype_id, k,
+                                                        self._stream(stream)))
         return X, t, thr
 
     def run(self, x, blocks_per_chunk, masking=True, synthesis=True, drown=0.0, graph=False):
@@ -316,6 +321,7 @@ class StreamingMDCT:
         addresses, shapes and arguments) are seen, and replayed from then on -- the gaps between the dependent launches
         go (one stereo clip in chunks of 256 blocks: 7.9 us per chunk against 11.9).  A replay reads the CURRENT contents
         of the same input buffers and overwrites the output tensors of the first call, which are returned again."""
+        _host.require_float32(self.mdct.compute_dtype, "StreamingMDCT.run (use the chunk calls for bfloat16 streams)")
         if graph:
             return self._run_graph(x, blocks_per_chunk, masking, synthesis, drown)
         k, N = int(blocks_per_chunk), self.mdct.filters_n
@@ -425,5 +431,6 @@ class StreamingMDCT:
                                                                          tuple(X.shape)))
         x = self._out(out, "out", (B, k * N, C), X)
         with _host.on_device(X.device):
-            _lib.check(self._lib.ac_stream_inverse(self._handle, _host.ptr(X), _host.ptr(x), k, self._stream(stream)))
+            _lib.check(self._lib.ac_stream_inverse_typed(self._handle, _host.ptr(X), _host.ptr(x), self.mdct._dtype_id, k,
+                                                         self._stream(stream)))
         return x

@@ -173,13 +173,7 @@ int ac_mdct_plan_create(int N, int window, int device, ac_mdct_plan** out) {
   return ac_mdct_plan_create_pre(N, window, AC_F64, device, out);
 }
 
-int ac_mdct_plan_create_pre(int N, int window, int precompute, int device, ac_mdct_plan** out) {
-  AC_REQUIRE(out != nullptr, "out is NULL");
-  *out = nullptr;
-  AC_REQUIRE_PRE(precompute);
-  AC_REQUIRE(N >= 2 && (N % 2) == 0, "number of filters used in mdct transformation needs to be even (got %d)", N);
-  AC_REQUIRE(N <= 8192, "filters_n = %d not supported (max 8192)", N);
-  AC_REQUIRE(valid_window(window), "unknown window id %d", window);
+static int mdct_plan_build(int N, int window, int precompute, const FoldCoef& c, int adjoint, int device, ac_mdct_plan** out) {
   int st = check_device(device);
   if (st) return st;
   DeviceGuard guard(device);
@@ -192,10 +186,10 @@ int ac_mdct_plan_create_pre(int N, int window, int precompute, int device, ac_md
   p->window = window;
   p->device = device;
   p->pre = precompute;
+  p->adjoint = adjoint;
+  p->coef = c;
   if (hipDeviceGetAttribute(&p->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || p->cus <= 0)
     p->cus = 256;
-  FoldCoef c;
-  fold_coefficients(N, window, c, precompute);
   const int h = N / 2;
   std::vector<float> coef(8 * (size_t)h);
   const std::vector<double>* v[8] = {&c.a1, &c.a2, &c.a3, &c.a4, &c.s1, &c.s2, &c.s3, &c.s4};
@@ -211,7 +205,7 @@ int ac_mdct_plan_create_pre(int N, int window, int precompute, int device, ac_md
   if (!st) st = upload(ctab, &p->d_ctab);
   if (!st) st = upload(coef64, &p->d_coef64);
   if (!st) st = upload(ctab64, &p->d_ctab64);
-  if (!st && fast_mdct_supported(N, window, precompute)) {
+  if (!st && fast_mdct_supported(N, c)) {
     st = fast_mdct_plan_init(p);
     if (!st) p->fast = 1;
   }
@@ -221,6 +215,42 @@ int ac_mdct_plan_create_pre(int N, int window, int precompute, int device, ac_md
   }
   *out = p;
   return AC_OK;
+}
+
+int ac_mdct_plan_create_pre(int N, int window, int precompute, int device, ac_mdct_plan** out) {
+  AC_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  AC_REQUIRE_PRE(precompute);
+  AC_REQUIRE(N >= 2 && (N % 2) == 0, "number of filters used in mdct transformation needs to be even (got %d)", N);
+  AC_REQUIRE(N <= 8192, "filters_n = %d not supported (max 8192)", N);
+  AC_REQUIRE(valid_window(window), "unknown window id %d", window);
+  FoldCoef c;
+  fold_coefficients(N, window, c, precompute);
+  return mdct_plan_build(N, window, precompute, c, 0, device, out);
+}
+
+// The transposed filter bank of `plan` as a plan of its own: with T = the analysis bank (x -> X) and S = the synthesis bank
+// (X -> x) of `plan`,  ac_mdct_inverse(adjoint, g)[:, N:-N] = 4 N T^T g   and   ac_mdct_forward(adjoint, g)[:, 1:-1] = S^T g / (4 N).
+// The DCT-IV is symmetric, so only the O(N) fold transposes: block m of T^T g takes the second half of frame m through
+// (a1, a2) and the first half of frame m + 1 through (a3, a4) -- the synthesis form with s1' = reverse(a3), s2' = a1,
+// s3' = reverse(a4), s4' = a2; likewise a1' = s2, a2' = s4, a3' = reverse(s1), a4' = reverse(s3).  For Princen-Bradley
+// windows computed in float64 the adjoint equals the plan itself (F^-1 = F^T); for the rectangular window
+// (mdctransformer.py:209-229) and float32-precomputed ones it does not, and the backward passes need it.
+int ac_mdct_plan_adjoint(const ac_mdct_plan* plan, ac_mdct_plan** out) {
+  AC_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  AC_REQUIRE(plan != nullptr, "plan is NULL");
+  const FoldCoef& c = plan->coef;
+  FoldCoef t;
+  t.a1 = c.s2;
+  t.a2 = c.s4;
+  t.a3.assign(c.s1.rbegin(), c.s1.rend());
+  t.a4.assign(c.s3.rbegin(), c.s3.rend());
+  t.s1.assign(c.a3.rbegin(), c.a3.rend());
+  t.s2 = c.a1;
+  t.s3.assign(c.a4.rbegin(), c.a4.rend());
+  t.s4 = c.a2;
+  return mdct_plan_build(plan->N, plan->window, plan->pre, t, plan->adjoint ? 0 : 1, plan->device, out);
 }
 
 int ac_mdct_plan_destroy(ac_mdct_plan* p) {
@@ -988,6 +1018,68 @@ int ac_encode_fused_typed(const ac_mdct_plan* mdct, const ac_psy_plan* psy, cons
   if (!st) st = ac_tonality_typed(psy, X, t, dtype, B, K + 1, C, stream);
   if (!st) st = ac_mask_threshold_typed(psy, X, t, drown, thr, dtype, B, K + 1, C, stream);
   return st;
+}
+
+// ---- streaming on bfloat16 tensors: the wave-level kernels (filters_n 1024 / 2048, mono / stereo) with the conversion in
+// their loads and stores; the state stays float32 (a bfloat16 block is exact in it, the aliased half is kept unrounded),
+// so chunked results equal the one-shot *_typed calls bit for bit
+static int stream_typed_check(const ac_stream* s, int dtype, int k) {
+  AC_REQUIRE(s != nullptr, "stream is NULL");
+  AC_REQUIRE_DTYPE(dtype);
+  AC_REQUIRE(k >= 0, "negative chunk length %d", k);
+  if (dtype == AC_F64 || !(s->plan->fast && fast_mdct_frames_per_wave(s->N) == 1 && s->C <= 2 && !g_force_generic)) {
+    set_error("streaming on %s tensors is served by the wave-level kernels only (filters_n 1024 / 2048, mono / stereo, "
+              "bfloat16); float32 streams take every size", dtype == AC_F64 ? "float64" : "bfloat16");
+    return AC_EUNSUPPORTED;
+  }
+  return AC_OK;
+}
+
+int ac_stream_encode_typed(ac_stream* s, const ac_psy_plan* psy, const void* x_chunk, void* X, void* t, void* thr, double drown,
+                           int dtype, int k, void* stream) {
+  AC_REQUIRE_DTYPE(dtype);
+  if (dtype == AC_F32) {
+    if (psy) return ac_stream_encode(s, psy, static_cast<const float*>(x_chunk), static_cast<float*>(X), static_cast<float*>(t),
+                                     static_cast<float*>(thr), (float)drown, k, stream);
+    return ac_stream_forward(s, static_cast<const float*>(x_chunk), static_cast<float*>(X), k, stream);
+  }
+  int st = stream_typed_check(s, dtype, k);
+  if (st) return st;
+  if (k == 0) return AC_OK;
+  AC_REQUIRE(x_chunk != nullptr && X != nullptr, "NULL tensor pointer");
+  AC_REQUIRE_ALIGNED(x_chunk, X, thr);
+  const ac_mdct_plan* p = s->plan;
+  if (psy) {
+    AC_REQUIRE(t != nullptr && thr != nullptr, "NULL tensor pointer");
+    AC_REQUIRE(p->N == psy->N && p->device == psy->device, "plans do not belong together");
+    AC_REQUIRE(psy->fast, "internal: the masking model of this size has no bfloat16 wave-level kernels");
+  }
+  DeviceGuard guard(s->device);
+  hipStream_t hs = (hipStream_t)stream;
+  const bool fused = psy && !(p->N == 2048 && s->C == 1);   // (as ac_encode_fused_typed)
+  st = launch_fwd_fast(p, fused ? psy : nullptr, x_chunk, 2, static_cast<float*>(X), fused ? static_cast<float*>(t) : nullptr,
+                       fused ? static_cast<float*>(thr) : nullptr, (float)drown, s->d_prev_block, s->B, k, k, s->C, hs, s->d_prev_tmp);
+  if (st) return st;
+  std::swap(s->d_prev_block, s->d_prev_tmp);
+  if (psy && !fused)
+    st = launch_psy_fast(psy, static_cast<const float*>(X), nullptr, static_cast<float*>(t), static_cast<float*>(thr), (float)drown,
+                         s->B, k, s->C, hs, 2);
+  return st;
+}
+
+int ac_stream_inverse_typed(ac_stream* s, const void* X_chunk, void* x, int dtype, int k, void* stream) {
+  AC_REQUIRE_DTYPE(dtype);
+  if (dtype == AC_F32) return ac_stream_inverse(s, static_cast<const float*>(X_chunk), static_cast<float*>(x), k, stream);
+  int st = stream_typed_check(s, dtype, k);
+  if (st) return st;
+  if (k == 0) return AC_OK;
+  AC_REQUIRE(X_chunk != nullptr && x != nullptr, "NULL tensor pointer");
+  AC_REQUIRE_ALIGNED(X_chunk, x);
+  DeviceGuard guard(s->device);
+  st = launch_inv_fast(s->plan, static_cast<const float*>(X_chunk), x, 2, s->d_tail, s->d_tail_tmp, s->B, k, k, s->C, (hipStream_t)stream);
+  if (st) return st;
+  std::swap(s->d_tail, s->d_tail_tmp);
+  return AC_OK;
 }
 
 int ac_amplitude_to_db_typed(const void* a, void* out, size_t n, int norm, int dtype, void* stream) {

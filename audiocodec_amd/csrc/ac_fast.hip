@@ -950,6 +950,8 @@ __device__ __forceinline__ void fwd_fast_body(const FwdArgs& a, char* lds, const
   using pcm_t = typename std::conditional<IOF != 0, int16_t, float>::type;
   const pcm_t* __restrict__ xin = static_cast<const pcm_t*>(a.x);
   const pcm_t* __restrict__ xstate = IOF != 0 ? nullptr : reinterpret_cast<const pcm_t*>(a.prev_block);
+  // bfloat16 tensors (IOF 2): the streaming state stays float32 (a bfloat16 block is exact in it)
+  const float* __restrict__ fstate = IOF == 2 ? a.prev_block : nullptr;
 
   // loads block fn (WHICH 0) or block fn-1 (WHICH 1) of frame (pr, fn) in natural order.  A missing block (before the
   // first / after the last) is loaded from a neighbouring, valid address and zeroed when it is consumed (returns false),
@@ -964,6 +966,12 @@ __device__ __forceinline__ void fwd_fast_body(const FwdArgs& a, char* lds, const
       s0 = xin + row_off(q.b0, a.Kin, blkidx, blk, q.c0);
       s1 = xin + row_off(q.b1, a.Kin, blkidx, blk, q.c1);
     } else {
+      if constexpr (IOF == 2) {
+        if (fn < 1 && fstate) {   // block -1 = the stored float32 state
+          load_row<CMODE, false, R>(fstate + row_off(q.b0, 1, 0, blk, q.c0), fstate + row_off(q.b1, 1, 0, blk, q.c1), C, q.has1, lane, dst);
+          return true;
+        }
+      }
       ok = (fn >= 1) || xstate;
       if (fn >= 1 || !xstate) {
         const int blkidx = fn >= 1 ? fn - 1 : 0;
@@ -1001,7 +1009,7 @@ __device__ __forceinline__ void fwd_fast_body(const FwdArgs& a, char* lds, const
       const bool prv_ok = issue_loads(kPrv, pair, n, pb);
       if (!cur_ok) zero_row(cb);   // edge frames only (wave-uniform)
       if (!prv_ok) zero_row(pb);
-      if constexpr (IOF == 0) {
+      if constexpr (IOF != 1) {
         if (a.state_out && n == a.Kin - 1)   // streaming: the chunk's last block is the next chunk's block -1
           store_row<CMODE, R>(a.state_out + row_off(pq.b0, 1, 0, blk, pq.c0), a.state_out + row_off(pq.b1, 1, 0, blk, pq.c1),
                               C, pq.has1, lane, cb);
@@ -1070,7 +1078,7 @@ __device__ __forceinline__ void fwd_fast_body(const FwdArgs& a, char* lds, const
       v4f cb[R];
       const bool cur_ok = issue_loads(kCur, pair, n, cb);
       if (!cur_ok) zero_row(cb);
-      if constexpr (IOF == 0) {
+      if constexpr (IOF != 1) {
         if (a.state_out && n == a.Kin - 1)
           store_row<CMODE, R>(a.state_out + row_off(pq.b0, 1, 0, blk, pq.c0), a.state_out + row_off(pq.b1, 1, 0, blk, pq.c1),
                               C, pq.has1, lane, cb);
@@ -2405,12 +2413,10 @@ PsyParams psy_params(const ac_psy_plan* p, float drown) {
 // host side
 // ------------------------------------------------------------------------------------------------------
 template <int R>
-static bool build_mdct_fast_R(int N, int window, int pre, std::vector<float>* out) {
+static bool build_mdct_fast_R(int N, const FoldCoef& c, std::vector<float>* out) {
   using G = Geo<R>;
   if (N != G::FN) return false;
   const int h = N / 2;
-  FoldCoef c;
-  fold_coefficients(N, window, c, pre);
   std::vector<float> t(2 * G::I_TOTAL, 0.f);
   float* tf = t.data();                 // analysis image
   float* ti = t.data() + G::I_TOTAL;    // synthesis image
@@ -2469,13 +2475,11 @@ static bool build_mdct_fast_R(int N, int window, int pre, std::vector<float>* ou
 // *fold4 (may be null): set when some fold block is not a rotation (float32-precomputed constants, mdctransformer.py:218-221
 // in float32; the rectangular window, :209-211): the kernels then take the FOLD4 form, which reads the block's other two
 // coefficients from I_COEF2.  A caller that passes no fold4 gets false for such tables.
-static bool build_mdct_multi(int N, int window, int pre, std::vector<float>* out, bool* fold4) {
+static bool build_mdct_multi(int N, const FoldCoef& c, std::vector<float>* out, bool* fold4) {
   using G = Geo<8>;
   if (N != 512 && N != 256 && N != 128 && N != 64) return false;
   const int LB = N / 16, Q2 = LB >= 8 ? LB / 8 : 1, h = N / 2, FH = 8 * LB;
   const bool two_halves = N == 64;   // input side on 8 lanes x 4 registers (see load_half), output side on LB = 4 lanes
-  FoldCoef c;
-  fold_coefficients(N, window, c, pre);
   bool general = false;
   std::vector<float> t(2 * G::I_TOTAL, 0.f);
   float* tf = t.data();
@@ -2534,11 +2538,11 @@ static bool build_mdct_multi(int N, int window, int pre, std::vector<float>* out
 // Builds the two table images; false when the size is not served (filters_n 1024 and 2048 are) or the window's fold
 // blocks are not rotations (the rectangular "window", mdctransformer.py:209-211), which the two-coefficient fold
 // cannot express.
-static bool build_mdct_fast(int N, int window, int pre, std::vector<float>* out, bool* fold4) {
+static bool build_mdct_fast(int N, const FoldCoef& c, std::vector<float>* out, bool* fold4) {
   if (fold4) *fold4 = false;
-  if (N == Geo<8>::FN) return build_mdct_fast_R<8>(N, window, pre, out);
-  if (N == Geo<16>::FN) return build_mdct_fast_R<16>(N, window, pre, out);
-  if (N == 512 || N == 256 || N == 128 || N == 64) return build_mdct_multi(N, window, pre, out, fold4);
+  if (N == Geo<8>::FN) return build_mdct_fast_R<8>(N, c, out);
+  if (N == Geo<16>::FN) return build_mdct_fast_R<16>(N, c, out);
+  if (N == 512 || N == 256 || N == 128 || N == 64) return build_mdct_multi(N, c, out, fold4);
   return false;
 }
 
@@ -2558,15 +2562,15 @@ bool fast_multi_fuses(const ac_mdct_plan* p, const ac_psy_plan* psy, int C, int 
          (size_t)AC_WAVES * WAVE_LDS + 12800 + (size_t)psy->mid_words * 4 <= 160 * 1024;
 }
 
-bool fast_mdct_supported(int N, int window, int pre) {
+bool fast_mdct_supported(int N, const FoldCoef& c) {
   bool fold4;
-  return build_mdct_fast(N, window, pre, nullptr, &fold4);
+  return build_mdct_fast(N, c, nullptr, &fold4);
 }
 
 int fast_mdct_plan_init(ac_mdct_plan* p) {
   std::vector<float> t;
   bool fold4 = false;
-  if (!build_mdct_fast(p->N, p->window, p->pre, &t, &fold4)) {
+  if (!build_mdct_fast(p->N, p->coef, &t, &fold4)) {
     set_error("internal: wave-level kernels not supported for this configuration");
     return AC_EUNSUPPORTED;
   }

@@ -103,6 +103,8 @@ struct ac_mdct_plan {
   int fast = 0;                // 1: wave-level FFT kernels available for this N
   int pre = AC_F64;            // arithmetic type the constants were computed in (the reference's precompute_dtype)
   int fold4 = 0;               // 1: the wave-level kernels run their FOLD4 form (fold blocks that are not rotations)
+  int adjoint = 0;             // 1: a plan made by ac_mdct_plan_adjoint (the transposed filter bank of another plan)
+  ac::FoldCoef coef;           // the plan's fold coefficients (host copy)
   float* d_coef = nullptr;     // [8][N/2]  a1 a2 a3 a4 s1 s2 s3 s4
   float* d_ctab = nullptr;     // [8N]      cos(pi i / (4N)), generic kernels
   double* d_coef64 = nullptr;  // the same two tables in float64 (AC_F64 entry points)
@@ -169,7 +171,7 @@ int launch_threshold_generic(const ac_psy_plan* p, const float* X, const float* 
                              int F, int C, hipStream_t s);
 
 // wave-level FFT kernels (ac_fast.hip)
-bool fast_mdct_supported(int N, int window, int pre);
+bool fast_mdct_supported(int N, const FoldCoef& c);
 // filters_n 512 / 256 run several frames per wave (2 / 4); those kernels serve float32 mono / stereo tensors with at least
 // one block (streaming state included) -- everything else at these sizes takes the LDS-FFT tier
 int fast_mdct_frames_per_wave(int N);

@@ -18,9 +18,11 @@ from . import _host, _lib, placement
 
 
 class _TransformFn(torch.autograd.Function):
-    """Differentiable ``transform``.  The analysis bank T is linear; for Princen-Bradley windows the synthesis bank is
-    its scaled transpose (F^-1 = F^T and the DCT-IV is orthogonal), so
-    ``T^T g = inverse_transform(g)[:, N:-N] / (4 N)`` -- the backward pass is one launch of the synthesis kernel."""
+    """Differentiable ``transform`` (the reference is differentiated by TensorFlow when it sits in a training graph).  The
+    analysis bank T is linear and the DCT-IV symmetric, so T^T is the synthesis kernel run on the TRANSPOSED fold
+    coefficients (``ac_mdct_plan_adjoint``): ``T^T g = inverse_transform_adjoint(g)[:, N:-N] / (4 N)``, one launch.  For
+    Princen-Bradley windows computed in float64 the adjoint plan equals the plan (F^-1 = F^T); for the rectangular window
+    (``mdctransformer.py:209-229``: 2x2 blocks [[1, 1], [1, 0]]) and float32-precomputed constants it does not."""
 
     @staticmethod
     def forward(ctx, x, mdct):
@@ -30,14 +32,13 @@ class _TransformFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gX):
         m = ctx.mdct
-        m._require_adjoint()
         N = m.filters_n
-        gx = m._inverse(gX.contiguous())[:, N:-N] / (4.0 * N)
+        gx = m._inverse(gX.contiguous(), adjoint=True)[:, N:-N] / (4.0 * N)
         return gx, None
 
 
 class _InverseFn(torch.autograd.Function):
-    """Differentiable ``inverse_transform``: ``S^T g = 4 N * transform(g)[:, 1:-1]`` (see ``_TransformFn``)."""
+    """Differentiable ``inverse_transform``: ``S^T g = 4 N * transform_adjoint(g)[:, 1:-1]`` (see ``_TransformFn``)."""
 
     @staticmethod
     def forward(ctx, X, mdct):
@@ -47,8 +48,7 @@ class _InverseFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gx):
         m = ctx.mdct
-        m._require_adjoint()
-        gX = m._transform(gx.contiguous())[:, 1:-1] * (4.0 * m.filters_n)
+        gX = m._transform(gx.contiguous(), adjoint=True)[:, 1:-1] * (4.0 * m.filters_n)
         return gX, None
 
 
@@ -82,6 +82,10 @@ class MDCTransformer:
         n, w, pre, lib = self.filters_n, self._window, self._pre_id, self._lib
         self._plans = _host.PlanCache(self, lambda dev, out: lib.ac_mdct_plan_create_pre(n, w, pre, dev, out),
                                       lib.ac_mdct_plan_destroy)
+        # the transposed bank, for the backward passes (built on first use)
+        plans = self._plans
+        self._adjoint_plans = _host.PlanCache(
+            self, lambda dev, out: lib.ac_mdct_plan_adjoint(plans.get(torch.device("cuda", dev)), out), lib.ac_mdct_plan_destroy)
 
     # ---- dense polyphase matrices, for attribute parity only (mdctransformer.py:58-59) -------------
     def _dense(self):
@@ -131,15 +135,7 @@ class MDCTransformer:
             return _TransformFn.apply(x, self)
         return self._transform(x)
 
-    def _require_adjoint(self):
-        if self._pre_id != _host.DTYPE_IDS[torch.float64]:
-            raise NotImplementedError("backward needs float64-precomputed constants: with float32 ones the synthesis bank "
-                                      "is the transpose of the analysis bank only to float32 rounding")
-        if self._window == _lib.WINDOW_RECT:
-            raise NotImplementedError("backward needs a Princen-Bradley window ('vorbis' or 'sine'): the rectangular "
-                                      "window's synthesis bank is not the transpose of its analysis bank")
-
-    def _transform(self, x):
+    def _transform(self, x, adjoint=False):
         x = _host.check_device_tensor(x, "x", self.compute_dtype, 3)
         B, S, C = x.shape
         N = self.filters_n
@@ -148,7 +144,7 @@ class MDCTransformer:
         K = S // N
         X = placement.empty(placement.REGION_SPECTRA, (B, K + 1, N, C), x.dtype, x.device)   # (see placement.py)
         with _host.on_device(x.device):
-            _lib.check(self._lib.ac_mdct_forward_typed(self._plans.get(x.device), _host.ptr(x), _host.ptr(X),
+            _lib.check(self._lib.ac_mdct_forward_typed((self._adjoint_plans if adjoint else self._plans).get(x.device), _host.ptr(x), _host.ptr(X),
                                                        self._dtype_id, B, K, C, _host.stream_ptr(x.device)))
         return X
 
@@ -164,14 +160,14 @@ class MDCTransformer:
             return _InverseFn.apply(mdct_amplitudes, self)
         return self._inverse(mdct_amplitudes)
 
-    def _inverse(self, mdct_amplitudes):
+    def _inverse(self, mdct_amplitudes, adjoint=False):
         X = _host.check_device_tensor(mdct_amplitudes, "mdct_amplitudes", self.compute_dtype, 4)
         B, Kp, N, C = X.shape
         if N != self.filters_n:
             raise ValueError("axis 2 of mdct_amplitudes (%d) != filters_n (%d)" % (N, self.filters_n))
         x = placement.empty(placement.REGION_OTHER, (B, (Kp + 1) * N, C), X.dtype, X.device)
         with _host.on_device(X.device):
-            _lib.check(self._lib.ac_mdct_inverse_typed(self._plans.get(X.device), _host.ptr(X), _host.ptr(x),
+            _lib.check(self._lib.ac_mdct_inverse_typed((self._adjoint_plans if adjoint else self._plans).get(X.device), _host.ptr(X), _host.ptr(x),
                                                        self._dtype_id, B, Kp, C, _host.stream_ptr(X.device)))
         return x
 

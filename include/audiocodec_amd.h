@@ -124,6 +124,13 @@ AC_API int ac_psy_plan_destroy(ac_psy_plan* plan);
  * float32), the LDS-FFT / O(N^2) tiers elsewhere.  ac_psy_plan_create_pre: spreading = AC_SPREAD_* or -1 for the default
  * of ac_psy_plan_create. */
 AC_API int ac_mdct_plan_create_pre(int N, int window, int precompute, int device, ac_mdct_plan** out);
+/* The transposed filter bank of `plan` as a plan of its own (same size, device, kernels): with T the analysis bank and S the
+ * synthesis bank of `plan`, ac_mdct_inverse(adjoint, g)[:, N:-N] = 4 N T^T g and ac_mdct_forward(adjoint, g)[:, 1:-1] =
+ * S^T g / (4 N) -- what the backward passes of transform / inverse_transform need (the reference is differentiated by
+ * TensorFlow, mdctransformer.py:62-153).  The DCT-IV is symmetric, so only the O(N) fold transposes.  For Princen-Bradley
+ * windows computed in float64 the adjoint equals the plan itself; for the rectangular window (mdctransformer.py:209-229)
+ * and float32-precomputed constants it does not. */
+AC_API int ac_mdct_plan_adjoint(const ac_mdct_plan* plan, ac_mdct_plan** out);
 AC_API int ac_psy_plan_create_pre(int N, int M, double sample_rate, double alpha, int device, int spreading, int precompute,
                                   ac_psy_plan** out);
 
@@ -322,7 +329,9 @@ AC_API int ac_probe_placement(const ac_mdct_plan* mdct, const ac_psy_plan* psy, 
  *            X and the tonality to bfloat16 before the masking model uses them, so fused and un-fused calls agree),
  *            else the LDS-FFT kernels for filters_n from 16 to 4096 with a 5-smooth half and the O(N^2) kernels; results carry
  *            bfloat16's output rounding (2^-9 relative) -- more accurate than the reference's all-bfloat16 op sequence.
- * No streaming state and no backward passes for AC_F64 / AC_BF16.
+ * Streaming (ac_stream_*_typed) serves AC_F32 at every size and AC_BF16 where the wave-level kernels do (filters_n 1024 /
+ * 2048, mono / stereo; the state stays float32, chunked results equal the one-shot calls bit for bit); no backward passes
+ * for AC_F64 / AC_BF16.
  * ---------------------------------------------------------------------------------------- */
 AC_API int ac_mdct_forward_typed(const ac_mdct_plan* plan, const void* x, void* X, int dtype, int B, int K, int C, void* stream);
 AC_API int ac_mdct_inverse_typed(const ac_mdct_plan* plan, const void* X, void* x, int dtype, int B, int Kp, int C, void* stream);
@@ -331,6 +340,10 @@ AC_API int ac_mask_threshold_typed(const ac_psy_plan* plan, const void* X, const
                             int B, int F, int C, void* stream);
 AC_API int ac_encode_fused_typed(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const void* x, void* X, void* t, void* thr,
                           double drown, int dtype, int B, int K, int C, void* stream);
+/* ac_stream_forward / ac_stream_encode (psy may be NULL: then t, thr are ignored) and ac_stream_inverse on tensors of `dtype` */
+AC_API int ac_stream_encode_typed(ac_stream* s, const ac_psy_plan* psy, const void* x_chunk, void* X, void* t, void* thr,
+                                  double drown, int dtype, int k, void* stream);
+AC_API int ac_stream_inverse_typed(ac_stream* s, const void* X_chunk, void* x, int dtype, int k, void* stream);
 AC_API int ac_amplitude_to_db_typed(const void* a, void* out, size_t n, int norm, int dtype, void* stream);
 AC_API int ac_add_noise_typed(const void* X, const void* thr, void* out, size_t n, uint64_t seed, int dtype, void* stream);
 

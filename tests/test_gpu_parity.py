@@ -1065,10 +1065,43 @@ def test_autograd_of_the_filter_bank(path, N, wt):
     lhs = float((y.detach().double() * gy.double()).sum())
     rhs = float((Xv.detach().double() * Xv.grad.double()).sum())
     assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
-    with pytest.raises(NotImplementedError):
-        mr = audiocodec_amd.MDCTransformer(64, window_type="rect")
-        xr = torch.rand(1, 128, 1, device="cuda", requires_grad=True)
-        mr.transform(xr).sum().backward()
+
+
+@pytest.mark.parametrize("N,wt,pre,C", [(64, "rect", "float64", 2), (16, "rect", "float64", 3), (256, None, "float64", 1),
+                                         (64, "vorbis", "float32", 2), (128, "sine", "float32", 1), (1024, "rect", "float64", 2),
+                                         (960, "vorbis", "float32", 2)])
+def test_autograd_where_the_synthesis_bank_is_not_the_transpose(path, N, wt, pre, C):
+    """Backward of transform / inverse_transform for the rectangular window (mdctransformer.py:209-229: 2x2 fold blocks
+    [[1, 1], [1, 0]], whose inverse is not their transpose) and for float32-precomputed windows: the transposed bank runs as
+    the synthesis / analysis kernels on transposed fold coefficients (ac_mdct_plan_adjoint).  Reference = the ORACLE's
+    linear maps: T and S assembled column by column from oracle.transform / inverse_transform on unit impulses (float64),
+    then T^T g and S^T g -- no self-comparison.  N = 1024 / 960: inner products only (the dense maps would be GBs)."""
+    K, B = 3, 2
+    m = audiocodec_amd.MDCTransformer(N, window_type=wt, precompute_dtype=pre)
+    o = MDCTOracle(N, wt, np.float64, precompute_dtype=np.float32 if pre == "float32" else np.float64)
+    g = torch.Generator(device="cuda").manual_seed(N + C)
+    x = (torch.rand(B, K * N, C, device="cuda", generator=g) * 2 - 1).requires_grad_(True)
+    gX = torch.randn(B, K + 1, N, C, device="cuda", generator=g)
+    X = m.transform(x)
+    (X * gX).sum().backward()
+    lhs, rhs = float((X.detach().double() * gX.double()).sum()), float((x.detach().double() * x.grad.double()).sum())
+    assert abs(lhs - rhs) <= 2e-5 * max(1.0, abs(lhs))
+    Xv = torch.randn(B, K, N, C, device="cuda", generator=g).requires_grad_(True)
+    gy = torch.randn(B, (K + 1) * N, C, device="cuda", generator=g)
+    y = m.inverse_transform(Xv)
+    (y * gy).sum().backward()
+    lhs, rhs = float((y.detach().double() * gy.double()).sum()), float((Xv.detach().double() * Xv.grad.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+    if N > 256:
+        return
+    eye = np.eye(K * N).reshape(K * N, K * N, 1)                                   # unit impulses as a batch of mono signals
+    T = o.transform(eye).reshape(K * N, (K + 1) * N)                               # row i = T e_i  ->  T^T g = T_rows @ g
+    gx_ref = np.einsum("if,bfc->bic", T, host(gX).astype(np.float64).reshape(B, (K + 1) * N, C))
+    assert np.max(np.abs(host(x.grad) - gx_ref)) <= 2e-5 * max(1.0, np.max(np.abs(gx_ref)))
+    eyeX = np.eye(K * N).reshape(K * N, K, N, 1)
+    S = o.inverse_transform(eyeX).reshape(K * N, (K + 1) * N)                      # row i = S e_i
+    gX_ref = np.einsum("is,bsc->bic", S, host(gy).astype(np.float64)).reshape(B, K, N, C)
+    assert np.max(np.abs(host(Xv.grad) - gX_ref)) <= 1e-4 * max(1.0, np.max(np.abs(gX_ref)))
 
 
 def test_tensors_beyond_4_gib():
@@ -1328,6 +1361,39 @@ def test_bfloat16_filter_bank(path, N, wt, C):
     assert np.max(np.abs(xh - ref)) <= 4e-3 * max(1.0, np.max(np.abs(ref)))
     if wt != "rect":
         assert np.max(np.abs(xh[:, N:-N] - x)) <= 2e-2       # round trip through bfloat16 coefficients
+
+
+@pytest.mark.parametrize("N,C", [(1024, 2), (1024, 1), (2048, 2), (2048, 1)])
+def test_bfloat16_streaming(N, C):
+    """Streaming overlap-add on bfloat16 tensors (ac_stream_*_typed: the wave-level kernels, state kept in float32): chunk
+    by chunk -- ragged chunk lengths -- the spectra, tonality, thresholds and the synthesised PCM equal the one-shot
+    bfloat16 calls bit for bit; against the float64 ORACLE on the bfloat16-rounded input they stay within bfloat16's
+    rounding (coefficients 4e-3 of the frame peak, round trip 2e-2)."""
+    _lib.load().ac_set_force_generic(0)
+    B, K = 3, 9
+    rng = np.random.default_rng(N + C)
+    x = _bf16_round(rng.uniform(-1, 1, (B, K * N, C)))
+    xd = dev(x).to(torch.bfloat16)
+    codec = audiocodec_amd.AudioCodec(48000, N, compute_dtype=torch.bfloat16)
+    X, t, thr = codec.encode(xd, drown=0.2)
+    xh = codec.decode(X)
+    st = codec.stream(B, C)
+    cuts = ((0, 2), (2, 3), (3, 9))
+    parts = [st.encode_chunk(xd[:, a * N:b * N].contiguous(), drown=0.2) for a, b in cuts]
+    for i, ref in enumerate((X, t, thr)):
+        assert torch.equal(torch.cat([p_[i] for p_ in parts], dim=1), ref[:, :K])
+    back = torch.cat([st.inverse_chunk(p_[0]) for p_ in parts], dim=1)
+    assert back.dtype == torch.bfloat16 and torch.equal(back, xh[:, :K * N])
+    st.reset()
+    again = torch.cat([st.transform_chunk(xd[:, a * N:b * N].contiguous()) for a, b in cuts], dim=1)
+    assert torch.equal(again, codec.mdct.transform(xd)[:, :K])
+    o = MDCTOracle(N, "vorbis", np.float64)
+    assert rel_peak(host(X.double()), o.transform(x)) <= 4e-3
+    assert np.max(np.abs(host(back.double())[:, N:] - x[:, :-N])) <= 2e-2
+    st.close()
+    with pytest.raises(_lib.AudioCodecError):
+        audiocodec_amd.StreamingMDCT(audiocodec_amd.MDCTransformer(512, compute_dtype=torch.bfloat16), 1, 2).transform_chunk(
+            torch.zeros(1, 512, 2, device="cuda", dtype=torch.bfloat16))
 
 
 @pytest.mark.parametrize("sr,N,M,C", [(48000, 1024, 64, 2), (44100, 256, 48, 3), (48000, 2048, 64, 1)])
