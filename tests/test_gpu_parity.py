@@ -1454,8 +1454,12 @@ def test_codec_in_other_compute_dtypes(dtype):
     xh = codec.decode(X)
     assert xh.dtype == dtype
     assert float((xh[:, N:-N] - x).double().abs().max()) <= (1e-12 if dtype == torch.float64 else 2e-2)
-    with pytest.raises(NotImplementedError):
-        audiocodec_amd.StreamingMDCT(codec.mdct, 2, 2)
+    if dtype == torch.float64:                      # (bfloat16 streams exist where the wave-level kernels serve them: N = 1024 / 2048)
+        with pytest.raises(NotImplementedError):
+            audiocodec_amd.StreamingMDCT(codec.mdct, 2, 2)
+    else:
+        with pytest.raises(_lib.AudioCodecError):
+            audiocodec_amd.StreamingMDCT(codec.mdct, 2, 2).transform_chunk(x[:, :N].contiguous())
     with pytest.raises(NotImplementedError):
         codec.psy.tonality(X.clone().requires_grad_())
 
@@ -1774,11 +1778,11 @@ def test_bench_one_rank_over_rccl():
     """The RCCL branch on the hardware there is: `python bench.py --gpus 1 --dist nccl` starts ONE rank under
     torch.distributed.run; its barrier, max-over-ranks time, checksum reductions and the closing barrier(device_ids=...) /
     destroy_process_group go through RCCL on the device -- the code the 1 / 2 / 4 / 8 curve depends on
-    (no data-path collective: clips are independent, mdctransformer.py:292-295).  Same results bit for bit, and the same value
-    as the plain run within 8 % on BASELINE configs[1] itself (two processes: where the allocator puts X and thr moves the
-    step by up to 7 % on its own, DESIGN.md section 5, and RCCL's own buffers shift every later allocation)."""
-    common = ("--steps", 60, "--warmup", 5, "--no-cpu-baseline", "--no-other-configs", "--no-workspace", "--no-encode-api",
-              "--no-smi")
+    (no data-path collective: clips are independent, mdctransformer.py:292-295).  Same results bit for bit, and the same
+    rate as the plain run on BASELINE configs[1] itself: within 5 % on library-placed tensors (AudioCodec.encode / decode),
+    within 15 % on caller-owned plain ones (two processes: where the allocator puts X and thr moves the step by up to 11 %
+    on its own, and RCCL's own buffers shift every later allocation)."""
+    common = ("--steps", 60, "--warmup", 5, "--no-cpu-baseline", "--no-other-configs", "--no-workspace", "--no-smi")
     nccl = _run_bench("--gpus", 1, "--dist", "nccl", *common)
     plain = _run_bench("--gpus", 1, *common)
     assert nccl["config"]["backend"] == "nccl" and plain["config"]["backend"] is None
@@ -1787,8 +1791,12 @@ def test_bench_one_rank_over_rccl():
     assert a["frames_per_step"] == b["frames_per_step"] == 256 * 2 * 468
     for k in ("checksum_X", "checksum_thr", "checksum_pcm", "checksum_tonality", "round_trip_max_abs_err"):
         assert a[k] == b[k], (k, a[k], b[k])
-    print("one rank over RCCL %.1f M frames/s, plain %.1f M frames/s" % (nccl["value"] / 1e6, plain["value"] / 1e6))
-    assert abs(nccl["value"] / plain["value"] - 1.0) < 0.08, (nccl["value"], plain["value"])
+    print("one rank over RCCL %.1f M frames/s (library-placed tensors %.1f M), plain %.1f M (%.1f M)"
+          % (nccl["value"] / 1e6, nccl["encode_api_value"] / 1e6, plain["value"] / 1e6, plain["encode_api_value"] / 1e6))
+    # caller-owned plain tensors: where the allocator puts X and thr moves the step by up to 11 % between two processes
+    # (254 ... 283 M measured), so the like-for-like comparison is the one on library-placed tensors
+    assert abs(nccl["value"] / plain["value"] - 1.0) < 0.15, (nccl["value"], plain["value"])
+    assert abs(nccl["encode_api_value"] / plain["encode_api_value"] - 1.0) < 0.05, (nccl["encode_api_value"], plain["encode_api_value"])
     # the driver's own form of the same thing: torch.distributed.run --nproc-per-node 1 bench.py --gpus 1
     import json
     import os
@@ -1797,7 +1805,7 @@ def test_bench_one_rank_over_rccl():
     from conftest import ROOT
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
                           "127.0.0.1", "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--clips", "16",
-                          "--blocks", "32"] + [str(v) for v in common], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                          "--blocks", "32", "--no-encode-api"] + [str(v) for v in common], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stdout + out.stderr
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["config"]["backend"] == "nccl" and d["n_gpus"] == 1
