@@ -1,6 +1,9 @@
 // Generic kernels: any even N, any channel count, any Bark-band count.  O(N^2) direct DCT-IV.
 // They are the path for sizes the wave-level FFT kernels (ac_fast.hip) do not cover and an
 // independent on-device cross-check for them.  gfx950 only.
+#include <algorithm>
+#include <cstdlib>
+
 #include "ac_internal.h"
 
 namespace ac {
@@ -160,10 +163,16 @@ __device__ __forceinline__ float2 cis_neg(const float* __restrict__ ctab, int id
 struct cpair {
   float2 re, im;   // (c0, c1)
 };
+// (the two channels of a pair as one 2-vector: the compiler then emits packed v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 --
+// half the vector-ALU instructions of the same arithmetic written on .x / .y)
+typedef float pk2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk2 pk(float2 v) { return pk2{v.x, v.y}; }
+__device__ __forceinline__ float2 unpk(pk2 v) { return make_float2(v.x, v.y); }
 __device__ __forceinline__ cpair cmulw(cpair a, float2 w) {
+  const pk2 re = pk(a.re), im = pk(a.im);
   cpair r;
-  r.re = make_float2(a.re.x * w.x - a.im.x * w.y, a.re.y * w.x - a.im.y * w.y);
-  r.im = make_float2(a.re.x * w.y + a.im.x * w.x, a.re.y * w.y + a.im.y * w.x);
+  r.re = unpk(re * w.x - im * w.y);
+  r.im = unpk(re * w.y + im * w.x);
   return r;
 }
 __device__ __forceinline__ float2 ld2(const float* p, int C, bool has1) {   // the pair's two samples at one index
@@ -197,17 +206,11 @@ __device__ __forceinline__ void st2(bf16_t* p, float2 v, int C, bool has1) {
   if (has1) p[1] = (bf16_t)v.y;
 }
 
-__device__ __forceinline__ cpair cadd(cpair a, cpair b) {
-  return {make_float2(a.re.x + b.re.x, a.re.y + b.re.y), make_float2(a.im.x + b.im.x, a.im.y + b.im.y)};
-}
-__device__ __forceinline__ cpair csub(cpair a, cpair b) {
-  return {make_float2(a.re.x - b.re.x, a.re.y - b.re.y), make_float2(a.im.x - b.im.x, a.im.y - b.im.y)};
-}
-__device__ __forceinline__ cpair cscale(cpair a, float s) {
-  return {make_float2(a.re.x * s, a.re.y * s), make_float2(a.im.x * s, a.im.y * s)};
-}
+__device__ __forceinline__ cpair cadd(cpair a, cpair b) { return {unpk(pk(a.re) + pk(b.re)), unpk(pk(a.im) + pk(b.im))}; }
+__device__ __forceinline__ cpair csub(cpair a, cpair b) { return {unpk(pk(a.re) - pk(b.re)), unpk(pk(a.im) - pk(b.im))}; }
+__device__ __forceinline__ cpair cscale(cpair a, float s) { return {unpk(pk(a.re) * s), unpk(pk(a.im) * s)}; }
 __device__ __forceinline__ cpair cmul_mi(cpair a) {   // a * (-i)
-  return {a.im, make_float2(-a.re.x, -a.re.y)};
+  return {a.im, unpk(-pk(a.re))};
 }
 // radix of the next Stockham pass over what is left of the transform length (4 while it divides, then 2, 3, 5)
 static inline __host__ __device__ int next_radix(int rem) { return rem % 4 == 0 ? 4 : rem % 2 == 0 ? 2 : rem % 3 == 0 ? 3 : 5; }
@@ -320,6 +323,227 @@ __device__ void dct4_lds(float2* v, cpair* A, cpair* B, const float* __restrict_
   }
   __syncthreads();
 }
+
+// ------------------------------------------------------------------------------------------------
+// The same transform with one group of <= 64 lanes INSIDE ONE WAVE per frame (filters_n <= 2048): no workgroup barrier
+// anywhere in a frame (LDS operations of a wave execute in order; wave_sync only pins the compiler), two or three radix
+// stages per LDS round trip -- a pass has a super-radix R = R1 R2 <= 16 (16 = 4 x 4, 15 = 3 x 5, 12 = 4 x 3, 10 = 2 x 5,
+// 9 = 3 x 3, 8 = 4 x 2, 6 = 2 x 3, or a plain 5 / 4 / 3 / 2), computed in registers with compile-time inner twiddles, so
+// filters_n = 960 takes 3 round trips instead of 5, 480 two -- and padded buffers: element i of a buffer lives at
+// i + (i >> 4), which spreads the stride-R writes of the first pass (and every other power-of-two stride) over the banks.
+// The fold buffer shares the bytes of the second FFT buffer: 17 N bytes of LDS per frame, 9 frames resident per CU at
+// filters_n = 960 (the three-buffer workgroup form above: 6).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
+static inline __host__ __device__ int padded_len(int n) { return n + (n >> 4) + 1; }
+
+// compile-time cos / sin of 2 pi e / R (Taylor series on the angle reduced to [-pi, pi])
+constexpr double c_series(double x, bool sine) {
+  double term = sine ? x : 1.0, sum = term;
+  for (int k = 1; k < 16; ++k) {
+    const double a = sine ? 2.0 * k : 2.0 * k - 1.0;
+    term *= -x * x / (a * (a + 1.0));
+    sum += term;
+  }
+  return sum;
+}
+constexpr double c_angle(int e, int R) {
+  const int m = ((e % R) + R) % R;
+  const double a = 6.283185307179586476925 * (double)m / (double)R;
+  return a > 3.14159265358979323846 ? a - 6.283185307179586476925 : a;
+}
+template <int E, int R> struct Wc {   // exp(-2 pi i E / R)
+  static constexpr float re = (float)c_series(c_angle(E, R), false);
+  static constexpr float im = (float)(-c_series(c_angle(E, R), true));
+};
+
+// small DFTs (forward sign) on R cpairs in natural order, in place
+template <int R> __device__ __forceinline__ void dft_small(cpair* a);
+template <> __device__ __forceinline__ void dft_small<1>(cpair*) {}
+template <> __device__ __forceinline__ void dft_small<2>(cpair* a) {
+  const cpair s = cadd(a[0], a[1]), d = csub(a[0], a[1]);
+  a[0] = s;
+  a[1] = d;
+}
+template <> __device__ __forceinline__ void dft_small<3>(cpair* a) {
+  const cpair sm = cadd(a[1], a[2]), m1 = csub(a[0], cscale(sm, 0.5f));
+  const cpair m2 = cscale(cmul_mi(csub(a[1], a[2])), 0.86602540378443865f);   // -i sin(2 pi / 3) (x1 - x2)
+  a[0] = cadd(a[0], sm);
+  a[1] = cadd(m1, m2);
+  a[2] = csub(m1, m2);
+}
+template <> __device__ __forceinline__ void dft_small<4>(cpair* a) {
+  const cpair t0 = cadd(a[0], a[2]), t1 = csub(a[0], a[2]), t2 = cadd(a[1], a[3]), t3 = cmul_mi(csub(a[1], a[3]));
+  a[0] = cadd(t0, t2);
+  a[1] = cadd(t1, t3);
+  a[2] = csub(t0, t2);
+  a[3] = csub(t1, t3);
+}
+template <> __device__ __forceinline__ void dft_small<5>(cpair* a) {
+  const cpair a1 = cadd(a[1], a[4]), a2 = cadd(a[2], a[3]), b1 = csub(a[1], a[4]), b2 = csub(a[2], a[3]);
+  constexpr float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;   // cos(2 pi / 5), cos(4 pi / 5)
+  constexpr float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;    // sin(2 pi / 5), sin(4 pi / 5)
+  const cpair e1 = cadd(a[0], cadd(cscale(a1, c1), cscale(a2, c2))), e2 = cadd(a[0], cadd(cscale(a1, c2), cscale(a2, c1)));
+  const cpair d1 = cmul_mi(cadd(cscale(b1, s1), cscale(b2, s2))), d2 = cmul_mi(csub(cscale(b1, s2), cscale(b2, s1)));
+  a[0] = cadd(a[0], cadd(a1, a2));
+  a[1] = cadd(e1, d1);
+  a[2] = cadd(e2, d2);
+  a[3] = csub(e2, d2);
+  a[4] = csub(e1, d1);
+}
+// inner twiddles W_R^(n2 k1) of the two-stage form, applied row by row with compile-time constants
+template <int R1, int R2, int N2, int K1>
+struct TwRow {
+  static __device__ __forceinline__ void run(cpair* g) {   // g[k1], k1 = 0 .. R1 - 1, for a fixed n2 = N2
+    TwRow<R1, R2, N2, K1 - 1>::run(g);
+    if constexpr (K1 > 0 && N2 > 0) g[K1] = cmulw(g[K1], make_float2(Wc<N2 * K1, R1 * R2>::re, Wc<N2 * K1, R1 * R2>::im));
+  }
+};
+template <int R1, int R2, int N2>
+struct TwRow<R1, R2, N2, -1> {
+  static __device__ __forceinline__ void run(cpair*) {}
+};
+template <int R1, int R2, int N2>
+struct Stage1 {   // for n2 = 0 .. N2: DFT_R1 over n1 of x[n1 R2 + n2] (fetched by `load`), times W_R^(n2 k1) -> y[k1 R2 + n2]
+  template <class LOAD>
+  static __device__ __forceinline__ void run(const LOAD& load, cpair* y) {
+    Stage1<R1, R2, N2 - 1>::run(load, y);
+    cpair g[R1];
+#pragma unroll
+    for (int n1 = 0; n1 < R1; ++n1) g[n1] = load(n1 * R2 + N2);
+    dft_small<R1>(g);
+    TwRow<R1, R2, N2, R1 - 1>::run(g);
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) y[k1 * R2 + N2] = g[k1];
+  }
+};
+template <int R1, int R2>
+struct Stage1<R1, R2, -1> {
+  template <class LOAD>
+  static __device__ __forceinline__ void run(const LOAD&, cpair*) {}
+};
+
+// one Stockham pass of super-radix R = R1 R2 joining R transforms of length L (see dct4_lds), by the nt <= 64 lanes of a group
+// inside one wave; src / dst padded (pad16).  The R-point DFT runs in registers as R2 DFTs of R1 points (inputs fetched column
+// by column), compile-time inner twiddles, R1 DFTs of R2 points (outputs stored row by row):  n = n1 R2 + n2,  k = k1 + R1 k2.
+// first: the inputs are the folded frame v itself, element n = v[2 n] + i v[N - 1 - 2 n], times the pre-twiddle
+// exp(-i pi (n + 1/4) / N) (no separate pre-twiddle round trip); last_to_v: the outputs go to v in their final form,
+// y[2 k] = Re, y[N - 1 - 2 k] = -Im of out[k] exp(-i pi k / N) (no separate post-twiddle round trip).
+struct WaveTabs {
+  const float2* tw;    // exp(-2 pi i k / (N/2))
+  const float2* pre;   // exp(-i pi (n + 1/4) / N)
+  const float2* post;  // exp(-i pi k / N)
+};
+template <int R1, int R2>
+__device__ __forceinline__ void wave_pass(const cpair* __restrict__ src, cpair* __restrict__ dst, float2* v, int N, int L, int H,
+                                          const WaveTabs& tb, int tid, int nt, bool first, bool last_to_v) {
+  constexpr int R = R1 * R2;
+  const int m = H / (R * L), nb = H / R;
+  const unsigned invL = 0xFFFFFFFFu / (unsigned)L + 1u;   // j / L for j < 2^16 as a multiply-high
+  for (int j = tid; j < nb; j += nt) {
+    const int p = L == 1 ? j : (int)__umulhi((unsigned)j, invL), q = j - p * L;
+    const int base = q + L * p, tq = q * m, ob = q + L * R * p, Lm = L * m;
+    auto load = [&](int s2) {
+      const int n = base + Lm * s2;
+      if (first) {   // (L = 1, q = 0: no pass twiddle)
+        cpair t;
+        t.re = v[2 * n];
+        t.im = v[N - 1 - 2 * n];
+        return cmulw(t, tb.pre[n]);
+      }
+      const cpair x = src[pad16(n)];
+      return s2 > 0 ? cmulw(x, tb.tw[tq * s2]) : x;
+    };
+    auto store = [&](int t, const cpair& val) {
+      const int k = ob + L * t;
+      if (last_to_v) {
+        const cpair r = cmulw(val, tb.post[k]);
+        v[2 * k] = r.re;
+        v[N - 1 - 2 * k] = make_float2(-r.im.x, -r.im.y);
+      } else {
+        dst[pad16(k)] = val;
+      }
+    };
+    if constexpr (R2 == 1) {
+      cpair g[R1];
+#pragma unroll
+      for (int n1 = 0; n1 < R1; ++n1) g[n1] = load(n1);
+      dft_small<R1>(g);
+#pragma unroll
+      for (int t = 0; t < R1; ++t) store(t, g[t]);
+    } else {
+      cpair y[R];
+      Stage1<R1, R2, R2 - 1>::run(load, y);
+#pragma unroll
+      for (int k1 = 0; k1 < R1; ++k1) {
+        cpair h[R2];
+#pragma unroll
+        for (int n2 = 0; n2 < R2; ++n2) h[n2] = y[k1 * R2 + n2];
+        dft_small<R2>(h);
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) store(k1 + R1 * k2, h[k2]);
+      }
+    }
+  }
+}
+
+// the super-radices of a size, chosen on the host (lds_wave_plan): their product is N / 2
+struct WavePlan {
+  int n;
+  unsigned char r[6];
+  int nt;   // lanes per frame (a power of two <= 64; 64 / nt frames share a wave)
+};
+
+// v[N] (LDS, float2 per entry; its bytes are ALSO buffer Bp) -> DCT-IV written back into v, as dct4_lds.  Ap, Bp: padded_len(N/2)
+// cpairs each.  Called by all the lanes of a wave; tid = lane inside its group of nt.
+// Buffers: pass 1 reads v (pre-twiddle fused) and writes Ap; the passes then alternate Ap -> Bp -> Ap ...  An even number of
+// passes ends with a pass that reads Ap and writes v in final form (post-twiddle fused: v's bytes are Bp's, free by then); an
+// odd number ends in Ap, and a separate post-twiddle step writes v.
+__device__ void dct4_wave(float2* v, cpair* Ap, cpair* Bp, const WaveTabs& tb, int N, int tid, int nt, const WavePlan& wp) {
+  const int H = N >> 1;
+  const bool even = (wp.n & 1) == 0;
+  cpair* src = Bp;   // (unused by the first pass)
+  cpair* dst = Ap;
+  int L = 1;
+  for (int ps = 0; ps < wp.n; ++ps) {
+    const int r = wp.r[ps];
+    const bool first = ps == 0, lastv = even && ps == wp.n - 1;
+    switch (r) {
+      case 16: wave_pass<4, 4>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
+      case 15: wave_pass<3, 5>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
+      case 12: wave_pass<4, 3>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
+      case 10: wave_pass<2, 5>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
+      case 9: wave_pass<3, 3>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
+      case 8: wave_pass<4, 2>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
+      case 6: wave_pass<2, 3>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
+      case 5: wave_pass<5, 1>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
+      case 4: wave_pass<4, 1>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
+      case 3: wave_pass<3, 1>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
+      default: wave_pass<2, 1>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
+    }
+    wave_sync_lds();
+    cpair* t = (ps == 0) ? Bp : src;   // after pass 1 the data is in Ap and Bp (= v, read out) is free
+    src = dst;
+    dst = t;
+    L *= r;
+  }
+  if (!even) {
+    for (int k = tid; k < H; k += nt) {
+      const cpair r = cmulw(src[pad16(k)], tb.post[k]);   // src == Ap here
+      v[2 * k] = r.re;
+      v[N - 1 - 2 * k] = make_float2(-r.im.x, -r.im.y);
+    }
+    wave_sync_lds();
+  }
+}
+
+// LDS floats per frame of the wave form: Bp (= v) and Ap, padded
+static inline __host__ __device__ int wave_floats_per_group(int N) { return 2 * 4 * padded_len(N / 2); }
 
 // the FFT's twiddles exp(-2 pi i k / (N/2)), k < N/2, once per workgroup into LDS (every thread takes part; the caller
 // synchronises before the first use)
@@ -472,6 +696,162 @@ static __global__ __launch_bounds__(kThreads) void k_inv_lds(const TIO* __restri
     __syncthreads();
     for (int j = tid; j < h; j += nt) um[j] = make_float2(v[h + j].x * scale, v[h + j].y * scale);
     __syncthreads();
+  }
+}
+
+// ---- the wave form of the two kernels above (filters_n <= 2048): a group of wp.nt lanes inside one wave per frame / strip,
+// several tasks per group so that the twiddle table is built once per workgroup; no workgroup barrier after that
+template <typename TIO>
+static __global__ __launch_bounds__(kThreads, 2) void k_fwd_wave(const TIO* __restrict__ x, TIO* __restrict__ X,
+                                                       const TIO* __restrict__ prev_block, const float* __restrict__ coef,
+                                                       const float* __restrict__ ctab, int Kin, int F, int C, int CP, int N,
+                                                       long long ntasks, int T, WavePlan wp) {
+  float* smem = reinterpret_cast<float*>(smem_raw);
+  const int nt = wp.nt, gpw = (int)blockDim.x / nt, grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
+  const int per = wave_floats_per_group(N), h = N >> 1;
+  float2* tw = reinterpret_cast<float2*>(smem + (size_t)gpw * per);   // three tables of N/2 behind the groups' buffers
+  for (int k = threadIdx.x; k < h; k += blockDim.x) {
+    tw[k] = cis_neg(ctab, 16 * k, N);            // exp(-2 pi i k / (N/2))
+    tw[h + k] = cis_neg(ctab, 4 * k + 1, N);     // exp(-i pi (k + 1/4) / N)
+    tw[2 * h + k] = cis_neg(ctab, 4 * k, N);     // exp(-i pi k / N)
+  }
+  __syncthreads();
+  const WaveTabs tb = {tw, tw + h, tw + 2 * h};
+  float* base = smem + (size_t)grp * per;
+  float2* v = reinterpret_cast<float2*>(base);                                   // [N], sharing the bytes of Bp
+  cpair* Bp = reinterpret_cast<cpair*>(base);
+  cpair* Ap = reinterpret_cast<cpair*>(base + 4 * padded_len(h));
+  const float *a1 = coef, *a2 = coef + h, *a3 = coef + 2 * h, *a4 = coef + 3 * h;
+  const float scale = (float)(1.0 / ((double)N * 1.4142135623730951));   // 1/sqrt(4N) * sqrt(2/N)
+  for (int t = 0; t < T; ++t) {
+    const long long wg = ((long long)blockIdx.x * T + t) * gpw + grp;
+    if (wg >= ntasks) return;
+    const int n = (int)(wg % F);
+    const long long sig = wg / F;
+    const int c = 2 * (int)(sig % CP);
+    const bool has1 = c + 1 < C;
+    const long long b = sig / CP;
+    const bool has_cur = n < Kin;
+    const TIO* xc = x + ((size_t)b * Kin + (size_t)n) * N * C + c;
+    const TIO* xp = nullptr;
+    if (n >= 1) xp = x + ((size_t)b * Kin + (size_t)(n - 1)) * N * C + c;
+    else if (prev_block) xp = prev_block + (size_t)b * N * C + c;
+    // the frame's PCM in batches of eight steps: all the loads of a batch are in flight together (a wave that waits for
+    // each step's loads in turn keeps a few hundred bytes in flight, and the tier ran at a quarter of the memory rate)
+    for (int j0 = tid; j0 < h; j0 += 8 * nt) {
+      float2 pc[8], qc[8], pp[8], qp[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int j = j0 + i * nt;
+        pc[i] = qc[i] = pp[i] = qp[i] = make_float2(0.f, 0.f);
+        if (j < h) {
+          if (has_cur) {
+            pc[i] = ld2(xc + (size_t)j * C, C, has1);
+            qc[i] = ld2(xc + (size_t)(N - 1 - j) * C, C, has1);
+          }
+          if (xp) {
+            pp[i] = ld2(xp + (size_t)(h - 1 - j) * C, C, has1);
+            qp[i] = ld2(xp + (size_t)(h + j) * C, C, has1);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int j = j0 + i * nt;
+        if (j < h) {
+          v[h + j] = make_float2(a1[j] * pc[i].x + a2[j] * qc[i].x, a1[j] * pc[i].y + a2[j] * qc[i].y);
+          v[j] = make_float2(a3[j] * pp[i].x + a4[j] * qp[i].x, a3[j] * pp[i].y + a4[j] * qp[i].y);
+        }
+      }
+    }
+    wave_sync_lds();
+    dct4_wave(v, Ap, Bp, tb, N, tid, nt, wp);
+    TIO* Xo = X + (((size_t)b * F + (size_t)n) * N) * C + c;
+    for (int k = tid; k < N; k += nt) st2(Xo + (size_t)k * C, make_float2(v[k].x * scale, v[k].y * scale), C, has1);
+    wave_sync_lds();   // v is read out before the next task folds into it
+  }
+}
+
+template <typename TIO>
+static __global__ __launch_bounds__(kThreads, 2) void k_inv_wave(const TIO* __restrict__ X, TIO* __restrict__ x,
+                                                       const float* __restrict__ tail_in, float* __restrict__ tail_out,
+                                                       const float* __restrict__ coef, const float* __restrict__ ctab,
+                                                       int Kp, int nblk, int seg, int nseg, int C, int CP, int N,
+                                                       long long ntasks, WavePlan wp) {
+  float* smem = reinterpret_cast<float*>(smem_raw);
+  const int nt = wp.nt, gpw = (int)blockDim.x / nt, grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
+  const int h = N >> 1, per = wave_floats_per_group(N) + N;   // + um [N/2] float2
+  float2* tw = reinterpret_cast<float2*>(smem + (size_t)gpw * per);
+  for (int k = threadIdx.x; k < h; k += blockDim.x) {
+    tw[k] = cis_neg(ctab, 16 * k, N);
+    tw[h + k] = cis_neg(ctab, 4 * k + 1, N);
+    tw[2 * h + k] = cis_neg(ctab, 4 * k, N);
+  }
+  __syncthreads();
+  const WaveTabs tb = {tw, tw + h, tw + 2 * h};
+  float* base = smem + (size_t)grp * per;
+  float2* v = reinterpret_cast<float2*>(base);
+  cpair* Bp = reinterpret_cast<cpair*>(base);
+  cpair* Ap = reinterpret_cast<cpair*>(base + 4 * padded_len(h));
+  float2* um = reinterpret_cast<float2*>(base + wave_floats_per_group(N));   // u_{n-1}[h + j]
+  const long long wg = (long long)blockIdx.x * gpw + grp;
+  if (wg >= ntasks) return;
+  const int sgm = (int)(wg % nseg);
+  const long long sig = wg / nseg;
+  const int c = 2 * (int)(sig % CP);
+  const bool has1 = c + 1 < C;
+  const long long b = sig / CP;
+  const float *s1 = coef + 4 * h, *s2 = coef + 5 * h, *s3 = coef + 6 * h, *s4 = coef + 7 * h;
+  const float scale = 2.0f * 1.4142135623730951f;   // sqrt(4N) * sqrt(2/N)
+  const int nlast = nblk + (tail_out ? 1 : 0);      // blocks incl. the virtual state block
+  const int n0 = sgm * seg;
+  const size_t ts = ((size_t)b * C + c) * h;        // stream state rows of the pair: ts, ts + h
+  // aliased half before the strip: the stream state or zero for a signal's first strip, else frame n0 - 1 (step t = -1 of
+  // the loop below: one call site of the transform)
+  if (n0 == 0) {
+    for (int j = tid; j < h; j += nt)
+      um[j] = tail_in ? make_float2(tail_in[ts + j], has1 ? tail_in[ts + h + j] : 0.f) : make_float2(0.f, 0.f);
+    wave_sync_lds();
+  }
+  for (int t = (n0 >= 1 ? -1 : 0); t < seg; ++t) {
+    const int n = n0 + t;
+    if (t >= 0 && n >= nlast) break;         // nothing left to write
+    const bool has_n = t < 0 || (n < Kp && n < nblk);   // the virtual state block (n == nblk) has no current frame
+    {
+      const TIO* Xi = X + (((size_t)b * Kp + (size_t)(has_n ? n : 0)) * N) * C + c;
+      for (int k0 = tid; k0 < N; k0 += 16 * nt) {   // sixteen loads in flight per lane (see k_fwd_wave)
+        float2 r[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int k = k0 + i * nt;
+          r[i] = (has_n && k < N) ? ld2(Xi + (size_t)k * C, C, has1) : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int k = k0 + i * nt;
+          if (k < N) v[k] = r[i];
+        }
+      }
+    }
+    wave_sync_lds();
+    if (has_n) dct4_wave(v, Ap, Bp, tb, N, tid, nt, wp);   // (the DCT-IV of a zero frame is zero)
+    if (t >= 0) {
+      for (int j = tid; j < h; j += nt) {
+        const float2 a = make_float2(v[h - 1 - j].x * scale, v[h - 1 - j].y * scale);   // u_n[h-1-j]
+        const float2 bb = um[j];                                                        // u_{n-1}[h+j]
+        if (n < nblk) {
+          TIO* xo = x + (((size_t)b * nblk + (size_t)n) * N) * C + c;
+          st2(xo + (size_t)j * C, make_float2(s1[j] * a.x + s2[j] * bb.x, s1[j] * a.y + s2[j] * bb.y), C, has1);
+          st2(xo + (size_t)(N - 1 - j) * C, make_float2(s3[j] * a.x + s4[j] * bb.x, s3[j] * a.y + s4[j] * bb.y), C, has1);
+        } else if (tail_out) {
+          tail_out[ts + j] = bb.x;
+          if (has1) tail_out[ts + h + j] = bb.y;
+        }
+      }
+      wave_sync_lds();
+    }
+    for (int j = tid; j < h; j += nt) um[j] = make_float2(v[h + j].x * scale, v[h + j].y * scale);
+    wave_sync_lds();
   }
 }
 
@@ -836,11 +1216,135 @@ static int check_grid(long long n) {
   return 0;
 }
 
+// ---- the wave form of the LDS-FFT tier (filters_n <= 2048) ------------------------------------------------------------
+#ifndef AC_LDS_WAVE_MAX
+#define AC_LDS_WAVE_MAX 2048   // (0: the workgroup form everywhere, for A/B measurements)
+#endif
+// Which of the two forms serves a size is measured, not derived (profiles/r3/lds_fft_tier_wave_vs_workgroup.txt, B = 64
+// stereo, 10 s): the wave form wins the analysis where one wave has enough butterflies per pass and few passes (N / 2 from
+// 208 to 512: 480 +12 %, 960 +18 %) and at the very small sizes (N <= 64: 2-3 x, several frames share a wave), the workgroup
+// form keeps 96 ... 416 and everything above 1024 (-7 ... -25 % otherwise); the synthesis wins up to N = 1536 (+6 ... +32 %).
+// AC_LDS_WAVE_MAX (tuning hook; 0: the workgroup form everywhere) caps both.
+static bool lds_wave_ok(int N, bool synthesis) {
+  static const int wave_max = [] { const char* e = getenv("AC_LDS_WAVE_MAX"); return e ? atoi(e) : AC_LDS_WAVE_MAX; }();
+  if (!lds_fft_ok(N) || N > wave_max) return false;
+  const int H = N / 2;
+  return synthesis ? N <= 1536 : (H <= 32 || (H >= 208 && H <= 512));
+}
+// super-radices of N / 2 (a pass of radix r runs (N / 2) / r butterflies of r points in registers): the factorisation with
+// the least estimated work -- every pass costs a round trip through LDS, a butterfly ~ r (log2 r + 3) operations, and the
+// butterflies of a pass are dealt to nt lanes
+static WavePlan lds_wave_plan(int N) {
+  const int H = N / 2;
+  WavePlan best{};
+  static const int nt_min = [] { const char* e = getenv("AC_LDS_WAVE_NT_MIN"); return e ? atoi(e) : 4; }();   // tuning hook
+  int nt = nt_min < 4 ? 4 : nt_min > 64 ? 64 : nt_min;
+  while (nt < 64 && nt < H / 8) nt <<= 1;
+  best.nt = nt;
+  static const int cand[] = {16, 15, 12, 10, 9, 8, 6, 5, 4, 3, 2};
+  double best_cost = 1e300;
+  int cur[6];
+  auto cost_of = [&](int n) {
+    double c = 0;
+    for (int i = 0; i < n; ++i) {
+      const int r = cur[i], nb = H / r;
+      int lg = 0;
+      while ((1 << lg) < r) ++lg;
+      c += (double)((nb + nt - 1) / nt) * r * (lg + 3) + 24.0;
+    }
+    return c;
+  };
+  // depth-first over non-increasing factor sequences (the largest radix first: its pass has the stride-r writes the padding absorbs)
+  struct Rec {
+    static void go(int rem, int depth, int maxr, int* cur, const int* cand, double& best_cost, WavePlan& best,
+                   const decltype(cost_of)& cost) {
+      if (rem == 1) {
+        const double c = cost(depth);
+        if (c < best_cost) {
+          best_cost = c;
+          best.n = depth;
+          for (int i = 0; i < depth; ++i) best.r[i] = (unsigned char)cur[i];
+        }
+        return;
+      }
+      if (depth == 6) return;
+      for (int i = 0; i < 11; ++i) {
+        const int r = cand[i];
+        if (r > maxr || rem % r) continue;
+        cur[depth] = r;
+        go(rem / r, depth + 1, r, cur, cand, best_cost, best, cost);
+      }
+    }
+  };
+  Rec::go(H, 0, 16, cur, cand, best_cost, best, cost_of);
+  return best;
+}
+// waves per workgroup that leave the most waves resident per CU (160 KB of LDS)
+static int lds_wave_block(int N, const WavePlan& wp, int extra_floats, size_t* lds_bytes) {
+  int best_w = 1;
+  long best_res = 0;
+  for (int w = 1; w <= 4; ++w) {
+    const size_t lds = ((size_t)(64 / wp.nt) * w * (wave_floats_per_group(N) + extra_floats) + 3 * N) * sizeof(float);
+    const long res = (long)std::min<size_t>(8, 160 * 1024 / std::max<size_t>(lds, 1)) * w;
+    if (lds <= 160 * 1024 && res >= best_res) {
+      best_res = res;
+      best_w = w;
+    }
+  }
+  *lds_bytes = ((size_t)(64 / wp.nt) * best_w * (wave_floats_per_group(N) + extra_floats) + 3 * N) * sizeof(float);   // + the three tables
+  return best_w;
+}
+
+template <typename TIO>
+static int launch_fwd_wave(const ac_mdct_plan* p, const TIO* x, TIO* X, const TIO* prev_block, int B, int Kin, int F, int C,
+                           hipStream_t s) {
+  const WavePlan wp = lds_wave_plan(p->N);
+  size_t lds = 0;
+  const int w = lds_wave_block(p->N, wp, 0, &lds);
+  const int CP = (C + 1) / 2, gpw = w * (64 / wp.nt);
+  const long long ntasks = (long long)B * CP * F;
+  int T = 4;
+  while (T > 1 && ntasks < (long long)gpw * T * p->cus * 4) T >>= 1;
+  const int st = allow_lds(k_fwd_wave<TIO>, lds);
+  if (st) return st;
+  const long long g = (ntasks + (long long)gpw * T - 1) / ((long long)gpw * T);
+  const int st2 = check_grid(g);
+  if (st2) return st2 < 0 ? st2 : AC_OK;
+  hipLaunchKernelGGL(k_fwd_wave<TIO>, dim3((unsigned)g), dim3(64 * w), lds, s, x, X, prev_block, p->d_coef, p->d_ctab, Kin, F, C,
+                     CP, p->N, ntasks, T, wp);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+template <typename TIO>
+static int launch_inv_wave(const ac_mdct_plan* p, const TIO* X, TIO* x, const float* tail_in, float* tail_out, int B, int Kp,
+                           int nblk, int C, hipStream_t s) {
+  const WavePlan wp = lds_wave_plan(p->N);
+  size_t lds = 0;
+  const int w = lds_wave_block(p->N, wp, p->N, &lds);
+  const int per_sig = nblk + (tail_out ? 1 : 0);
+  const int CP = (C + 1) / 2, gpw = w * (64 / wp.nt);
+  // blocks per strip: every strip but a signal's first pays one more transform for the frame before it
+  int seg = 8;
+  while (seg > 1 && (long long)B * CP * ((per_sig + seg - 1) / seg) < (long long)gpw * p->cus * 4) seg >>= 1;
+  const int nseg = (per_sig + seg - 1) / seg;
+  const long long ntasks = (long long)B * CP * nseg;
+  const int st = allow_lds(k_inv_wave<TIO>, lds);
+  if (st) return st;
+  const long long g = (ntasks + gpw - 1) / gpw;
+  const int st2 = check_grid(g);
+  if (st2) return st2 < 0 ? st2 : AC_OK;
+  hipLaunchKernelGGL(k_inv_wave<TIO>, dim3((unsigned)g), dim3(64 * w), lds, s, X, x, tail_in, tail_out, p->d_coef, p->d_ctab, Kp,
+                     nblk, seg, nseg, C, CP, p->N, ntasks, wp);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
 int launch_fwd_generic(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin,
                        int F, int C, hipStream_t s) {
   const long long nwg = (long long)B * C * F;
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
+  if (lds_wave_ok(p->N, false) && !g_force_generic) return launch_fwd_wave<float>(p, x, X, prev_block, B, Kin, F, C, s);
   if (lds_fft_ok(p->N) && !g_force_generic) {
     const int CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const long long ntasks = (long long)B * CP * F;
@@ -872,6 +1376,7 @@ int launch_inv_generic(const ac_mdct_plan* p, const float* X, float* x, const fl
   const long long nwg = (long long)B * C * per_sig;
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
+  if (lds_wave_ok(p->N, true) && !g_force_generic) return launch_inv_wave<float>(p, X, x, tail_in, tail_out, B, Kp, nblk, C, s);
   if (lds_fft_ok(p->N) && !g_force_generic) {
     const int seg = 8, CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const int nseg = (per_sig + seg - 1) / seg;
@@ -1011,6 +1516,7 @@ int launch_fwd_bf16(const ac_mdct_plan* p, const bf16_t* x, bf16_t* X, int B, in
   const long long nwg = (long long)B * C * F;
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
+  if (lds_wave_ok(p->N, false) && !g_force_generic) return launch_fwd_wave<bf16_t>(p, x, X, (const bf16_t*)nullptr, B, Kin, F, C, s);
   if (lds_fft_ok(p->N) && !g_force_generic) {
     const int CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const long long ntasks = (long long)B * CP * F;
@@ -1040,6 +1546,7 @@ int launch_inv_bf16(const ac_mdct_plan* p, const bf16_t* X, bf16_t* x, int B, in
   const long long nwg = (long long)B * C * nblk;
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
+  if (lds_wave_ok(p->N, true) && !g_force_generic) return launch_inv_wave<bf16_t>(p, X, x, nullptr, nullptr, B, Kp, nblk, C, s);
   if (lds_fft_ok(p->N) && !g_force_generic) {
     const int seg = 8, CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const int nseg = (nblk + seg - 1) / seg;

@@ -9,7 +9,7 @@ def timeit(fn, n=5):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-for N in (960, 480, 240, 120, 576, 4096, 32, 2048):
+for N in (960, 480, 240, 120, 576, 1920, 1536, 192, 4096, 32, 16):
     B, C = 64, 2
     K = 468 * 1024 // N
     x = torch.rand(B, K * N, C, device="cuda") * 2 - 1
