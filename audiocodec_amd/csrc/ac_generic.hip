@@ -160,7 +160,7 @@ __device__ __forceinline__ float2 cis_neg(const float* __restrict__ ctab, int id
   const int s = idx - 2 * N;
   return make_float2(ctab[idx], -ctab[s < 0 ? -s : s]);
 }
-struct cpair {
+struct alignas(16) cpair {   // (16-byte aligned: one ds_read_b128 / ds_write_b128 per value)
   float2 re, im;   // (c0, c1)
 };
 // (the two channels of a pair as one 2-vector: the compiler then emits packed v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 --
@@ -439,9 +439,9 @@ struct WaveTabs {
   const float2* pre;   // exp(-i pi (n + 1/4) / N)
   const float2* post;  // exp(-i pi k / N)
 };
-template <int R1, int R2>
+template <int R1, int R2, bool first, bool last_to_v>
 __device__ __forceinline__ void wave_pass(const cpair* __restrict__ src, cpair* __restrict__ dst, float2* v, int N, int L, int H,
-                                          const WaveTabs& tb, int tid, int nt, bool first, bool last_to_v) {
+                                          const WaveTabs& tb, int tid, int nt) {
   constexpr int R = R1 * R2;
   const int m = H / (R * L), nb = H / R;
   const unsigned invL = 0xFFFFFFFFu / (unsigned)L + 1u;   // j / L for j < 2^16 as a multiply-high
@@ -450,18 +450,19 @@ __device__ __forceinline__ void wave_pass(const cpair* __restrict__ src, cpair* 
     const int base = q + L * p, tq = q * m, ob = q + L * R * p, Lm = L * m;
     auto load = [&](int s2) {
       const int n = base + Lm * s2;
-      if (first) {   // (L = 1, q = 0: no pass twiddle)
+      if constexpr (first) {   // (L = 1, q = 0: no pass twiddle)
         cpair t;
         t.re = v[2 * n];
         t.im = v[N - 1 - 2 * n];
         return cmulw(t, tb.pre[n]);
+      } else {
+        const cpair x = src[pad16(n)];
+        return s2 > 0 ? cmulw(x, tb.tw[tq * s2]) : x;
       }
-      const cpair x = src[pad16(n)];
-      return s2 > 0 ? cmulw(x, tb.tw[tq * s2]) : x;
     };
     auto store = [&](int t, const cpair& val) {
       const int k = ob + L * t;
-      if (last_to_v) {
+      if constexpr (last_to_v) {
         const cpair r = cmulw(val, tb.post[k]);
         v[2 * k] = r.re;
         v[N - 1 - 2 * k] = make_float2(-r.im.x, -r.im.y);
@@ -492,6 +493,10 @@ __device__ __forceinline__ void wave_pass(const cpair* __restrict__ src, cpair* 
   }
 }
 
+// largest super-radix compiled in: 16 / 15 / 12 take two passes off some sizes but push the kernels past 256 registers
+#ifndef AC_WAVE_MAX_RADIX
+#define AC_WAVE_MAX_RADIX 10
+#endif
 // the super-radices of a size, chosen on the host (lds_wave_plan): their product is N / 2
 struct WavePlan {
   int n;
@@ -513,19 +518,27 @@ __device__ void dct4_wave(float2* v, cpair* Ap, cpair* Bp, const WaveTabs& tb, i
   for (int ps = 0; ps < wp.n; ++ps) {
     const int r = wp.r[ps];
     const bool first = ps == 0, lastv = even && ps == wp.n - 1;
+#define AC_WAVE_PASS(A, B)                                                                   \
+  if (first) wave_pass<A, B, true, false>(src, dst, v, N, L, H, tb, tid, nt);                \
+  else if (lastv) wave_pass<A, B, false, true>(src, dst, v, N, L, H, tb, tid, nt);           \
+  else wave_pass<A, B, false, false>(src, dst, v, N, L, H, tb, tid, nt);                     \
+  break
     switch (r) {
-      case 16: wave_pass<4, 4>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
-      case 15: wave_pass<3, 5>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
-      case 12: wave_pass<4, 3>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
-      case 10: wave_pass<2, 5>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
-      case 9: wave_pass<3, 3>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
-      case 8: wave_pass<4, 2>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
-      case 6: wave_pass<2, 3>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
-      case 5: wave_pass<5, 1>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
-      case 4: wave_pass<4, 1>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
-      case 3: wave_pass<3, 1>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
-      default: wave_pass<2, 1>(src, dst, v, N, L, H, tb, tid, nt, first, lastv); break;
+#if AC_WAVE_MAX_RADIX >= 16
+      case 16: AC_WAVE_PASS(4, 4);
+      case 15: AC_WAVE_PASS(3, 5);
+      case 12: AC_WAVE_PASS(4, 3);
+#endif
+      case 10: AC_WAVE_PASS(2, 5);
+      case 9: AC_WAVE_PASS(3, 3);
+      case 8: AC_WAVE_PASS(4, 2);
+      case 6: AC_WAVE_PASS(2, 3);
+      case 5: AC_WAVE_PASS(5, 1);
+      case 4: AC_WAVE_PASS(4, 1);
+      case 3: AC_WAVE_PASS(3, 1);
+      default: AC_WAVE_PASS(2, 1);
     }
+#undef AC_WAVE_PASS
     wave_sync_lds();
     cpair* t = (ps == 0) ? Bp : src;   // after pass 1 the data is in Ap and Bp (= v, read out) is free
     src = dst;
@@ -1221,15 +1234,18 @@ static int check_grid(long long n) {
 #define AC_LDS_WAVE_MAX 2048   // (0: the workgroup form everywhere, for A/B measurements)
 #endif
 // Which of the two forms serves a size is measured, not derived (profiles/r3/lds_fft_tier_wave_vs_workgroup.txt, B = 64
-// stereo, 10 s): the wave form wins the analysis where one wave has enough butterflies per pass and few passes (N / 2 from
-// 208 to 512: 480 +12 %, 960 +18 %) and at the very small sizes (N <= 64: 2-3 x, several frames share a wave), the workgroup
-// form keeps 96 ... 416 and everything above 1024 (-7 ... -25 % otherwise); the synthesis wins up to N = 1536 (+6 ... +32 %).
-// AC_LDS_WAVE_MAX (tuning hook; 0: the workgroup form everywhere) caps both.
+// stereo, 10 s, same process): the wave form wins the analysis up to filters_n = 1024 (960: 0.272 against 0.364 ms, 480: 0.253
+// against 0.325, 192 / 576: +6 ... +10 %, <= 32: 2-3 x, several frames share a wave) except where a frame gets 16 lanes and
+// three passes (N / 2 from 97 to 127, e.g. 240: -15 %), and loses above (1536 / 1920: -7 %); the synthesis wins up to 1536
+// (960: 0.332 against 0.489 ms, 576: 0.264 against 0.398) and ties at 1920.  AC_LDS_WAVE_MAX (tuning hook; 0: the workgroup
+// form everywhere) caps both, AC_LDS_WAVE_FORCE=1 takes the wave form wherever it exists.
 static bool lds_wave_ok(int N, bool synthesis) {
   static const int wave_max = [] { const char* e = getenv("AC_LDS_WAVE_MAX"); return e ? atoi(e) : AC_LDS_WAVE_MAX; }();
   if (!lds_fft_ok(N) || N > wave_max) return false;
+  static const int force = [] { const char* e = getenv("AC_LDS_WAVE_FORCE"); return e ? atoi(e) : 0; }();   // (A/B measurements)
+  if (force) return true;
   const int H = N / 2;
-  return synthesis ? N <= 1536 : (H <= 32 || (H >= 208 && H <= 512));
+  return synthesis ? N <= 1536 : (N <= 1024 && !(H > 96 && H < 128));
 }
 // super-radices of N / 2 (a pass of radix r runs (N / 2) / r butterflies of r points in registers): the factorisation with
 // the least estimated work -- every pass costs a round trip through LDS, a butterfly ~ r (log2 r + 3) operations, and the
@@ -1270,7 +1286,7 @@ static WavePlan lds_wave_plan(int N) {
       if (depth == 6) return;
       for (int i = 0; i < 11; ++i) {
         const int r = cand[i];
-        if (r > maxr || rem % r) continue;
+        if (r > maxr || r > AC_WAVE_MAX_RADIX || rem % r) continue;
         cur[depth] = r;
         go(rem / r, depth + 1, r, cur, cand, best_cost, best, cost);
       }
