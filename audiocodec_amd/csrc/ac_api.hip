@@ -809,7 +809,7 @@ int ac_stream_run(ac_stream* s, const ac_psy_plan* psy, int nchunks, int k, cons
   // launch as the synthesis of chunk i (k_duplex_fast) -- the two are independent, and a chunk's two dependent launches
   // of ~8 us each are latency, not bandwidth.  (Synthesis on a second HIP stream beside the analysis was measured slower
   // on MI355X: 25-30 us per chunk of 256 stereo frames against 17-20 us -- a cross-stream event hop costs more than
-  // the ~7 us kernel it would hide)  Same kernel bodies: the results equal the chain's.
+  // the ~7 us kernel it would hide; DESIGN_LOG.md section 7.)  Same kernel bodies: the results equal the chain's.
   const ac_mdct_plan* p = s->plan;
   hipStream_t hs = (hipStream_t)stream;
   if (psy) {

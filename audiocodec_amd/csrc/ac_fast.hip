@@ -20,7 +20,7 @@
 //     (spread_mfma: split-bf16 v_mfma_f32_4x4x4_16b_bf16) or as f32 multiply-adds (AC_SPREAD_F32);
 //   * the same kernels take 16-bit PCM (IOF 1) or bfloat16 tensors (IOF 2): the conversion sits in the row loads / stores;
 //   * synthesis carries the aliased half of a frame's DCT-IV in registers along a short strip of output blocks.
-// Frames are dealt to waves in order, so the chip works on one contiguous window of every tensor.
+// Frames are dealt to waves in order, so the chip works on one contiguous window of every tensor (DESIGN_LOG.md section 9).
 //
 // Index maps and their bank behaviour are emulated lane by lane in tests/emulate_wave_fft.py.
 // Reference formulas: mdctransformer.py:62-153 (closed forms in SURVEY.md App. A), psychoacoustic.py:102-210,301-331.
@@ -2385,7 +2385,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_inv_multi(InvMArgs a) {
 // synthesis strips: short, so that the strips in flight cover a nearly contiguous window of memory (HBM rewards that:
 // 0.42 ms at 15 blocks per strip, 0.38 ms at 4 with an extra DCT-IV per strip, 0.355-0.365 ms at 3 with the hand-over
 // between the waves of a workgroup; B = 256, K = 468)
-// (re-measured on well-placed tensors, DESIGN.md 9a: stereo N = 1024 0.343 ms at 2 blocks per strip against 0.352 at 3;
+// (re-measured on well-placed tensors, DESIGN_LOG.md 9a: stereo N = 1024 0.343 ms at 2 blocks per strip against 0.352 at 3;
 // N = 2048 0.373 at 3 against 0.396 at 2; mono N = 1024 0.190 at 3 against 0.197 at 2)
 int pick_seglen(long long pairs, int frames, int preferred) {
   static const int fixed = [] {

@@ -1,4 +1,4 @@
-// ac_workspace_*: device buffers for one encode / decode batch shape, placed for the MI355X's HBM (DESIGN.md, "placement").
+// ac_workspace_*: device buffers for one encode / decode batch shape, placed for the MI355X's HBM (DESIGN.md section 3, "placement").
 //
 // The fused encode streams three tensors side by side (reads x, writes X and thr in lockstep), the decode two (reads X,
 // writes the PCM).  Measured on MI355X: VRAM falls into stretches of 8 ... 64 GiB that belong to a few classes; when the

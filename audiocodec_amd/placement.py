@@ -1,7 +1,7 @@
 """Where the tensors the library allocates live in the MI355X's HBM.
 
 The fused encode writes ``X`` and ``thr`` side by side, the decode reads ``X`` and writes the PCM; when the two tensors a
-kernel streams side by side sit in stretches of VRAM of the same class the kernel runs 10-15 % slower (DESIGN.md,
+kernel streams side by side sit in stretches of VRAM of the same class the kernel runs 10-15 % slower (DESIGN.md section 3,
 "placement": one class takes ~5.5 TB/s of row-per-wave writes, two take 6.9).  A caller that brings its own output tensors
 (``encode_into`` / ``decode_into`` / the C ABI) decides that itself; for the tensors the reference's API makes the LIBRARY
 allocate -- what ``transform``, ``global_masking_threshold``, ``inverse_transform``, ``AudioCodec.encode`` / ``decode``

@@ -1,5 +1,5 @@
 """Caller-owned buffers for one encode / decode batch shape, placed for the MI355X's HBM (the Python face of the C ABI's
-``ac_workspace_*``; see ``include/audiocodec_amd.h`` and DESIGN.md, "placement").
+``ac_workspace_*``; see ``include/audiocodec_amd.h`` and DESIGN.md section 3, "placement").
 
 The fused encode writes the spectrum ``X`` and the threshold ``thr`` side by side, the decode reads ``X`` and writes the
 PCM; when the two tensors a kernel streams side by side lie in stretches of VRAM of the same class the kernel runs 10-15 %

@@ -323,7 +323,7 @@ def run_steps(torch, codec, x, X, t, thr, xh, n, timed=False):
 
 def settle(torch, codec, x, X, t, thr, xh, settle_ms):
     """Keeps the device busy with the step for `settle_ms` (no idle gap longer than a synchronisation).  An MI355X that
-    has idled for more than ~5 ms runs the first ~30 ms of any sustained load at reduced clocks (DESIGN.md section 5,
+    has idled for more than ~5 ms runs the first ~30 ms of any sustained load at reduced clocks (DESIGN_LOG.md section 5a,
     tools/ramp_probe2.py / ramp_probe3.py: steps 3..30 after an idle gap take up to 25 % longer, whatever ran before the
     gap); a warm-up of 5 steps ends in the middle of that.  Returns the number of steps run."""
     if settle_ms <= 0:
@@ -716,7 +716,7 @@ def main():
             except Exception as e:
                 side["encode_api"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if not args.no_workspace and world == 1:
-            # the same step on tensors placed by audiocodec_amd.Workspace, beside the headline
+            # the same step on tensors placed by audiocodec_amd.Workspace (DESIGN_LOG.md 9a), beside the headline
             try:
                 ws = audiocodec_amd.Workspace(codec, B, K, C, device=dev)
                 ws.x.copy_(x)

@@ -279,7 +279,7 @@ AC_API int ac_amplitude_to_db_backward(const float* a, const float* grad_out, fl
 AC_API int ac_add_noise(const float* X, const float* thr, float* out, size_t n, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Placed buffers (see the performance note at the top; DESIGN.md "placement").  ac_workspace_create allocates, straight
+ * Placed buffers (see the performance note at the top).  ac_workspace_create allocates, straight
  * from the HIP runtime, device buffers for batches of B clips x K blocks x C channels of this (mdct, psy) pair:
  *   region A = [copies x (X [B,K+1,N,C] | t [B,K+1,1,C]) | x [B,K*N,C]],   region B = [copies x (thr like X | xhat [B,(K+2)*N,C])]
  * and places region B for the MI355X's HBM: up to max_tries candidate allocations are timed with the fused encode itself

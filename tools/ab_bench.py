@@ -1,5 +1,5 @@
 """A/B of library variants on the SAME tensors in one process (placement varies from process to process by more than most
-kernel changes).  Usage (GPU box):
+kernel changes; see DESIGN_LOG.md 9a).  Usage (GPU box):
     python tools/ab_bench.py [--n 1024] [--clips 256] [--blocks 468] [--rounds 5] name=path.so [name=path.so ...]
 Each variant: its own plans (ac_mdct_plan_create / ac_psy_plan_create), fused encode + decode on shared buffers, device
 settled first, `rounds` interleaved rounds of 20 steps, median per variant; outputs of every variant compared with the

@@ -13,7 +13,7 @@ gt = torch.rand_like(t)
 def timeit(fn, n=10):
     import time
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < 0.1:      # settle the device
+    while time.perf_counter() - t0 < 0.1:      # settle the device (DESIGN_LOG.md 5a)
         fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

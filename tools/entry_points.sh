@@ -2,11 +2,12 @@
 # Timings of every entry point on the bench-sized workloads -> gpurun_out/entry_points.txt (copied to profiles/)
 out=gpurun_out/entry_points.txt
 {
-  echo "(plain torch allocations: the stereo float32 kernels run 5-15 % faster on Workspace-placed tensors, DESIGN.md 9a)"
+  echo "(encode_into on plain torch allocations; transform / inverse / threshold allocate their results: placed by audiocodec_amd/placement.py once a large encode() has run)"
   echo "== N = 1024, B = 256 stereo, K = 468 (tools/microbench.py)"; python tools/microbench.py 2>/dev/null
   echo; echo "== N = 2048, B = 256 stereo, K = 234"; N=2048 python tools/microbench.py 2>/dev/null
   echo; echo "== N = 1024, B = 256 mono, K = 468"; C=1 python tools/microbench.py 2>/dev/null
   echo; echo "== N = 512 (two frames per wave), B = 256 stereo, K = 936"; N=512 python tools/microbench.py 2>/dev/null | sed -n 1,5p
+  echo; echo "== N = 960 (LDS-FFT tier), B = 64 stereo, K = 499"; N=960 B=64 K=499 python tools/microbench.py 2>/dev/null | sed -n 1,5p
   echo; echo "== N = 512, B = 256 mono, K = 936"; N=512 C=1 python tools/microbench.py 2>/dev/null | sed -n 1,5p
   echo; echo "== N = 256 (four frames per wave), B = 256 stereo, K = 1872"; N=256 python tools/microbench.py 2>/dev/null | sed -n 1,5p
   echo; echo "== N = 128 (eight frames per wave), B = 256 stereo, K = 3744"; N=128 python tools/microbench.py 2>/dev/null | sed -n 2,3p

@@ -7,7 +7,7 @@ thr = torch.rand_like(X) * 0.1
 def timeit(fn, n=20):
     import time
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < 0.1:      # settle the device
+    while time.perf_counter() - t0 < 0.1:      # settle the device (DESIGN_LOG.md 5a)
         fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -15,7 +15,7 @@ thr = torch.empty_like(X); xh = torch.empty((B, (K + 2) * N, C), device=dev)
 frames = B * C * K
 
 def timeit(fn, n=20):
-    # (an MI355X that has idled for a few ms runs the first ~30 ms of any load up to 25 % slower, DESIGN.md 5a: keep it
+    # (an MI355X that has idled for a few ms runs the first ~30 ms of any load up to 25 % slower, DESIGN_LOG.md 5a: keep it
     # busy for ~100 ms before the timed launches, as bench.py does)
     t_end = time.perf_counter() + 0.1
     while time.perf_counter() < t_end:

@@ -9,15 +9,16 @@
 #   pmc_short_frames_n256.txt   the same counters for transform / inverse / threshold at filters_n = 256
 #   entry_points.txt            every entry point on bench-sized workloads (tools/entry_points.sh)
 # Copy the directory's files into profiles/rNN afterwards.
-r=${1:-r2}
+r=${1:-r3}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+make -s -C audiocodec_amd/csrc || exit 1   # never build under the profiler
 out=gpurun_out/profile_$r
 mkdir -p $out
 python bench.py --steps 20 --warmup 5 > $out/bench_driver_style.json 2> $out/bench_driver_style.err || exit 1
 echo "driver-style bench done"
 python bench.py --no-cpu-baseline --no-other-configs > $out/bench.json 2> $out/bench.err || exit 1
 echo "default bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-workspace --no-smi > $out/bench_under_rocprof.json 2> $out/trace.log || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-workspace --no-encode-api --no-smi > $out/bench_under_rocprof.json 2> $out/trace.log || exit 1
 cp $out/trace/*/*kernel_stats.csv $out/bench_kernel_stats.csv
 python - $out <<'PY'
 import csv, glob, json, sys, collections
@@ -73,15 +74,28 @@ print(open(out + "/traffic.json").read())
 PY
 # the several-frames-per-wave kernels and the masking model for general band layouts at filters_n = 256: counters + traffic
 {
-  for what in transform inverse psy; do
+  for what in encode transform inverse psy; do
     N=256 tools/pmc.sh $what ${r}_n256_$what > /dev/null 2>&1
     echo "== filters_n = 256, B = 256 stereo, K = 1872: $what (algorithmic bytes per launch: $(python3 -c "
 f = 256 * 2 * 1872
-print({'transform': 2048 * f, 'inverse': 2048 * f, 'psy': 2052 * f}['$what'])"); FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE to be doubled on gfx950)"
+print({'encode': 3076 * f, 'transform': 2048 * f, 'inverse': 2048 * f, 'psy': 2052 * f}['$what'])"); FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE to be doubled on gfx950)"
     cat gpurun_out/pmc_${r}_n256_$what.txt
   done
 } > $out/pmc_short_frames_n256.txt
 echo "pmc short frames done"
+{
+  for what in encode; do
+    N=512 tools/pmc.sh $what ${r}_n512_$what > /dev/null 2>&1
+    echo "== filters_n = 512, B = 256 stereo, K = 936: fused $what (algorithmic bytes per launch: $((6148 * 256 * 2 * 936)))"
+    cat gpurun_out/pmc_${r}_n512_$what.txt
+  done
+  for what in transform inverse; do
+    N=960 B=64 tools/pmc.sh $what ${r}_n960_$what > /dev/null 2>&1
+    echo "== filters_n = 960 (LDS-FFT tier, wave form), B = 64 stereo, K = 499: $what (algorithmic bytes per launch: $((7680 * 64 * 2 * 499)))"
+    cat gpurun_out/pmc_${r}_n960_$what.txt
+  done
+} > $out/pmc_fused_n512_and_lds_fft_n960.txt
+echo "pmc n512 / n960 done"
 tools/entry_points.sh > /dev/null 2>&1; cp gpurun_out/entry_points.txt $out/entry_points.txt
 echo "entry points done"
 ls -la $out

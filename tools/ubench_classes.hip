@@ -1,4 +1,4 @@
-// What about two write streams in one "class" of VRAM stretches is slow?  Maps the classes of a
+// What about two write streams in one "class" of VRAM stretches (DESIGN_LOG.md section 9a) is slow?  Maps the classes of a
 // 160 GiB arena against a stream A at 2 GiB (two-stream write time per 4 GiB step), picks one same-class and one other-class
 // place for B, and times variants of how the two streams are interleaved (design aid, not product).
 // Build: hipcc --offload-arch=gfx950 -O3 tools/ubench_classes.hip -o audiocodec_amd/lib/ubench_classes

@@ -1,6 +1,6 @@
 // Two write streams of 1 GB each, written side by side by one kernel (row i of A, then row i of B, rows dealt to
 // workgroups in order), against where B sits relative to A inside one 160 GiB allocation: the pure form of the placement
-// effect of DESIGN.md section 9a (design aid, not product).
+// effect of DESIGN_LOG.md section 9a (design aid, not product).
 // Build: hipcc --offload-arch=gfx950 -O3 tools/ubench_two_streams.hip -o audiocodec_amd/lib/ubench_two_streams
 #include <hip/hip_runtime.h>
 
