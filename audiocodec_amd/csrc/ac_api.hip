@@ -202,6 +202,21 @@ static int mdct_plan_build(int N, int window, int precompute, const FoldCoef& c,
     for (int j = 0; j < h; ++j) coef64[(size_t)i * h + j] = (*v[i])[j];
   for (size_t i = 0; i < ctab64.size(); ++i) ctab64[i] = std::cos(3.14159265358979323846 * (double)i / (4.0 * N));
   st = upload(coef, &p->d_coef);
+  if (!st && N % 4 == 0) {
+    // per pair of samples (2 i, 2 i + 1), i < N / 4: analysis (a1, a2)(2i), (a1, a2)(2i+1) | (a3, a4)(h-1-2i), (a3, a4)(h-2-2i);
+    // synthesis (behind the N / 2 analysis entries) (s1, s2)(2i), (s1, s2)(2i+1) | (s3, s4)(2i), (s3, s4)(2i+1)
+    std::vector<float> cv(8 * (size_t)h);
+    for (int i = 0; i < h / 2; ++i) {
+      float* f = &cv[8 * (size_t)i];
+      float* g = &cv[4 * (size_t)h + 8 * (size_t)i];
+      const int j = 2 * i, m = h - 1 - 2 * i;
+      f[0] = (float)c.a1[j], f[1] = (float)c.a2[j], f[2] = (float)c.a1[j + 1], f[3] = (float)c.a2[j + 1];
+      f[4] = (float)c.a3[m], f[5] = (float)c.a4[m], f[6] = (float)c.a3[m - 1], f[7] = (float)c.a4[m - 1];
+      g[0] = (float)c.s1[j], g[1] = (float)c.s2[j], g[2] = (float)c.s1[j + 1], g[3] = (float)c.s2[j + 1];
+      g[4] = (float)c.s3[j], g[5] = (float)c.s4[j], g[6] = (float)c.s3[j + 1], g[7] = (float)c.s4[j + 1];
+    }
+    st = upload(cv, &p->d_coefv);
+  }
   if (!st) st = upload(ctab, &p->d_ctab);
   if (!st) st = upload(coef64, &p->d_coef64);
   if (!st) st = upload(ctab64, &p->d_ctab64);
@@ -257,6 +272,7 @@ int ac_mdct_plan_destroy(ac_mdct_plan* p) {
   if (!p) return AC_OK;
   DeviceGuard guard(p->device);
   (void)hipFree(p->d_coef);
+  (void)hipFree(p->d_coefv);
   (void)hipFree(p->d_ctab);
   (void)hipFree(p->d_coef64);
   (void)hipFree(p->d_ctab64);

@@ -439,13 +439,13 @@ struct WaveTabs {
   const float2* pre;   // exp(-i pi (n + 1/4) / N)
   const float2* post;  // exp(-i pi k / N)
 };
-template <int R1, int R2, bool first, bool last_to_v>
+template <int R1, int R2, bool first, bool last_to_v, bool CT = false>
 __device__ __forceinline__ void wave_pass(const cpair* __restrict__ src, cpair* __restrict__ dst, float2* v, int N, int L, int H,
                                           const WaveTabs& tb, int tid, int nt) {
   constexpr int R = R1 * R2;
   const int m = H / (R * L), nb = H / R;
   const unsigned invL = 0xFFFFFFFFu / (unsigned)L + 1u;   // j / L for j < 2^16 as a multiply-high
-  for (int j = tid; j < nb; j += nt) {
+  auto butterfly = [&](int j) {
     const int p = L == 1 ? j : (int)__umulhi((unsigned)j, invL), q = j - p * L;
     const int base = q + L * p, tq = q * m, ob = q + L * R * p, Lm = L * m;
     auto load = [&](int s2) {
@@ -490,6 +490,16 @@ __device__ __forceinline__ void wave_pass(const cpair* __restrict__ src, cpair* 
         for (int k2 = 0; k2 < R2; ++k2) store(k1 + R1 * k2, h[k2]);
       }
     }
+  };
+  if constexpr (CT) {   // N and nt are compile-time constants of the caller: the rounds unroll, the strides fold
+    const int rounds = (nb + nt - 1) / nt;
+#pragma unroll
+    for (int rd = 0; rd < rounds; ++rd) {
+      const int j = tid + rd * nt;
+      if (j < nb) butterfly(j);
+    }
+  } else {
+    for (int j = tid; j < nb; j += nt) butterfly(j);
   }
 }
 
@@ -550,6 +560,50 @@ __device__ void dct4_wave(float2* v, cpair* Ap, cpair* Bp, const WaveTabs& tb, i
       const cpair r = cmulw(src[pad16(k)], tb.post[k]);   // src == Ap here
       v[2 * k] = r.re;
       v[N - 1 - 2 * k] = make_float2(-r.im.x, -r.im.y);
+    }
+    wave_sync_lds();
+  }
+}
+
+// the same with the size, the lanes per frame and the super-radices known at compile time (R3 / R2 = 0: three / two passes):
+// strides, rounds and buffer offsets fold into immediates
+template <int R> struct RadixSplit { static constexpr int A = R, B = 1; };
+template <> struct RadixSplit<16> { static constexpr int A = 4, B = 4; };
+template <> struct RadixSplit<15> { static constexpr int A = 3, B = 5; };
+template <> struct RadixSplit<12> { static constexpr int A = 4, B = 3; };
+template <> struct RadixSplit<10> { static constexpr int A = 2, B = 5; };
+template <> struct RadixSplit<9> { static constexpr int A = 3, B = 3; };
+template <> struct RadixSplit<8> { static constexpr int A = 4, B = 2; };
+template <> struct RadixSplit<6> { static constexpr int A = 2, B = 3; };
+template <int NC, int NTC, int R0, int R1, int R2, int R3>
+__device__ __forceinline__ void dct4_wave_ct(float2* v, cpair* Ap, cpair* Bp, const WaveTabs& tb, int tid) {
+  constexpr int H = NC / 2, NP = 1 + (R1 > 0) + (R2 > 0) + (R3 > 0);
+  static_assert(R0 * (R1 ? R1 : 1) * (R2 ? R2 : 1) * (R3 ? R3 : 1) == H, "the super-radices multiply to N / 2");
+  constexpr bool even = (NP & 1) == 0;
+  // pass 1: v -> Ap; then Ap -> Bp -> Ap ...; an even count ends in v (= Bp's bytes) in final form
+  wave_pass<RadixSplit<R0>::A, RadixSplit<R0>::B, true, false, true>(Bp, Ap, v, NC, 1, H, tb, tid, NTC);
+  wave_sync_lds();
+  if constexpr (NP >= 2) {
+    wave_pass<RadixSplit<R1>::A, RadixSplit<R1>::B, false, NP == 2, true>(Ap, Bp, v, NC, R0, H, tb, tid, NTC);
+    wave_sync_lds();
+  }
+  if constexpr (NP >= 3) {
+    wave_pass<RadixSplit<R2>::A, RadixSplit<R2>::B, false, false, true>(Bp, Ap, v, NC, R0 * R1, H, tb, tid, NTC);
+    wave_sync_lds();
+  }
+  if constexpr (NP >= 4) {
+    wave_pass<RadixSplit<R3>::A, RadixSplit<R3>::B, false, true, true>(Ap, Bp, v, NC, R0 * R1 * R2, H, tb, tid, NTC);
+    wave_sync_lds();
+  }
+  if constexpr (!even) {
+#pragma unroll
+    for (int rd = 0; rd < (H + NTC - 1) / NTC; ++rd) {
+      const int k = tid + rd * NTC;
+      if (k < H) {
+        const cpair r = cmulw(Ap[pad16(k)], tb.post[k]);
+        v[2 * k] = r.re;
+        v[NC - 1 - 2 * k] = make_float2(-r.im.x, -r.im.y);
+      }
     }
     wave_sync_lds();
   }
@@ -778,7 +832,9 @@ static __global__ __launch_bounds__(kThreads, 2) void k_fwd_wave(const TIO* __re
       }
     }
     wave_sync_lds();
+#ifndef AC_T_NODCT
     dct4_wave(v, Ap, Bp, tb, N, tid, nt, wp);
+#endif
     TIO* Xo = X + (((size_t)b * F + (size_t)n) * N) * C + c;
     for (int k = tid; k < N; k += nt) st2(Xo + (size_t)k * C, make_float2(v[k].x * scale, v[k].y * scale), C, has1);
     wave_sync_lds();   // v is read out before the next task folds into it
@@ -847,7 +903,9 @@ static __global__ __launch_bounds__(kThreads, 2) void k_inv_wave(const TIO* __re
       }
     }
     wave_sync_lds();
+#ifndef AC_T_NODCT
     if (has_n) dct4_wave(v, Ap, Bp, tb, N, tid, nt, wp);   // (the DCT-IV of a zero frame is zero)
+#endif
     if (t >= 0) {
       for (int j = tid; j < h; j += nt) {
         const float2 a = make_float2(v[h - 1 - j].x * scale, v[h - 1 - j].y * scale);   // u_n[h-1-j]
@@ -864,6 +922,212 @@ static __global__ __launch_bounds__(kThreads, 2) void k_inv_wave(const TIO* __re
       wave_sync_lds();
     }
     for (int j = tid; j < h; j += nt) um[j] = make_float2(v[h + j].x * scale, v[h + j].y * scale);
+    wave_sync_lds();
+  }
+}
+
+// ---- the wave form for float32 stereo rows (C == 2, N % 4 == 0, N <= 16 nt): 16-byte accesses and every PCM block read ONCE.
+// A lane owns the sample pairs j = 2 i, 2 i + 1 (i = tid + s nt, s < 4) and their mirrors N - 1 - j.  Block n enters frame n
+// through (a1, a2) (second half of the fold) and frame n + 1 through (a3, a4) (first half): with j' = h - 1 - j the second
+// is  v[h - 1 - j] = a3[h - 1 - j] x[j] + a4[h - 1 - j] x[N - 1 - j],  i.e. the SAME two samples the lane already holds, so
+// it is formed at once and carried in registers to the next frame of the strip.  coefv (ac_mdct_plan::d_coefv) holds the
+// coefficients in that order, 16 bytes per lane and step.  The next block's loads are issued before the transform of the
+// current frame and land while it runs.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+constexpr int kWaveVSteps = 4;
+template <int NC, int NTC, int R0, int R1, int R2, int R3>
+static __global__ __launch_bounds__(kThreads, 2) void k_fwd_wave_v(const float* __restrict__ x, float* __restrict__ X,
+                                                          const float* __restrict__ prev_block, const v4f_t* __restrict__ coefv,
+                                                          const float* __restrict__ ctab, int Kin, int F, int N_rt, long long ntasks,
+                                                          int T, int nstrip, WavePlan wp) {
+  float* smem = reinterpret_cast<float*>(smem_raw);
+  const int N = NC ? NC : N_rt, nt = NC ? NTC : wp.nt, gpw = (int)blockDim.x / nt, grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
+  const int per = wave_floats_per_group(N), h = N >> 1, q = N >> 2;
+  float2* tw = reinterpret_cast<float2*>(smem + (size_t)gpw * per);
+  for (int k = threadIdx.x; k < h; k += blockDim.x) {
+    tw[k] = cis_neg(ctab, 16 * k, N);
+    tw[h + k] = cis_neg(ctab, 4 * k + 1, N);
+    tw[2 * h + k] = cis_neg(ctab, 4 * k, N);
+  }
+  __syncthreads();
+  const WaveTabs tb = {tw, tw + h, tw + 2 * h};
+  float* base = smem + (size_t)grp * per;
+  float2* v = reinterpret_cast<float2*>(base);
+  cpair* Bp = reinterpret_cast<cpair*>(base);
+  cpair* Ap = reinterpret_cast<cpair*>(base + 4 * padded_len(h));
+  const float scale = (float)(1.0 / ((double)N * 1.4142135623730951));
+  const long long wg = (long long)blockIdx.x * gpw + grp;
+  if (wg >= ntasks) return;
+  const int sp = (int)(wg % nstrip);
+  const long long b = wg / nstrip;
+  const int n0 = sp * T, n1 = min(n0 + T, F);
+  v4f_t d0[kWaveVSteps], d1[kWaveVSteps], cy[kWaveVSteps];
+  auto load_block = [&](const float* xb) {
+#pragma unroll
+    for (int s = 0; s < kWaveVSteps; ++s) {
+      const int i = tid + s * nt;
+      if (i < q) {
+        d0[s] = *reinterpret_cast<const v4f_t*>(xb + 4 * i);                 // samples 2 i, 2 i + 1
+        d1[s] = *reinterpret_cast<const v4f_t*>(xb + 2 * (N - 2 - 2 * i));   // samples N - 2 - 2 i, N - 1 - 2 i
+      }
+    }
+  };
+  auto carry_of = [&](int s, int i) {   // (v[h - 2 - 2 i], v[h - 1 - 2 i]) of the NEXT frame
+    const v4f_t g = coefv[2 * i + 1];
+    return v4f_t{g.z * d0[s].z + g.w * d1[s].x, g.z * d0[s].w + g.w * d1[s].y, g.x * d0[s].x + g.y * d1[s].z,
+                 g.x * d0[s].y + g.y * d1[s].w};
+  };
+  {
+    const float* xb = n0 >= 1 ? x + ((size_t)b * Kin + (size_t)(n0 - 1)) * N * 2 : prev_block ? prev_block + (size_t)b * N * 2 : nullptr;
+    if (xb) load_block(xb);
+#pragma unroll
+    for (int s = 0; s < kWaveVSteps; ++s) {
+      const int i = tid + s * nt;
+      cy[s] = (xb && i < q) ? carry_of(s, i) : v4f_t{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  if (n0 < Kin) load_block(x + ((size_t)b * Kin + (size_t)n0) * N * 2);
+  for (int n = n0; n < n1; ++n) {
+    const bool has_cur = n < Kin;
+#pragma unroll
+    for (int s = 0; s < kWaveVSteps; ++s) {
+      const int i = tid + s * nt;
+      if (i < q) {
+        v4f_t hi = {0.f, 0.f, 0.f, 0.f};
+        if (has_cur) {
+          const v4f_t f = coefv[2 * i];
+          hi = v4f_t{f.x * d0[s].x + f.y * d1[s].z, f.x * d0[s].y + f.y * d1[s].w, f.z * d0[s].z + f.w * d1[s].x,
+                     f.z * d0[s].w + f.w * d1[s].y};
+        }
+        *reinterpret_cast<v4f_t*>(v + h + 2 * i) = hi;
+        *reinterpret_cast<v4f_t*>(v + h - 2 - 2 * i) = cy[s];
+        if (has_cur) cy[s] = carry_of(s, i);
+      }
+    }
+    if (n + 1 < n1 && n + 1 < Kin) load_block(x + ((size_t)b * Kin + (size_t)(n + 1)) * N * 2);   // lands during the transform
+    wave_sync_lds();
+#ifndef AC_T_NODCT
+    if constexpr (NC != 0) dct4_wave_ct<NC, NTC, R0, R1, R2, R3>(v, Ap, Bp, tb, tid);
+    else dct4_wave(v, Ap, Bp, tb, N, tid, nt, wp);
+#endif
+    float* Xo = X + ((size_t)b * F + (size_t)n) * N * 2;
+#pragma unroll
+    for (int s = 0; s < 2 * kWaveVSteps; ++s) {
+      const int i = tid + s * nt;
+      if (i < h) {
+        const v4f_t r = *reinterpret_cast<const v4f_t*>(v + 2 * i);
+        __builtin_nontemporal_store(r * scale, reinterpret_cast<v4f_t*>(Xo + 4 * i));
+      }
+    }
+    wave_sync_lds();
+  }
+}
+
+// the synthesis in the same form: 16-byte spectrum loads (the next frame's issued before the overlap-add of this one), the
+// two output samples j, N - 1 - j of a lane's pairs as two 16-byte stores
+template <int NC, int NTC, int R0, int R1, int R2, int R3>
+static __global__ __launch_bounds__(kThreads, 2) void k_inv_wave_v(const float* __restrict__ X, float* __restrict__ x,
+                                                          const float* __restrict__ tail_in, float* __restrict__ tail_out,
+                                                          const v4f_t* __restrict__ coefv, const float* __restrict__ ctab, int Kp,
+                                                          int nblk, int seg, int nseg, int N_rt, long long ntasks, WavePlan wp) {
+  float* smem = reinterpret_cast<float*>(smem_raw);
+  const int N = NC ? NC : N_rt, nt = NC ? NTC : wp.nt, gpw = (int)blockDim.x / nt, grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
+  const int h = N >> 1, q = N >> 2, per = wave_floats_per_group(N);
+  float2* tw = reinterpret_cast<float2*>(smem + (size_t)gpw * per);
+  for (int k = threadIdx.x; k < h; k += blockDim.x) {
+    tw[k] = cis_neg(ctab, 16 * k, N);
+    tw[h + k] = cis_neg(ctab, 4 * k + 1, N);
+    tw[2 * h + k] = cis_neg(ctab, 4 * k, N);
+  }
+  __syncthreads();
+  const WaveTabs tb = {tw, tw + h, tw + 2 * h};
+  float* base = smem + (size_t)grp * per;
+  float2* v = reinterpret_cast<float2*>(base);
+  cpair* Bp = reinterpret_cast<cpair*>(base);
+  cpair* Ap = reinterpret_cast<cpair*>(base + 4 * padded_len(h));
+  const long long wg = (long long)blockIdx.x * gpw + grp;
+  if (wg >= ntasks) return;
+  const int sgm = (int)(wg % nseg);
+  const long long b = wg / nseg;
+  const v4f_t* cv = coefv + h;   // the synthesis half of the table
+  const float scale = 2.0f * 1.4142135623730951f;
+  const int nlast = nblk + (tail_out ? 1 : 0);
+  const int n0 = sgm * seg;
+  const size_t ts = (size_t)b * 2 * h;
+  // the aliased half u_{n-1}[h + 2 i], [h + 2 i + 1] of the lane's pairs stays in registers from frame to frame
+  v4f_t um[kWaveVSteps];
+#pragma unroll
+  for (int s = 0; s < kWaveVSteps; ++s) {
+    const int i = tid + s * nt;
+    um[s] = (n0 == 0 && tail_in && i < q) ? v4f_t{tail_in[ts + 2 * i], tail_in[ts + h + 2 * i], tail_in[ts + 2 * i + 1], tail_in[ts + h + 2 * i + 1]}
+                                          : v4f_t{0.f, 0.f, 0.f, 0.f};
+  }
+  v4f_t r[2 * kWaveVSteps];
+  auto frame_ok = [&](int t) { const int n = n0 + t; return t < 0 || (n < Kp && n < nblk); };
+  auto load_frame = [&](int t) {
+    const float* Xi = X + ((size_t)b * Kp + (size_t)(n0 + t)) * N * 2;
+#pragma unroll
+    for (int s = 0; s < 2 * kWaveVSteps; ++s) {
+      const int i = tid + s * nt;
+      if (i < h) r[s] = *reinterpret_cast<const v4f_t*>(Xi + 4 * i);
+    }
+  };
+  const int t0 = n0 >= 1 ? -1 : 0;
+  if (frame_ok(t0)) load_frame(t0);
+  for (int t = t0; t < seg; ++t) {
+    const int n = n0 + t;
+    if (t >= 0 && n >= nlast) break;
+    const bool has_n = frame_ok(t);
+#pragma unroll
+    for (int s = 0; s < 2 * kWaveVSteps; ++s) {
+      const int i = tid + s * nt;
+      if (i < h) *reinterpret_cast<v4f_t*>(v + 2 * i) = has_n ? r[s] : v4f_t{0.f, 0.f, 0.f, 0.f};
+    }
+    {   // the next frame's loads land during the transform and the overlap-add
+      const int tn = t + 1;
+      if (tn < seg && n0 + tn < nlast && frame_ok(tn)) load_frame(tn);
+    }
+    wave_sync_lds();
+#ifndef AC_T_NODCT
+    if (has_n) {
+      if constexpr (NC != 0) dct4_wave_ct<NC, NTC, R0, R1, R2, R3>(v, Ap, Bp, tb, tid);
+      else dct4_wave(v, Ap, Bp, tb, N, tid, nt, wp);
+    }
+#endif
+    if (t >= 0) {
+      if (n < nblk) {
+        float* xo = x + ((size_t)b * nblk + (size_t)n) * N * 2;
+#pragma unroll
+        for (int s = 0; s < kWaveVSteps; ++s) {
+          const int i = tid + s * nt;
+          if (i < q) {
+            const v4f_t A = *reinterpret_cast<const v4f_t*>(v + h - 2 - 2 * i) * scale;   // u_n[h-2-2i], u_n[h-1-2i]
+            const v4f_t Bm = um[s];                                                         // u_{n-1}[h+2i], [h+2i+1]
+            const v4f_t c0 = cv[2 * i], c1 = cv[2 * i + 1];   // (s1, s2)(2i), (s1, s2)(2i+1) | (s3, s4)(2i), (s3, s4)(2i+1)
+            const v4f_t o0 = {c0.x * A.z + c0.y * Bm.x, c0.x * A.w + c0.y * Bm.y, c0.z * A.x + c0.w * Bm.z, c0.z * A.y + c0.w * Bm.w};
+            const v4f_t o1 = {c1.z * A.x + c1.w * Bm.z, c1.z * A.y + c1.w * Bm.w, c1.x * A.z + c1.y * Bm.x, c1.x * A.w + c1.y * Bm.y};
+            __builtin_nontemporal_store(o0, reinterpret_cast<v4f_t*>(xo + 4 * i));
+            __builtin_nontemporal_store(o1, reinterpret_cast<v4f_t*>(xo + 2 * (N - 2 - 2 * i)));
+          }
+        }
+      } else if (tail_out) {
+#pragma unroll
+        for (int s = 0; s < kWaveVSteps; ++s) {
+          const int i = tid + s * nt;
+          if (i < q) {
+            tail_out[ts + 2 * i] = um[s].x;
+            tail_out[ts + h + 2 * i] = um[s].y;
+            tail_out[ts + 2 * i + 1] = um[s].z;
+            tail_out[ts + h + 2 * i + 1] = um[s].w;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < kWaveVSteps; ++s) {
+      const int i = tid + s * nt;
+      if (i < q) um[s] = *reinterpret_cast<const v4f_t*>(v + h + 2 * i) * scale;
+    }
     wave_sync_lds();
   }
 }
@@ -1234,18 +1498,73 @@ static int check_grid(long long n) {
 #define AC_LDS_WAVE_MAX 2048   // (0: the workgroup form everywhere, for A/B measurements)
 #endif
 // Which of the two forms serves a size is measured, not derived (profiles/r3/lds_fft_tier_wave_vs_workgroup.txt, B = 64
-// stereo, 10 s, same process): the wave form wins the analysis up to filters_n = 1024 (960: 0.272 against 0.364 ms, 480: 0.253
-// against 0.325, 192 / 576: +6 ... +10 %, <= 32: 2-3 x, several frames share a wave) except where a frame gets 16 lanes and
-// three passes (N / 2 from 97 to 127, e.g. 240: -15 %), and loses above (1536 / 1920: -7 %); the synthesis wins up to 1536
-// (960: 0.332 against 0.489 ms, 576: 0.264 against 0.398) and ties at 1920.  AC_LDS_WAVE_MAX (tuning hook; 0: the workgroup
-// form everywhere) caps both, AC_LDS_WAVE_FORCE=1 takes the wave form wherever it exists.
-static bool lds_wave_ok(int N, bool synthesis) {
+// stereo, 10 s, same process).  float32 stereo rows with filters_n % 4 == 0 up to 1024 take the 16-byte wave kernels wherever
+// the tier applies (every such size at 2.2 - 6.0 TB/s; the workgroup form 1.3 - 2.0).  Other layouts (mono, more channels,
+// bfloat16) run the 8-byte wave kernels where they measured faster: the analysis up to filters_n = 1024 except where a frame
+// gets 16 lanes and three passes (N / 2 from 97 to 127), the synthesis up to 1536.  AC_LDS_WAVE_MAX (tuning hook; 0: the
+// workgroup form everywhere) caps both, AC_LDS_WAVE_FORCE=1 takes the wave form wherever it exists.
+static bool lds_wave_vec_shape(int N, int C, bool f32) { return f32 && C == 2 && N % 4 == 0 && N <= 1024; }
+static bool lds_wave_ok(int N, bool synthesis, int C, bool f32) {
   static const int wave_max = [] { const char* e = getenv("AC_LDS_WAVE_MAX"); return e ? atoi(e) : AC_LDS_WAVE_MAX; }();
   if (!lds_fft_ok(N) || N > wave_max) return false;
   static const int force = [] { const char* e = getenv("AC_LDS_WAVE_FORCE"); return e ? atoi(e) : 0; }();   // (A/B measurements)
-  if (force) return true;
+  if (force || lds_wave_vec_shape(N, C, f32)) return true;
   const int H = N / 2;
   return synthesis ? N <= 1536 : (N <= 1024 && !(H > 96 && H < 128));
+}
+// Sizes with compile-time instances of the 16-byte kernels: filters_n, lanes per frame, super-radices (every filters_n % 4 == 0
+// up to 1024 with a 5-smooth half that the wave-level kernels of ac_fast.hip do not serve; the plan the search below would
+// pick).  Strides, round counts and buffer offsets fold into immediates: 960 runs 0.156 -> 0.103 ms against the run-time form of
+// the same kernel.  lds_wave_plan returns these plans, so the launch geometry and the instance agree by construction; any
+// other size runs the run-time form.
+#define AC_WAVE_CT_SIZES \
+  AC_WAVE_CT(16, 4, 8, 0, 0, 0) \
+  AC_WAVE_CT(20, 4, 10, 0, 0, 0) \
+  AC_WAVE_CT(24, 4, 4, 3, 0, 0) \
+  AC_WAVE_CT(32, 4, 4, 4, 0, 0) \
+  AC_WAVE_CT(36, 4, 6, 3, 0, 0) \
+  AC_WAVE_CT(40, 4, 5, 4, 0, 0) \
+  AC_WAVE_CT(48, 4, 6, 4, 0, 0) \
+  AC_WAVE_CT(60, 4, 10, 3, 0, 0) \
+  AC_WAVE_CT(72, 4, 9, 4, 0, 0) \
+  AC_WAVE_CT(80, 8, 8, 5, 0, 0) \
+  AC_WAVE_CT(96, 8, 8, 6, 0, 0) \
+  AC_WAVE_CT(100, 8, 10, 5, 0, 0) \
+  AC_WAVE_CT(108, 8, 9, 6, 0, 0) \
+  AC_WAVE_CT(120, 8, 10, 6, 0, 0) \
+  AC_WAVE_CT(144, 16, 9, 8, 0, 0) \
+  AC_WAVE_CT(160, 16, 10, 8, 0, 0) \
+  AC_WAVE_CT(180, 16, 10, 9, 0, 0) \
+  AC_WAVE_CT(192, 16, 8, 6, 2, 0) \
+  AC_WAVE_CT(200, 16, 10, 10, 0, 0) \
+  AC_WAVE_CT(216, 16, 9, 4, 3, 0) \
+  AC_WAVE_CT(240, 16, 8, 5, 3, 0) \
+  AC_WAVE_CT(288, 32, 6, 6, 4, 0) \
+  AC_WAVE_CT(300, 32, 6, 5, 5, 0) \
+  AC_WAVE_CT(320, 32, 8, 5, 4, 0) \
+  AC_WAVE_CT(324, 32, 9, 6, 3, 0) \
+  AC_WAVE_CT(360, 32, 6, 6, 5, 0) \
+  AC_WAVE_CT(384, 32, 8, 6, 4, 0) \
+  AC_WAVE_CT(400, 32, 8, 5, 5, 0) \
+  AC_WAVE_CT(432, 32, 9, 8, 3, 0) \
+  AC_WAVE_CT(480, 32, 10, 8, 3, 0) \
+  AC_WAVE_CT(500, 32, 10, 5, 5, 0) \
+  AC_WAVE_CT(540, 64, 9, 6, 5, 0) \
+  AC_WAVE_CT(576, 64, 8, 6, 6, 0) \
+  AC_WAVE_CT(600, 64, 10, 6, 5, 0) \
+  AC_WAVE_CT(640, 64, 8, 8, 5, 0) \
+  AC_WAVE_CT(648, 64, 9, 6, 6, 0) \
+  AC_WAVE_CT(720, 64, 10, 6, 6, 0) \
+  AC_WAVE_CT(768, 64, 8, 8, 6, 0) \
+  AC_WAVE_CT(800, 64, 10, 8, 5, 0) \
+  AC_WAVE_CT(864, 64, 9, 8, 6, 0) \
+  AC_WAVE_CT(900, 64, 10, 9, 5, 0) \
+  AC_WAVE_CT(960, 64, 10, 8, 6, 0) \
+  AC_WAVE_CT(972, 64, 9, 9, 6, 0) \
+  AC_WAVE_CT(1000, 64, 10, 10, 5, 0)
+static bool wave_ct_off() {
+  static const int off = [] { const char* e = getenv("AC_LDS_WAVE_NOCT"); return e ? atoi(e) : 0; }();   // (A/B measurements)
+  return off != 0;
 }
 // super-radices of N / 2 (a pass of radix r runs (N / 2) / r butterflies of r points in registers): the factorisation with
 // the least estimated work -- every pass costs a round trip through LDS, a butterfly ~ r (log2 r + 3) operations, and the
@@ -1253,6 +1572,15 @@ static bool lds_wave_ok(int N, bool synthesis) {
 static WavePlan lds_wave_plan(int N) {
   const int H = N / 2;
   WavePlan best{};
+#define AC_WAVE_CT(NC, NTC, R0, R1, R2, R3)                                \
+  if (N == NC) {                                                           \
+    best.n = 1 + (R1 > 0) + (R2 > 0) + (R3 > 0);                           \
+    best.r[0] = R0, best.r[1] = R1, best.r[2] = R2, best.r[3] = R3;        \
+    best.nt = NTC;                                                         \
+    return best;                                                           \
+  }
+  AC_WAVE_CT_SIZES
+#undef AC_WAVE_CT
   static const int nt_min = [] { const char* e = getenv("AC_LDS_WAVE_NT_MIN"); return e ? atoi(e) : 4; }();   // tuning hook
   int nt = nt_min < 4 ? 4 : nt_min > 64 ? 64 : nt_min;
   while (nt < 64 && nt < H / 8) nt <<= 1;
@@ -1311,10 +1639,109 @@ static int lds_wave_block(int N, const WavePlan& wp, int extra_floats, size_t* l
   return best_w;
 }
 
+// the 16-byte kernels serve float32 stereo rows whose lanes cover a frame's sample pairs in four steps
+static bool lds_wave_vec_ok(const ac_mdct_plan* p, const WavePlan& wp, int C) {
+  static const int off = [] { const char* e = getenv("AC_LDS_WAVE_NOVEC"); return e ? atoi(e) : 0; }();   // (A/B measurements)
+  return !off && lds_wave_vec_shape(p->N, C, true) && p->d_coefv && p->N / 4 <= kWaveVSteps * wp.nt;
+}
+// frames per strip of the 16-byte kernels: a strip pays `extra` frames' worth of work before its first frame (the block /
+// the transform before it), a launch runs in rounds of as many workgroups as are resident; the least rounds x (frames + extra)
+static int wave_strip(int B, int per_sig, int gpw, int w, size_t lds, int cus, double extra) {
+  static const int t_max = [] { const char* e = getenv("AC_LDS_WAVE_STRIP"); return e ? atoi(e) : 32; }();   // tuning hook
+  const long resident = (long)cus * std::max<long>(1, std::min<long>(160 * 1024 / (long)std::max<size_t>(lds, 1), 8 / w));
+  static const int cand[] = {32, 24, 16, 12, 8, 6, 4, 3, 2, 1};
+  int best = 1;
+  double best_cost = 1e300;
+  for (int seg : cand) {
+    if (seg > t_max && seg > 1) continue;
+    const int len = std::min(seg, per_sig);
+    const long long wgs = ((long long)B * ((per_sig + len - 1) / len) + gpw - 1) / gpw;
+    const double rounds = wgs <= 4 * resident ? (double)((wgs + resident - 1) / resident) : (double)wgs / (double)resident;
+    const double cost = rounds * (len + extra);
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = len;
+    }
+  }
+  return best;
+}
+static int launch_fwd_wave_v(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin, int F,
+                             hipStream_t s) {
+  const WavePlan wp = lds_wave_plan(p->N);
+  size_t lds = 0;
+  const int w = lds_wave_block(p->N, wp, 0, &lds);
+  const int gpw = w * (64 / wp.nt);
+  const int T = wave_strip(B, F, gpw, w, lds, p->cus, 0.25);   // (every strip reads one block more than it has frames)
+  const int nstrip = (F + T - 1) / T;
+  const long long ntasks = (long long)B * nstrip;
+  const long long g = (ntasks + gpw - 1) / gpw;
+  const int st2 = check_grid(g);
+  if (st2) return st2 < 0 ? st2 : AC_OK;
+  int st = AC_OK;
+  bool done = false;
+#define AC_WAVE_CT(NC, NTC, R0, R1, R2, R3)                                                                                   \
+  if (!done && p->N == NC && !wave_ct_off()) {                                                          \
+    done = true;                                                                                                               \
+    st = allow_lds(k_fwd_wave_v<NC, NTC, R0, R1, R2, R3>, lds);                                                                \
+    if (!st)                                                                                                                   \
+      hipLaunchKernelGGL((k_fwd_wave_v<NC, NTC, R0, R1, R2, R3>), dim3((unsigned)g), dim3(64 * w), lds, s, x, X, prev_block,   \
+                         reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kin, F, p->N, ntasks, T, nstrip, wp);          \
+  }
+  AC_WAVE_CT_SIZES
+#undef AC_WAVE_CT
+  if (!done) {
+    st = allow_lds(k_fwd_wave_v<0, 0, 0, 0, 0, 0>, lds);
+    if (!st)
+      hipLaunchKernelGGL((k_fwd_wave_v<0, 0, 0, 0, 0, 0>), dim3((unsigned)g), dim3(64 * w), lds, s, x, X, prev_block,
+                         reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kin, F, p->N, ntasks, T, nstrip, wp);
+  }
+  if (st) return st;
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+static int launch_inv_wave_v(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out, int B,
+                             int Kp, int nblk, hipStream_t s) {
+  const WavePlan wp = lds_wave_plan(p->N);
+  size_t lds = 0;
+  const int w = lds_wave_block(p->N, wp, 0, &lds);
+  const int per_sig = nblk + (tail_out ? 1 : 0);
+  const int gpw = w * (64 / wp.nt);
+  const int seg = wave_strip(B, per_sig, gpw, w, lds, p->cus, 1.0);   // (every strip but a signal's first transforms one frame more)
+  const int nseg = (per_sig + seg - 1) / seg;
+  const long long ntasks = (long long)B * nseg;
+  const long long g = (ntasks + gpw - 1) / gpw;
+  const int st2 = check_grid(g);
+  if (st2) return st2 < 0 ? st2 : AC_OK;
+  int st = AC_OK;
+  bool done = false;
+#define AC_WAVE_CT(NC, NTC, R0, R1, R2, R3)                                                                                   \
+  if (!done && p->N == NC && !wave_ct_off()) {                                                          \
+    done = true;                                                                                                               \
+    st = allow_lds(k_inv_wave_v<NC, NTC, R0, R1, R2, R3>, lds);                                                                \
+    if (!st)                                                                                                                   \
+      hipLaunchKernelGGL((k_inv_wave_v<NC, NTC, R0, R1, R2, R3>), dim3((unsigned)g), dim3(64 * w), lds, s, X, x, tail_in,      \
+                         tail_out, reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kp, nblk, seg, nseg, p->N, ntasks,   \
+                         wp);                                                                                                  \
+  }
+  AC_WAVE_CT_SIZES
+#undef AC_WAVE_CT
+  if (!done) {
+    st = allow_lds(k_inv_wave_v<0, 0, 0, 0, 0, 0>, lds);
+    if (!st)
+      hipLaunchKernelGGL((k_inv_wave_v<0, 0, 0, 0, 0, 0>), dim3((unsigned)g), dim3(64 * w), lds, s, X, x, tail_in, tail_out,
+                         reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kp, nblk, seg, nseg, p->N, ntasks, wp);
+  }
+  if (st) return st;
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
 template <typename TIO>
 static int launch_fwd_wave(const ac_mdct_plan* p, const TIO* x, TIO* X, const TIO* prev_block, int B, int Kin, int F, int C,
                            hipStream_t s) {
   const WavePlan wp = lds_wave_plan(p->N);
+  if constexpr (std::is_same<TIO, float>::value)
+    if (lds_wave_vec_ok(p, wp, C)) return launch_fwd_wave_v(p, x, X, prev_block, B, Kin, F, s);
   size_t lds = 0;
   const int w = lds_wave_block(p->N, wp, 0, &lds);
   const int CP = (C + 1) / 2, gpw = w * (64 / wp.nt);
@@ -1335,6 +1762,8 @@ template <typename TIO>
 static int launch_inv_wave(const ac_mdct_plan* p, const TIO* X, TIO* x, const float* tail_in, float* tail_out, int B, int Kp,
                            int nblk, int C, hipStream_t s) {
   const WavePlan wp = lds_wave_plan(p->N);
+  if constexpr (std::is_same<TIO, float>::value)
+    if (lds_wave_vec_ok(p, wp, C)) return launch_inv_wave_v(p, X, x, tail_in, tail_out, B, Kp, nblk, s);
   size_t lds = 0;
   const int w = lds_wave_block(p->N, wp, p->N, &lds);
   const int per_sig = nblk + (tail_out ? 1 : 0);
@@ -1360,7 +1789,7 @@ int launch_fwd_generic(const ac_mdct_plan* p, const float* x, float* X, const fl
   const long long nwg = (long long)B * C * F;
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
-  if (lds_wave_ok(p->N, false) && !g_force_generic) return launch_fwd_wave<float>(p, x, X, prev_block, B, Kin, F, C, s);
+  if (lds_wave_ok(p->N, false, C, true) && !g_force_generic) return launch_fwd_wave<float>(p, x, X, prev_block, B, Kin, F, C, s);
   if (lds_fft_ok(p->N) && !g_force_generic) {
     const int CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const long long ntasks = (long long)B * CP * F;
@@ -1392,7 +1821,7 @@ int launch_inv_generic(const ac_mdct_plan* p, const float* X, float* x, const fl
   const long long nwg = (long long)B * C * per_sig;
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
-  if (lds_wave_ok(p->N, true) && !g_force_generic) return launch_inv_wave<float>(p, X, x, tail_in, tail_out, B, Kp, nblk, C, s);
+  if (lds_wave_ok(p->N, true, C, true) && !g_force_generic) return launch_inv_wave<float>(p, X, x, tail_in, tail_out, B, Kp, nblk, C, s);
   if (lds_fft_ok(p->N) && !g_force_generic) {
     const int seg = 8, CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const int nseg = (per_sig + seg - 1) / seg;
@@ -1532,7 +1961,7 @@ int launch_fwd_bf16(const ac_mdct_plan* p, const bf16_t* x, bf16_t* X, int B, in
   const long long nwg = (long long)B * C * F;
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
-  if (lds_wave_ok(p->N, false) && !g_force_generic) return launch_fwd_wave<bf16_t>(p, x, X, (const bf16_t*)nullptr, B, Kin, F, C, s);
+  if (lds_wave_ok(p->N, false, C, false) && !g_force_generic) return launch_fwd_wave<bf16_t>(p, x, X, (const bf16_t*)nullptr, B, Kin, F, C, s);
   if (lds_fft_ok(p->N) && !g_force_generic) {
     const int CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const long long ntasks = (long long)B * CP * F;
@@ -1562,7 +1991,7 @@ int launch_inv_bf16(const ac_mdct_plan* p, const bf16_t* X, bf16_t* x, int B, in
   const long long nwg = (long long)B * C * nblk;
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
-  if (lds_wave_ok(p->N, true) && !g_force_generic) return launch_inv_wave<bf16_t>(p, X, x, nullptr, nullptr, B, Kp, nblk, C, s);
+  if (lds_wave_ok(p->N, true, C, false) && !g_force_generic) return launch_inv_wave<bf16_t>(p, X, x, nullptr, nullptr, B, Kp, nblk, C, s);
   if (lds_fft_ok(p->N) && !g_force_generic) {
     const int seg = 8, CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const int nseg = (nblk + seg - 1) / seg;

@@ -106,6 +106,7 @@ struct ac_mdct_plan {
   int adjoint = 0;             // 1: a plan made by ac_mdct_plan_adjoint (the transposed filter bank of another plan)
   ac::FoldCoef coef;           // the plan's fold coefficients (host copy)
   float* d_coef = nullptr;     // [8][N/2]  a1 a2 a3 a4 s1 s2 s3 s4
+  float* d_coefv = nullptr;    // the same coefficients in the order of the 16-byte wave kernels (k_fwd_wave_v / k_inv_wave_v), N % 4 == 0
   float* d_ctab = nullptr;     // [8N]      cos(pi i / (4N)), generic kernels
   double* d_coef64 = nullptr;  // the same two tables in float64 (AC_F64 entry points)
   double* d_ctab64 = nullptr;

@@ -174,6 +174,66 @@ def test_mdct_random_vs_oracle(path, B, K, C, N):
     assert np.max(np.abs(xh - xo)) <= LSB
 
 
+def _smooth_half(N):
+    h = N // 2
+    for r in (2, 3, 5):
+        while h % r == 0:
+            h //= r
+    return h == 1
+
+
+# every filters_n the 16-byte kernels of the LDS-FFT wave tier serve (float32 stereo rows, filters_n % 4 == 0 up to 1024 with
+# a 5-smooth half, beside the powers of two of the wave-level kernels): one compile-time instance each (ac_generic.hip
+# AC_WAVE_CT_SIZES); the reference takes any even filters_n (mdctransformer.py:26)
+WAVE16_SIZES = [N for N in range(16, 1025, 4) if _smooth_half(N) and N not in (64, 128, 256, 512, 1024)]
+
+
+@pytest.mark.parametrize("N", WAVE16_SIZES)
+def test_lds_fft_wave_16_byte_kernels_every_size(N):
+    """Strips longer and shorter than the kernels' strip length (32 frames at most), two signals, against the fp64 oracle:
+    analysis, synthesis incl. the aliased head / tail blocks, and the round trip to 1 LSB."""
+    rng = np.random.default_rng(N)
+    B, K, C = 2, (70 if N <= 128 else 37 if N <= 480 else 11), 2
+    x = rng.uniform(-1, 1, (B, K * N, C)).astype(np.float32)
+    m = audiocodec_amd.MDCTransformer(N)
+    o = MDCTOracle(N, "vorbis", np.float64)
+    X = host(m.transform(dev(x)))
+    Xo = o.transform(x.astype(np.float64))
+    assert rel_peak(X, Xo) <= TOL and rel_l2(X, Xo) <= TOL
+    xh = host(m.inverse_transform(dev(X)))
+    assert np.max(np.abs(xh[:, N:-N] - x)) <= LSB
+    assert np.max(np.abs(xh - o.inverse_transform(Xo))) <= LSB
+
+
+def test_lds_fft_wave_16_byte_kernels_run_time_form(tmp_path):
+    """The same kernels with the size as a run-time argument (AC_LDS_WAVE_NOCT=1, the A/B reference of the compile-time
+    instances) agree with the instances to float32 rounding (the compiler contracts the two forms differently)."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    sizes = (960, 480, 120, 48, 16)
+    code = ("import sys, numpy as np, torch, audiocodec_amd\n"
+            "out = {}\n"
+            "for N in %r:\n"
+            "    g = torch.Generator(device='cuda').manual_seed(N)\n"
+            "    x = torch.empty(2, 35 * N, 2, device='cuda').uniform_(-1, 1, generator=g)\n"
+            "    m = audiocodec_amd.MDCTransformer(N)\n"
+            "    X = m.transform(x)\n"
+            "    out['X%%d' %% N] = X.cpu().numpy()\n"
+            "    out['y%%d' %% N] = m.inverse_transform(X).cpu().numpy()\n"
+            "np.savez(sys.argv[1], **out)\n" % (sizes,))
+    got = []
+    for noct in ("0", "1"):
+        f = str(tmp_path / ("noct%s.npz" % noct))
+        r = subprocess.run([sys.executable, "-c", code, f], cwd=ROOT, env=dict(os.environ, AC_LDS_WAVE_NOCT=noct),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got.append(np.load(f))
+    for N in sizes:
+        for k in ("X%d" % N, "y%d" % N):
+            a, b = got[0][k], got[1][k]
+            assert np.max(np.abs(a - b)) <= 2e-6 * np.max(np.abs(a)), k
+
+
 def test_int16_pcm_round_trip_exact(path):
     """PCM that came from int16 survives encode -> decode bit-exactly after re-quantisation."""
     rng = np.random.default_rng(7)
@@ -468,7 +528,9 @@ def test_db_and_noise(golden, path):
 
 @pytest.mark.parametrize("N,C,chunks", [(1024, 2, (3, 1, 4, 2)), (256, 1, (2, 2, 5)), (1024, 1, (5, 3)), (960, 2, (2, 3, 1)),
                                         (2048, 2, (2, 5, 1)), (128, 2, (3, 9, 1, 4)), (128, 1, (11, 2)), (512, 2, (1, 3, 2)),
-                                        (64, 2, (5, 17, 1, 16)), (64, 1, (33, 2))])
+                                        (64, 2, (5, 17, 1, 16)), (64, 1, (33, 2)),
+                                        # strips of the 16-byte LDS-FFT wave kernels: longer / shorter than a strip, state in and out
+                                        (480, 2, (40, 3, 1)), (120, 2, (70, 1)), (16, 2, (100, 3)), (48, 2, (5,)), (960, 2, (33,))])
 def test_streaming_equals_one_shot(path, N, C, chunks):
     B, K = 2, sum(chunks)
     x = torch.rand(B, K * N, C, device="cuda") * 2 - 1

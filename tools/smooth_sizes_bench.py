@@ -9,7 +9,7 @@ def timeit(fn, n=5):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-for N in (960, 480, 240, 120, 576, 1920, 1536, 192, 4096, 32, 16):
+for N in [int(v) for v in os.environ.get("SIZES", "960,480,240,120,576,1920,1536,192,4096,32,16").split(",")]:
     B, C = 64, 2
     K = 468 * 1024 // N
     x = torch.rand(B, K * N, C, device="cuda") * 2 - 1
