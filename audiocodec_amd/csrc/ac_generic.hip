@@ -609,8 +609,94 @@ __device__ __forceinline__ void dct4_wave_ct(float2* v, cpair* Ap, cpair* Bp, co
   }
 }
 
-// LDS floats per frame of the wave form: Bp (= v) and Ap, padded
+// ---- the same passes for a frame dealt to NTC = 128 / 256 lanes (two / four waves: filters_n above 1024), IN PLACE in one
+// padded buffer that shares the bytes of v: a pass loads and transforms all its butterflies in registers (one or two per
+// lane), the group synchronises, then the outputs go back.  8.5 N bytes of LDS per frame; the pre-twiddles are formed from
+// the post-twiddle table (exp(-i pi (n + 1/4) / N) = post[n] exp(-i pi / (4 N))): two tables beside the frame, so that
+// filters_n = 4096 keeps two workgroups (eight waves) per CU.
+template <int NTC>
+__device__ __forceinline__ void group_sync() {
+  if constexpr (NTC > 64) __syncthreads();
+  else wave_sync_lds();
+}
+template <int NC, int NTC, int L, int R, bool first, bool last_to_v>
+__device__ __forceinline__ void group_pass(cpair* buf, float2* v, const WaveTabs& tb, float2 pre0, int tid) {
+  constexpr int R1 = RadixSplit<R>::A, R2 = RadixSplit<R>::B;
+  constexpr int H = NC / 2, m = H / (R * L), nb = H / R, Lm = L * m, rounds = (nb + NTC - 1) / NTC;
+  cpair out[rounds][R];
+#pragma unroll
+  for (int rd = 0; rd < rounds; ++rd) {
+    const int j = tid + rd * NTC;
+    if (j < nb) {
+      const int p = j / L, q = j - p * L;
+      const int base = q + L * p, tq = q * m;
+      auto load = [&](int s2) {
+        const int n = base + Lm * s2;
+        if constexpr (first) {
+          cpair t;
+          t.re = v[2 * n];
+          t.im = v[NC - 1 - 2 * n];
+          const float2 w = tb.post[n];
+          return cmulw(t, make_float2(w.x * pre0.x - w.y * pre0.y, w.x * pre0.y + w.y * pre0.x));
+        } else {
+          const cpair x = buf[pad16(n)];
+          return s2 > 0 ? cmulw(x, tb.tw[tq * s2]) : x;
+        }
+      };
+      if constexpr (R2 == 1) {
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) out[rd][n1] = load(n1);
+        dft_small<R1>(out[rd]);
+      } else {
+        cpair y[R];
+        Stage1<R1, R2, R2 - 1>::run(load, y);
+#pragma unroll
+        for (int k1 = 0; k1 < R1; ++k1) {
+          cpair h[R2];
+#pragma unroll
+          for (int n2 = 0; n2 < R2; ++n2) h[n2] = y[k1 * R2 + n2];
+          dft_small<R2>(h);
+#pragma unroll
+          for (int k2 = 0; k2 < R2; ++k2) out[rd][k1 + R1 * k2] = h[k2];
+        }
+      }
+    }
+  }
+  group_sync<NTC>();
+#pragma unroll
+  for (int rd = 0; rd < rounds; ++rd) {
+    const int j = tid + rd * NTC;
+    if (j < nb) {
+      const int p = j / L, q = j - p * L, ob = q + L * R * p;
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        const int k = ob + L * t;
+        if constexpr (last_to_v) {
+          const cpair r = cmulw(out[rd][t], tb.post[k]);
+          v[2 * k] = r.re;
+          v[NC - 1 - 2 * k] = make_float2(-r.im.x, -r.im.y);
+        } else {
+          buf[pad16(k)] = out[rd][t];
+        }
+      }
+    }
+  }
+  group_sync<NTC>();
+}
+template <int NC, int NTC, int R0, int R1, int R2, int R3>
+__device__ __forceinline__ void dct4_group_ct(float2* v, cpair* buf, const WaveTabs& tb, float2 pre0, int tid) {
+  constexpr int H = NC / 2, NP = 1 + (R1 > 0) + (R2 > 0) + (R3 > 0);
+  static_assert(R0 * (R1 ? R1 : 1) * (R2 ? R2 : 1) * (R3 ? R3 : 1) == H, "the super-radices multiply to N / 2");
+  static_assert(NP >= 2, "at least two passes (the first reads v, the last writes it)");
+  group_pass<NC, NTC, 1, R0, true, false>(buf, v, tb, pre0, tid);
+  group_pass<NC, NTC, R0, R1, false, NP == 2>(buf, v, tb, pre0, tid);
+  if constexpr (NP >= 3) group_pass<NC, NTC, R0 * R1, R2, false, NP == 3>(buf, v, tb, pre0, tid);
+  if constexpr (NP >= 4) group_pass<NC, NTC, R0 * R1 * R2, R3, false, true>(buf, v, tb, pre0, tid);
+}
+
+// LDS floats per frame of the wave form: Bp (= v) and Ap, padded; of the in-place form above: one buffer
 static inline __host__ __device__ int wave_floats_per_group(int N) { return 2 * 4 * padded_len(N / 2); }
+static inline __host__ __device__ int group_floats_per_frame(int N) { return 4 * padded_len(N / 2); }
 
 // the FFT's twiddles exp(-2 pi i k / (N/2)), k < N/2, once per workgroup into LDS (every thread takes part; the caller
 // synchronises before the first use)
@@ -942,15 +1028,17 @@ static __global__ __launch_bounds__(kThreads, 2) void k_fwd_wave_v(const float* 
                                                           int T, int nstrip, WavePlan wp) {
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int N = NC ? NC : N_rt, nt = NC ? NTC : wp.nt, gpw = (int)blockDim.x / nt, grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
-  const int per = wave_floats_per_group(N), h = N >> 1, q = N >> 2;
+  constexpr bool GRP = NTC > 64;   // one frame per workgroup of NTC lanes, transformed in place
+  const int per = GRP ? group_floats_per_frame(N) : wave_floats_per_group(N), h = N >> 1, q = N >> 2;
   float2* tw = reinterpret_cast<float2*>(smem + (size_t)gpw * per);
   for (int k = threadIdx.x; k < h; k += blockDim.x) {
     tw[k] = cis_neg(ctab, 16 * k, N);
-    tw[h + k] = cis_neg(ctab, 4 * k + 1, N);
-    tw[2 * h + k] = cis_neg(ctab, 4 * k, N);
+    tw[h + k] = cis_neg(ctab, 4 * k, N);
+    if constexpr (!GRP) tw[2 * h + k] = cis_neg(ctab, 4 * k + 1, N);
   }
   __syncthreads();
-  const WaveTabs tb = {tw, tw + h, tw + 2 * h};
+  const WaveTabs tb = {tw, tw + 2 * h, tw + h};   // (the in-place form has no pre-twiddle table)
+  const float2 pre0 = cis_neg(ctab, 1, N);        // exp(-i pi / (4 N))
   float* base = smem + (size_t)grp * per;
   float2* v = reinterpret_cast<float2*>(base);
   cpair* Bp = reinterpret_cast<cpair*>(base);
@@ -1005,9 +1093,10 @@ static __global__ __launch_bounds__(kThreads, 2) void k_fwd_wave_v(const float* 
       }
     }
     if (n + 1 < n1 && n + 1 < Kin) load_block(x + ((size_t)b * Kin + (size_t)(n + 1)) * N * 2);   // lands during the transform
-    wave_sync_lds();
+    group_sync<NTC>();
 #ifndef AC_T_NODCT
-    if constexpr (NC != 0) dct4_wave_ct<NC, NTC, R0, R1, R2, R3>(v, Ap, Bp, tb, tid);
+    if constexpr (GRP) dct4_group_ct<NC, NTC, R0, R1, R2, R3>(v, Bp, tb, pre0, tid);
+    else if constexpr (NC != 0) dct4_wave_ct<NC, NTC, R0, R1, R2, R3>(v, Ap, Bp, tb, tid);
     else dct4_wave(v, Ap, Bp, tb, N, tid, nt, wp);
 #endif
     float* Xo = X + ((size_t)b * F + (size_t)n) * N * 2;
@@ -1019,7 +1108,7 @@ static __global__ __launch_bounds__(kThreads, 2) void k_fwd_wave_v(const float* 
         __builtin_nontemporal_store(r * scale, reinterpret_cast<v4f_t*>(Xo + 4 * i));
       }
     }
-    wave_sync_lds();
+    group_sync<NTC>();
   }
 }
 
@@ -1032,15 +1121,17 @@ static __global__ __launch_bounds__(kThreads, 2) void k_inv_wave_v(const float* 
                                                           int nblk, int seg, int nseg, int N_rt, long long ntasks, WavePlan wp) {
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int N = NC ? NC : N_rt, nt = NC ? NTC : wp.nt, gpw = (int)blockDim.x / nt, grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
-  const int h = N >> 1, q = N >> 2, per = wave_floats_per_group(N);
+  constexpr bool GRP = NTC > 64;
+  const int h = N >> 1, q = N >> 2, per = GRP ? group_floats_per_frame(N) : wave_floats_per_group(N);
   float2* tw = reinterpret_cast<float2*>(smem + (size_t)gpw * per);
   for (int k = threadIdx.x; k < h; k += blockDim.x) {
     tw[k] = cis_neg(ctab, 16 * k, N);
-    tw[h + k] = cis_neg(ctab, 4 * k + 1, N);
-    tw[2 * h + k] = cis_neg(ctab, 4 * k, N);
+    tw[h + k] = cis_neg(ctab, 4 * k, N);
+    if constexpr (!GRP) tw[2 * h + k] = cis_neg(ctab, 4 * k + 1, N);
   }
   __syncthreads();
-  const WaveTabs tb = {tw, tw + h, tw + 2 * h};
+  const WaveTabs tb = {tw, tw + 2 * h, tw + h};   // (the in-place form has no pre-twiddle table)
+  const float2 pre0 = cis_neg(ctab, 1, N);        // exp(-i pi / (4 N))
   float* base = smem + (size_t)grp * per;
   float2* v = reinterpret_cast<float2*>(base);
   cpair* Bp = reinterpret_cast<cpair*>(base);
@@ -1087,10 +1178,11 @@ static __global__ __launch_bounds__(kThreads, 2) void k_inv_wave_v(const float* 
       const int tn = t + 1;
       if (tn < seg && n0 + tn < nlast && frame_ok(tn)) load_frame(tn);
     }
-    wave_sync_lds();
+    group_sync<NTC>();
 #ifndef AC_T_NODCT
     if (has_n) {
-      if constexpr (NC != 0) dct4_wave_ct<NC, NTC, R0, R1, R2, R3>(v, Ap, Bp, tb, tid);
+      if constexpr (GRP) dct4_group_ct<NC, NTC, R0, R1, R2, R3>(v, Bp, tb, pre0, tid);
+      else if constexpr (NC != 0) dct4_wave_ct<NC, NTC, R0, R1, R2, R3>(v, Ap, Bp, tb, tid);
       else dct4_wave(v, Ap, Bp, tb, N, tid, nt, wp);
     }
 #endif
@@ -1128,7 +1220,7 @@ static __global__ __launch_bounds__(kThreads, 2) void k_inv_wave_v(const float* 
       const int i = tid + s * nt;
       if (i < q) um[s] = *reinterpret_cast<const v4f_t*>(v + h + 2 * i) * scale;
     }
-    wave_sync_lds();
+    group_sync<NTC>();
   }
 }
 
@@ -1503,12 +1595,17 @@ static int check_grid(long long n) {
 // bfloat16) run the 8-byte wave kernels where they measured faster: the analysis up to filters_n = 1024 except where a frame
 // gets 16 lanes and three passes (N / 2 from 97 to 127), the synthesis up to 1536.  AC_LDS_WAVE_MAX (tuning hook; 0: the
 // workgroup form everywhere) caps both, AC_LDS_WAVE_FORCE=1 takes the wave form wherever it exists.
-static bool lds_wave_vec_shape(int N, int C, bool f32) { return f32 && C == 2 && N % 4 == 0 && N <= 1024; }
+static bool lds_wave_ct_size(int N);
+static bool lds_wave_vec_shape(int N, int C, bool f32) {
+  return f32 && C == 2 && N % 4 == 0 && (N <= 1024 || lds_wave_ct_size(N));   // (above 1024: the in-place instances only)
+}
 static bool lds_wave_ok(int N, bool synthesis, int C, bool f32) {
   static const int wave_max = [] { const char* e = getenv("AC_LDS_WAVE_MAX"); return e ? atoi(e) : AC_LDS_WAVE_MAX; }();
-  if (!lds_fft_ok(N) || N > wave_max) return false;
+  if (!lds_fft_ok(N) || wave_max <= 0) return false;
+  if (lds_wave_vec_shape(N, C, f32)) return true;
+  if (N > wave_max) return false;
   static const int force = [] { const char* e = getenv("AC_LDS_WAVE_FORCE"); return e ? atoi(e) : 0; }();   // (A/B measurements)
-  if (force || lds_wave_vec_shape(N, C, f32)) return true;
+  if (force) return true;
   const int H = N / 2;
   return synthesis ? N <= 1536 : (N <= 1024 && !(H > 96 && H < 128));
 }
@@ -1561,7 +1658,48 @@ static bool lds_wave_ok(int N, bool synthesis, int C, bool f32) {
   AC_WAVE_CT(900, 64, 10, 9, 5, 0) \
   AC_WAVE_CT(960, 64, 10, 8, 6, 0) \
   AC_WAVE_CT(972, 64, 9, 9, 6, 0) \
-  AC_WAVE_CT(1000, 64, 10, 10, 5, 0)
+  AC_WAVE_CT(1000, 64, 10, 10, 5, 0) \
+  AC_WAVE_CT(1080, 128, 10, 9, 6, 0) \
+  AC_WAVE_CT(1152, 128, 9, 8, 8, 0) \
+  AC_WAVE_CT(1200, 128, 10, 10, 6, 0) \
+  AC_WAVE_CT(1280, 128, 10, 8, 8, 0) \
+  AC_WAVE_CT(1296, 128, 9, 9, 8, 0) \
+  AC_WAVE_CT(1440, 128, 10, 9, 8, 0) \
+  AC_WAVE_CT(1500, 128, 6, 5, 5, 5) \
+  AC_WAVE_CT(1536, 128, 8, 8, 6, 2) \
+  AC_WAVE_CT(1600, 128, 10, 10, 8, 0) \
+  AC_WAVE_CT(1620, 128, 10, 9, 9, 0) \
+  AC_WAVE_CT(1728, 128, 9, 8, 4, 3) \
+  AC_WAVE_CT(1800, 128, 10, 10, 9, 0) \
+  AC_WAVE_CT(1920, 128, 8, 8, 5, 3) \
+  AC_WAVE_CT(1944, 128, 9, 9, 4, 3) \
+  AC_WAVE_CT(2000, 128, 10, 10, 10, 0) \
+  AC_WAVE_CT(2160, 256, 6, 6, 6, 5) \
+  AC_WAVE_CT(2304, 256, 8, 6, 6, 4) \
+  AC_WAVE_CT(2400, 256, 8, 6, 5, 5) \
+  AC_WAVE_CT(2500, 256, 10, 5, 5, 5) \
+  AC_WAVE_CT(2560, 256, 8, 8, 5, 4) \
+  AC_WAVE_CT(2592, 256, 6, 6, 6, 6) \
+  AC_WAVE_CT(2700, 256, 9, 6, 5, 5) \
+  AC_WAVE_CT(2880, 256, 8, 6, 6, 5) \
+  AC_WAVE_CT(2916, 256, 9, 9, 6, 3) \
+  AC_WAVE_CT(3000, 256, 10, 6, 5, 5) \
+  AC_WAVE_CT(3072, 256, 8, 8, 6, 4) \
+  AC_WAVE_CT(3200, 256, 8, 8, 5, 5) \
+  AC_WAVE_CT(3240, 256, 9, 9, 5, 4) \
+  AC_WAVE_CT(3456, 256, 9, 8, 8, 3) \
+  AC_WAVE_CT(3600, 256, 9, 8, 5, 5) \
+  AC_WAVE_CT(3840, 256, 10, 8, 8, 3) \
+  AC_WAVE_CT(3888, 256, 9, 9, 8, 3) \
+  AC_WAVE_CT(4000, 256, 10, 8, 5, 5) \
+  AC_WAVE_CT(4096, 256, 8, 8, 8, 4)
+static bool lds_wave_ct_size(int N) {
+#define AC_WAVE_CT(NC, NTC, R0, R1, R2, R3) \
+  if (N == NC) return true;
+  AC_WAVE_CT_SIZES
+#undef AC_WAVE_CT
+  return false;
+}
 static bool wave_ct_off() {
   static const int off = [] { const char* e = getenv("AC_LDS_WAVE_NOCT"); return e ? atoi(e) : 0; }();   // (A/B measurements)
   return off != 0;
@@ -1569,11 +1707,11 @@ static bool wave_ct_off() {
 // super-radices of N / 2 (a pass of radix r runs (N / 2) / r butterflies of r points in registers): the factorisation with
 // the least estimated work -- every pass costs a round trip through LDS, a butterfly ~ r (log2 r + 3) operations, and the
 // butterflies of a pass are dealt to nt lanes
-static WavePlan lds_wave_plan(int N) {
+static WavePlan lds_wave_plan(int N, bool groups = true) {   // groups: frames dealt to more than one wave allowed (the 16-byte kernels)
   const int H = N / 2;
   WavePlan best{};
 #define AC_WAVE_CT(NC, NTC, R0, R1, R2, R3)                                \
-  if (N == NC) {                                                           \
+  if (N == NC && (groups || NTC <= 64)) {                                  \
     best.n = 1 + (R1 > 0) + (R2 > 0) + (R3 > 0);                           \
     best.r[0] = R0, best.r[1] = R1, best.r[2] = R2, best.r[3] = R3;        \
     best.nt = NTC;                                                         \
@@ -1642,7 +1780,7 @@ static int lds_wave_block(int N, const WavePlan& wp, int extra_floats, size_t* l
 // the 16-byte kernels serve float32 stereo rows whose lanes cover a frame's sample pairs in four steps
 static bool lds_wave_vec_ok(const ac_mdct_plan* p, const WavePlan& wp, int C) {
   static const int off = [] { const char* e = getenv("AC_LDS_WAVE_NOVEC"); return e ? atoi(e) : 0; }();   // (A/B measurements)
-  return !off && lds_wave_vec_shape(p->N, C, true) && p->d_coefv && p->N / 4 <= kWaveVSteps * wp.nt;
+  return !off && lds_wave_vec_shape(p->N, C, true) && p->d_coefv && p->N / 4 <= kWaveVSteps * wp.nt && !(wp.nt > 64 && wave_ct_off());
 }
 // frames per strip of the 16-byte kernels: a strip pays `extra` frames' worth of work before its first frame (the block /
 // the transform before it), a launch runs in rounds of as many workgroups as are resident; the least rounds x (frames + extra)
@@ -1665,12 +1803,24 @@ static int wave_strip(int B, int per_sig, int gpw, int w, size_t lds, int cus, d
   }
   return best;
 }
+// waves per workgroup, frames per workgroup and LDS bytes of the 16-byte kernels: the wave form packs frames as lds_wave_block
+// says; a frame on more than one wave (in place) is a workgroup of its own with two tables behind its buffer
+static void wave_v_geometry(int N, const WavePlan& wp, int* w, int* gpw, size_t* lds) {
+  if (wp.nt > 64) {
+    *w = wp.nt / 64;
+    *gpw = 1;
+    *lds = ((size_t)group_floats_per_frame(N) + 2 * (size_t)N) * sizeof(float);
+  } else {
+    *w = lds_wave_block(N, wp, 0, lds);
+    *gpw = *w * (64 / wp.nt);
+  }
+}
 static int launch_fwd_wave_v(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin, int F,
                              hipStream_t s) {
   const WavePlan wp = lds_wave_plan(p->N);
   size_t lds = 0;
-  const int w = lds_wave_block(p->N, wp, 0, &lds);
-  const int gpw = w * (64 / wp.nt);
+  int w = 1, gpw = 1;
+  wave_v_geometry(p->N, wp, &w, &gpw, &lds);
   const int T = wave_strip(B, F, gpw, w, lds, p->cus, 0.25);   // (every strip reads one block more than it has frames)
   const int nstrip = (F + T - 1) / T;
   const long long ntasks = (long long)B * nstrip;
@@ -1703,9 +1853,9 @@ static int launch_inv_wave_v(const ac_mdct_plan* p, const float* X, float* x, co
                              int Kp, int nblk, hipStream_t s) {
   const WavePlan wp = lds_wave_plan(p->N);
   size_t lds = 0;
-  const int w = lds_wave_block(p->N, wp, 0, &lds);
+  int w = 1, gpw = 1;
+  wave_v_geometry(p->N, wp, &w, &gpw, &lds);
   const int per_sig = nblk + (tail_out ? 1 : 0);
-  const int gpw = w * (64 / wp.nt);
   const int seg = wave_strip(B, per_sig, gpw, w, lds, p->cus, 1.0);   // (every strip but a signal's first transforms one frame more)
   const int nseg = (per_sig + seg - 1) / seg;
   const long long ntasks = (long long)B * nseg;
@@ -1739,9 +1889,10 @@ static int launch_inv_wave_v(const ac_mdct_plan* p, const float* X, float* x, co
 template <typename TIO>
 static int launch_fwd_wave(const ac_mdct_plan* p, const TIO* x, TIO* X, const TIO* prev_block, int B, int Kin, int F, int C,
                            hipStream_t s) {
-  const WavePlan wp = lds_wave_plan(p->N);
+  const WavePlan wp0 = lds_wave_plan(p->N);
   if constexpr (std::is_same<TIO, float>::value)
-    if (lds_wave_vec_ok(p, wp, C)) return launch_fwd_wave_v(p, x, X, prev_block, B, Kin, F, s);
+    if (lds_wave_vec_ok(p, wp0, C)) return launch_fwd_wave_v(p, x, X, prev_block, B, Kin, F, s);
+  const WavePlan wp = lds_wave_plan(p->N, false);
   size_t lds = 0;
   const int w = lds_wave_block(p->N, wp, 0, &lds);
   const int CP = (C + 1) / 2, gpw = w * (64 / wp.nt);
@@ -1761,9 +1912,10 @@ static int launch_fwd_wave(const ac_mdct_plan* p, const TIO* x, TIO* X, const TI
 template <typename TIO>
 static int launch_inv_wave(const ac_mdct_plan* p, const TIO* X, TIO* x, const float* tail_in, float* tail_out, int B, int Kp,
                            int nblk, int C, hipStream_t s) {
-  const WavePlan wp = lds_wave_plan(p->N);
+  const WavePlan wp0 = lds_wave_plan(p->N);
   if constexpr (std::is_same<TIO, float>::value)
-    if (lds_wave_vec_ok(p, wp, C)) return launch_inv_wave_v(p, X, x, tail_in, tail_out, B, Kp, nblk, s);
+    if (lds_wave_vec_ok(p, wp0, C)) return launch_inv_wave_v(p, X, x, tail_in, tail_out, B, Kp, nblk, s);
+  const WavePlan wp = lds_wave_plan(p->N, false);
   size_t lds = 0;
   const int w = lds_wave_block(p->N, wp, p->N, &lds);
   const int per_sig = nblk + (tail_out ? 1 : 0);
