@@ -1012,20 +1012,60 @@ static __global__ __launch_bounds__(kThreads, 2) void k_inv_wave(const TIO* __re
   }
 }
 
-// ---- the wave form for float32 stereo rows (C == 2, N % 4 == 0, N <= 16 nt): 16-byte accesses and every PCM block read ONCE.
+// ---- the 16-byte kernels of the tier (float32, N % 4 == 0, N <= 16 nt): wide accesses and every PCM block read ONCE.
 // A lane owns the sample pairs j = 2 i, 2 i + 1 (i = tid + s nt, s < 4) and their mirrors N - 1 - j.  Block n enters frame n
 // through (a1, a2) (second half of the fold) and frame n + 1 through (a3, a4) (first half): with j' = h - 1 - j the second
 // is  v[h - 1 - j] = a3[h - 1 - j] x[j] + a4[h - 1 - j] x[N - 1 - j],  i.e. the SAME two samples the lane already holds, so
 // it is formed at once and carried in registers to the next frame of the strip.  coefv (ac_mdct_plan::d_coefv) holds the
 // coefficients in that order, 16 bytes per lane and step.  The next block's loads are issued before the transform of the
 // current frame and land while it runs.
+// The two rows a complex pair carries through the transform: the channels of a stereo signal (one 16-byte access per two
+// samples) or, MONO, two mono signals b, b + 1 (8 bytes each; the last pair of an odd batch is half empty).  Other channel
+// counts run the 8-byte kernels above.
 typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef float v2f_t __attribute__((ext_vector_type(2)));
 constexpr int kWaveVSteps = 4;
-template <int NC, int NTC, int R0, int R1, int R2, int R3>
+template <bool MONO>
+struct RowPair {
+  bool has1;
+  // samples m, m + 1 (m even) of the two rows starting at a (and b): (row0[m], row1[m], row0[m+1], row1[m+1])
+  __device__ __forceinline__ v4f_t load2(const float* a, const float* b, int m) const {
+    if constexpr (!MONO) {
+      return *reinterpret_cast<const v4f_t*>(a + 2 * m);
+    } else {
+      const v2f_t fa = *reinterpret_cast<const v2f_t*>(a + m);
+      const v2f_t fb = has1 ? *reinterpret_cast<const v2f_t*>(b + m) : v2f_t{0.f, 0.f};
+      return v4f_t{fa.x, fb.x, fa.y, fb.y};
+    }
+  }
+  __device__ __forceinline__ void store2(float* a, float* b, int m, v4f_t v) const {
+    if constexpr (!MONO) {
+      __builtin_nontemporal_store(v, reinterpret_cast<v4f_t*>(a + 2 * m));
+    } else {
+      __builtin_nontemporal_store(v2f_t{v.x, v.z}, reinterpret_cast<v2f_t*>(a + m));
+      if (has1) __builtin_nontemporal_store(v2f_t{v.y, v.w}, reinterpret_cast<v2f_t*>(b + m));
+    }
+  }
+};
+// pair p of a tensor [B, blocks_per_signal * N, C]: float offsets of its row(s), floats between successive blocks; the stream
+// state rows of pair p are 2 p, 2 p + 1 of [B * C][N / 2] in both layouts
+struct PairGeo {
+  size_t off_a, off_b, block_stride;
+};
+template <bool MONO>
+__device__ __forceinline__ PairGeo pair_geo(long long p, int N, size_t blocks_per_signal) {
+  PairGeo g;
+  g.block_stride = (size_t)N * (MONO ? 1 : 2);
+  g.off_a = (size_t)(MONO ? 2 * p : p) * blocks_per_signal * g.block_stride;
+  g.off_b = g.off_a + blocks_per_signal * g.block_stride;   // (MONO: the next signal)
+  return g;
+}
+
+template <int NC, int NTC, int R0, int R1, int R2, int R3, bool MONO>
 static __global__ __launch_bounds__(kThreads, 2) void k_fwd_wave_v(const float* __restrict__ x, float* __restrict__ X,
                                                           const float* __restrict__ prev_block, const v4f_t* __restrict__ coefv,
                                                           const float* __restrict__ ctab, int Kin, int F, int N_rt, long long ntasks,
-                                                          int T, int nstrip, WavePlan wp) {
+                                                          int T, int nstrip, int B, WavePlan wp) {
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int N = NC ? NC : N_rt, nt = NC ? NTC : wp.nt, gpw = (int)blockDim.x / nt, grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
   constexpr bool GRP = NTC > 64;   // one frame per workgroup of NTC lanes, transformed in place
@@ -1047,16 +1087,18 @@ static __global__ __launch_bounds__(kThreads, 2) void k_fwd_wave_v(const float* 
   const long long wg = (long long)blockIdx.x * gpw + grp;
   if (wg >= ntasks) return;
   const int sp = (int)(wg % nstrip);
-  const long long b = wg / nstrip;
+  const long long pr = wg / nstrip;
+  const RowPair<MONO> rp = {!MONO || 2 * pr + 1 < B};
+  const PairGeo gx = pair_geo<MONO>(pr, N, (size_t)Kin), gX = pair_geo<MONO>(pr, N, (size_t)F), gp = pair_geo<MONO>(pr, N, 1);
   const int n0 = sp * T, n1 = min(n0 + T, F);
   v4f_t d0[kWaveVSteps], d1[kWaveVSteps], cy[kWaveVSteps];
-  auto load_block = [&](const float* xb) {
+  auto load_block = [&](const float* xa, const float* xb) {
 #pragma unroll
     for (int s = 0; s < kWaveVSteps; ++s) {
       const int i = tid + s * nt;
       if (i < q) {
-        d0[s] = *reinterpret_cast<const v4f_t*>(xb + 4 * i);                 // samples 2 i, 2 i + 1
-        d1[s] = *reinterpret_cast<const v4f_t*>(xb + 2 * (N - 2 - 2 * i));   // samples N - 2 - 2 i, N - 1 - 2 i
+        d0[s] = rp.load2(xa, xb, 2 * i);           // samples 2 i, 2 i + 1
+        d1[s] = rp.load2(xa, xb, N - 2 - 2 * i);   // samples N - 2 - 2 i, N - 1 - 2 i
       }
     }
   };
@@ -1066,15 +1108,16 @@ static __global__ __launch_bounds__(kThreads, 2) void k_fwd_wave_v(const float* 
                  g.x * d0[s].y + g.y * d1[s].w};
   };
   {
-    const float* xb = n0 >= 1 ? x + ((size_t)b * Kin + (size_t)(n0 - 1)) * N * 2 : prev_block ? prev_block + (size_t)b * N * 2 : nullptr;
-    if (xb) load_block(xb);
+    const bool have = n0 >= 1 || prev_block != nullptr;
+    if (n0 >= 1) load_block(x + gx.off_a + (size_t)(n0 - 1) * gx.block_stride, x + gx.off_b + (size_t)(n0 - 1) * gx.block_stride);
+    else if (prev_block) load_block(prev_block + gp.off_a, prev_block + gp.off_b);
 #pragma unroll
     for (int s = 0; s < kWaveVSteps; ++s) {
       const int i = tid + s * nt;
-      cy[s] = (xb && i < q) ? carry_of(s, i) : v4f_t{0.f, 0.f, 0.f, 0.f};
+      cy[s] = (have && i < q) ? carry_of(s, i) : v4f_t{0.f, 0.f, 0.f, 0.f};
     }
   }
-  if (n0 < Kin) load_block(x + ((size_t)b * Kin + (size_t)n0) * N * 2);
+  if (n0 < Kin) load_block(x + gx.off_a + (size_t)n0 * gx.block_stride, x + gx.off_b + (size_t)n0 * gx.block_stride);
   for (int n = n0; n < n1; ++n) {
     const bool has_cur = n < Kin;
 #pragma unroll
@@ -1092,33 +1135,33 @@ static __global__ __launch_bounds__(kThreads, 2) void k_fwd_wave_v(const float* 
         if (has_cur) cy[s] = carry_of(s, i);
       }
     }
-    if (n + 1 < n1 && n + 1 < Kin) load_block(x + ((size_t)b * Kin + (size_t)(n + 1)) * N * 2);   // lands during the transform
+    if (n + 1 < n1 && n + 1 < Kin)   // lands during the transform
+      load_block(x + gx.off_a + (size_t)(n + 1) * gx.block_stride, x + gx.off_b + (size_t)(n + 1) * gx.block_stride);
     group_sync<NTC>();
 #ifndef AC_T_NODCT
     if constexpr (GRP) dct4_group_ct<NC, NTC, R0, R1, R2, R3>(v, Bp, tb, pre0, tid);
     else if constexpr (NC != 0) dct4_wave_ct<NC, NTC, R0, R1, R2, R3>(v, Ap, Bp, tb, tid);
     else dct4_wave(v, Ap, Bp, tb, N, tid, nt, wp);
 #endif
-    float* Xo = X + ((size_t)b * F + (size_t)n) * N * 2;
+    float* Xa = X + gX.off_a + (size_t)n * gX.block_stride;
+    float* Xb = X + gX.off_b + (size_t)n * gX.block_stride;
 #pragma unroll
     for (int s = 0; s < 2 * kWaveVSteps; ++s) {
       const int i = tid + s * nt;
-      if (i < h) {
-        const v4f_t r = *reinterpret_cast<const v4f_t*>(v + 2 * i);
-        __builtin_nontemporal_store(r * scale, reinterpret_cast<v4f_t*>(Xo + 4 * i));
-      }
+      if (i < h) rp.store2(Xa, Xb, 2 * i, *reinterpret_cast<const v4f_t*>(v + 2 * i) * scale);
     }
     group_sync<NTC>();
   }
 }
 
-// the synthesis in the same form: 16-byte spectrum loads (the next frame's issued before the overlap-add of this one), the
-// two output samples j, N - 1 - j of a lane's pairs as two 16-byte stores
-template <int NC, int NTC, int R0, int R1, int R2, int R3>
+// the synthesis in the same form: wide spectrum loads (the next frame's issued before the overlap-add of this one), the two
+// output samples j, N - 1 - j of a lane's pairs as two wide stores, the aliased half of the previous frame in registers
+template <int NC, int NTC, int R0, int R1, int R2, int R3, bool MONO>
 static __global__ __launch_bounds__(kThreads, 2) void k_inv_wave_v(const float* __restrict__ X, float* __restrict__ x,
                                                           const float* __restrict__ tail_in, float* __restrict__ tail_out,
                                                           const v4f_t* __restrict__ coefv, const float* __restrict__ ctab, int Kp,
-                                                          int nblk, int seg, int nseg, int N_rt, long long ntasks, WavePlan wp) {
+                                                          int nblk, int seg, int nseg, int N_rt, long long ntasks, int B,
+                                                          WavePlan wp) {
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int N = NC ? NC : N_rt, nt = NC ? NTC : wp.nt, gpw = (int)blockDim.x / nt, grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
   constexpr bool GRP = NTC > 64;
@@ -1130,8 +1173,8 @@ static __global__ __launch_bounds__(kThreads, 2) void k_inv_wave_v(const float* 
     if constexpr (!GRP) tw[2 * h + k] = cis_neg(ctab, 4 * k + 1, N);
   }
   __syncthreads();
-  const WaveTabs tb = {tw, tw + 2 * h, tw + h};   // (the in-place form has no pre-twiddle table)
-  const float2 pre0 = cis_neg(ctab, 1, N);        // exp(-i pi / (4 N))
+  const WaveTabs tb = {tw, tw + 2 * h, tw + h};
+  const float2 pre0 = cis_neg(ctab, 1, N);
   float* base = smem + (size_t)grp * per;
   float2* v = reinterpret_cast<float2*>(base);
   cpair* Bp = reinterpret_cast<cpair*>(base);
@@ -1139,28 +1182,38 @@ static __global__ __launch_bounds__(kThreads, 2) void k_inv_wave_v(const float* 
   const long long wg = (long long)blockIdx.x * gpw + grp;
   if (wg >= ntasks) return;
   const int sgm = (int)(wg % nseg);
-  const long long b = wg / nseg;
+  const long long pr = wg / nseg;
+  const RowPair<MONO> rp = {!MONO || 2 * pr + 1 < B};
+  const PairGeo gX = pair_geo<MONO>(pr, N, (size_t)Kp), gx = pair_geo<MONO>(pr, N, (size_t)nblk);
   const v4f_t* cv = coefv + h;   // the synthesis half of the table
   const float scale = 2.0f * 1.4142135623730951f;
   const int nlast = nblk + (tail_out ? 1 : 0);
   const int n0 = sgm * seg;
-  const size_t ts = (size_t)b * 2 * h;
+  const size_t ts = (size_t)(2 * pr) * h;   // stream state rows of the pair: ts, ts + h
   // the aliased half u_{n-1}[h + 2 i], [h + 2 i + 1] of the lane's pairs stays in registers from frame to frame
   v4f_t um[kWaveVSteps];
 #pragma unroll
   for (int s = 0; s < kWaveVSteps; ++s) {
     const int i = tid + s * nt;
-    um[s] = (n0 == 0 && tail_in && i < q) ? v4f_t{tail_in[ts + 2 * i], tail_in[ts + h + 2 * i], tail_in[ts + 2 * i + 1], tail_in[ts + h + 2 * i + 1]}
-                                          : v4f_t{0.f, 0.f, 0.f, 0.f};
+    um[s] = v4f_t{0.f, 0.f, 0.f, 0.f};
+    if (n0 == 0 && tail_in && i < q) {
+      um[s].x = tail_in[ts + 2 * i];
+      um[s].z = tail_in[ts + 2 * i + 1];
+      if (rp.has1) {
+        um[s].y = tail_in[ts + h + 2 * i];
+        um[s].w = tail_in[ts + h + 2 * i + 1];
+      }
+    }
   }
   v4f_t r[2 * kWaveVSteps];
   auto frame_ok = [&](int t) { const int n = n0 + t; return t < 0 || (n < Kp && n < nblk); };
   auto load_frame = [&](int t) {
-    const float* Xi = X + ((size_t)b * Kp + (size_t)(n0 + t)) * N * 2;
+    const float* Xa = X + gX.off_a + (size_t)(n0 + t) * gX.block_stride;
+    const float* Xb = X + gX.off_b + (size_t)(n0 + t) * gX.block_stride;
 #pragma unroll
     for (int s = 0; s < 2 * kWaveVSteps; ++s) {
       const int i = tid + s * nt;
-      if (i < h) r[s] = *reinterpret_cast<const v4f_t*>(Xi + 4 * i);
+      if (i < h) r[s] = rp.load2(Xa, Xb, 2 * i);
     }
   };
   const int t0 = n0 >= 1 ? -1 : 0;
@@ -1188,7 +1241,8 @@ static __global__ __launch_bounds__(kThreads, 2) void k_inv_wave_v(const float* 
 #endif
     if (t >= 0) {
       if (n < nblk) {
-        float* xo = x + ((size_t)b * nblk + (size_t)n) * N * 2;
+        float* xa = x + gx.off_a + (size_t)n * gx.block_stride;
+        float* xb = x + gx.off_b + (size_t)n * gx.block_stride;
 #pragma unroll
         for (int s = 0; s < kWaveVSteps; ++s) {
           const int i = tid + s * nt;
@@ -1198,8 +1252,8 @@ static __global__ __launch_bounds__(kThreads, 2) void k_inv_wave_v(const float* 
             const v4f_t c0 = cv[2 * i], c1 = cv[2 * i + 1];   // (s1, s2)(2i), (s1, s2)(2i+1) | (s3, s4)(2i), (s3, s4)(2i+1)
             const v4f_t o0 = {c0.x * A.z + c0.y * Bm.x, c0.x * A.w + c0.y * Bm.y, c0.z * A.x + c0.w * Bm.z, c0.z * A.y + c0.w * Bm.w};
             const v4f_t o1 = {c1.z * A.x + c1.w * Bm.z, c1.z * A.y + c1.w * Bm.w, c1.x * A.z + c1.y * Bm.x, c1.x * A.w + c1.y * Bm.y};
-            __builtin_nontemporal_store(o0, reinterpret_cast<v4f_t*>(xo + 4 * i));
-            __builtin_nontemporal_store(o1, reinterpret_cast<v4f_t*>(xo + 2 * (N - 2 - 2 * i)));
+            rp.store2(xa, xb, 2 * i, o0);
+            rp.store2(xa, xb, N - 2 - 2 * i, o1);
           }
         }
       } else if (tail_out) {
@@ -1208,9 +1262,11 @@ static __global__ __launch_bounds__(kThreads, 2) void k_inv_wave_v(const float* 
           const int i = tid + s * nt;
           if (i < q) {
             tail_out[ts + 2 * i] = um[s].x;
-            tail_out[ts + h + 2 * i] = um[s].y;
             tail_out[ts + 2 * i + 1] = um[s].z;
-            tail_out[ts + h + 2 * i + 1] = um[s].w;
+            if (rp.has1) {
+              tail_out[ts + h + 2 * i] = um[s].y;
+              tail_out[ts + h + 2 * i + 1] = um[s].w;
+            }
           }
         }
       }
@@ -1597,7 +1653,7 @@ static int check_grid(long long n) {
 // workgroup form everywhere) caps both, AC_LDS_WAVE_FORCE=1 takes the wave form wherever it exists.
 static bool lds_wave_ct_size(int N);
 static bool lds_wave_vec_shape(int N, int C, bool f32) {
-  return f32 && C == 2 && N % 4 == 0 && (N <= 1024 || lds_wave_ct_size(N));   // (above 1024: the in-place instances only)
+  return f32 && (C == 1 || C == 2) && N % 4 == 0 && (N <= 1024 || lds_wave_ct_size(N));   // (above 1024: the in-place instances only)
 }
 static bool lds_wave_ok(int N, bool synthesis, int C, bool f32) {
   static const int wave_max = [] { const char* e = getenv("AC_LDS_WAVE_MAX"); return e ? atoi(e) : AC_LDS_WAVE_MAX; }();
@@ -1778,30 +1834,12 @@ static int lds_wave_block(int N, const WavePlan& wp, int extra_floats, size_t* l
 }
 
 // the 16-byte kernels serve float32 stereo rows whose lanes cover a frame's sample pairs in four steps
-static bool lds_wave_vec_ok(const ac_mdct_plan* p, const WavePlan& wp, int C) {
+static bool lds_wave_vec_ok(const ac_mdct_plan* p, const WavePlan& wp, int C, std::initializer_list<const void*> ptrs) {
   static const int off = [] { const char* e = getenv("AC_LDS_WAVE_NOVEC"); return e ? atoi(e) : 0; }();   // (A/B measurements)
+  uintptr_t bits = 0;
+  for (const void* q : ptrs) bits |= reinterpret_cast<uintptr_t>(q);
+  if (bits & (C == 2 ? 15 : 7)) return false;   // (rows of a tensor that does not start on a 16- / 8-byte boundary: the 8-byte kernels)
   return !off && lds_wave_vec_shape(p->N, C, true) && p->d_coefv && p->N / 4 <= kWaveVSteps * wp.nt && !(wp.nt > 64 && wave_ct_off());
-}
-// frames per strip of the 16-byte kernels: a strip pays `extra` frames' worth of work before its first frame (the block /
-// the transform before it), a launch runs in rounds of as many workgroups as are resident; the least rounds x (frames + extra)
-static int wave_strip(int B, int per_sig, int gpw, int w, size_t lds, int cus, double extra) {
-  static const int t_max = [] { const char* e = getenv("AC_LDS_WAVE_STRIP"); return e ? atoi(e) : 32; }();   // tuning hook
-  const long resident = (long)cus * std::max<long>(1, std::min<long>(160 * 1024 / (long)std::max<size_t>(lds, 1), 8 / w));
-  static const int cand[] = {32, 24, 16, 12, 8, 6, 4, 3, 2, 1};
-  int best = 1;
-  double best_cost = 1e300;
-  for (int seg : cand) {
-    if (seg > t_max && seg > 1) continue;
-    const int len = std::min(seg, per_sig);
-    const long long wgs = ((long long)B * ((per_sig + len - 1) / len) + gpw - 1) / gpw;
-    const double rounds = wgs <= 4 * resident ? (double)((wgs + resident - 1) / resident) : (double)wgs / (double)resident;
-    const double cost = rounds * (len + extra);
-    if (cost < best_cost) {
-      best_cost = cost;
-      best = len;
-    }
-  }
-  return best;
 }
 // waves per workgroup, frames per workgroup and LDS bytes of the 16-byte kernels: the wave form packs frames as lds_wave_block
 // says; a frame on more than one wave (in place) is a workgroup of its own with two tables behind its buffer
@@ -1815,40 +1853,65 @@ static void wave_v_geometry(int N, const WavePlan& wp, int* w, int* gpw, size_t*
     *gpw = *w * (64 / wp.nt);
   }
 }
+// frames per strip of the 16-byte kernels: a strip pays `extra` frames' worth of work before its first frame (the block /
+// the transform before it), a launch runs in rounds of as many workgroups as are resident; the least rounds x (frames + extra)
+static int wave_strip(long long pairs, int per_sig, int gpw, int w, size_t lds, int cus, double extra) {
+  static const int t_max = [] { const char* e = getenv("AC_LDS_WAVE_STRIP"); return e ? atoi(e) : 32; }();   // tuning hook
+  const long resident = (long)cus * std::max<long>(1, std::min<long>(160 * 1024 / (long)std::max<size_t>(lds, 1), 8 / w));
+  static const int cand[] = {32, 24, 16, 12, 8, 6, 4, 3, 2, 1};
+  int best = 1;
+  double best_cost = 1e300;
+  for (int seg : cand) {
+    if (seg > t_max && seg > 1) continue;
+    const int len = std::min(seg, per_sig);
+    const long long wgs = (pairs * ((per_sig + len - 1) / len) + gpw - 1) / gpw;
+    const double rounds = wgs <= 4 * resident ? (double)((wgs + resident - 1) / resident) : (double)wgs / (double)resident;
+    const double cost = rounds * (len + extra);
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = len;
+    }
+  }
+  return best;
+}
+template <bool MONO>
 static int launch_fwd_wave_v(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin, int F,
                              hipStream_t s) {
   const WavePlan wp = lds_wave_plan(p->N);
   size_t lds = 0;
   int w = 1, gpw = 1;
   wave_v_geometry(p->N, wp, &w, &gpw, &lds);
-  const int T = wave_strip(B, F, gpw, w, lds, p->cus, 0.25);   // (every strip reads one block more than it has frames)
+  const long long pairs = MONO ? ((long long)B + 1) / 2 : (long long)B;
+  const int T = wave_strip(pairs, F, gpw, w, lds, p->cus, 0.25);   // (every strip reads one block more than it has frames)
   const int nstrip = (F + T - 1) / T;
-  const long long ntasks = (long long)B * nstrip;
+  const long long ntasks = pairs * nstrip;
   const long long g = (ntasks + gpw - 1) / gpw;
   const int st2 = check_grid(g);
   if (st2) return st2 < 0 ? st2 : AC_OK;
   int st = AC_OK;
   bool done = false;
 #define AC_WAVE_CT(NC, NTC, R0, R1, R2, R3)                                                                                   \
-  if (!done && p->N == NC && !wave_ct_off()) {                                                          \
+  if (!done && p->N == NC && !wave_ct_off()) {                                                                                 \
     done = true;                                                                                                               \
-    st = allow_lds(k_fwd_wave_v<NC, NTC, R0, R1, R2, R3>, lds);                                                                \
+    st = allow_lds(k_fwd_wave_v<NC, NTC, R0, R1, R2, R3, MONO>, lds);                                                          \
     if (!st)                                                                                                                   \
-      hipLaunchKernelGGL((k_fwd_wave_v<NC, NTC, R0, R1, R2, R3>), dim3((unsigned)g), dim3(64 * w), lds, s, x, X, prev_block,   \
-                         reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kin, F, p->N, ntasks, T, nstrip, wp);          \
+      hipLaunchKernelGGL((k_fwd_wave_v<NC, NTC, R0, R1, R2, R3, MONO>), dim3((unsigned)g), dim3(64 * w), lds, s, x, X,         \
+                         prev_block, reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kin, F, p->N, ntasks, T, nstrip,   \
+                         B, wp);                                                                                               \
   }
   AC_WAVE_CT_SIZES
 #undef AC_WAVE_CT
   if (!done) {
-    st = allow_lds(k_fwd_wave_v<0, 0, 0, 0, 0, 0>, lds);
+    st = allow_lds(k_fwd_wave_v<0, 0, 0, 0, 0, 0, MONO>, lds);
     if (!st)
-      hipLaunchKernelGGL((k_fwd_wave_v<0, 0, 0, 0, 0, 0>), dim3((unsigned)g), dim3(64 * w), lds, s, x, X, prev_block,
-                         reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kin, F, p->N, ntasks, T, nstrip, wp);
+      hipLaunchKernelGGL((k_fwd_wave_v<0, 0, 0, 0, 0, 0, MONO>), dim3((unsigned)g), dim3(64 * w), lds, s, x, X, prev_block,
+                         reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kin, F, p->N, ntasks, T, nstrip, B, wp);
   }
   if (st) return st;
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }
+template <bool MONO>
 static int launch_inv_wave_v(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out, int B,
                              int Kp, int nblk, hipStream_t s) {
   const WavePlan wp = lds_wave_plan(p->N);
@@ -1856,42 +1919,57 @@ static int launch_inv_wave_v(const ac_mdct_plan* p, const float* X, float* x, co
   int w = 1, gpw = 1;
   wave_v_geometry(p->N, wp, &w, &gpw, &lds);
   const int per_sig = nblk + (tail_out ? 1 : 0);
-  const int seg = wave_strip(B, per_sig, gpw, w, lds, p->cus, 1.0);   // (every strip but a signal's first transforms one frame more)
+  const long long pairs = MONO ? ((long long)B + 1) / 2 : (long long)B;
+  const int seg = wave_strip(pairs, per_sig, gpw, w, lds, p->cus, 1.0);   // (every strip but a signal's first transforms one frame more)
   const int nseg = (per_sig + seg - 1) / seg;
-  const long long ntasks = (long long)B * nseg;
+  const long long ntasks = pairs * nseg;
   const long long g = (ntasks + gpw - 1) / gpw;
   const int st2 = check_grid(g);
   if (st2) return st2 < 0 ? st2 : AC_OK;
   int st = AC_OK;
   bool done = false;
 #define AC_WAVE_CT(NC, NTC, R0, R1, R2, R3)                                                                                   \
-  if (!done && p->N == NC && !wave_ct_off()) {                                                          \
+  if (!done && p->N == NC && !wave_ct_off()) {                                                                                 \
     done = true;                                                                                                               \
-    st = allow_lds(k_inv_wave_v<NC, NTC, R0, R1, R2, R3>, lds);                                                                \
+    st = allow_lds(k_inv_wave_v<NC, NTC, R0, R1, R2, R3, MONO>, lds);                                                          \
     if (!st)                                                                                                                   \
-      hipLaunchKernelGGL((k_inv_wave_v<NC, NTC, R0, R1, R2, R3>), dim3((unsigned)g), dim3(64 * w), lds, s, X, x, tail_in,      \
-                         tail_out, reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kp, nblk, seg, nseg, p->N, ntasks,   \
-                         wp);                                                                                                  \
+      hipLaunchKernelGGL((k_inv_wave_v<NC, NTC, R0, R1, R2, R3, MONO>), dim3((unsigned)g), dim3(64 * w), lds, s, X, x,         \
+                         tail_in, tail_out, reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kp, nblk, seg, nseg, p->N,  \
+                         ntasks, B, wp);                                                                                       \
   }
   AC_WAVE_CT_SIZES
 #undef AC_WAVE_CT
   if (!done) {
-    st = allow_lds(k_inv_wave_v<0, 0, 0, 0, 0, 0>, lds);
+    st = allow_lds(k_inv_wave_v<0, 0, 0, 0, 0, 0, MONO>, lds);
     if (!st)
-      hipLaunchKernelGGL((k_inv_wave_v<0, 0, 0, 0, 0, 0>), dim3((unsigned)g), dim3(64 * w), lds, s, X, x, tail_in, tail_out,
-                         reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kp, nblk, seg, nseg, p->N, ntasks, wp);
+      hipLaunchKernelGGL((k_inv_wave_v<0, 0, 0, 0, 0, 0, MONO>), dim3((unsigned)g), dim3(64 * w), lds, s, X, x, tail_in, tail_out,
+                         reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kp, nblk, seg, nseg, p->N, ntasks, B, wp);
   }
   if (st) return st;
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }
 
+#ifdef AC_WAVE_ROWS_TU
+// ---- this file compiled a second time as ac_wave_rows.hip: only the instances of the 16-byte kernels for mono rows (a
+// translation unit of their own: the instances of one row layout take a minute to compile)
+int launch_fwd_wave_mono(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin, int F,
+                         hipStream_t s) {
+  return launch_fwd_wave_v<true>(p, x, X, prev_block, B, Kin, F, s);
+}
+int launch_inv_wave_mono(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out, int B, int Kp,
+                         int nblk, hipStream_t s) {
+  return launch_inv_wave_v<true>(p, X, x, tail_in, tail_out, B, Kp, nblk, s);
+}
+#else
+
 template <typename TIO>
 static int launch_fwd_wave(const ac_mdct_plan* p, const TIO* x, TIO* X, const TIO* prev_block, int B, int Kin, int F, int C,
                            hipStream_t s) {
   const WavePlan wp0 = lds_wave_plan(p->N);
   if constexpr (std::is_same<TIO, float>::value)
-    if (lds_wave_vec_ok(p, wp0, C)) return launch_fwd_wave_v(p, x, X, prev_block, B, Kin, F, s);
+    if (lds_wave_vec_ok(p, wp0, C, {x, X, prev_block}))
+      return C == 2 ? launch_fwd_wave_v<false>(p, x, X, prev_block, B, Kin, F, s) : launch_fwd_wave_mono(p, x, X, prev_block, B, Kin, F, s);
   const WavePlan wp = lds_wave_plan(p->N, false);
   size_t lds = 0;
   const int w = lds_wave_block(p->N, wp, 0, &lds);
@@ -1914,7 +1992,9 @@ static int launch_inv_wave(const ac_mdct_plan* p, const TIO* X, TIO* x, const fl
                            int nblk, int C, hipStream_t s) {
   const WavePlan wp0 = lds_wave_plan(p->N);
   if constexpr (std::is_same<TIO, float>::value)
-    if (lds_wave_vec_ok(p, wp0, C)) return launch_inv_wave_v(p, X, x, tail_in, tail_out, B, Kp, nblk, s);
+    if (lds_wave_vec_ok(p, wp0, C, {X, x}))
+      return C == 2 ? launch_inv_wave_v<false>(p, X, x, tail_in, tail_out, B, Kp, nblk, s)
+                    : launch_inv_wave_mono(p, X, x, tail_in, tail_out, B, Kp, nblk, s);
   const WavePlan wp = lds_wave_plan(p->N, false);
   size_t lds = 0;
   const int w = lds_wave_block(p->N, wp, p->N, &lds);
@@ -2235,5 +2315,7 @@ int launch_add_noise_typed(const void* X, const void* thr, void* out, size_t n, 
   return launch_add_noise_T(static_cast<const bf16_t*>(X), static_cast<const bf16_t*>(thr), static_cast<bf16_t*>(out), n, seed,
                             s);
 }
+
+#endif   // AC_WAVE_ROWS_TU
 
 }  // namespace ac

@@ -163,6 +163,11 @@ struct ac_stream {
 namespace ac {
 
 // generic O(N^2) kernels: any even N, any C, any M
+// the 16-byte kernels of the LDS-FFT tier on mono rows (ac_wave_rows.hip)
+int launch_fwd_wave_mono(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin, int F,
+                         hipStream_t s);
+int launch_inv_wave_mono(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out, int B, int Kp,
+                         int nblk, hipStream_t s);
 int launch_fwd_generic(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin,
                        int F, int C, hipStream_t s);
 int launch_inv_generic(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out,

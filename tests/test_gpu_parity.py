@@ -189,12 +189,14 @@ def _smooth_half(N):
 WAVE16_SIZES = [N for N in range(16, 4097, 4) if _smooth_half(N) and N not in (64, 128, 256, 512, 1024, 2048)]
 
 
+@pytest.mark.parametrize("C", [2, 1])
 @pytest.mark.parametrize("N", WAVE16_SIZES)
-def test_lds_fft_wave_16_byte_kernels_every_size(N):
-    """Strips longer and shorter than the kernels' strip length (32 frames at most), two signals, against the fp64 oracle:
-    analysis, synthesis incl. the aliased head / tail blocks, and the round trip to 1 LSB."""
-    rng = np.random.default_rng(N)
-    B, K, C = 2, (70 if N <= 128 else 37 if N <= 480 else 11 if N <= 2048 else 6), 2
+def test_lds_fft_wave_16_byte_kernels_every_size(N, C):
+    """Strips longer and shorter than the kernels' strip length (32 frames at most), three signals (mono: two signals per
+    complex pair, the last pair half empty), against the fp64 oracle: analysis, synthesis incl. the aliased head / tail
+    blocks, and the round trip to 1 LSB."""
+    rng = np.random.default_rng(N + C)
+    B, K = 3, (70 if N <= 128 else 37 if N <= 480 else 11 if N <= 2048 else 6)
     x = rng.uniform(-1, 1, (B, K * N, C)).astype(np.float32)
     m = audiocodec_amd.MDCTransformer(N)
     o = MDCTOracle(N, "vorbis", np.float64)
@@ -204,6 +206,26 @@ def test_lds_fft_wave_16_byte_kernels_every_size(N):
     xh = host(m.inverse_transform(dev(X)))
     assert np.max(np.abs(xh[:, N:-N] - x)) <= LSB
     assert np.max(np.abs(xh - o.inverse_transform(Xo))) <= LSB
+
+
+@pytest.mark.parametrize("N,C", [(960, 2), (480, 1), (1920, 2), (48, 1)])
+def test_lds_fft_tier_rows_off_the_16_byte_grid(N, C):
+    """A tensor whose first element is not on a 16-byte (mono: 8-byte) boundary takes the 8-byte kernels of the tier; same
+    values to float32 rounding."""
+    B, K = 2, 9
+    g = torch.Generator(device="cuda").manual_seed(N)
+    flat = torch.empty(B * K * N * C + 4, device="cuda").uniform_(-1, 1, generator=g)
+    x_off = flat[1:1 + B * K * N * C].view(B, K * N, C)
+    assert x_off.is_contiguous() and x_off.data_ptr() % 8 == 4
+    x = x_off.clone()
+    m = audiocodec_amd.MDCTransformer(N)
+    X, X_off = m.transform(x), m.transform(x_off)
+    assert float((X - X_off).abs().max()) <= 2e-6 * float(X.abs().max())
+    Xf = torch.empty(X.numel() + 4, device="cuda")
+    X_view = Xf[1:1 + X.numel()].view(X.shape)
+    X_view.copy_(X)
+    y, y_off = m.inverse_transform(X), m.inverse_transform(X_view)
+    assert float((y - y_off).abs().max()) <= 2e-6
 
 
 def test_lds_fft_wave_16_byte_kernels_run_time_form(tmp_path):
@@ -532,7 +554,7 @@ def test_db_and_noise(golden, path):
                                         (64, 2, (5, 17, 1, 16)), (64, 1, (33, 2)),
                                         # strips of the 16-byte LDS-FFT wave kernels: longer / shorter than a strip, state in and out
                                         (480, 2, (40, 3, 1)), (120, 2, (70, 1)), (16, 2, (100, 3)), (48, 2, (5,)), (960, 2, (33,)), (1920, 2, (3, 9)),
-                                        (4096, 2, (2, 1, 3)), (1536, 1, (2, 3))])
+                                        (4096, 2, (2, 1, 3)), (1536, 1, (2, 3)), (480, 1, (40, 3, 1)), (1920, 1, (3, 2)), (24, 1, (7, 60))])
 def test_streaming_equals_one_shot(path, N, C, chunks):
     B, K = 2, sum(chunks)
     x = torch.rand(B, K * N, C, device="cuda") * 2 - 1

@@ -10,7 +10,7 @@ def timeit(fn, n=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 for N in [int(v) for v in os.environ.get("SIZES", "960,480,240,120,576,1920,1536,192,4096,32,16").split(",")]:
-    B, C = 64, 2
+    C = int(os.environ.get("C", 2)); B = int(os.environ.get("B", 128 // C))
     K = 468 * 1024 // N
     x = torch.rand(B, K * N, C, device="cuda") * 2 - 1
     m = audiocodec_amd.MDCTransformer(N)
