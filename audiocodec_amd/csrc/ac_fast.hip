@@ -2195,7 +2195,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
             a.t[((size_t)pq.b0 * a.F + (size_t)nn) * C + pq.c0] = t[fb].x;
             if (pq.has1) a.t[((size_t)pq.b1 * a.F + (size_t)nn) * C + pq.c1] = t[fb].y;
           }
-        mid::threshold_frames<RP, FB>(xq, t, a.mp, pimg, ib, 8 * FN, lane, [&](int fb, int i, const v4f& th) {
+        mid::threshold_frames<RP, FB>(xq, t, a.mp, pimg, reinterpret_cast<const uint4*>(pimg + a.mp.off_wi), ib, 8 * FN, lane, [&](int fb, int i, const v4f& th) {
           if (!ok[fb]) return;
           if (CMODE == 0) {
             __builtin_nontemporal_store(th, reinterpret_cast<v4f*>(a.thr + o0[fb]) + 64 * i + lane);

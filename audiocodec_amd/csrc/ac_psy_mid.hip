@@ -1,6 +1,6 @@
 // Wave-level masking model for the configurations the fused epilogue of ac_fast.hip does not serve: any even
-// filter_bands_n up to 1024 (a frame is up to R = 1, 2, 4 or 8 granule registers per lane, the last ones partly filled
-// when filter_bands_n is not a multiple of 128: 960, 576, 480 ...) with any Bark-band count up to 64 and any band layout (a bin may overlap several bands, bands may share
+// filter_bands_n up to 4096 (a frame is up to R = 1, 2, 4, 8, 16 or 32 granule registers per lane, the last ones partly filled
+// when filter_bands_n is not a multiple of 128: 960, 576, 480 ...; above 1024 the W_inv entries stay in global memory) with any Bark-band count up to 64 and any band layout (a bin may overlap several bands, bands may share
 // bins freely) -- e.g. the models beside the several-frames-per-wave MDCT kernels (filters_n 256 / 512), where the
 // O(N)-per-workgroup generic kernels ran at 0.5-0.8 TB/s.  gfx950 only.
 //
@@ -36,18 +36,20 @@ struct MidArgs {
 // tables sit in one image copied to LDS per workgroup; a wave walks T frames so that the copy is paid once per 4 T frames.
 // wave buffer: FB slots of [N] v2f intensities (c0, c1), the head of a slot reused for the frame's 64 G_j
 template <int R, int CMODE, bool WANT_T, bool WANT_THR, int FB>
-__global__ __launch_bounds__(256, ((WANT_THR && (FB > 1 || R >= 8)) ? 3 : 4)) void k_psy_mid(MidArgs a) {
+__global__ __launch_bounds__(256, (R >= 32 ? 1 : R >= 16 ? 2 : (WANT_THR && (FB > 1 || R >= 8)) ? 3 : 4)) void k_psy_mid(MidArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int N = a.p.N;
   const int SLOT = N >= 64 ? 8 * N : 512, WAVE_BYTES = FB * SLOT;   // (a slot also takes the frame's 64 G_j: 512 bytes)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   uint32_t* img = reinterpret_cast<uint32_t*>(smem);
   if (WANT_THR) {
-    for (int i = threadIdx.x; i < a.p.img_words / 4; i += blockDim.x)
+    for (int i = threadIdx.x; i < a.p.lds_words / 4; i += blockDim.x)
       reinterpret_cast<uint4*>(img)[i] = reinterpret_cast<const uint4*>(a.img)[i];
     __syncthreads();
   }
-  char* buf = smem + (size_t)a.p.img_words * 4 + (size_t)wave * WAVE_BYTES;
+  char* buf = smem + (size_t)a.p.lds_words * 4 + (size_t)wave * WAVE_BYTES;
+  // the W_inv entries: in the LDS image, or (R >= 16) read where the plan keeps them
+  const uint4* wi = R >= 16 ? reinterpret_cast<const uint4*>(a.img + a.p.off_wi) : reinterpret_cast<const uint4*>(img + a.p.off_wi);
   const int C = a.C;
   const long long task0 = (long long)blockIdx.x * nw * a.T + wave;
   for (int tt = 0; tt < a.T && task0 + (long long)tt * nw < a.ntasks; tt += FB) {   // (no workgroup barrier inside)
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256, ((WANT_THR && (FB > 1 || R >= 8)) ? 3 : 4)) vo
       for (int fb = 0; fb < FB; ++fb) t[fb] = v2f{a.t_in[t0[fb]], has1[fb] ? a.t_in[t1[fb]] : 0.f};
     }
     if (!WANT_THR) continue;
-    threshold_frames<R, FB>(xq, t, a.p, img, buf, SLOT, lane, [&](int fb, int i, const v4f& th) {
+    threshold_frames<R, FB>(xq, t, a.p, img, wi, buf, SLOT, lane, [&](int fb, int i, const v4f& th) {
       if (!ok[fb]) return;
       if (CMODE == 0) {
         __builtin_nontemporal_store(th, reinterpret_cast<v4f*>(a.thr + o0[fb]) + 64 * i + lane);
@@ -113,6 +115,7 @@ __global__ __launch_bounds__(256, ((WANT_THR && (FB > 1 || R >= 8)) ? 3 : 4)) vo
 
 // frames a wave handles side by side: as many as keep the frames' registers (4 R each) within the budget
 constexpr int mid_fb(int R) { return R >= 8 ? 1 : R == 4 ? 2 : 4; }
+constexpr int mid_r(int N) { return N <= 128 ? 1 : N <= 256 ? 2 : N <= 512 ? 4 : N <= 1024 ? 8 : N <= 2048 ? 16 : 32; }   // granule registers per lane
 
 struct MidLayout {
   int wi_w = 0, off_S = 0, off_band = 0, off_wbe = 0, off_wi = 0, words = 0;
@@ -121,7 +124,7 @@ struct MidLayout {
 bool build_mid(const ac_psy_plan* p, std::vector<uint32_t>* out, MidLayout* lay) {
   const PsyTables& t = p->host;
   const int N = t.N, M = t.M;
-  if (N < 2 || N > 1024 || (N & 1) || M < 1 || M > 64) return false;
+  if (N < 2 || N > 4096 || (N & 1) || M < 1 || M > 64) return false;
   SparseRows wb, wi;
   w_by_band(t, wb);
   winv_by_bin(t, wi);
@@ -196,7 +199,7 @@ bool build_mid(const ac_psy_plan* p, std::vector<uint32_t>* out, MidLayout* lay)
   return true;
 }
 
-size_t mid_lds_bytes(int N, int words, int nw, int fb) { return (size_t)words * 4 + (size_t)nw * fb * (N >= 64 ? 8 * (size_t)N : 512); }
+size_t mid_lds_bytes(int N, int lds_words, int nw, int fb) { return (size_t)lds_words * 4 + (size_t)nw * fb * (N >= 64 ? 8 * (size_t)N : 512); }
 
 template <int R, int CMODE>
 int launch_mid_R(const MidArgs& a, bool want_t, bool want_thr, unsigned grid, int nw, size_t lds, hipStream_t s) {
@@ -219,6 +222,7 @@ bool mid_psy_supported(const ac_psy_plan* p) { return build_mid(p, nullptr, null
 mid::MidParams mid_params(const ac_psy_plan* p, float drown) {
   mid::MidParams m;
   m.img_words = p->mid_words;
+  m.lds_words = mid_r(p->N) >= 16 ? p->mid_off_wi : p->mid_words;   // (off_wi is 16-byte aligned)
   m.N = p->N;
   m.M = p->M;
   m.wi_w = p->mid_wi_w;
@@ -274,12 +278,24 @@ int launch_psy_mid(const ac_psy_plan* p, const float* X, const float* t_in, floa
   a.nsig = (long long)B * C;
   a.ntasks = ((C == 2) ? (long long)B : (a.nsig + 1) / 2) * F;
   const bool want_t = t_out != nullptr, want_thr = thr != nullptr;
-  const int R = p->N <= 128 ? 1 : p->N <= 256 ? 2 : p->N <= 512 ? 4 : 8;   // granule registers per lane
+  const int R = mid_r(p->N);
   const int fb = mid_fb(R);
-  // four waves per workgroup when the image and the wave buffers fit three workgroups to a CU, else two
+  // four waves per workgroup when the image and the wave buffers fit three workgroups to a CU, else two; frames above
+  // 1024 bins (32 KB of intensities per wave at 4096): the workgroup size that leaves the most waves resident
   int nw = 4;
-  if (mid_lds_bytes(p->N, L.words, nw, fb) > 53 * 1024) nw = 2;
-  const size_t lds = want_thr ? mid_lds_bytes(p->N, L.words, nw, fb) : 0;
+  if (mid_lds_bytes(p->N, a.p.lds_words, nw, fb) > 53 * 1024) nw = 2;
+  if (R >= 16) {
+    long best = 0;
+    for (int w : {4, 2, 1}) {
+      const size_t b = mid_lds_bytes(p->N, a.p.lds_words, w, fb);
+      const long res = b > 160 * 1024 ? 0 : (long)std::min<size_t>(8, 160 * 1024 / b) * w;
+      if (res > best) {
+        best = res;
+        nw = w;
+      }
+    }
+  }
+  const size_t lds = want_thr ? mid_lds_bytes(p->N, a.p.lds_words, nw, fb) : 0;
   if (lds > 160 * 1024) {
     set_error("internal: masking-model tables too large for LDS (%zu bytes)", lds);
     return AC_EUNSUPPORTED;
@@ -300,11 +316,15 @@ int launch_psy_mid(const ac_psy_plan* p, const float* X, const float* t_in, floa
   if (C == 2) st = R == 1 ? launch_mid_R<1, 0>(a, want_t, want_thr, grid, nw, lds, s)
                  : R == 2 ? launch_mid_R<2, 0>(a, want_t, want_thr, grid, nw, lds, s)
                  : R == 4 ? launch_mid_R<4, 0>(a, want_t, want_thr, grid, nw, lds, s)
-                          : launch_mid_R<8, 0>(a, want_t, want_thr, grid, nw, lds, s);
+                 : R == 8 ? launch_mid_R<8, 0>(a, want_t, want_thr, grid, nw, lds, s)
+                 : R == 16 ? launch_mid_R<16, 0>(a, want_t, want_thr, grid, nw, lds, s)
+                           : launch_mid_R<32, 0>(a, want_t, want_thr, grid, nw, lds, s);
   else st = R == 1 ? launch_mid_R<1, 2>(a, want_t, want_thr, grid, nw, lds, s)
             : R == 2 ? launch_mid_R<2, 2>(a, want_t, want_thr, grid, nw, lds, s)
             : R == 4 ? launch_mid_R<4, 2>(a, want_t, want_thr, grid, nw, lds, s)
-                     : launch_mid_R<8, 2>(a, want_t, want_thr, grid, nw, lds, s);
+            : R == 8 ? launch_mid_R<8, 2>(a, want_t, want_thr, grid, nw, lds, s)
+            : R == 16 ? launch_mid_R<16, 2>(a, want_t, want_thr, grid, nw, lds, s)
+                      : launch_mid_R<32, 2>(a, want_t, want_thr, grid, nw, lds, s);
   if (st) return st;
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;

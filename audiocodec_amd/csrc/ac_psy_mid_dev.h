@@ -127,7 +127,8 @@ __device__ __forceinline__ void spread_tiles(const v2f (&Q)[FB], const char* mf,
 //             nothing loaded before)
 //   off_wi:   entry-major: [e < wi_w][bin f] {byte offset of G[band] in the wave's G area, weight}  (weight 0 pads)
 struct MidParams {
-  int img_words;
+  int img_words;         // the whole image
+  int lds_words;         // its part that is copied to LDS: all of it, or everything before the W_inv entries (filter_bands_n > 1024)
   int N, M;
   int wi_w;              // entries per bin in the fixed-width W_inv table
   int off_S, off_band, off_wbe, off_wi;   // word offsets inside the image
@@ -184,9 +185,11 @@ __device__ __forceinline__ void tonality_frames(const v4f (&xq)[FB][R], const Mi
 // ibuf + fb * istride: 8 N bytes of LDS per frame for its intensities (bin f at byte 8 f: (s0, s1)) -- may be the very bytes
 // the caller read xq from; the frame's G_j (64 v2f) later takes the first 512 bytes of the same slot.  img: the LDS copy of
 // the image.  The caller orders its earlier accesses to the slots before the call (wave_sync) and its later ones after it.
+// wi: the W_inv entry table -- img + a.off_wi when the whole image sits in LDS, or the plan's copy in global memory (frames
+// above 1024 bins: the table alone would take 16 N bytes of LDS; its reads are coalesced 16-byte rows and L2-resident).
 template <int R, int FB, class EMIT>
 __device__ __forceinline__ void threshold_frames(const v4f (&xq)[FB][R], const v2f (&t)[FB], const MidParams& a, const uint32_t* img,
-                                                 char* ibuf, int istride, int lane, EMIT emit) {
+                                                 const uint4* wi, char* ibuf, int istride, int lane, EMIT emit) {
   const int half = a.N >> 1, M = a.M;
   // intensities in natural order: bin f at byte 8 f (c0, c1)
 #pragma unroll
@@ -242,8 +245,7 @@ __device__ __forceinline__ void threshold_frames(const v4f (&xq)[FB][R], const v
   }
   wave_sync();
   // thr_f = sqrt(max(eps, sum_j G_j W_inv[j, f]))  (:330-331)
-  const uint4* wi = reinterpret_cast<const uint4*>(img + a.off_wi);   // [e][granule q]: the entries of bins 2 q, 2 q + 1
-  const int W = a.wi_w;
+  const int W = a.wi_w;   // wi: [e][granule q]: the entries of bins 2 q, 2 q + 1
 #pragma unroll
   for (int i = 0; i < R; ++i) {
     const int q = 64 * i + lane;

@@ -22,6 +22,7 @@ value = frames/s over all GPUs, a frame being one 1024-sample hop of one channel
 """
 
 import argparse
+import ctypes
 import json
 import os
 import socket
@@ -493,6 +494,24 @@ def other_configs(torch, np, audiocodec_amd, dev, steps, warmup, settle_ms):
                          "frames_per_s_bf16x2_mfma": fr / ((rows["bf16x2_mfma"]["encode_ms"] + dec) * 1e-3),
                          "encode_GBs_bf16x2_mfma": (12 * n + 4) * fr / (rows["bf16x2_mfma"]["encode_ms"] * 1e-3) / 1e9}
     del x, X, t, thr, ref, xh
+    # (c2) filters_n beside the powers of two (the reference takes any even filters_n, mdctransformer.py:26): the LDS-FFT tier
+    #     on B = 64 stereo 10-s clips, MDCT analysis / synthesis into preallocated tensors, algorithmic 8 N bytes per frame
+    rows = {}
+    for n in (960, 480, 4096):
+        K = 468 * 1024 // n
+        m = audiocodec_amd.MDCTransformer(n)
+        x = make_clips(torch, dev, 0, 64, K, n=n)
+        X = m.transform(x)
+        xh = m.inverse_transform(X)
+        lib, plan, st = m._lib, m._plan(dev), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        px, pX, pxh = (ctypes.c_void_p(v.data_ptr()) for v in (x, X, xh))   # (the C ABI directly: no allocation in the timed calls)
+        fwd = med(lambda: lib.ac_mdct_forward(plan, px, pX, 64, K, 2, st))
+        inv = med(lambda: lib.ac_mdct_inverse(plan, pX, pxh, 64, K + 1, 2, st))
+        fr = 64 * 2 * K
+        rows[str(n)] = {"analysis_ms": fwd, "synthesis_ms": inv, "analysis_GBs": 8 * n * fr / fwd / 1e6,
+                        "synthesis_GBs": 8 * n * fr / inv / 1e6}
+        del x, X, xh
+    out["lds_fft_tier"] = {"workload": "batch=64 stereo 48 kHz clips of 10 s, MDCT analysis / synthesis alone", "filters_n": rows}
     # (d) configs[4]: streaming overlap-add through the device-resident state, chunks of 256 blocks.  One clip gives a
     #     launch only 256 wave tasks, so a chunk costs launch + one frame's latency, not bandwidth: reported are the
     #     10-minute pass as one dependent chain (analysis, then synthesis of the same chunk, one stream), the same pipelined
@@ -742,6 +761,10 @@ def main():
                 flat["k46_value"] = oc["k46_cache_resident"]["value"]
                 flat["configs3_encode_ms"] = oc["configs[3]"]["spreading"]["bf16x2_mfma"]["encode_ms"]
                 flat["configs3_decode_ms"] = oc["configs[3]"]["decode_ms"]
+                flat["n960_analysis_GBs"] = oc["lds_fft_tier"]["filters_n"]["960"]["analysis_GBs"]
+                flat["n960_synthesis_GBs"] = oc["lds_fft_tier"]["filters_n"]["960"]["synthesis_GBs"]
+                flat["n4096_analysis_GBs"] = oc["lds_fft_tier"]["filters_n"]["4096"]["analysis_GBs"]
+                flat["n4096_synthesis_GBs"] = oc["lds_fft_tier"]["filters_n"]["4096"]["synthesis_GBs"]
                 flat["configs4_one_clip_frames_per_s"] = oc["configs[4]"]["one_clip_encode"]["ac_stream_run_graph_replay"]["frames_per_s"]
                 flat["configs4_batch64_frames_per_s"] = oc["configs[4]"]["batch64_encode"]["ac_stream_run_graph_replay"]["frames_per_s"]
             except Exception as e:   # side measurements must never cost the headline line
