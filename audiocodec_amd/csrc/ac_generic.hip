@@ -1062,7 +1062,7 @@ __device__ __forceinline__ PairGeo pair_geo(long long p, int N, size_t blocks_pe
 }
 
 template <int NC, int NTC, int R0, int R1, int R2, int R3, bool MONO>
-static __global__ __launch_bounds__(kThreads, 2) void k_fwd_wave_v(const float* __restrict__ x, float* __restrict__ X,
+static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k_fwd_wave_v(const float* __restrict__ x, float* __restrict__ X,
                                                           const float* __restrict__ prev_block, const v4f_t* __restrict__ coefv,
                                                           const float* __restrict__ ctab, int Kin, int F, int N_rt, long long ntasks,
                                                           int T, int nstrip, int B, WavePlan wp) {
@@ -1157,7 +1157,7 @@ static __global__ __launch_bounds__(kThreads, 2) void k_fwd_wave_v(const float* 
 // the synthesis in the same form: wide spectrum loads (the next frame's issued before the overlap-add of this one), the two
 // output samples j, N - 1 - j of a lane's pairs as two wide stores, the aliased half of the previous frame in registers
 template <int NC, int NTC, int R0, int R1, int R2, int R3, bool MONO>
-static __global__ __launch_bounds__(kThreads, 2) void k_inv_wave_v(const float* __restrict__ X, float* __restrict__ x,
+static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k_inv_wave_v(const float* __restrict__ X, float* __restrict__ x,
                                                           const float* __restrict__ tail_in, float* __restrict__ tail_out,
                                                           const v4f_t* __restrict__ coefv, const float* __restrict__ ctab, int Kp,
                                                           int nblk, int seg, int nseg, int N_rt, long long ntasks, int B,
@@ -1657,9 +1657,9 @@ static bool lds_wave_vec_shape(int N, int C, bool f32) {
 }
 static bool lds_wave_ok(int N, bool synthesis, int C, bool f32) {
   static const int wave_max = [] { const char* e = getenv("AC_LDS_WAVE_MAX"); return e ? atoi(e) : AC_LDS_WAVE_MAX; }();
-  if (!lds_fft_ok(N) || wave_max <= 0) return false;
-  if (lds_wave_vec_shape(N, C, f32)) return true;
-  if (N > wave_max) return false;
+  if (wave_max <= 0) return false;
+  if (lds_wave_vec_shape(N, C, f32) && (lds_fft_ok(N) || lds_wave_ct_size(N))) return true;   // (instances reach 8192, the tier's other forms 4096)
+  if (!lds_fft_ok(N) || N > wave_max) return false;
   static const int force = [] { const char* e = getenv("AC_LDS_WAVE_FORCE"); return e ? atoi(e) : 0; }();   // (A/B measurements)
   if (force) return true;
   const int H = N / 2;
@@ -1748,7 +1748,29 @@ static bool lds_wave_ok(int N, bool synthesis, int C, bool f32) {
   AC_WAVE_CT(3840, 256, 10, 8, 8, 3) \
   AC_WAVE_CT(3888, 256, 9, 9, 8, 3) \
   AC_WAVE_CT(4000, 256, 10, 8, 5, 5) \
-  AC_WAVE_CT(4096, 256, 8, 8, 8, 4)
+  AC_WAVE_CT(4096, 256, 8, 8, 8, 4) \
+  AC_WAVE_CT(4320, 512, 9, 8, 6, 5) \
+  AC_WAVE_CT(4500, 512, 10, 9, 5, 5) \
+  AC_WAVE_CT(4608, 512, 8, 8, 6, 6) \
+  AC_WAVE_CT(4800, 512, 10, 8, 6, 5) \
+  AC_WAVE_CT(4860, 512, 9, 9, 6, 5) \
+  AC_WAVE_CT(5000, 512, 10, 10, 5, 5) \
+  AC_WAVE_CT(5120, 512, 8, 8, 8, 5) \
+  AC_WAVE_CT(5184, 512, 9, 8, 6, 6) \
+  AC_WAVE_CT(5400, 512, 10, 9, 6, 5) \
+  AC_WAVE_CT(5760, 512, 10, 8, 6, 6) \
+  AC_WAVE_CT(5832, 512, 9, 9, 6, 6) \
+  AC_WAVE_CT(6000, 512, 10, 10, 6, 5) \
+  AC_WAVE_CT(6144, 512, 8, 8, 8, 6) \
+  AC_WAVE_CT(6400, 512, 10, 8, 8, 5) \
+  AC_WAVE_CT(6480, 512, 9, 9, 8, 5) \
+  AC_WAVE_CT(6912, 512, 9, 8, 8, 6) \
+  AC_WAVE_CT(7200, 512, 10, 9, 8, 5) \
+  AC_WAVE_CT(7680, 512, 10, 8, 8, 6) \
+  AC_WAVE_CT(7776, 512, 9, 9, 8, 6) \
+  AC_WAVE_CT(8000, 512, 10, 10, 8, 5) \
+  AC_WAVE_CT(8100, 512, 10, 9, 9, 5) \
+  AC_WAVE_CT(8192, 512, 8, 8, 8, 8)
 static bool lds_wave_ct_size(int N) {
 #define AC_WAVE_CT(NC, NTC, R0, R1, R2, R3) \
   if (N == NC) return true;
@@ -1963,6 +1985,13 @@ int launch_inv_wave_mono(const ac_mdct_plan* p, const float* X, float* x, const 
 }
 #else
 
+// returned by launch_fwd_wave / launch_inv_wave when the tensors at hand are not for the 16-byte kernels (rows off the 16-byte
+// grid, tuning hooks) and the size is past the 8-byte wave kernels' range: the caller goes on to the next tier
+constexpr int kWaveDeclined = -12345;
+static bool wave_8_byte_range(int N, bool synthesis) {
+  static const int wave_max = [] { const char* e = getenv("AC_LDS_WAVE_MAX"); return e ? atoi(e) : AC_LDS_WAVE_MAX; }();
+  return lds_fft_ok(N) && N <= wave_max;
+}
 template <typename TIO>
 static int launch_fwd_wave(const ac_mdct_plan* p, const TIO* x, TIO* X, const TIO* prev_block, int B, int Kin, int F, int C,
                            hipStream_t s) {
@@ -1970,6 +1999,7 @@ static int launch_fwd_wave(const ac_mdct_plan* p, const TIO* x, TIO* X, const TI
   if constexpr (std::is_same<TIO, float>::value)
     if (lds_wave_vec_ok(p, wp0, C, {x, X, prev_block}))
       return C == 2 ? launch_fwd_wave_v<false>(p, x, X, prev_block, B, Kin, F, s) : launch_fwd_wave_mono(p, x, X, prev_block, B, Kin, F, s);
+  if (!wave_8_byte_range(p->N, false)) return kWaveDeclined;
   const WavePlan wp = lds_wave_plan(p->N, false);
   size_t lds = 0;
   const int w = lds_wave_block(p->N, wp, 0, &lds);
@@ -1995,6 +2025,7 @@ static int launch_inv_wave(const ac_mdct_plan* p, const TIO* X, TIO* x, const fl
     if (lds_wave_vec_ok(p, wp0, C, {X, x}))
       return C == 2 ? launch_inv_wave_v<false>(p, X, x, tail_in, tail_out, B, Kp, nblk, s)
                     : launch_inv_wave_mono(p, X, x, tail_in, tail_out, B, Kp, nblk, s);
+  if (!wave_8_byte_range(p->N, true)) return kWaveDeclined;
   const WavePlan wp = lds_wave_plan(p->N, false);
   size_t lds = 0;
   const int w = lds_wave_block(p->N, wp, p->N, &lds);
@@ -2021,7 +2052,10 @@ int launch_fwd_generic(const ac_mdct_plan* p, const float* x, float* X, const fl
   const long long nwg = (long long)B * C * F;
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
-  if (lds_wave_ok(p->N, false, C, true) && !g_force_generic) return launch_fwd_wave<float>(p, x, X, prev_block, B, Kin, F, C, s);
+  if (lds_wave_ok(p->N, false, C, true) && !g_force_generic) {
+    const int r = launch_fwd_wave<float>(p, x, X, prev_block, B, Kin, F, C, s);
+    if (r != kWaveDeclined) return r;
+  }
   if (lds_fft_ok(p->N) && !g_force_generic) {
     const int CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const long long ntasks = (long long)B * CP * F;
@@ -2053,7 +2087,10 @@ int launch_inv_generic(const ac_mdct_plan* p, const float* X, float* x, const fl
   const long long nwg = (long long)B * C * per_sig;
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
-  if (lds_wave_ok(p->N, true, C, true) && !g_force_generic) return launch_inv_wave<float>(p, X, x, tail_in, tail_out, B, Kp, nblk, C, s);
+  if (lds_wave_ok(p->N, true, C, true) && !g_force_generic) {
+    const int r = launch_inv_wave<float>(p, X, x, tail_in, tail_out, B, Kp, nblk, C, s);
+    if (r != kWaveDeclined) return r;
+  }
   if (lds_fft_ok(p->N) && !g_force_generic) {
     const int seg = 8, CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const int nseg = (per_sig + seg - 1) / seg;
@@ -2193,7 +2230,10 @@ int launch_fwd_bf16(const ac_mdct_plan* p, const bf16_t* x, bf16_t* X, int B, in
   const long long nwg = (long long)B * C * F;
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
-  if (lds_wave_ok(p->N, false, C, false) && !g_force_generic) return launch_fwd_wave<bf16_t>(p, x, X, (const bf16_t*)nullptr, B, Kin, F, C, s);
+  if (lds_wave_ok(p->N, false, C, false) && !g_force_generic) {
+    const int r = launch_fwd_wave<bf16_t>(p, x, X, (const bf16_t*)nullptr, B, Kin, F, C, s);
+    if (r != kWaveDeclined) return r;
+  }
   if (lds_fft_ok(p->N) && !g_force_generic) {
     const int CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const long long ntasks = (long long)B * CP * F;
@@ -2223,7 +2263,10 @@ int launch_inv_bf16(const ac_mdct_plan* p, const bf16_t* X, bf16_t* x, int B, in
   const long long nwg = (long long)B * C * nblk;
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
-  if (lds_wave_ok(p->N, true, C, false) && !g_force_generic) return launch_inv_wave<bf16_t>(p, X, x, nullptr, nullptr, B, Kp, nblk, C, s);
+  if (lds_wave_ok(p->N, true, C, false) && !g_force_generic) {
+    const int r = launch_inv_wave<bf16_t>(p, X, x, nullptr, nullptr, B, Kp, nblk, C, s);
+    if (r != kWaveDeclined) return r;
+  }
   if (lds_fft_ok(p->N) && !g_force_generic) {
     const int seg = 8, CP = (C + 1) / 2, gpw = kThreads / lds_group_threads(p->N);
     const int nseg = (nblk + seg - 1) / seg;

@@ -182,11 +182,11 @@ def _smooth_half(N):
     return h == 1
 
 
-# every filters_n the 16-byte kernels of the LDS-FFT tier serve (float32 stereo rows, filters_n % 4 == 0 up to 4096 with a
+# every filters_n the 16-byte kernels of the LDS-FFT tier serve (float32 stereo rows, filters_n % 4 == 0 up to 8192 with a
 # 5-smooth half, beside the powers of two of the wave-level kernels): one compile-time instance each (ac_generic.hip
-# AC_WAVE_CT_SIZES; a frame per group of lanes inside a wave up to 1024, per workgroup of two / four waves and in place
-# above); the reference takes any even filters_n (mdctransformer.py:26)
-WAVE16_SIZES = [N for N in range(16, 4097, 4) if _smooth_half(N) and N not in (64, 128, 256, 512, 1024, 2048)]
+# AC_WAVE_CT_SIZES; a frame per group of lanes inside a wave up to 1024, per workgroup of two / four / eight waves and in
+# place above, up to 8192 -- 7500 has no plan of four passes and stays on the O(N^2) kernels); the reference takes any even filters_n (mdctransformer.py:26)
+WAVE16_SIZES = [N for N in range(16, 8193, 4) if _smooth_half(N) and N not in (64, 128, 256, 512, 1024, 2048, 7500)]
 
 
 @pytest.mark.parametrize("C", [2, 1])
@@ -196,7 +196,7 @@ def test_lds_fft_wave_16_byte_kernels_every_size(N, C):
     complex pair, the last pair half empty), against the fp64 oracle: analysis, synthesis incl. the aliased head / tail
     blocks, and the round trip to 1 LSB."""
     rng = np.random.default_rng(N + C)
-    B, K = 3, (70 if N <= 128 else 37 if N <= 480 else 11 if N <= 2048 else 6)
+    B, K = 3, (70 if N <= 128 else 37 if N <= 480 else 11 if N <= 2048 else 6 if N <= 4096 else 3)
     x = rng.uniform(-1, 1, (B, K * N, C)).astype(np.float32)
     m = audiocodec_amd.MDCTransformer(N)
     o = MDCTOracle(N, "vorbis", np.float64)
@@ -554,7 +554,7 @@ def test_db_and_noise(golden, path):
                                         (64, 2, (5, 17, 1, 16)), (64, 1, (33, 2)),
                                         # strips of the 16-byte LDS-FFT wave kernels: longer / shorter than a strip, state in and out
                                         (480, 2, (40, 3, 1)), (120, 2, (70, 1)), (16, 2, (100, 3)), (48, 2, (5,)), (960, 2, (33,)), (1920, 2, (3, 9)),
-                                        (4096, 2, (2, 1, 3)), (1536, 1, (2, 3)), (480, 1, (40, 3, 1)), (1920, 1, (3, 2)), (24, 1, (7, 60))])
+                                        (4096, 2, (2, 1, 3)), (1536, 1, (2, 3)), (8192, 2, (2, 1)), (480, 1, (40, 3, 1)), (1920, 1, (3, 2)), (24, 1, (7, 60))])
 def test_streaming_equals_one_shot(path, N, C, chunks):
     B, K = 2, sum(chunks)
     x = torch.rand(B, K * N, C, device="cuda") * 2 - 1
