@@ -128,7 +128,7 @@ def load():
             fn = getattr(lib, name)          # AttributeError here = header/library mismatch
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.ac_version() < 170:
+        if lib.ac_version() < 171:
             raise ImportError("libaudiocodec_amd too old: %d" % lib.ac_version())
         _lib = lib
     return _lib

@@ -34,7 +34,7 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(lib, s), "libaudiocodec_amd.so does not export %s" % s
     assert sorted(_lib.PROTOTYPES) == syms, "ctypes prototypes and header disagree"
-    assert lib.ac_version() == 170
+    assert lib.ac_version() == 171
     assert _header_symbols(("audiocodec_amd_testing.h",)) == ["ac_set_force_generic"]
     assert "ac_set_force_generic" not in _header_symbols(("audiocodec_amd.h",))
 
