@@ -8,6 +8,9 @@ out=gpurun_out/entry_points.txt
   echo; echo "== N = 1024, B = 256 mono, K = 468"; C=1 python tools/microbench.py 2>/dev/null
   echo; echo "== N = 512 (two frames per wave), B = 256 stereo, K = 936"; N=512 python tools/microbench.py 2>/dev/null | sed -n 1,5p
   echo; echo "== N = 960 (LDS-FFT tier), B = 64 stereo, K = 499"; N=960 B=64 K=499 python tools/microbench.py 2>/dev/null | sed -n 1,5p
+  echo; echo "== N = 960, B = 256 stereo, K = 499"; N=960 python tools/microbench.py 2>/dev/null | sed -n 1,6p
+  echo; echo "== N = 1920 (LDS-FFT tier, two waves per frame; masking model with 16 granule registers), B = 256 stereo, K = 249"; N=1920 python tools/microbench.py 2>/dev/null | sed -n 1,6p
+  echo; echo "== N = 4096 (four waves per frame; 32 granule registers), B = 256 stereo, K = 117"; N=4096 python tools/microbench.py 2>/dev/null | sed -n 1,6p
   echo; echo "== N = 512, B = 256 mono, K = 936"; N=512 C=1 python tools/microbench.py 2>/dev/null | sed -n 1,5p
   echo; echo "== N = 256 (four frames per wave), B = 256 stereo, K = 1872"; N=256 python tools/microbench.py 2>/dev/null | sed -n 1,5p
   echo; echo "== N = 128 (eight frames per wave), B = 256 stereo, K = 3744"; N=128 python tools/microbench.py 2>/dev/null | sed -n 2,3p

@@ -7,6 +7,7 @@
 #   pmc_encode.txt, pmc_decode.txt   rocprofv3 --pmc, separate passes (tools/pmc.sh)
 #   traffic.json                FETCH_SIZE (doubled: gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE per launch
 #   pmc_short_frames_n256.txt   the same counters for transform / inverse / threshold at filters_n = 256
+#   lds_fft_tier_sizes.txt      the LDS-FFT tier over its sizes (stereo, mono, three channels; the A/B forms of the kernels)
 #   entry_points.txt            every entry point on bench-sized workloads (tools/entry_points.sh)
 # Copy the directory's files into profiles/rNN afterwards.
 r=${1:-r3}
@@ -91,11 +92,29 @@ echo "pmc short frames done"
   done
   for what in transform inverse; do
     N=960 B=64 tools/pmc.sh $what ${r}_n960_$what > /dev/null 2>&1
-    echo "== filters_n = 960 (LDS-FFT tier, wave form), B = 64 stereo, K = 499: $what (algorithmic bytes per launch: $((7680 * 64 * 2 * 499)))"
+    echo "== filters_n = 960 (LDS-FFT tier, 16-byte kernels, one wave per frame), B = 64 stereo, K = 499: $what (algorithmic bytes per launch: $((7680 * 64 * 2 * 499)))"
     cat gpurun_out/pmc_${r}_n960_$what.txt
   done
-} > $out/pmc_fused_n512_and_lds_fft_n960.txt
-echo "pmc n512 / n960 done"
+  for what in transform inverse; do
+    N=4096 B=64 tools/pmc.sh $what ${r}_n4096_$what > /dev/null 2>&1
+    echo "== filters_n = 4096 (LDS-FFT tier, 16-byte kernels, four waves per frame, in place), B = 64 stereo, K = 117: $what (algorithmic bytes per launch: $((32768 * 64 * 2 * 117)))"
+    cat gpurun_out/pmc_${r}_n4096_$what.txt
+  done
+} > $out/pmc_fused_n512_and_lds_fft_n960_n4096.txt
+echo "pmc n512 / n960 / n4096 done"
+# the LDS-FFT tier over its sizes: B = 64 stereo / B = 128 mono clips of 10 s, analysis and synthesis through the Python API
+{
+  echo "== LDS-FFT tier, float32, 64 stereo clips of 10 s (algorithmic 8 N bytes per frame; times include the result's allocation)"
+  SIZES=16,24,32,48,96,120,160,192,240,320,384,480,576,640,768,800,960,1000,1152,1280,1536,1920,2304,2880,3072,3840,4096,5120,6144,7680,8192 python tools/smooth_sizes_bench.py 2>&1 | grep "^N"
+  echo "== the same, 128 mono clips"
+  C=1 SIZES=32,120,240,480,960,1920,4096,8192 python tools/smooth_sizes_bench.py 2>&1 | grep "^N"
+  echo "== the same, 42 clips of 3 channels (8-byte wave kernels / workgroup form: run-time sizes)"
+  C=3 B=42 SIZES=120,480,960,1920,4096 python tools/smooth_sizes_bench.py 2>&1 | grep "^N"
+  echo "== 64 stereo clips, the run-time form of the 16-byte kernels (AC_LDS_WAVE_NOCT=1) and the 8-byte kernels (AC_LDS_WAVE_NOVEC=1)"
+  AC_LDS_WAVE_NOCT=1 SIZES=120,480,960 python tools/smooth_sizes_bench.py 2>&1 | grep "^N"
+  AC_LDS_WAVE_NOVEC=1 SIZES=120,480,960,1920,4096 python tools/smooth_sizes_bench.py 2>&1 | grep "^N"
+} > $out/lds_fft_tier_sizes.txt
+echo "lds-fft sizes done"
 tools/entry_points.sh > /dev/null 2>&1; cp gpurun_out/entry_points.txt $out/entry_points.txt
 echo "entry points done"
 ls -la $out
