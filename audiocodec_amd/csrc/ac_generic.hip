@@ -3,6 +3,9 @@
 // independent on-device cross-check for them.  gfx950 only.
 #include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "ac_internal.h"
 
@@ -1033,8 +1036,10 @@ struct RowPair {
     if constexpr (!MONO) {
       return *reinterpret_cast<const v4f_t*>(a + 2 * m);
     } else {
+      // (no branch on has1: a conditional load would make the wave wait for it at the join, before the transform it is meant
+      // to overlap; the half-empty last pair of an odd batch reads row a twice -- pair_geo -- and never stores row b)
       const v2f_t fa = *reinterpret_cast<const v2f_t*>(a + m);
-      const v2f_t fb = has1 ? *reinterpret_cast<const v2f_t*>(b + m) : v2f_t{0.f, 0.f};
+      const v2f_t fb = *reinterpret_cast<const v2f_t*>(b + m);
       return v4f_t{fa.x, fb.x, fa.y, fb.y};
     }
   }
@@ -1053,11 +1058,11 @@ struct PairGeo {
   size_t off_a, off_b, block_stride;
 };
 template <bool MONO>
-__device__ __forceinline__ PairGeo pair_geo(long long p, int N, size_t blocks_per_signal) {
+__device__ __forceinline__ PairGeo pair_geo(long long p, int N, size_t blocks_per_signal, bool has1) {
   PairGeo g;
   g.block_stride = (size_t)N * (MONO ? 1 : 2);
   g.off_a = (size_t)(MONO ? 2 * p : p) * blocks_per_signal * g.block_stride;
-  g.off_b = g.off_a + blocks_per_signal * g.block_stride;   // (MONO: the next signal)
+  g.off_b = g.off_a + (has1 ? blocks_per_signal * g.block_stride : 0);   // (MONO: the next signal, or the same one again)
   return g;
 }
 
@@ -1089,7 +1094,8 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
   const int sp = (int)(wg % nstrip);
   const long long pr = wg / nstrip;
   const RowPair<MONO> rp = {!MONO || 2 * pr + 1 < B};
-  const PairGeo gx = pair_geo<MONO>(pr, N, (size_t)Kin), gX = pair_geo<MONO>(pr, N, (size_t)F), gp = pair_geo<MONO>(pr, N, 1);
+  const PairGeo gx = pair_geo<MONO>(pr, N, (size_t)Kin, rp.has1), gX = pair_geo<MONO>(pr, N, (size_t)F, rp.has1),
+                gp = pair_geo<MONO>(pr, N, 1, rp.has1);
   const int n0 = sp * T, n1 = min(n0 + T, F);
   v4f_t d0[kWaveVSteps], d1[kWaveVSteps], cy[kWaveVSteps];
   auto load_block = [&](const float* xa, const float* xb) {
@@ -1184,7 +1190,7 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
   const int sgm = (int)(wg % nseg);
   const long long pr = wg / nseg;
   const RowPair<MONO> rp = {!MONO || 2 * pr + 1 < B};
-  const PairGeo gX = pair_geo<MONO>(pr, N, (size_t)Kp), gx = pair_geo<MONO>(pr, N, (size_t)nblk);
+  const PairGeo gX = pair_geo<MONO>(pr, N, (size_t)Kp, rp.has1), gx = pair_geo<MONO>(pr, N, (size_t)nblk, rp.has1);
   const v4f_t* cv = coefv + h;   // the synthesis half of the table
   const float scale = 2.0f * 1.4142135623730951f;
   const int nlast = nblk + (tail_out ? 1 : 0);
@@ -1623,12 +1629,21 @@ static bool lds_fft_ok(int N) {
     while (h % r == 0) h /= r;
   return h == 1;
 }
-// dynamic LDS beyond the default 64 KB cap must be requested once per kernel (and per device)
+// dynamic LDS beyond the default 64 KB cap must be requested once per kernel and device: remembered, so that a launch in a
+// streaming chain does not pay a driver call each time
 template <typename K>
 static int allow_lds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return AC_OK;
-  AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)bytes));
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> granted;
+  int dev = 0;
+  AC_HIP_CHECK(hipGetDevice(&dev));
+  const std::pair<const void*, int> key(reinterpret_cast<const void*>(kernel), dev);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = granted.find(key);
+  if (it != granted.end() && it->second >= bytes) return AC_OK;
+  AC_HIP_CHECK(hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  granted[key] = bytes;
   return AC_OK;
 }
 
