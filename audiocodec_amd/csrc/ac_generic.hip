@@ -1665,18 +1665,20 @@ static int check_grid(long long n) {
 // the tier applies (every such size at 2.2 - 6.0 TB/s; the workgroup form 1.3 - 2.0).  Other layouts (mono, more channels,
 // bfloat16) run the 8-byte wave kernels where they measured faster: the analysis up to filters_n = 1024 except where a frame
 // gets 16 lanes and three passes (N / 2 from 97 to 127), the synthesis up to 1536.  AC_LDS_WAVE_MAX (tuning hook; 0: the
-// workgroup form everywhere) caps both, AC_LDS_WAVE_FORCE=1 takes the wave form wherever it exists.
+// workgroup form everywhere) caps both.
 static bool lds_wave_ct_size(int N);
 static bool lds_wave_vec_shape(int N, int C, bool f32) {
   return f32 && (C == 1 || C == 2) && N % 4 == 0 && (N <= 1024 || lds_wave_ct_size(N));   // (above 1024: the in-place instances only)
 }
-static bool lds_wave_ok(int N, bool synthesis, int C, bool f32) {
+static int lds_wave_max() {
   static const int wave_max = [] { const char* e = getenv("AC_LDS_WAVE_MAX"); return e ? atoi(e) : AC_LDS_WAVE_MAX; }();
+  return wave_max;
+}
+static bool lds_wave_ok(int N, bool synthesis, int C, bool f32) {
+  const int wave_max = lds_wave_max();
   if (wave_max <= 0) return false;
   if (lds_wave_vec_shape(N, C, f32) && (lds_fft_ok(N) || lds_wave_ct_size(N))) return true;   // (instances reach 8192, the tier's other forms 4096)
   if (!lds_fft_ok(N) || N > wave_max) return false;
-  static const int force = [] { const char* e = getenv("AC_LDS_WAVE_FORCE"); return e ? atoi(e) : 0; }();   // (A/B measurements)
-  if (force) return true;
   const int H = N / 2;
   return synthesis ? N <= 1536 : (N <= 1024 && !(H > 96 && H < 128));
 }
@@ -1812,8 +1814,7 @@ static WavePlan lds_wave_plan(int N, bool groups = true) {   // groups: frames d
   }
   AC_WAVE_CT_SIZES
 #undef AC_WAVE_CT
-  static const int nt_min = [] { const char* e = getenv("AC_LDS_WAVE_NT_MIN"); return e ? atoi(e) : 4; }();   // tuning hook
-  int nt = nt_min < 4 ? 4 : nt_min > 64 ? 64 : nt_min;
+  int nt = 4;
   while (nt < 64 && nt < H / 8) nt <<= 1;
   best.nt = nt;
   static const int cand[] = {16, 15, 12, 10, 9, 8, 6, 5, 4, 3, 2};
@@ -2003,10 +2004,7 @@ int launch_inv_wave_mono(const ac_mdct_plan* p, const float* X, float* x, const 
 // returned by launch_fwd_wave / launch_inv_wave when the tensors at hand are not for the 16-byte kernels (rows off the 16-byte
 // grid, tuning hooks) and the size is past the 8-byte wave kernels' range: the caller goes on to the next tier
 constexpr int kWaveDeclined = -12345;
-static bool wave_8_byte_range(int N, bool synthesis) {
-  static const int wave_max = [] { const char* e = getenv("AC_LDS_WAVE_MAX"); return e ? atoi(e) : AC_LDS_WAVE_MAX; }();
-  return lds_fft_ok(N) && N <= wave_max;
-}
+static bool wave_8_byte_range(int N) { return lds_fft_ok(N) && N <= lds_wave_max(); }
 template <typename TIO>
 static int launch_fwd_wave(const ac_mdct_plan* p, const TIO* x, TIO* X, const TIO* prev_block, int B, int Kin, int F, int C,
                            hipStream_t s) {
@@ -2014,7 +2012,7 @@ static int launch_fwd_wave(const ac_mdct_plan* p, const TIO* x, TIO* X, const TI
   if constexpr (std::is_same<TIO, float>::value)
     if (lds_wave_vec_ok(p, wp0, C, {x, X, prev_block}))
       return C == 2 ? launch_fwd_wave_v<false>(p, x, X, prev_block, B, Kin, F, s) : launch_fwd_wave_mono(p, x, X, prev_block, B, Kin, F, s);
-  if (!wave_8_byte_range(p->N, false)) return kWaveDeclined;
+  if (!wave_8_byte_range(p->N)) return kWaveDeclined;
   const WavePlan wp = lds_wave_plan(p->N, false);
   size_t lds = 0;
   const int w = lds_wave_block(p->N, wp, 0, &lds);
@@ -2040,7 +2038,7 @@ static int launch_inv_wave(const ac_mdct_plan* p, const TIO* X, TIO* x, const fl
     if (lds_wave_vec_ok(p, wp0, C, {X, x}))
       return C == 2 ? launch_inv_wave_v<false>(p, X, x, tail_in, tail_out, B, Kp, nblk, s)
                     : launch_inv_wave_mono(p, X, x, tail_in, tail_out, B, Kp, nblk, s);
-  if (!wave_8_byte_range(p->N, true)) return kWaveDeclined;
+  if (!wave_8_byte_range(p->N)) return kWaveDeclined;
   const WavePlan wp = lds_wave_plan(p->N, false);
   size_t lds = 0;
   const int w = lds_wave_block(p->N, wp, p->N, &lds);
