@@ -1660,7 +1660,7 @@ static int check_grid(long long n) {
 #ifndef AC_LDS_WAVE_MAX
 #define AC_LDS_WAVE_MAX 2048   // (0: the workgroup form everywhere, for A/B measurements)
 #endif
-// Which of the two forms serves a size is measured, not derived (profiles/r3/lds_fft_tier_wave_vs_workgroup.txt, B = 64
+// Which of the two forms serves a size is measured, not derived (profiles/r3/lds_fft_tier_sizes.txt, B = 64
 // stereo, 10 s, same process).  float32 stereo rows with filters_n % 4 == 0 up to 1024 take the 16-byte wave kernels wherever
 // the tier applies (every such size at 2.2 - 6.0 TB/s; the workgroup form 1.3 - 2.0).  Other layouts (mono, more channels,
 // bfloat16) run the 8-byte wave kernels where they measured faster: the analysis up to filters_n = 1024 except where a frame
