@@ -1108,10 +1108,14 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
       }
     }
   };
+  // a x + b y with one fixed rounding order (a product, then one fused multiply-add): the carry is formed at two places -- at
+  // a strip's start and inside the frame loop -- and a frame must not depend on which one served it (chunked = one-shot, bit
+  // for bit); left to the compiler's contraction the two sites may fuse the other product
+  auto fold2 = [](float a, float x, float b, float y) { return __builtin_fmaf(a, x, b * y); };
   auto carry_of = [&](int s, int i) {   // (v[h - 2 - 2 i], v[h - 1 - 2 i]) of the NEXT frame
     const v4f_t g = coefv[2 * i + 1];
-    return v4f_t{g.z * d0[s].z + g.w * d1[s].x, g.z * d0[s].w + g.w * d1[s].y, g.x * d0[s].x + g.y * d1[s].z,
-                 g.x * d0[s].y + g.y * d1[s].w};
+    return v4f_t{fold2(g.z, d0[s].z, g.w, d1[s].x), fold2(g.z, d0[s].w, g.w, d1[s].y), fold2(g.x, d0[s].x, g.y, d1[s].z),
+                 fold2(g.x, d0[s].y, g.y, d1[s].w)};
   };
   {
     const bool have = n0 >= 1 || prev_block != nullptr;
@@ -1133,8 +1137,8 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
         v4f_t hi = {0.f, 0.f, 0.f, 0.f};
         if (has_cur) {
           const v4f_t f = coefv[2 * i];
-          hi = v4f_t{f.x * d0[s].x + f.y * d1[s].z, f.x * d0[s].y + f.y * d1[s].w, f.z * d0[s].z + f.w * d1[s].x,
-                     f.z * d0[s].w + f.w * d1[s].y};
+          hi = v4f_t{fold2(f.x, d0[s].x, f.y, d1[s].z), fold2(f.x, d0[s].y, f.y, d1[s].w), fold2(f.z, d0[s].z, f.w, d1[s].x),
+                     fold2(f.z, d0[s].w, f.w, d1[s].y)};
         }
         *reinterpret_cast<v4f_t*>(v + h + 2 * i) = hi;
         *reinterpret_cast<v4f_t*>(v + h - 2 - 2 * i) = cy[s];
@@ -1894,7 +1898,9 @@ static void wave_v_geometry(int N, const WavePlan& wp, int* w, int* gpw, size_t*
 // frames per strip of the 16-byte kernels: a strip pays `extra` frames' worth of work before its first frame (the block /
 // the transform before it), a launch runs in rounds of as many workgroups as are resident; the least rounds x (frames + extra)
 static int wave_strip(long long pairs, int per_sig, int gpw, int w, size_t lds, int cus, double extra) {
-  static const int t_max = [] { const char* e = getenv("AC_LDS_WAVE_STRIP"); return e ? atoi(e) : 32; }();   // tuning hook
+  static const int forced = [] { const char* e = getenv("AC_LDS_WAVE_STRIP"); return e ? atoi(e) : 0; }();   // (A/B measurements, tests)
+  if (forced > 0) return std::min(forced, std::max(per_sig, 1));
+  const int t_max = 32;
   const long resident = (long)cus * std::max<long>(1, std::min<long>(160 * 1024 / (long)std::max<size_t>(lds, 1), 8 / w));
   static const int cand[] = {32, 24, 16, 12, 8, 6, 4, 3, 2, 1};
   int best = 1;

@@ -228,6 +228,78 @@ def test_lds_fft_tier_rows_off_the_16_byte_grid(N, C):
     assert float((y - y_off).abs().max()) <= 2e-6
 
 
+def test_lds_fft_wave_16_byte_kernels_strip_lengths(tmp_path):
+    """A frame's bits do not depend on where in a strip it falls (small batches run strips of one frame, large ones up to
+    32: AC_LDS_WAVE_STRIP forces a length), nor on where a stream is cut: one-shot and chunked analysis agree bit for bit at
+    every strip length, the synthesis to rounding."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    code = ("import sys, numpy as np, torch, audiocodec_amd\n"
+            "out = {}\n"
+            "for N, C in ((960, 2), (480, 1), (120, 2), (1920, 2), (4096, 1), (32, 2)):\n"
+            "    g = torch.Generator(device='cuda').manual_seed(N)\n"
+            "    K = 21\n"
+            "    x = torch.empty(3, K * N, C, device='cuda').uniform_(-1, 1, generator=g)\n"
+            "    m = audiocodec_amd.MDCTransformer(N)\n"
+            "    X = m.transform(x)\n"
+            "    st = audiocodec_amd.StreamingMDCT(m, 3, C)\n"
+            "    Xs = torch.cat([st.transform_chunk(x[:, a * N:b * N].contiguous()) for a, b in ((0, 5), (5, 6), (6, 19), (19, 21))]\n"
+            "                   + [st.transform_chunk(torch.zeros(3, N, C, device='cuda'))], dim=1)\n"
+            "    assert torch.equal(Xs, X), ('chunked != one-shot', N, C)\n"
+            "    out['X%d' % N] = X.cpu().numpy()\n"
+            "    out['y%d' % N] = m.inverse_transform(X).cpu().numpy()\n"
+            "np.savez(sys.argv[1], **out)\n")
+    got = {}
+    for strip in ("0", "1", "4", "32"):
+        f = str(tmp_path / ("strip%s.npz" % strip))
+        env = dict(os.environ)
+        env.pop("AC_LDS_WAVE_STRIP", None)
+        if strip != "0":
+            env["AC_LDS_WAVE_STRIP"] = strip
+        r = subprocess.run([sys.executable, "-c", code, f], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[strip] = np.load(f)
+    for strip in ("1", "4", "32"):
+        for k in got["0"].files:
+            a, b = got["0"][k], got[strip][k]
+            if k.startswith("X"):
+                assert np.array_equal(a, b), (k, strip)
+            else:
+                assert np.max(np.abs(a - b)) <= 1e-6, (k, strip)
+
+
+def test_lds_fft_wave_16_byte_kernels_every_size_inside_a_strip(tmp_path):
+    """test_lds_fft_wave_16_byte_kernels_every_size runs small batches, i.e. strips of one frame; here every instance (both row
+    layouts) with strips of five frames -- the carried fold / aliased half -- against the strips-of-one results, which that
+    test holds to the oracle."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    code = ("import sys, json, numpy as np, torch, audiocodec_amd\n"
+            "out = {}\n"
+            "for N in json.loads(sys.argv[2]):\n"
+            "    for C in (2, 1):\n"
+            "        g = torch.Generator(device='cuda').manual_seed(N + C)\n"
+            "        x = torch.empty(3, 7 * N, C, device='cuda').uniform_(-1, 1, generator=g)\n"
+            "        m = audiocodec_amd.MDCTransformer(N)\n"
+            "        X = m.transform(x)\n"
+            "        out['X%d_%d' % (N, C)] = X.cpu().numpy()\n"
+            "        out['y%d_%d' % (N, C)] = m.inverse_transform(X).cpu().numpy()\n"
+            "np.savez(sys.argv[1], **out)\n")
+    got = {}
+    for strip in ("1", "5"):
+        f = str(tmp_path / ("strip%s.npz" % strip))
+        r = subprocess.run([sys.executable, "-c", code, f, json.dumps(WAVE16_SIZES)], cwd=ROOT,
+                           env=dict(os.environ, AC_LDS_WAVE_STRIP=strip), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[strip] = np.load(f)
+    for k in got["1"].files:
+        a, b = got["1"][k], got["5"][k]
+        if k.startswith("X"):
+            assert np.array_equal(a, b), k
+        else:
+            assert np.max(np.abs(a - b)) <= 1e-6, k
+
+
 def test_lds_fft_wave_16_byte_kernels_run_time_form(tmp_path):
     """The same kernels with the size as a run-time argument (AC_LDS_WAVE_NOCT=1, the A/B reference of the compile-time
     instances) agree with the instances to float32 rounding (the compiler contracts the two forms differently)."""
