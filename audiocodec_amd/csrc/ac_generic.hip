@@ -1022,55 +1022,87 @@ static __global__ __launch_bounds__(kThreads, 2) void k_inv_wave(const TIO* __re
 // it is formed at once and carried in registers to the next frame of the strip.  coefv (ac_mdct_plan::d_coefv) holds the
 // coefficients in that order, 16 bytes per lane and step.  The next block's loads are issued before the transform of the
 // current frame and land while it runs.
-// The two rows a complex pair carries through the transform: the channels of a stereo signal (one 16-byte access per two
-// samples) or, MONO, two mono signals b, b + 1 (8 bytes each; the last pair of an odd batch is half empty).  Other channel
-// counts run the 8-byte kernels above.
+// The two rows a complex pair carries through the transform (LAY): 0 the channels of a stereo signal (one 16-byte access
+// per two samples); 1 two mono signals b, b + 1 (8 bytes each; the last pair of an odd batch is half empty); 2 the channels
+// c, c + 1 of any channel count, rows anywhere on the 4-byte grid (4-byte accesses; the last pair of an odd count is half
+// empty).  bfloat16 tensors and filters_n % 4 == 2 run the 8-byte kernels above.
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 constexpr int kWaveVSteps = 4;
-template <bool MONO>
+template <int LAY>
 struct RowPair {
   bool has1;
-  // samples m, m + 1 (m even) of the two rows starting at a (and b): (row0[m], row1[m], row0[m+1], row1[m+1])
+  int C;   // (LAY 2) floats between successive samples
+  // samples m, m + 1 (m even) of the two rows starting at a (and b): (row0[m], row1[m], row0[m+1], row1[m+1]).  No branch on
+  // has1: a conditional load would make the wave wait for it at the join, before the transform it is meant to overlap; a
+  // half-empty pair reads its one row twice (pair_geo) and never stores the second.
   __device__ __forceinline__ v4f_t load2(const float* a, const float* b, int m) const {
-    if constexpr (!MONO) {
+    if constexpr (LAY == 0) {
       return *reinterpret_cast<const v4f_t*>(a + 2 * m);
-    } else {
-      // (no branch on has1: a conditional load would make the wave wait for it at the join, before the transform it is meant
-      // to overlap; the half-empty last pair of an odd batch reads row a twice -- pair_geo -- and never stores row b)
+    } else if constexpr (LAY == 1) {
       const v2f_t fa = *reinterpret_cast<const v2f_t*>(a + m);
       const v2f_t fb = *reinterpret_cast<const v2f_t*>(b + m);
       return v4f_t{fa.x, fb.x, fa.y, fb.y};
+    } else {
+      int o = m * C;   // (formed where it is used: hoisted out of the frame loop, the addresses of a lane's 64 accesses spill)
+      asm volatile("" : "+v"(o));
+      const float *p0 = a + o, *p1 = b + o;
+      return v4f_t{p0[0], p1[0], p0[C], p1[C]};
     }
   }
   __device__ __forceinline__ void store2(float* a, float* b, int m, v4f_t v) const {
-    if constexpr (!MONO) {
+    if constexpr (LAY == 0) {
       __builtin_nontemporal_store(v, reinterpret_cast<v4f_t*>(a + 2 * m));
-    } else {
+    } else if constexpr (LAY == 1) {
       __builtin_nontemporal_store(v2f_t{v.x, v.z}, reinterpret_cast<v2f_t*>(a + m));
       if (has1) __builtin_nontemporal_store(v2f_t{v.y, v.w}, reinterpret_cast<v2f_t*>(b + m));
+    } else {
+      int o = m * C;
+      asm volatile("" : "+v"(o));
+      float *p0 = a + o, *p1 = b + o;
+      p0[0] = v.x;
+      p0[C] = v.z;
+      if (has1) {
+        p1[0] = v.y;
+        p1[C] = v.w;
+      }
     }
   }
 };
-// pair p of a tensor [B, blocks_per_signal * N, C]: float offsets of its row(s), floats between successive blocks; the stream
-// state rows of pair p are 2 p, 2 p + 1 of [B * C][N / 2] in both layouts
+// pair p of a tensor [B, blocks_per_signal * N, C]: float offsets of its row(s), floats between successive blocks, the
+// first of its two stream state rows ([B * C][N / 2]), and whether its second row exists
 struct PairGeo {
   size_t off_a, off_b, block_stride;
+  long long row0;
+  bool has1;
 };
-template <bool MONO>
-__device__ __forceinline__ PairGeo pair_geo(long long p, int N, size_t blocks_per_signal, bool has1) {
+template <int LAY>
+__device__ __forceinline__ PairGeo pair_geo(long long p, int N, int B, int C, size_t blocks_per_signal) {
   PairGeo g;
-  g.block_stride = (size_t)N * (MONO ? 1 : 2);
-  g.off_a = (size_t)(MONO ? 2 * p : p) * blocks_per_signal * g.block_stride;
-  g.off_b = g.off_a + (has1 ? blocks_per_signal * g.block_stride : 0);   // (MONO: the next signal, or the same one again)
+  if constexpr (LAY == 2) {
+    const int CP = (C + 1) / 2;
+    const long long b0 = p / CP;
+    const int c = 2 * (int)(p - b0 * CP);
+    g.has1 = c + 1 < C;
+    g.block_stride = (size_t)N * C;
+    g.off_a = (size_t)b0 * blocks_per_signal * g.block_stride + c;
+    g.off_b = g.off_a + (g.has1 ? 1 : 0);
+    g.row0 = b0 * C + c;
+  } else {
+    g.has1 = LAY == 0 || 2 * p + 1 < B;
+    g.block_stride = (size_t)N * (LAY == 1 ? 1 : 2);
+    g.off_a = (size_t)(LAY == 1 ? 2 * p : p) * blocks_per_signal * g.block_stride;
+    g.off_b = g.off_a + (g.has1 ? blocks_per_signal * g.block_stride : 0);   // (LAY 1: the next signal, or the same one again)
+    g.row0 = 2 * p;
+  }
   return g;
 }
 
-template <int NC, int NTC, int R0, int R1, int R2, int R3, bool MONO>
+template <int NC, int NTC, int R0, int R1, int R2, int R3, int LAY>
 static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k_fwd_wave_v(const float* __restrict__ x, float* __restrict__ X,
                                                           const float* __restrict__ prev_block, const v4f_t* __restrict__ coefv,
                                                           const float* __restrict__ ctab, int Kin, int F, int N_rt, long long ntasks,
-                                                          int T, int nstrip, int B, WavePlan wp) {
+                                                          int T, int nstrip, int B, int C, WavePlan wp) {
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int N = NC ? NC : N_rt, nt = NC ? NTC : wp.nt, gpw = (int)blockDim.x / nt, grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
   constexpr bool GRP = NTC > 64;   // one frame per workgroup of NTC lanes, transformed in place
@@ -1093,9 +1125,9 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
   if (wg >= ntasks) return;
   const int sp = (int)(wg % nstrip);
   const long long pr = wg / nstrip;
-  const RowPair<MONO> rp = {!MONO || 2 * pr + 1 < B};
-  const PairGeo gx = pair_geo<MONO>(pr, N, (size_t)Kin, rp.has1), gX = pair_geo<MONO>(pr, N, (size_t)F, rp.has1),
-                gp = pair_geo<MONO>(pr, N, 1, rp.has1);
+  const PairGeo gx = pair_geo<LAY>(pr, N, B, C, (size_t)Kin), gX = pair_geo<LAY>(pr, N, B, C, (size_t)F),
+                gp = pair_geo<LAY>(pr, N, B, C, 1);
+  const RowPair<LAY> rp = {gx.has1, C};
   const int n0 = sp * T, n1 = min(n0 + T, F);
   v4f_t d0[kWaveVSteps], d1[kWaveVSteps], cy[kWaveVSteps];
   auto load_block = [&](const float* xa, const float* xb) {
@@ -1166,12 +1198,12 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
 
 // the synthesis in the same form: wide spectrum loads (the next frame's issued before the overlap-add of this one), the two
 // output samples j, N - 1 - j of a lane's pairs as two wide stores, the aliased half of the previous frame in registers
-template <int NC, int NTC, int R0, int R1, int R2, int R3, bool MONO>
+template <int NC, int NTC, int R0, int R1, int R2, int R3, int LAY>
 static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k_inv_wave_v(const float* __restrict__ X, float* __restrict__ x,
                                                           const float* __restrict__ tail_in, float* __restrict__ tail_out,
                                                           const v4f_t* __restrict__ coefv, const float* __restrict__ ctab, int Kp,
                                                           int nblk, int seg, int nseg, int N_rt, long long ntasks, int B,
-                                                          WavePlan wp) {
+                                                          int C, WavePlan wp) {
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int N = NC ? NC : N_rt, nt = NC ? NTC : wp.nt, gpw = (int)blockDim.x / nt, grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
   constexpr bool GRP = NTC > 64;
@@ -1193,13 +1225,13 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
   if (wg >= ntasks) return;
   const int sgm = (int)(wg % nseg);
   const long long pr = wg / nseg;
-  const RowPair<MONO> rp = {!MONO || 2 * pr + 1 < B};
-  const PairGeo gX = pair_geo<MONO>(pr, N, (size_t)Kp, rp.has1), gx = pair_geo<MONO>(pr, N, (size_t)nblk, rp.has1);
+  const PairGeo gX = pair_geo<LAY>(pr, N, B, C, (size_t)Kp), gx = pair_geo<LAY>(pr, N, B, C, (size_t)nblk);
+  const RowPair<LAY> rp = {gx.has1, C};
   const v4f_t* cv = coefv + h;   // the synthesis half of the table
   const float scale = 2.0f * 1.4142135623730951f;
   const int nlast = nblk + (tail_out ? 1 : 0);
   const int n0 = sgm * seg;
-  const size_t ts = (size_t)(2 * pr) * h;   // stream state rows of the pair: ts, ts + h
+  const size_t ts = (size_t)gx.row0 * h;   // stream state rows of the pair: ts, ts + h
   // the aliased half u_{n-1}[h + 2 i], [h + 2 i + 1] of the lane's pairs stays in registers from frame to frame
   v4f_t um[kWaveVSteps];
 #pragma unroll
@@ -1672,7 +1704,7 @@ static int check_grid(long long n) {
 // workgroup form everywhere) caps both.
 static bool lds_wave_ct_size(int N);
 static bool lds_wave_vec_shape(int N, int C, bool f32) {
-  return f32 && (C == 1 || C == 2) && N % 4 == 0 && (N <= 1024 || lds_wave_ct_size(N));   // (above 1024: the in-place instances only)
+  return f32 && C >= 1 && N % 4 == 0 && (N <= 1024 || lds_wave_ct_size(N));   // (above 1024: the in-place instances only)
 }
 static int lds_wave_max() {
   static const int wave_max = [] { const char* e = getenv("AC_LDS_WAVE_MAX"); return e ? atoi(e) : AC_LDS_WAVE_MAX; }();
@@ -1876,12 +1908,17 @@ static int lds_wave_block(int N, const WavePlan& wp, int extra_floats, size_t* l
 }
 
 // the 16-byte kernels serve float32 stereo rows whose lanes cover a frame's sample pairs in four steps
-static bool lds_wave_vec_ok(const ac_mdct_plan* p, const WavePlan& wp, int C, std::initializer_list<const void*> ptrs) {
+static bool lds_wave_vec_ok(const ac_mdct_plan* p, const WavePlan& wp, int C) {
   static const int off = [] { const char* e = getenv("AC_LDS_WAVE_NOVEC"); return e ? atoi(e) : 0; }();   // (A/B measurements)
+  return !off && lds_wave_vec_shape(p->N, C, true) && p->d_coefv && p->N / 4 <= kWaveVSteps * wp.nt && !(wp.nt > 64 && wave_ct_off());
+}
+// which rows a complex pair carries (RowPair): by channel count and by what the tensors' alignment allows
+static int wave_v_layout(int C, std::initializer_list<const void*> ptrs) {
   uintptr_t bits = 0;
   for (const void* q : ptrs) bits |= reinterpret_cast<uintptr_t>(q);
-  if (bits & (C == 2 ? 15 : 7)) return false;   // (rows of a tensor that does not start on a 16- / 8-byte boundary: the 8-byte kernels)
-  return !off && lds_wave_vec_shape(p->N, C, true) && p->d_coefv && p->N / 4 <= kWaveVSteps * wp.nt && !(wp.nt > 64 && wave_ct_off());
+  if (C == 2 && !(bits & 15)) return 0;
+  if (C == 1 && !(bits & 7)) return 1;
+  return 2;
 }
 // waves per workgroup, frames per workgroup and LDS bytes of the 16-byte kernels: the wave form packs frames as lds_wave_block
 // says; a frame on more than one wave (in place) is a workgroup of its own with two tables behind its buffer
@@ -1918,14 +1955,14 @@ static int wave_strip(long long pairs, int per_sig, int gpw, int w, size_t lds, 
   }
   return best;
 }
-template <bool MONO>
+template <int LAY>
 static int launch_fwd_wave_v(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin, int F,
-                             hipStream_t s) {
+                             int C, hipStream_t s) {
   const WavePlan wp = lds_wave_plan(p->N);
   size_t lds = 0;
   int w = 1, gpw = 1;
   wave_v_geometry(p->N, wp, &w, &gpw, &lds);
-  const long long pairs = MONO ? ((long long)B + 1) / 2 : (long long)B;
+  const long long pairs = LAY == 0 ? (long long)B : LAY == 1 ? ((long long)B + 1) / 2 : (long long)B * ((C + 1) / 2);
   const int T = wave_strip(pairs, F, gpw, w, lds, p->cus, 0.25);   // (every strip reads one block more than it has frames)
   const int nstrip = (F + T - 1) / T;
   const long long ntasks = pairs * nstrip;
@@ -1937,33 +1974,33 @@ static int launch_fwd_wave_v(const ac_mdct_plan* p, const float* x, float* X, co
 #define AC_WAVE_CT(NC, NTC, R0, R1, R2, R3)                                                                                   \
   if (!done && p->N == NC && !wave_ct_off()) {                                                                                 \
     done = true;                                                                                                               \
-    st = allow_lds(k_fwd_wave_v<NC, NTC, R0, R1, R2, R3, MONO>, lds);                                                          \
+    st = allow_lds(k_fwd_wave_v<NC, NTC, R0, R1, R2, R3, LAY>, lds);                                                          \
     if (!st)                                                                                                                   \
-      hipLaunchKernelGGL((k_fwd_wave_v<NC, NTC, R0, R1, R2, R3, MONO>), dim3((unsigned)g), dim3(64 * w), lds, s, x, X,         \
+      hipLaunchKernelGGL((k_fwd_wave_v<NC, NTC, R0, R1, R2, R3, LAY>), dim3((unsigned)g), dim3(64 * w), lds, s, x, X,         \
                          prev_block, reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kin, F, p->N, ntasks, T, nstrip,   \
-                         B, wp);                                                                                               \
+                         B, C, wp);                                                                                            \
   }
   AC_WAVE_CT_SIZES
 #undef AC_WAVE_CT
   if (!done) {
-    st = allow_lds(k_fwd_wave_v<0, 0, 0, 0, 0, 0, MONO>, lds);
+    st = allow_lds(k_fwd_wave_v<0, 0, 0, 0, 0, 0, LAY>, lds);
     if (!st)
-      hipLaunchKernelGGL((k_fwd_wave_v<0, 0, 0, 0, 0, 0, MONO>), dim3((unsigned)g), dim3(64 * w), lds, s, x, X, prev_block,
-                         reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kin, F, p->N, ntasks, T, nstrip, B, wp);
+      hipLaunchKernelGGL((k_fwd_wave_v<0, 0, 0, 0, 0, 0, LAY>), dim3((unsigned)g), dim3(64 * w), lds, s, x, X, prev_block,
+                         reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kin, F, p->N, ntasks, T, nstrip, B, C, wp);
   }
   if (st) return st;
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }
-template <bool MONO>
+template <int LAY>
 static int launch_inv_wave_v(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out, int B,
-                             int Kp, int nblk, hipStream_t s) {
+                             int Kp, int nblk, int C, hipStream_t s) {
   const WavePlan wp = lds_wave_plan(p->N);
   size_t lds = 0;
   int w = 1, gpw = 1;
   wave_v_geometry(p->N, wp, &w, &gpw, &lds);
   const int per_sig = nblk + (tail_out ? 1 : 0);
-  const long long pairs = MONO ? ((long long)B + 1) / 2 : (long long)B;
+  const long long pairs = LAY == 0 ? (long long)B : LAY == 1 ? ((long long)B + 1) / 2 : (long long)B * ((C + 1) / 2);
   const int seg = wave_strip(pairs, per_sig, gpw, w, lds, p->cus, 1.0);   // (every strip but a signal's first transforms one frame more)
   const int nseg = (per_sig + seg - 1) / seg;
   const long long ntasks = pairs * nseg;
@@ -1975,19 +2012,19 @@ static int launch_inv_wave_v(const ac_mdct_plan* p, const float* X, float* x, co
 #define AC_WAVE_CT(NC, NTC, R0, R1, R2, R3)                                                                                   \
   if (!done && p->N == NC && !wave_ct_off()) {                                                                                 \
     done = true;                                                                                                               \
-    st = allow_lds(k_inv_wave_v<NC, NTC, R0, R1, R2, R3, MONO>, lds);                                                          \
+    st = allow_lds(k_inv_wave_v<NC, NTC, R0, R1, R2, R3, LAY>, lds);                                                          \
     if (!st)                                                                                                                   \
-      hipLaunchKernelGGL((k_inv_wave_v<NC, NTC, R0, R1, R2, R3, MONO>), dim3((unsigned)g), dim3(64 * w), lds, s, X, x,         \
+      hipLaunchKernelGGL((k_inv_wave_v<NC, NTC, R0, R1, R2, R3, LAY>), dim3((unsigned)g), dim3(64 * w), lds, s, X, x,         \
                          tail_in, tail_out, reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kp, nblk, seg, nseg, p->N,  \
-                         ntasks, B, wp);                                                                                       \
+                         ntasks, B, C, wp);                                                                                    \
   }
   AC_WAVE_CT_SIZES
 #undef AC_WAVE_CT
   if (!done) {
-    st = allow_lds(k_inv_wave_v<0, 0, 0, 0, 0, 0, MONO>, lds);
+    st = allow_lds(k_inv_wave_v<0, 0, 0, 0, 0, 0, LAY>, lds);
     if (!st)
-      hipLaunchKernelGGL((k_inv_wave_v<0, 0, 0, 0, 0, 0, MONO>), dim3((unsigned)g), dim3(64 * w), lds, s, X, x, tail_in, tail_out,
-                         reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kp, nblk, seg, nseg, p->N, ntasks, B, wp);
+      hipLaunchKernelGGL((k_inv_wave_v<0, 0, 0, 0, 0, 0, LAY>), dim3((unsigned)g), dim3(64 * w), lds, s, X, x, tail_in, tail_out,
+                         reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kp, nblk, seg, nseg, p->N, ntasks, B, C, wp);
   }
   if (st) return st;
   AC_HIP_CHECK(hipGetLastError());
@@ -1995,16 +2032,28 @@ static int launch_inv_wave_v(const ac_mdct_plan* p, const float* X, float* x, co
 }
 
 #ifdef AC_WAVE_ROWS_TU
-// ---- this file compiled a second time as ac_wave_rows.hip: only the instances of the 16-byte kernels for mono rows (a
-// translation unit of their own: the instances of one row layout take a minute to compile)
+// ---- this file compiled again as ac_wave_rows.hip (AC_WAVE_ROWS_TU = 1: mono rows) and ac_wave_rows2.hip (= 2: channel
+// pairs of any channel count): only the instances of the 16-byte kernels for that row layout and their two launchers (the
+// instances of one layout take a minute to compile: translation units of their own)
+#if AC_WAVE_ROWS_TU == 1
 int launch_fwd_wave_mono(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin, int F,
                          hipStream_t s) {
-  return launch_fwd_wave_v<true>(p, x, X, prev_block, B, Kin, F, s);
+  return launch_fwd_wave_v<1>(p, x, X, prev_block, B, Kin, F, 1, s);
 }
 int launch_inv_wave_mono(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out, int B, int Kp,
                          int nblk, hipStream_t s) {
-  return launch_inv_wave_v<true>(p, X, x, tail_in, tail_out, B, Kp, nblk, s);
+  return launch_inv_wave_v<1>(p, X, x, tail_in, tail_out, B, Kp, nblk, 1, s);
 }
+#else
+int launch_fwd_wave_strided(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin, int F,
+                            int C, hipStream_t s) {
+  return launch_fwd_wave_v<2>(p, x, X, prev_block, B, Kin, F, C, s);
+}
+int launch_inv_wave_strided(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out, int B,
+                            int Kp, int nblk, int C, hipStream_t s) {
+  return launch_inv_wave_v<2>(p, X, x, tail_in, tail_out, B, Kp, nblk, C, s);
+}
+#endif
 #else
 
 // returned by launch_fwd_wave / launch_inv_wave when the tensors at hand are not for the 16-byte kernels (rows off the 16-byte
@@ -2016,8 +2065,12 @@ static int launch_fwd_wave(const ac_mdct_plan* p, const TIO* x, TIO* X, const TI
                            hipStream_t s) {
   const WavePlan wp0 = lds_wave_plan(p->N);
   if constexpr (std::is_same<TIO, float>::value)
-    if (lds_wave_vec_ok(p, wp0, C, {x, X, prev_block}))
-      return C == 2 ? launch_fwd_wave_v<false>(p, x, X, prev_block, B, Kin, F, s) : launch_fwd_wave_mono(p, x, X, prev_block, B, Kin, F, s);
+    if (lds_wave_vec_ok(p, wp0, C)) {
+      const int lay = wave_v_layout(C, {x, X, prev_block});
+      return lay == 0 ? launch_fwd_wave_v<0>(p, x, X, prev_block, B, Kin, F, 2, s)
+             : lay == 1 ? launch_fwd_wave_mono(p, x, X, prev_block, B, Kin, F, s)
+                        : launch_fwd_wave_strided(p, x, X, prev_block, B, Kin, F, C, s);
+    }
   if (!wave_8_byte_range(p->N)) return kWaveDeclined;
   const WavePlan wp = lds_wave_plan(p->N, false);
   size_t lds = 0;
@@ -2041,9 +2094,12 @@ static int launch_inv_wave(const ac_mdct_plan* p, const TIO* X, TIO* x, const fl
                            int nblk, int C, hipStream_t s) {
   const WavePlan wp0 = lds_wave_plan(p->N);
   if constexpr (std::is_same<TIO, float>::value)
-    if (lds_wave_vec_ok(p, wp0, C, {X, x}))
-      return C == 2 ? launch_inv_wave_v<false>(p, X, x, tail_in, tail_out, B, Kp, nblk, s)
-                    : launch_inv_wave_mono(p, X, x, tail_in, tail_out, B, Kp, nblk, s);
+    if (lds_wave_vec_ok(p, wp0, C)) {
+      const int lay = wave_v_layout(C, {X, x});
+      return lay == 0 ? launch_inv_wave_v<0>(p, X, x, tail_in, tail_out, B, Kp, nblk, 2, s)
+             : lay == 1 ? launch_inv_wave_mono(p, X, x, tail_in, tail_out, B, Kp, nblk, s)
+                        : launch_inv_wave_strided(p, X, x, tail_in, tail_out, B, Kp, nblk, C, s);
+    }
   if (!wave_8_byte_range(p->N)) return kWaveDeclined;
   const WavePlan wp = lds_wave_plan(p->N, false);
   size_t lds = 0;

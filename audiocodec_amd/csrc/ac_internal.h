@@ -168,6 +168,11 @@ int launch_fwd_wave_mono(const ac_mdct_plan* p, const float* x, float* X, const 
                          hipStream_t s);
 int launch_inv_wave_mono(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out, int B, int Kp,
                          int nblk, hipStream_t s);
+// ... and on channel pairs of any channel count / rows off the 16-byte grid (ac_wave_rows2.hip)
+int launch_fwd_wave_strided(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin, int F,
+                            int C, hipStream_t s);
+int launch_inv_wave_strided(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out, int B,
+                            int Kp, int nblk, int C, hipStream_t s);
 int launch_fwd_generic(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin,
                        int F, int C, hipStream_t s);
 int launch_inv_generic(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out,

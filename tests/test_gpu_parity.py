@@ -189,12 +189,12 @@ def _smooth_half(N):
 WAVE16_SIZES = [N for N in range(16, 8193, 4) if _smooth_half(N) and N not in (64, 128, 256, 512, 1024, 2048, 7500)]
 
 
-@pytest.mark.parametrize("C", [2, 1])
+@pytest.mark.parametrize("C", [2, 1, 3])
 @pytest.mark.parametrize("N", WAVE16_SIZES)
 def test_lds_fft_wave_16_byte_kernels_every_size(N, C):
-    """Strips longer and shorter than the kernels' strip length (32 frames at most), three signals (mono: two signals per
-    complex pair, the last pair half empty), against the fp64 oracle: analysis, synthesis incl. the aliased head / tail
-    blocks, and the round trip to 1 LSB."""
+    """Every instance in its three row layouts (stereo; mono: two signals per complex pair, the last pair of the odd batch
+    half empty; three channels: pairs (0, 1) and (2, -)), against the fp64 oracle: analysis, synthesis incl. the aliased
+    head / tail blocks, and the round trip to 1 LSB."""
     rng = np.random.default_rng(N + C)
     B, K = 3, (70 if N <= 128 else 37 if N <= 480 else 11 if N <= 2048 else 6 if N <= 4096 else 3)
     x = rng.uniform(-1, 1, (B, K * N, C)).astype(np.float32)
@@ -210,7 +210,7 @@ def test_lds_fft_wave_16_byte_kernels_every_size(N, C):
 
 @pytest.mark.parametrize("N,C", [(960, 2), (480, 1), (1920, 2), (48, 1)])
 def test_lds_fft_tier_rows_off_the_16_byte_grid(N, C):
-    """A tensor whose first element is not on a 16-byte (mono: 8-byte) boundary takes the 8-byte kernels of the tier; same
+    """A tensor whose first element is not on a 16-byte (mono: 8-byte) boundary takes the instances with 4-byte accesses; same
     values to float32 rounding."""
     B, K = 2, 9
     g = torch.Generator(device="cuda").manual_seed(N)
@@ -277,7 +277,7 @@ def test_lds_fft_wave_16_byte_kernels_every_size_inside_a_strip(tmp_path):
     code = ("import sys, json, numpy as np, torch, audiocodec_amd\n"
             "out = {}\n"
             "for N in json.loads(sys.argv[2]):\n"
-            "    for C in (2, 1):\n"
+            "    for C in (2, 1, 5):\n"
             "        g = torch.Generator(device='cuda').manual_seed(N + C)\n"
             "        x = torch.empty(3, 7 * N, C, device='cuda').uniform_(-1, 1, generator=g)\n"
             "        m = audiocodec_amd.MDCTransformer(N)\n"
@@ -626,7 +626,7 @@ def test_db_and_noise(golden, path):
                                         (64, 2, (5, 17, 1, 16)), (64, 1, (33, 2)),
                                         # strips of the 16-byte LDS-FFT wave kernels: longer / shorter than a strip, state in and out
                                         (480, 2, (40, 3, 1)), (120, 2, (70, 1)), (16, 2, (100, 3)), (48, 2, (5,)), (960, 2, (33,)), (1920, 2, (3, 9)),
-                                        (4096, 2, (2, 1, 3)), (1536, 1, (2, 3)), (8192, 2, (2, 1)), (480, 1, (40, 3, 1)), (1920, 1, (3, 2)), (24, 1, (7, 60))])
+                                        (4096, 2, (2, 1, 3)), (1536, 1, (2, 3)), (8192, 2, (2, 1)), (960, 3, (5, 2)), (480, 6, (40, 3)), (1920, 5, (2, 2)), (480, 1, (40, 3, 1)), (1920, 1, (3, 2)), (24, 1, (7, 60))])
 def test_streaming_equals_one_shot(path, N, C, chunks):
     B, K = 2, sum(chunks)
     x = torch.rand(B, K * N, C, device="cuda") * 2 - 1
