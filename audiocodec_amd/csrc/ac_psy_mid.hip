@@ -82,7 +82,9 @@ __global__ __launch_bounds__(256, (R >= 32 ? 1 : R >= 16 ? 2 : (WANT_THR && (FB 
 #pragma unroll
         for (int i = 0; i < R; ++i) {
           const v2f u = in(i) ? reinterpret_cast<const v2f*>(a.X + o0[fb])[64 * i + lane] : v2f{0.f, 0.f};
-          const v2f w = (in(i) && has1[fb]) ? reinterpret_cast<const v2f*>(a.X + o1[fb])[64 * i + lane] : v2f{0.f, 0.f};
+          // (no branch on has1: the half-empty last pair of an odd batch reads its one signal twice -- b1 above -- and
+          // never stores the second; a conditional load would hold the wave at the join)
+          const v2f w = in(i) ? reinterpret_cast<const v2f*>(a.X + o1[fb])[64 * i + lane] : v2f{0.f, 0.f};
           xq[fb][i] = v4f{u.x, w.x, u.y, w.y};
         }
       }
@@ -106,8 +108,8 @@ __global__ __launch_bounds__(256, (R >= 32 ? 1 : R >= 16 ? 2 : (WANT_THR && (FB 
       if (CMODE == 0) {
         __builtin_nontemporal_store(th, reinterpret_cast<v4f*>(a.thr + o0[fb]) + 64 * i + lane);
       } else {
-        reinterpret_cast<v2f*>(a.thr + o0[fb])[64 * i + lane] = v2f{th.x, th.z};
-        if (has1[fb]) reinterpret_cast<v2f*>(a.thr + o1[fb])[64 * i + lane] = v2f{th.y, th.w};
+        __builtin_nontemporal_store(v2f{th.x, th.z}, reinterpret_cast<v2f*>(a.thr + o0[fb]) + 64 * i + lane);
+        if (has1[fb]) __builtin_nontemporal_store(v2f{th.y, th.w}, reinterpret_cast<v2f*>(a.thr + o1[fb]) + 64 * i + lane);
       }
     });
   }   // groups of frames of the wave
