@@ -1912,7 +1912,8 @@ static bool lds_wave_vec_ok(const ac_mdct_plan* p, const WavePlan& wp, int C) {
   static const int off = [] { const char* e = getenv("AC_LDS_WAVE_NOVEC"); return e ? atoi(e) : 0; }();   // (A/B measurements)
   return !off && lds_wave_vec_shape(p->N, C, true) && p->d_coefv && p->N / 4 <= kWaveVSteps * wp.nt && !(wp.nt > 64 && wave_ct_off());
 }
-// which rows a complex pair carries (RowPair): by channel count and by what the tensors' alignment allows
+// which rows a complex pair carries (RowPair): by channel count (the C ABI takes 16-byte aligned tensors; a pointer that is
+// not -- an internal caller's -- gets the 4-byte layout)
 static int wave_v_layout(int C, std::initializer_list<const void*> ptrs) {
   uintptr_t bits = 0;
   for (const void* q : ptrs) bits |= reinterpret_cast<uintptr_t>(q);

@@ -45,7 +45,7 @@ extern "C" {
 #endif
 
 #define AC_VERSION 171 /* 0.1.8: no new entry points; the LDS-FFT tier on 16-byte kernels with compile-time instances (filters_n % 4 == 0
-                          * with a 5-smooth half up to 8192, mono / stereo float32); masking model for general band layouts up to 4096 bins.
+                          * with a 5-smooth half up to 8192, float32); masking model for general band layouts up to 4096 bins.
                           * 0.1.7: only the ac_* entry points are exported; ac_stream_settle (home buffers for the streaming state);
                           * float32 precompute (ac_*_create_pre, ac_*_host_pre); fused encode at filters_n 64 ... 512; ac_workspace_*.
                           * (0.1.6: ac_stream_run replayable as a HIP graph, duplex launches; filters_n 64 / 128 and 16-bit PCM on the
@@ -152,8 +152,8 @@ AC_API int ac_psy_plan_create_ex(int N, int M, double sample_rate, double alpha,
 AC_API int ac_psy_plan_spreading(const ac_psy_plan* plan);
 
 /* 1 when the plan runs the wave-level kernels (filters_n 1024 / 2048, Princen-Bradley window; 64 Bark bands), 0 when it
- * runs the LDS-FFT middle tier (filters_n from 16 to 4096 with a 5-smooth half: 2^a 3^b 5^c; up to 8192 for mono / stereo
- * float32 tensors with filters_n % 4 == 0) or the generic O(N^2) kernels. */
+ * runs the LDS-FFT middle tier (filters_n from 16 to 4096 with a 5-smooth half: 2^a 3^b 5^c; up to 8192 for float32
+ * tensors with filters_n % 4 == 0) or the generic O(N^2) kernels. */
 AC_API int ac_mdct_plan_is_fast(const ac_mdct_plan* plan);
 AC_API int ac_psy_plan_is_fast(const ac_psy_plan* plan);
 /* Which kernels serve the masking model of a plan: 2 = the wave-level kernels fused into the encode (filter_bands_n 1024 /

@@ -210,8 +210,8 @@ def test_lds_fft_wave_16_byte_kernels_every_size(N, C):
 
 @pytest.mark.parametrize("N,C", [(960, 2), (480, 1), (1920, 2), (48, 1)])
 def test_lds_fft_tier_rows_off_the_16_byte_grid(N, C):
-    """A tensor whose first element is not on a 16-byte (mono: 8-byte) boundary takes the instances with 4-byte accesses; same
-    values to float32 rounding."""
+    """A view whose first element is not on a 16-byte boundary: the C ABI wants 16-byte aligned tensors (AC_REQUIRE_ALIGNED),
+    the package hands it an aligned copy; same values."""
     B, K = 2, 9
     g = torch.Generator(device="cuda").manual_seed(N)
     flat = torch.empty(B * K * N * C + 4, device="cuda").uniform_(-1, 1, generator=g)
