@@ -41,6 +41,7 @@ PROTOTYPES = {
     "ac_psy_plan_create": (c_int, [c_int, c_int, c_double, c_double, c_int, POINTER(c_void_p)]),
     "ac_psy_plan_destroy": (c_int, [c_void_p]),
     "ac_mdct_plan_is_fast": (c_int, [c_void_p]),
+    "ac_mdct_plan_tier": (c_int, [c_void_p, c_int]),
     "ac_psy_plan_is_fast": (c_int, [c_void_p]),
     "ac_psy_plan_tier": (c_int, [c_void_p]),
     "ac_psy_plan_create_ex": (c_int, [c_int, c_int, c_double, c_double, c_int, c_int, POINTER(c_void_p)]),

@@ -439,6 +439,7 @@ int ac_psy_plan_destroy(ac_psy_plan* p) {
 }
 
 int ac_mdct_plan_is_fast(const ac_mdct_plan* p) { return p ? p->fast : 0; }
+
 int ac_psy_plan_is_fast(const ac_psy_plan* p) { return p ? p->fast : 0; }
 int ac_psy_plan_spreading(const ac_psy_plan* p) { return p ? p->spread : 0; }
 int ac_psy_plan_tier(const ac_psy_plan* p) { return !p ? 0 : p->fast ? 2 : p->mid ? 1 : 0; }
@@ -449,6 +450,12 @@ int ac_psy_plan_tier(const ac_psy_plan* p) { return !p ? 0 : p->fast ? 2 : p->mi
 static bool wave_level(const ac_mdct_plan* p, int C, int iof, int blocks) {
   if (!p->fast || g_force_generic) return false;
   return fast_mdct_frames_per_wave(p->N) == 1 || fast_multi_serves(p, C, iof, blocks);
+}
+
+int ac_mdct_plan_tier(const ac_mdct_plan* p, int C) {
+  if (!p || C < 1) return -1;
+  if (wave_level(p, C, 0, 1)) return 3;
+  return lds_fft_tier_of(p, C);
 }
 
 static int check_dims(int B, int K, int C) {

@@ -1719,8 +1719,8 @@ static bool lds_wave_ok(int N, bool synthesis, int C, bool f32) {
   return synthesis ? N <= 1536 : (N <= 1024 && !(H > 96 && H < 128));
 }
 // Sizes with compile-time instances of the 16-byte kernels: filters_n, lanes per frame, super-radices (every filters_n % 4 == 0
-// up to 1024 with a 5-smooth half that the wave-level kernels of ac_fast.hip do not serve; the plan the search below would
-// pick).  Strides, round counts and buffer offsets fold into immediates: 960 runs 0.156 -> 0.103 ms against the run-time form of
+// with a 5-smooth half up to 8192 -- the powers of two as well: the wave-level kernels of ac_fast.hip leave them the
+// rectangular window and, below 1024, more than two channels; the plan the search below would pick, with lanes >= N / 16).  Strides, round counts and buffer offsets fold into immediates: 960 runs 0.156 -> 0.103 ms against the run-time form of
 // the same kernel.  lds_wave_plan returns these plans, so the launch geometry and the instance agree by construction; any
 // other size runs the run-time form.
 #define AC_WAVE_CT_SIZES \
@@ -1732,7 +1732,7 @@ static bool lds_wave_ok(int N, bool synthesis, int C, bool f32) {
   AC_WAVE_CT(40, 4, 5, 4, 0, 0) \
   AC_WAVE_CT(48, 4, 6, 4, 0, 0) \
   AC_WAVE_CT(60, 4, 10, 3, 0, 0) \
-  AC_WAVE_CT(72, 4, 9, 4, 0, 0) \
+  AC_WAVE_CT(72, 8, 9, 4, 0, 0) \
   AC_WAVE_CT(80, 8, 8, 5, 0, 0) \
   AC_WAVE_CT(96, 8, 8, 6, 0, 0) \
   AC_WAVE_CT(100, 8, 10, 5, 0, 0) \
@@ -1823,7 +1823,13 @@ static bool lds_wave_ok(int N, bool synthesis, int C, bool f32) {
   AC_WAVE_CT(7776, 512, 9, 9, 8, 6) \
   AC_WAVE_CT(8000, 512, 10, 10, 8, 5) \
   AC_WAVE_CT(8100, 512, 10, 9, 9, 5) \
-  AC_WAVE_CT(8192, 512, 8, 8, 8, 8)
+  AC_WAVE_CT(8192, 512, 8, 8, 8, 8) \
+  AC_WAVE_CT(64, 4, 8, 4, 0, 0) \
+  AC_WAVE_CT(128, 8, 8, 8, 0, 0) \
+  AC_WAVE_CT(256, 16, 8, 8, 2, 0) \
+  AC_WAVE_CT(512, 32, 8, 8, 4, 0) \
+  AC_WAVE_CT(1024, 64, 8, 8, 8, 0) \
+  AC_WAVE_CT(2048, 128, 8, 8, 8, 2)
 static bool lds_wave_ct_size(int N) {
 #define AC_WAVE_CT(NC, NTC, R0, R1, R2, R3) \
   if (N == NC) return true;
@@ -2121,6 +2127,14 @@ static int launch_inv_wave(const ac_mdct_plan* p, const TIO* X, TIO* x, const fl
                      nblk, seg, nseg, C, CP, p->N, ntasks, wp);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
+}
+
+// which LDS-FFT form serves float32 tensors of C channels at this plan's size: 2 = a compile-time instance of the 16-byte
+// kernels, 1 = the run-time forms of the tier, 0 = none (the O(N^2) kernels)
+int lds_fft_tier_of(const ac_mdct_plan* p, int C) {
+  if (g_force_generic) return 0;
+  if (lds_wave_ok(p->N, false, C, true) && lds_wave_vec_ok(p, lds_wave_plan(p->N), C)) return lds_wave_ct_size(p->N) && !wave_ct_off() ? 2 : 1;
+  return lds_fft_ok(p->N) ? 1 : 0;
 }
 
 int launch_fwd_generic(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin,

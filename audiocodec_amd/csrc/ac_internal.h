@@ -163,6 +163,7 @@ struct ac_stream {
 namespace ac {
 
 // generic O(N^2) kernels: any even N, any C, any M
+int lds_fft_tier_of(const ac_mdct_plan* p, int C);   // ac_generic.hip: 2 / 1 / 0, see ac_mdct_plan_tier
 // the 16-byte kernels of the LDS-FFT tier on mono rows (ac_wave_rows.hip)
 int launch_fwd_wave_mono(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin, int F,
                          hipStream_t s);

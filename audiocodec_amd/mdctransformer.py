@@ -122,6 +122,12 @@ class MDCTransformer:
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         return bool(self._lib.ac_mdct_plan_is_fast(self._plans.get(dev)))
 
+    def tier(self, channels_n=2, device=None):
+        """Which kernels serve float32 tensors of ``channels_n`` channels: 3 the wave-level kernels, 2 a compile-time instance
+        of the LDS-FFT tier, 1 the tier's run-time forms, 0 the O(N^2) kernels (``ac_mdct_plan_tier``)."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        return int(self._lib.ac_mdct_plan_tier(self._plans.get(dev), int(channels_n)))
+
     # ---- analysis ------------------------------------------------------------------------------------
     def transform(self, x):
         """MDCT analysis filter bank (reference ``transform``, ``mdctransformer.py:62-125``).

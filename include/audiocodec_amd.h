@@ -44,7 +44,7 @@ extern "C" {
 #define AC_API __attribute__((visibility("default")))
 #endif
 
-#define AC_VERSION 171 /* 0.1.8: no new entry points; the LDS-FFT tier on 16-byte kernels with compile-time instances (filters_n % 4 == 0
+#define AC_VERSION 171 /* 0.1.8: ac_mdct_plan_tier; the LDS-FFT tier on 16-byte kernels with compile-time instances (filters_n % 4 == 0
                           * with a 5-smooth half up to 8192, float32); masking model for general band layouts up to 4096 bins.
                           * 0.1.7: only the ac_* entry points are exported; ac_stream_settle (home buffers for the streaming state);
                           * float32 precompute (ac_*_create_pre, ac_*_host_pre); fused encode at filters_n 64 ... 512; ac_workspace_*.
@@ -155,6 +155,10 @@ AC_API int ac_psy_plan_spreading(const ac_psy_plan* plan);
  * runs the LDS-FFT middle tier (filters_n from 16 to 4096 with a 5-smooth half: 2^a 3^b 5^c; up to 8192 for float32
  * tensors with filters_n % 4 == 0) or the generic O(N^2) kernels. */
 AC_API int ac_mdct_plan_is_fast(const ac_mdct_plan* plan);
+/* Which kernels serve float32 tensors of `channels_n` channels: 3 = the wave-level kernels; 2 = a compile-time instance of the
+ * LDS-FFT tier's 16-byte kernels (filters_n % 4 == 0 with a 5-smooth half, up to 8192); 1 = the tier's run-time forms;
+ * 0 = the O(N^2) kernels; -1 = bad argument. */
+AC_API int ac_mdct_plan_tier(const ac_mdct_plan* plan, int channels_n);
 AC_API int ac_psy_plan_is_fast(const ac_psy_plan* plan);
 /* Which kernels serve the masking model of a plan: 2 = the wave-level kernels fused into the encode (filter_bands_n 1024 /
  * 2048, 64 Bark bands, every bin in at most two adjacent bands); 1 = the wave-level kernels for general band layouts

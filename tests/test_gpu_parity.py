@@ -196,6 +196,7 @@ def test_lds_fft_wave_16_byte_kernels_every_size(N, C):
     half empty; three channels: pairs (0, 1) and (2, -)), against the fp64 oracle: analysis, synthesis incl. the aliased
     head / tail blocks, and the round trip to 1 LSB."""
     rng = np.random.default_rng(N + C)
+    assert audiocodec_amd.MDCTransformer(N).tier(C) == 2   # (a silent fall to the run-time forms would pass the numerics)
     B, K = 3, (70 if N <= 128 else 37 if N <= 480 else 11 if N <= 2048 else 6 if N <= 4096 else 3)
     x = rng.uniform(-1, 1, (B, K * N, C)).astype(np.float32)
     m = audiocodec_amd.MDCTransformer(N)
@@ -226,6 +227,23 @@ def test_lds_fft_tier_rows_off_the_16_byte_grid(N, C):
     X_view.copy_(X)
     y, y_off = m.inverse_transform(X), m.inverse_transform(X_view)
     assert float((y - y_off).abs().max()) <= 2e-6
+
+
+@pytest.mark.parametrize("N,C,window", [(64, 3, "vorbis"), (128, 5, "sine"), (256, 3, "vorbis"), (512, 6, "vorbis"), (64, 3, "rect"),
+                                        (256, 4, "rect"), (512, 3, "rect"), (1024, 2, "rect"), (2048, 2, "rect"), (2048, 3, "rect")])
+def test_lds_fft_wave_16_byte_kernels_at_the_powers_of_two(N, C, window):
+    """What the wave-level kernels leave at their own sizes -- the rectangular window at 1024 / 2048, more than two channels
+    below 1024 -- runs instances of the LDS-FFT tier as well (mdctransformer.py:26, 199-211)."""
+    rng = np.random.default_rng(N + C)
+    m = audiocodec_amd.MDCTransformer(N, window)
+    assert m.tier(C) == 2
+    B, K = 2, 9
+    x = rng.uniform(-1, 1, (B, K * N, C)).astype(np.float32)
+    o = MDCTOracle(N, window, np.float64)
+    X = host(m.transform(dev(x)))
+    Xo = o.transform(x.astype(np.float64))
+    assert rel_peak(X, Xo) <= TOL and rel_l2(X, Xo) <= TOL
+    assert np.max(np.abs(host(m.inverse_transform(dev(X))) - o.inverse_transform(Xo))) <= LSB
 
 
 def test_lds_fft_wave_16_byte_kernels_strip_lengths(tmp_path):
@@ -1095,6 +1113,16 @@ def test_masking_model_general_band_layouts(sr, N, M, B, F, C):
     assert torch.equal(Xe, codec.mdct.transform(x))
     assert tonality_err(te, codec.psy.tonality(Xe)) <= 1e-3          # same arithmetic; another instantiation may round one ulp apart
     assert float(((thre - codec.psy.global_masking_threshold(Xe, te, 0.2)).abs() / thre).max()) <= 1e-6
+
+
+def test_mdct_tiers():
+    """ac_mdct_plan_tier: which kernels serve a size and channel count (so that a silent fall to a slower form shows)."""
+    tier = lambda N, C=2, w="vorbis": audiocodec_amd.MDCTransformer(N, w).tier(C)
+    assert [tier(N) for N in (64, 512, 1024, 2048)] == [3, 3, 3, 3] and tier(1024, 5) == 3
+    assert [tier(N, C) for N in (16, 120, 960, 1920, 4096, 8192) for C in (1, 2, 3, 6)] == [2] * 24
+    assert tier(1024, 2, "rect") == 2 and tier(256, 3) == 2          # what the wave-level kernels leave: instances too
+    assert tier(30) == 1 and tier(90, 1) == 1                         # filters_n % 4 == 2: the run-time forms
+    assert tier(7500) == 0 and tier(34) == 0 and tier(8190) == 0      # no plan / half not 5-smooth: O(N^2)
 
 
 def test_fast_path_selection():
