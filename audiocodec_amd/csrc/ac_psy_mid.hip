@@ -1,6 +1,6 @@
 // Wave-level masking model for the configurations the fused epilogue of ac_fast.hip does not serve: any even
 // filter_bands_n up to 4096 (a frame is up to R = 1, 2, 4, 8, 16 or 32 granule registers per lane, the last ones partly filled
-// when filter_bands_n is not a multiple of 128: 960, 576, 480 ...; above 1024 the W_inv entries stay in global memory) with any Bark-band count up to 64 and any band layout (a bin may overlap several bands, bands may share
+// when filter_bands_n is not a multiple of 128: 960, 576, 480 ...; above 512 the W_inv entries stay in global memory) with any Bark-band count up to 64 and any band layout (a bin may overlap several bands, bands may share
 // bins freely) -- e.g. the models beside the several-frames-per-wave MDCT kernels (filters_n 256 / 512), where the
 // O(N)-per-workgroup generic kernels ran at 0.5-0.8 TB/s.  gfx950 only.
 //
@@ -17,6 +17,13 @@ namespace ac {
 namespace {
 
 using namespace mid;
+
+// Granule registers per lane from which the W_inv entries are read from global memory instead of the LDS image: from 8 (frames
+// above 512 bins), where the table is 15 ... 64 KB and keeping it out of LDS doubles the resident waves (B = 256 stereo, the
+// un-fused encode: 960 0.912 -> 0.843 ms, 1000 0.921 -> 0.829, 768 unchanged; mono 960 0.736 -> 0.560).
+#ifndef AC_MID_WI_GLOBAL_R
+#define AC_MID_WI_GLOBAL_R 8
+#endif
 
 struct MidArgs {
   const float* X;
@@ -48,8 +55,8 @@ __global__ __launch_bounds__(256, (R >= 32 ? 1 : R >= 16 ? 2 : (WANT_THR && (FB 
     __syncthreads();
   }
   char* buf = smem + (size_t)a.p.lds_words * 4 + (size_t)wave * WAVE_BYTES;
-  // the W_inv entries: in the LDS image, or (R >= 16) read where the plan keeps them
-  const uint4* wi = R >= 16 ? reinterpret_cast<const uint4*>(a.img + a.p.off_wi) : reinterpret_cast<const uint4*>(img + a.p.off_wi);
+  // the W_inv entries: in the LDS image, or (frames above 512 bins) read where the plan keeps them
+  const uint4* wi = R >= AC_MID_WI_GLOBAL_R ? reinterpret_cast<const uint4*>(a.img + a.p.off_wi) : reinterpret_cast<const uint4*>(img + a.p.off_wi);
   const int C = a.C;
   const long long task0 = (long long)blockIdx.x * nw * a.T + wave;
   for (int tt = 0; tt < a.T && task0 + (long long)tt * nw < a.ntasks; tt += FB) {   // (no workgroup barrier inside)
@@ -224,7 +231,7 @@ bool mid_psy_supported(const ac_psy_plan* p) { return build_mid(p, nullptr, null
 mid::MidParams mid_params(const ac_psy_plan* p, float drown) {
   mid::MidParams m;
   m.img_words = p->mid_words;
-  m.lds_words = mid_r(p->N) >= 16 ? p->mid_off_wi : p->mid_words;   // (off_wi is 16-byte aligned)
+  m.lds_words = mid_r(p->N) >= AC_MID_WI_GLOBAL_R ? p->mid_off_wi : p->mid_words;   // (off_wi is 16-byte aligned)
   m.N = p->N;
   m.M = p->M;
   m.wi_w = p->mid_wi_w;
@@ -286,7 +293,7 @@ int launch_psy_mid(const ac_psy_plan* p, const float* X, const float* t_in, floa
   // 1024 bins (32 KB of intensities per wave at 4096): the workgroup size that leaves the most waves resident
   int nw = 4;
   if (mid_lds_bytes(p->N, a.p.lds_words, nw, fb) > 53 * 1024) nw = 2;
-  if (R >= 16) {
+  if (R >= AC_MID_WI_GLOBAL_R) {
     long best = 0;
     for (int w : {4, 2, 1}) {
       const size_t b = mid_lds_bytes(p->N, a.p.lds_words, w, fb);

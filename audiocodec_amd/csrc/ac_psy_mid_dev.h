@@ -186,7 +186,7 @@ __device__ __forceinline__ void tonality_frames(const v4f (&xq)[FB][R], const Mi
 // the caller read xq from; the frame's G_j (64 v2f) later takes the first 512 bytes of the same slot.  img: the LDS copy of
 // the image.  The caller orders its earlier accesses to the slots before the call (wave_sync) and its later ones after it.
 // wi: the W_inv entry table -- img + a.off_wi when the whole image sits in LDS, or the plan's copy in global memory (frames
-// above 1024 bins: the table alone would take 16 N bytes of LDS; its reads are coalesced 16-byte rows and L2-resident).
+// above 512 bins: the table alone would take 16 N bytes of LDS; its reads are coalesced 16-byte rows and L2-resident).
 template <int R, int FB, class EMIT>
 __device__ __forceinline__ void threshold_frames(const v4f (&xq)[FB][R], const v2f (&t)[FB], const MidParams& a, const uint32_t* img,
                                                  const uint4* wi, char* ibuf, int istride, int lane, EMIT emit) {
