@@ -342,8 +342,13 @@ __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
-static inline __host__ __device__ int padded_len(int n) { return n + (n >> 4) + 1; }
+// one 16-byte element of padding per 2^ps elements: ps = 4, but 2 at the two sizes where a survey of ps = 2 ... 5 over every
+// instance (B = 64 stereo) found another value faster on a second look (120: 0.106 / 0.095 -> 0.089 / 0.087 ms, 36: +5 %;
+// four other sizes of the first pass were noise)
+#define AC_PAD_SHIFT 4
+static inline __host__ __device__ constexpr int pad_shift_ct(int N) { return N == 120 || N == 36 ? 2 : AC_PAD_SHIFT; }
+__device__ __forceinline__ int pad16(int i, int ps = AC_PAD_SHIFT) { return i + (i >> ps); }
+static inline __host__ __device__ int padded_len(int n, int ps = AC_PAD_SHIFT) { return n + (n >> ps) + 1; }
 
 // compile-time cos / sin of 2 pi e / R (Taylor series on the angle reduced to [-pi, pi])
 constexpr double c_series(double x, bool sine) {
@@ -444,7 +449,7 @@ struct WaveTabs {
 };
 template <int R1, int R2, bool first, bool last_to_v, bool CT = false>
 __device__ __forceinline__ void wave_pass(const cpair* __restrict__ src, cpair* __restrict__ dst, float2* v, int N, int L, int H,
-                                          const WaveTabs& tb, int tid, int nt) {
+                                          const WaveTabs& tb, int tid, int nt, int ps = AC_PAD_SHIFT) {
   constexpr int R = R1 * R2;
   const int m = H / (R * L), nb = H / R;
   const unsigned invL = 0xFFFFFFFFu / (unsigned)L + 1u;   // j / L for j < 2^16 as a multiply-high
@@ -459,7 +464,7 @@ __device__ __forceinline__ void wave_pass(const cpair* __restrict__ src, cpair* 
         t.im = v[N - 1 - 2 * n];
         return cmulw(t, tb.pre[n]);
       } else {
-        const cpair x = src[pad16(n)];
+        const cpair x = src[pad16(n, ps)];
         return s2 > 0 ? cmulw(x, tb.tw[tq * s2]) : x;
       }
     };
@@ -470,7 +475,7 @@ __device__ __forceinline__ void wave_pass(const cpair* __restrict__ src, cpair* 
         v[2 * k] = r.re;
         v[N - 1 - 2 * k] = make_float2(-r.im.x, -r.im.y);
       } else {
-        dst[pad16(k)] = val;
+        dst[pad16(k, ps)] = val;
       }
     };
     if constexpr (R2 == 1) {
@@ -583,19 +588,20 @@ __device__ __forceinline__ void dct4_wave_ct(float2* v, cpair* Ap, cpair* Bp, co
   constexpr int H = NC / 2, NP = 1 + (R1 > 0) + (R2 > 0) + (R3 > 0);
   static_assert(R0 * (R1 ? R1 : 1) * (R2 ? R2 : 1) * (R3 ? R3 : 1) == H, "the super-radices multiply to N / 2");
   constexpr bool even = (NP & 1) == 0;
+  constexpr int PS = pad_shift_ct(NC);
   // pass 1: v -> Ap; then Ap -> Bp -> Ap ...; an even count ends in v (= Bp's bytes) in final form
-  wave_pass<RadixSplit<R0>::A, RadixSplit<R0>::B, true, false, true>(Bp, Ap, v, NC, 1, H, tb, tid, NTC);
+  wave_pass<RadixSplit<R0>::A, RadixSplit<R0>::B, true, false, true>(Bp, Ap, v, NC, 1, H, tb, tid, NTC, PS);
   wave_sync_lds();
   if constexpr (NP >= 2) {
-    wave_pass<RadixSplit<R1>::A, RadixSplit<R1>::B, false, NP == 2, true>(Ap, Bp, v, NC, R0, H, tb, tid, NTC);
+    wave_pass<RadixSplit<R1>::A, RadixSplit<R1>::B, false, NP == 2, true>(Ap, Bp, v, NC, R0, H, tb, tid, NTC, PS);
     wave_sync_lds();
   }
   if constexpr (NP >= 3) {
-    wave_pass<RadixSplit<R2>::A, RadixSplit<R2>::B, false, false, true>(Bp, Ap, v, NC, R0 * R1, H, tb, tid, NTC);
+    wave_pass<RadixSplit<R2>::A, RadixSplit<R2>::B, false, false, true>(Bp, Ap, v, NC, R0 * R1, H, tb, tid, NTC, PS);
     wave_sync_lds();
   }
   if constexpr (NP >= 4) {
-    wave_pass<RadixSplit<R3>::A, RadixSplit<R3>::B, false, true, true>(Ap, Bp, v, NC, R0 * R1 * R2, H, tb, tid, NTC);
+    wave_pass<RadixSplit<R3>::A, RadixSplit<R3>::B, false, true, true>(Ap, Bp, v, NC, R0 * R1 * R2, H, tb, tid, NTC, PS);
     wave_sync_lds();
   }
   if constexpr (!even) {
@@ -603,7 +609,7 @@ __device__ __forceinline__ void dct4_wave_ct(float2* v, cpair* Ap, cpair* Bp, co
     for (int rd = 0; rd < (H + NTC - 1) / NTC; ++rd) {
       const int k = tid + rd * NTC;
       if (k < H) {
-        const cpair r = cmulw(Ap[pad16(k)], tb.post[k]);
+        const cpair r = cmulw(Ap[pad16(k, PS)], tb.post[k]);
         v[2 * k] = r.re;
         v[NC - 1 - 2 * k] = make_float2(-r.im.x, -r.im.y);
       }
@@ -625,7 +631,7 @@ __device__ __forceinline__ void group_sync() {
 template <int NC, int NTC, int L, int R, bool first, bool last_to_v>
 __device__ __forceinline__ void group_pass(cpair* buf, float2* v, const WaveTabs& tb, float2 pre0, int tid) {
   constexpr int R1 = RadixSplit<R>::A, R2 = RadixSplit<R>::B;
-  constexpr int H = NC / 2, m = H / (R * L), nb = H / R, Lm = L * m, rounds = (nb + NTC - 1) / NTC;
+  constexpr int H = NC / 2, m = H / (R * L), nb = H / R, Lm = L * m, rounds = (nb + NTC - 1) / NTC, PS = pad_shift_ct(NC);
   cpair out[rounds][R];
 #pragma unroll
   for (int rd = 0; rd < rounds; ++rd) {
@@ -642,7 +648,7 @@ __device__ __forceinline__ void group_pass(cpair* buf, float2* v, const WaveTabs
           const float2 w = tb.post[n];
           return cmulw(t, make_float2(w.x * pre0.x - w.y * pre0.y, w.x * pre0.y + w.y * pre0.x));
         } else {
-          const cpair x = buf[pad16(n)];
+          const cpair x = buf[pad16(n, PS)];
           return s2 > 0 ? cmulw(x, tb.tw[tq * s2]) : x;
         }
       };
@@ -679,7 +685,7 @@ __device__ __forceinline__ void group_pass(cpair* buf, float2* v, const WaveTabs
           v[2 * k] = r.re;
           v[NC - 1 - 2 * k] = make_float2(-r.im.x, -r.im.y);
         } else {
-          buf[pad16(k)] = out[rd][t];
+          buf[pad16(k, PS)] = out[rd][t];
         }
       }
     }
@@ -698,8 +704,8 @@ __device__ __forceinline__ void dct4_group_ct(float2* v, cpair* buf, const WaveT
 }
 
 // LDS floats per frame of the wave form: Bp (= v) and Ap, padded; of the in-place form above: one buffer
-static inline __host__ __device__ int wave_floats_per_group(int N) { return 2 * 4 * padded_len(N / 2); }
-static inline __host__ __device__ int group_floats_per_frame(int N) { return 4 * padded_len(N / 2); }
+static inline __host__ __device__ int wave_floats_per_group(int N, int ps = AC_PAD_SHIFT) { return 2 * 4 * padded_len(N / 2, ps); }
+static inline __host__ __device__ int group_floats_per_frame(int N, int ps = AC_PAD_SHIFT) { return 4 * padded_len(N / 2, ps); }
 
 // the FFT's twiddles exp(-2 pi i k / (N/2)), k < N/2, once per workgroup into LDS (every thread takes part; the caller
 // synchronises before the first use)
@@ -1106,7 +1112,8 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int N = NC ? NC : N_rt, nt = NC ? NTC : wp.nt, gpw = (int)blockDim.x / nt, grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
   constexpr bool GRP = NTC > 64;   // one frame per workgroup of NTC lanes, transformed in place
-  const int per = GRP ? group_floats_per_frame(N) : wave_floats_per_group(N), h = N >> 1, q = N >> 2;
+  const int ps = NC ? pad_shift_ct(NC) : AC_PAD_SHIFT;
+  const int per = GRP ? group_floats_per_frame(N, ps) : wave_floats_per_group(N, ps), h = N >> 1, q = N >> 2;
   float2* tw = reinterpret_cast<float2*>(smem + (size_t)gpw * per);
   for (int k = threadIdx.x; k < h; k += blockDim.x) {
     tw[k] = cis_neg(ctab, 16 * k, N);
@@ -1119,7 +1126,7 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
   float* base = smem + (size_t)grp * per;
   float2* v = reinterpret_cast<float2*>(base);
   cpair* Bp = reinterpret_cast<cpair*>(base);
-  cpair* Ap = reinterpret_cast<cpair*>(base + 4 * padded_len(h));
+  cpair* Ap = reinterpret_cast<cpair*>(base + 4 * padded_len(h, ps));
   const float scale = (float)(1.0 / ((double)N * 1.4142135623730951));
   const long long wg = (long long)blockIdx.x * gpw + grp;
   if (wg >= ntasks) return;
@@ -1207,7 +1214,8 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int N = NC ? NC : N_rt, nt = NC ? NTC : wp.nt, gpw = (int)blockDim.x / nt, grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
   constexpr bool GRP = NTC > 64;
-  const int h = N >> 1, q = N >> 2, per = GRP ? group_floats_per_frame(N) : wave_floats_per_group(N);
+  const int ps = NC ? pad_shift_ct(NC) : AC_PAD_SHIFT;
+  const int h = N >> 1, q = N >> 2, per = GRP ? group_floats_per_frame(N, ps) : wave_floats_per_group(N, ps);
   float2* tw = reinterpret_cast<float2*>(smem + (size_t)gpw * per);
   for (int k = threadIdx.x; k < h; k += blockDim.x) {
     tw[k] = cis_neg(ctab, 16 * k, N);
@@ -1220,7 +1228,7 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
   float* base = smem + (size_t)grp * per;
   float2* v = reinterpret_cast<float2*>(base);
   cpair* Bp = reinterpret_cast<cpair*>(base);
-  cpair* Ap = reinterpret_cast<cpair*>(base + 4 * padded_len(h));
+  cpair* Ap = reinterpret_cast<cpair*>(base + 4 * padded_len(h, ps));
   const long long wg = (long long)blockIdx.x * gpw + grp;
   if (wg >= ntasks) return;
   const int sgm = (int)(wg % nseg);
@@ -1898,18 +1906,18 @@ static WavePlan lds_wave_plan(int N, bool groups = true) {   // groups: frames d
   return best;
 }
 // waves per workgroup that leave the most waves resident per CU (160 KB of LDS)
-static int lds_wave_block(int N, const WavePlan& wp, int extra_floats, size_t* lds_bytes) {
+static int lds_wave_block(int N, const WavePlan& wp, int extra_floats, size_t* lds_bytes, int ps = AC_PAD_SHIFT) {
   int best_w = 1;
   long best_res = 0;
   for (int w = 1; w <= 4; ++w) {
-    const size_t lds = ((size_t)(64 / wp.nt) * w * (wave_floats_per_group(N) + extra_floats) + 3 * N) * sizeof(float);
+    const size_t lds = ((size_t)(64 / wp.nt) * w * (wave_floats_per_group(N, ps) + extra_floats) + 3 * N) * sizeof(float);
     const long res = (long)std::min<size_t>(8, 160 * 1024 / std::max<size_t>(lds, 1)) * w;
     if (lds <= 160 * 1024 && res >= best_res) {
       best_res = res;
       best_w = w;
     }
   }
-  *lds_bytes = ((size_t)(64 / wp.nt) * best_w * (wave_floats_per_group(N) + extra_floats) + 3 * N) * sizeof(float);   // + the three tables
+  *lds_bytes = ((size_t)(64 / wp.nt) * best_w * (wave_floats_per_group(N, ps) + extra_floats) + 3 * N) * sizeof(float);   // + the three tables
   return best_w;
 }
 
@@ -1930,12 +1938,13 @@ static int wave_v_layout(int C, std::initializer_list<const void*> ptrs) {
 // waves per workgroup, frames per workgroup and LDS bytes of the 16-byte kernels: the wave form packs frames as lds_wave_block
 // says; a frame on more than one wave (in place) is a workgroup of its own with two tables behind its buffer
 static void wave_v_geometry(int N, const WavePlan& wp, int* w, int* gpw, size_t* lds) {
+  const int ps = (lds_wave_ct_size(N) && !wave_ct_off()) ? pad_shift_ct(N) : AC_PAD_SHIFT;   // (as the kernel that will run pads)
   if (wp.nt > 64) {
     *w = wp.nt / 64;
     *gpw = 1;
-    *lds = ((size_t)group_floats_per_frame(N) + 2 * (size_t)N) * sizeof(float);
+    *lds = ((size_t)group_floats_per_frame(N, ps) + 2 * (size_t)N) * sizeof(float);
   } else {
-    *w = lds_wave_block(N, wp, 0, lds);
+    *w = lds_wave_block(N, wp, 0, lds, ps);
     *gpw = *w * (64 / wp.nt);
   }
 }
