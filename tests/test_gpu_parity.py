@@ -358,6 +358,26 @@ def test_int16_pcm_round_trip_exact(path):
     assert np.array_equal(np.round(xh * 32768.0).astype(np.int32), pcm.astype(np.int32))
 
 
+@pytest.mark.parametrize("N,C", [(960, 2), (960, 1), (120, 3), (4096, 2), (8192, 1), (16, 2)])
+def test_empty_and_edge_shapes_on_the_lds_fft_instances(N, C):
+    """No samples, no clips, one block, one clip through the instances of the LDS-FFT tier (strips of one frame, a lone pair
+    of a mono batch, frames that are all aliased halves)."""
+    m = audiocodec_amd.MDCTransformer(N)
+    X = m.transform(torch.zeros(2, 0, C, device="cuda"))
+    assert tuple(X.shape) == (2, 1, N, C) and float(X.abs().max()) == 0.0
+    assert tuple(m.transform(torch.zeros(0, 2 * N, C, device="cuda")).shape) == (0, 3, N, C)
+    y = m.inverse_transform(torch.zeros(1, 0, N, C, device="cuda"))
+    assert tuple(y.shape) == (1, N, C) and float(y.abs().max()) == 0.0
+    rng = np.random.default_rng(N + C)
+    o = MDCTOracle(N, "vorbis", np.float64)
+    for B, K in ((1, 1), (1, 2), (5, 1)):
+        x = rng.uniform(-1, 1, (B, K * N, C)).astype(np.float32)
+        Xo = o.transform(x.astype(np.float64))
+        Xg = m.transform(dev(x))
+        assert rel_peak(host(Xg), Xo) <= TOL
+        assert np.max(np.abs(host(m.inverse_transform(Xg)) - o.inverse_transform(Xo))) <= LSB
+
+
 def test_empty_and_edge_shapes(path):
     m = audiocodec_amd.MDCTransformer(64)
     X = m.transform(torch.zeros(2, 0, 2, device="cuda"))
