@@ -475,8 +475,9 @@ static int mdct_forward(const ac_mdct_plan* p, const void* x, bool pcm16, float*
   if (wave_level(p, C, pcm16 ? 1 : 0, K))
     return launch_fwd_fast(p, nullptr, x, pcm16, X, nullptr, nullptr, 0.f, nullptr, B, K, K + 1, C, s);
   if (pcm16) {
-    set_error("16-bit PCM is served by the wave-level kernels only (filters_n 64 ... 2048 in powers of two, 'vorbis' or 'sine' "
-              "window; below 1024: mono / stereo)");
+    if (lds_fft_serves_pcm16(p, C)) return launch_fwd_lds_pcm16(p, static_cast<const int16_t*>(x), X, B, K, C, s);
+    set_error("16-bit PCM is served at filters_n 64 ... 2048 in powers of two ('vorbis' or 'sine' window; below 1024: mono / "
+              "stereo) and at 120 / 240 / 480 / 960 / 1920 / 576 / 1152 (mono / stereo)");
     return AC_EUNSUPPORTED;
   }
   return launch_fwd_generic(p, static_cast<const float*>(x), X, nullptr, B, K, K + 1, C, s);
@@ -493,8 +494,9 @@ static int mdct_inverse(const ac_mdct_plan* p, const float* X, void* x, bool pcm
   hipStream_t s = (hipStream_t)stream;
   if (wave_level(p, C, pcm16 ? 1 : 0, Kp)) return launch_inv_fast(p, X, x, pcm16, nullptr, nullptr, B, Kp, Kp + 1, C, s);
   if (pcm16) {
-    set_error("16-bit PCM is served by the wave-level kernels only (filters_n 64 ... 2048 in powers of two, 'vorbis' or 'sine' "
-              "window; below 1024: mono / stereo)");
+    if (lds_fft_serves_pcm16(p, C)) return launch_inv_lds_pcm16(p, X, static_cast<int16_t*>(x), B, Kp, C, s);
+    set_error("16-bit PCM is served at filters_n 64 ... 2048 in powers of two ('vorbis' or 'sine' window; below 1024: mono / "
+              "stereo) and at 120 / 240 / 480 / 960 / 1920 / 576 / 1152 (mono / stereo)");
     return AC_EUNSUPPORTED;
   }
   return launch_inv_generic(p, X, static_cast<float*>(x), nullptr, nullptr, B, Kp, Kp + 1, C, s);

@@ -1056,6 +1056,33 @@ struct RowPair {
       return v4f_t{p0[0], p1[0], p0[C], p1[C]};
     }
   }
+  // the same rows as 16-bit PCM (x = pcm / 32768 on the way in, clamp(round(32768 x)) on the way out, as the wave-level
+  // kernels of ac_fast.hip do): 8 / 4 bytes per access
+  __device__ __forceinline__ v4f_t load2(const int16_t* a, const int16_t* b, int m) const {
+    static_assert(LAY <= 1, "16-bit PCM: stereo or mono rows");
+    typedef short s4_t __attribute__((ext_vector_type(4)));
+    typedef short s2_t __attribute__((ext_vector_type(2)));
+    constexpr float k = 1.0f / 32768.0f;
+    if constexpr (LAY == 0) {
+      const s4_t q = *reinterpret_cast<const s4_t*>(a + 2 * m);
+      return v4f_t{(float)q.x * k, (float)q.y * k, (float)q.z * k, (float)q.w * k};
+    } else {
+      const s2_t qa = *reinterpret_cast<const s2_t*>(a + m), qb = *reinterpret_cast<const s2_t*>(b + m);
+      return v4f_t{(float)qa.x * k, (float)qb.x * k, (float)qa.y * k, (float)qb.y * k};
+    }
+  }
+  __device__ __forceinline__ void store2(int16_t* a, int16_t* b, int m, v4f_t v) const {
+    static_assert(LAY <= 1, "16-bit PCM: stereo or mono rows");
+    typedef short s4_t __attribute__((ext_vector_type(4)));
+    typedef short s2_t __attribute__((ext_vector_type(2)));
+    auto enc = [](float f) { return (short)__float2int_rn(fminf(fmaxf(f * 32768.0f, -32768.0f), 32767.0f)); };
+    if constexpr (LAY == 0) {
+      __builtin_nontemporal_store(s4_t{enc(v.x), enc(v.y), enc(v.z), enc(v.w)}, reinterpret_cast<s4_t*>(a + 2 * m));
+    } else {
+      __builtin_nontemporal_store(s2_t{enc(v.x), enc(v.z)}, reinterpret_cast<s2_t*>(a + m));
+      if (has1) __builtin_nontemporal_store(s2_t{enc(v.y), enc(v.w)}, reinterpret_cast<s2_t*>(b + m));
+    }
+  }
   __device__ __forceinline__ void store2(float* a, float* b, int m, v4f_t v) const {
     if constexpr (LAY == 0) {
       __builtin_nontemporal_store(v, reinterpret_cast<v4f_t*>(a + 2 * m));
@@ -1104,8 +1131,8 @@ __device__ __forceinline__ PairGeo pair_geo(long long p, int N, int B, int C, si
   return g;
 }
 
-template <int NC, int NTC, int R0, int R1, int R2, int R3, int LAY>
-static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k_fwd_wave_v(const float* __restrict__ x, float* __restrict__ X,
+template <int NC, int NTC, int R0, int R1, int R2, int R3, int LAY, typename TX = float>   // TX: float, or int16_t = 16-bit PCM in
+static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k_fwd_wave_v(const TX* __restrict__ x, float* __restrict__ X,
                                                           const float* __restrict__ prev_block, const v4f_t* __restrict__ coefv,
                                                           const float* __restrict__ ctab, int Kin, int F, int N_rt, long long ntasks,
                                                           int T, int nstrip, int B, int C, WavePlan wp) {
@@ -1137,7 +1164,7 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
   const RowPair<LAY> rp = {gx.has1, C};
   const int n0 = sp * T, n1 = min(n0 + T, F);
   v4f_t d0[kWaveVSteps], d1[kWaveVSteps], cy[kWaveVSteps];
-  auto load_block = [&](const float* xa, const float* xb) {
+  auto load_block = [&](auto xa, auto xb) {
 #pragma unroll
     for (int s = 0; s < kWaveVSteps; ++s) {
       const int i = tid + s * nt;
@@ -1205,8 +1232,8 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
 
 // the synthesis in the same form: wide spectrum loads (the next frame's issued before the overlap-add of this one), the two
 // output samples j, N - 1 - j of a lane's pairs as two wide stores, the aliased half of the previous frame in registers
-template <int NC, int NTC, int R0, int R1, int R2, int R3, int LAY>
-static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k_inv_wave_v(const float* __restrict__ X, float* __restrict__ x,
+template <int NC, int NTC, int R0, int R1, int R2, int R3, int LAY, typename TX = float>   // TX: float, or int16_t = 16-bit PCM out
+static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k_inv_wave_v(const float* __restrict__ X, TX* __restrict__ x,
                                                           const float* __restrict__ tail_in, float* __restrict__ tail_out,
                                                           const v4f_t* __restrict__ coefv, const float* __restrict__ ctab, int Kp,
                                                           int nblk, int seg, int nseg, int N_rt, long long ntasks, int B,
@@ -1291,8 +1318,8 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
 #endif
     if (t >= 0) {
       if (n < nblk) {
-        float* xa = x + gx.off_a + (size_t)n * gx.block_stride;
-        float* xb = x + gx.off_b + (size_t)n * gx.block_stride;
+        TX* xa = x + gx.off_a + (size_t)n * gx.block_stride;
+        TX* xb = x + gx.off_b + (size_t)n * gx.block_stride;
 #pragma unroll
         for (int s = 0; s < kWaveVSteps; ++s) {
           const int i = tid + s * nt;
@@ -1971,9 +1998,19 @@ static int wave_strip(long long pairs, int per_sig, int gpw, int w, size_t lds, 
   }
   return best;
 }
-template <int LAY>
-static int launch_fwd_wave_v(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin, int F,
+// sizes with instances on 16-bit PCM rows (stereo / mono): the frame lengths of the speech and music codecs this tier is for
+#define AC_WAVE_PCM_SIZES             \
+  AC_WAVE_CT(120, 8, 10, 6, 0, 0)    \
+  AC_WAVE_CT(240, 16, 8, 5, 3, 0)    \
+  AC_WAVE_CT(480, 32, 10, 8, 3, 0)   \
+  AC_WAVE_CT(960, 64, 10, 8, 6, 0)   \
+  AC_WAVE_CT(1920, 128, 8, 8, 5, 3)  \
+  AC_WAVE_CT(576, 64, 8, 6, 6, 0)    \
+  AC_WAVE_CT(1152, 128, 9, 8, 8, 0)
+template <int LAY, typename TX = float>
+static int launch_fwd_wave_v(const ac_mdct_plan* p, const TX* x, float* X, const float* prev_block, int B, int Kin, int F,
                              int C, hipStream_t s) {
+  constexpr bool PCM = !std::is_same<TX, float>::value;
   const WavePlan wp = lds_wave_plan(p->N);
   size_t lds = 0;
   int w = 1, gpw = 1;
@@ -1987,6 +2024,23 @@ static int launch_fwd_wave_v(const ac_mdct_plan* p, const float* x, float* X, co
   if (st2) return st2 < 0 ? st2 : AC_OK;
   int st = AC_OK;
   bool done = false;
+  if constexpr (PCM) {
+#define AC_WAVE_CT(NC, NTC, R0, R1, R2, R3)                                                                                   \
+  if (!done && p->N == NC) {                                                                                                   \
+    done = true;                                                                                                               \
+    st = allow_lds(k_fwd_wave_v<NC, NTC, R0, R1, R2, R3, LAY, TX>, lds);                                                       \
+    if (!st)                                                                                                                   \
+      hipLaunchKernelGGL((k_fwd_wave_v<NC, NTC, R0, R1, R2, R3, LAY, TX>), dim3((unsigned)g), dim3(64 * w), lds, s, x, X,      \
+                         prev_block, reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kin, F, p->N, ntasks, T, nstrip,   \
+                         B, C, wp);                                                                                            \
+  }
+    AC_WAVE_PCM_SIZES
+#undef AC_WAVE_CT
+    if (!done) return AC_EUNSUPPORTED;
+    if (st) return st;
+    AC_HIP_CHECK(hipGetLastError());
+    return AC_OK;
+  } else {
 #define AC_WAVE_CT(NC, NTC, R0, R1, R2, R3)                                                                                   \
   if (!done && p->N == NC && !wave_ct_off()) {                                                                                 \
     done = true;                                                                                                               \
@@ -2007,10 +2061,12 @@ static int launch_fwd_wave_v(const ac_mdct_plan* p, const float* x, float* X, co
   if (st) return st;
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
+  }
 }
-template <int LAY>
-static int launch_inv_wave_v(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out, int B,
+template <int LAY, typename TX = float>
+static int launch_inv_wave_v(const ac_mdct_plan* p, const float* X, TX* x, const float* tail_in, float* tail_out, int B,
                              int Kp, int nblk, int C, hipStream_t s) {
+  constexpr bool PCM = !std::is_same<TX, float>::value;
   const WavePlan wp = lds_wave_plan(p->N);
   size_t lds = 0;
   int w = 1, gpw = 1;
@@ -2025,6 +2081,23 @@ static int launch_inv_wave_v(const ac_mdct_plan* p, const float* X, float* x, co
   if (st2) return st2 < 0 ? st2 : AC_OK;
   int st = AC_OK;
   bool done = false;
+  if constexpr (PCM) {
+#define AC_WAVE_CT(NC, NTC, R0, R1, R2, R3)                                                                                   \
+  if (!done && p->N == NC) {                                                                                                   \
+    done = true;                                                                                                               \
+    st = allow_lds(k_inv_wave_v<NC, NTC, R0, R1, R2, R3, LAY, TX>, lds);                                                       \
+    if (!st)                                                                                                                   \
+      hipLaunchKernelGGL((k_inv_wave_v<NC, NTC, R0, R1, R2, R3, LAY, TX>), dim3((unsigned)g), dim3(64 * w), lds, s, X, x,      \
+                         tail_in, tail_out, reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kp, nblk, seg, nseg, p->N,  \
+                         ntasks, B, C, wp);                                                                                    \
+  }
+    AC_WAVE_PCM_SIZES
+#undef AC_WAVE_CT
+    if (!done) return AC_EUNSUPPORTED;
+    if (st) return st;
+    AC_HIP_CHECK(hipGetLastError());
+    return AC_OK;
+  } else {
 #define AC_WAVE_CT(NC, NTC, R0, R1, R2, R3)                                                                                   \
   if (!done && p->N == NC && !wave_ct_off()) {                                                                                 \
     done = true;                                                                                                               \
@@ -2045,6 +2118,7 @@ static int launch_inv_wave_v(const ac_mdct_plan* p, const float* X, float* x, co
   if (st) return st;
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
+  }
 }
 
 #ifdef AC_WAVE_ROWS_TU
@@ -2059,6 +2133,12 @@ int launch_fwd_wave_mono(const ac_mdct_plan* p, const float* x, float* X, const 
 int launch_inv_wave_mono(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out, int B, int Kp,
                          int nblk, hipStream_t s) {
   return launch_inv_wave_v<1>(p, X, x, tail_in, tail_out, B, Kp, nblk, 1, s);
+}
+int launch_fwd_wave_mono_pcm16(const ac_mdct_plan* p, const int16_t* x, float* X, int B, int Kin, int F, hipStream_t s) {
+  return launch_fwd_wave_v<1, int16_t>(p, x, X, nullptr, B, Kin, F, 1, s);
+}
+int launch_inv_wave_mono_pcm16(const ac_mdct_plan* p, const float* X, int16_t* x, int B, int Kp, int nblk, hipStream_t s) {
+  return launch_inv_wave_v<1, int16_t>(p, X, x, nullptr, nullptr, B, Kp, nblk, 1, s);
 }
 #else
 int launch_fwd_wave_strided(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin, int F,
@@ -2136,6 +2216,25 @@ static int launch_inv_wave(const ac_mdct_plan* p, const TIO* X, TIO* x, const fl
                      nblk, seg, nseg, C, CP, p->N, ntasks, wp);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
+}
+
+// 16-bit PCM at the boundary on the instances of AC_WAVE_PCM_SIZES (mono / stereo): AC_EUNSUPPORTED elsewhere
+static bool wave_pcm_size(int N) {
+#define AC_WAVE_CT(NC, NTC, R0, R1, R2, R3) \
+  if (N == NC) return true;
+  AC_WAVE_PCM_SIZES
+#undef AC_WAVE_CT
+  return false;
+}
+bool lds_fft_serves_pcm16(const ac_mdct_plan* p, int C) {
+  return !g_force_generic && !wave_ct_off() && p->d_coefv && (C == 1 || C == 2) && wave_pcm_size(p->N);
+}
+int launch_fwd_lds_pcm16(const ac_mdct_plan* p, const int16_t* x, float* X, int B, int K, int C, hipStream_t s) {
+  return C == 2 ? launch_fwd_wave_v<0, int16_t>(p, x, X, nullptr, B, K, K + 1, 2, s) : launch_fwd_wave_mono_pcm16(p, x, X, B, K, K + 1, s);
+}
+int launch_inv_lds_pcm16(const ac_mdct_plan* p, const float* X, int16_t* x, int B, int Kp, int C, hipStream_t s) {
+  return C == 2 ? launch_inv_wave_v<0, int16_t>(p, X, x, nullptr, nullptr, B, Kp, Kp + 1, 2, s)
+                : launch_inv_wave_mono_pcm16(p, X, x, B, Kp, Kp + 1, s);
 }
 
 // which LDS-FFT form serves float32 tensors of C channels at this plan's size: 2 = a compile-time instance of the 16-byte

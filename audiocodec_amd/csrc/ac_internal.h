@@ -169,6 +169,12 @@ int launch_fwd_wave_mono(const ac_mdct_plan* p, const float* x, float* X, const 
                          hipStream_t s);
 int launch_inv_wave_mono(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out, int B, int Kp,
                          int nblk, hipStream_t s);
+// 16-bit PCM at the boundary of the LDS-FFT tier (filters_n 120 / 240 / 480 / 960 / 1920 / 576 / 1152, mono / stereo)
+bool lds_fft_serves_pcm16(const ac_mdct_plan* p, int C);
+int launch_fwd_lds_pcm16(const ac_mdct_plan* p, const int16_t* x, float* X, int B, int K, int C, hipStream_t s);
+int launch_inv_lds_pcm16(const ac_mdct_plan* p, const float* X, int16_t* x, int B, int Kp, int C, hipStream_t s);
+int launch_fwd_wave_mono_pcm16(const ac_mdct_plan* p, const int16_t* x, float* X, int B, int Kin, int F, hipStream_t s);
+int launch_inv_wave_mono_pcm16(const ac_mdct_plan* p, const float* X, int16_t* x, int B, int Kp, int nblk, hipStream_t s);
 // ... and on channel pairs of any channel count / rows off the 16-byte grid (ac_wave_rows2.hip)
 int launch_fwd_wave_strided(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin, int F,
                             int C, hipStream_t s);

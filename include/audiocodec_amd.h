@@ -44,7 +44,7 @@ extern "C" {
 #define AC_API __attribute__((visibility("default")))
 #endif
 
-#define AC_VERSION 171 /* 0.1.8: ac_mdct_plan_tier; the LDS-FFT tier on 16-byte kernels with compile-time instances (filters_n % 4 == 0
+#define AC_VERSION 171 /* 0.1.8: ac_mdct_plan_tier; 16-bit PCM at the Opus / MP3 frame lengths; the LDS-FFT tier on 16-byte kernels with compile-time instances (filters_n % 4 == 0
                           * with a 5-smooth half up to 8192, float32); masking model for general band layouts up to 4096 bins.
                           * 0.1.7: only the ac_* entry points are exported; ac_stream_settle (home buffers for the streaming state);
                           * float32 precompute (ac_*_create_pre, ac_*_host_pre); fused encode at filters_n 64 ... 512; ac_workspace_*.
@@ -222,8 +222,9 @@ AC_API int ac_encode_fused_ex(const ac_mdct_plan* mdct, const ac_psy_plan* psy, 
 
 /* 16-bit PCM at the boundary (extension; the reference takes float PCM in [-1, 1] only, mdctransformer.py:104):
  * x = pcm / 32768 on the way in, pcm = clamp(round(32768 x), -32768, 32767) on the way out, fused into the kernels'
- * loads / stores, so a frame moves 2 bytes per sample instead of 4.  Served by the wave-level kernels (filters_n 1024
- * or 2048, 'vorbis' / 'sine' window); AC_EUNSUPPORTED otherwise.  Shapes as the float32 entry points. */
+ * loads / stores, so a frame moves 2 bytes per sample instead of 4.  Served by the wave-level kernels (filters_n 64 ... 2048
+ * in powers of two, 'vorbis' / 'sine' window; below 1024 mono / stereo) and by the LDS-FFT tier at filters_n 120, 240, 480,
+ * 960, 1920, 576, 1152 (mono / stereo, any window); AC_EUNSUPPORTED otherwise.  Shapes as the float32 entry points. */
 AC_API int ac_mdct_forward_pcm16(const ac_mdct_plan* plan, const int16_t* x, float* X, int B, int K, int C, void* stream);
 AC_API int ac_mdct_inverse_pcm16(const ac_mdct_plan* plan, const float* X, int16_t* x, int B, int Kp, int C, void* stream);
 AC_API int ac_encode_fused_pcm16(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const int16_t* x, float* X, float* t,

@@ -1421,10 +1421,31 @@ def test_pcm16_at_the_boundary(N, C):
     assert torch.equal(out[:, N:-N], pcm)
     ref = torch.clamp(torch.round(codec.decode(X) * 32768.0), -32768, 32767).to(torch.int16)
     assert torch.equal(out, ref)
-    with pytest.raises(_lib.AudioCodecError):      # the LDS-FFT / generic kernels do not take 16-bit PCM
-        audiocodec_amd.AudioCodec(48000, 960).encode(torch.zeros(1, 4 * 960, 2, device="cuda", dtype=torch.int16))
+    with pytest.raises(_lib.AudioCodecError):      # the LDS-FFT tier takes 16-bit PCM at seven sizes, mono / stereo
+        audiocodec_amd.AudioCodec(48000, 800).encode(torch.zeros(1, 4 * 800, 2, device="cuda", dtype=torch.int16))
+    with pytest.raises(_lib.AudioCodecError):
+        audiocodec_amd.AudioCodec(48000, 960).encode(torch.zeros(1, 4 * 960, 3, device="cuda", dtype=torch.int16))
     with pytest.raises(_lib.AudioCodecError):      # ... nor do the short-frame kernels for other channel counts
         audiocodec_amd.AudioCodec(48000, 256).encode(torch.zeros(1, 4 * 256, 3, device="cuda", dtype=torch.int16))
+
+
+@pytest.mark.parametrize("N", [120, 240, 480, 960, 1920, 576, 1152])
+@pytest.mark.parametrize("C", [2, 1])
+def test_pcm16_at_the_boundary_of_the_lds_fft_tier(N, C):
+    """int16 PCM in / out at the frame lengths of the speech and music codecs (Opus 2.5 ... 20 ms, 1920, MP3 576 / 1152):
+    bit-identical spectra to the float path fed pcm / 32768, the round trip returns the PCM exactly, an odd mono batch."""
+    B, K = 3, 37
+    pcm = torch.randint(-32768, 32768, (B, K * N, C), device="cuda", dtype=torch.int16)
+    pcm[0, :7, 0] = torch.tensor([-32768, 32767, 0, 1, -1, 12345, -12345], dtype=torch.int16)
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    X, t, thr = codec.encode(pcm)
+    Xf, tf, thrf = codec.encode(pcm.float() / 32768.0)
+    assert X.dtype == torch.float32 and torch.equal(X, Xf) and torch.equal(t, tf) and torch.equal(thr, thrf)
+    out = codec.decode(X, pcm16=True)
+    assert out.dtype == torch.int16 and tuple(out.shape) == (B, (K + 2) * N, C)
+    assert torch.equal(out[:, N:-N], pcm)
+    ref = torch.clamp(torch.round(codec.decode(X) * 32768.0), -32768, 32767).to(torch.int16)
+    assert torch.equal(out, ref)
 
 
 def test_plan_and_stream_lifecycle():
