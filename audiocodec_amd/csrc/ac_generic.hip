@@ -1030,10 +1030,10 @@ static __global__ __launch_bounds__(kThreads, 2) void k_inv_wave(const TIO* __re
 // current frame and land while it runs.
 // The two rows a complex pair carries through the transform (LAY): 0 the channels of a stereo signal (one 16-byte access
 // per two samples); 1 two mono signals b, b + 1 (8 bytes each; the last pair of an odd batch is half empty); 2 the channels
-// c, c + 1 of any channel count, rows anywhere on the 4-byte grid (4-byte accesses; the last pair of an odd count is half
-// empty).  bfloat16 tensors and filters_n % 4 == 2 run the 8-byte kernels above.
+// c, c + 1 of three or more channels (8-byte accesses on the 4-byte grid; the last pair of an odd count is half empty).  bfloat16 tensors and filters_n % 4 == 2 run the 8-byte kernels above.
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 typedef float v2f_t __attribute__((ext_vector_type(2)));
+typedef float v2u_t __attribute__((ext_vector_type(2), aligned(4)));   // two floats on the 4-byte grid
 constexpr int kWaveVSteps = 4;
 template <int LAY>
 struct RowPair {
@@ -1050,10 +1050,12 @@ struct RowPair {
       const v2f_t fb = *reinterpret_cast<const v2f_t*>(b + m);
       return v4f_t{fa.x, fb.x, fa.y, fb.y};
     } else {
-      int o = m * C;   // (formed where it is used: hoisted out of the frame loop, the addresses of a lane's 64 accesses spill)
+      // the pair's two channels are adjacent: one 8-byte access on the 4-byte grid per sample (gfx950 takes multi-dword global
+      // accesses at dword alignment); the half-empty last pair of an odd channel count reads (c - 1, c) instead of (c, c + 1)
+      int o = m * C - (has1 ? 0 : 1);   // (formed where it is used: hoisted out of the frame loop, the addresses of a lane's accesses spill)
       asm volatile("" : "+v"(o));
-      const float *p0 = a + o, *p1 = b + o;
-      return v4f_t{p0[0], p1[0], p0[C], p1[C]};
+      const v2u_t s0 = *reinterpret_cast<const v2u_t*>(a + o), s1 = *reinterpret_cast<const v2u_t*>(a + o + C);
+      return v4f_t{has1 ? s0.x : s0.y, s0.y, has1 ? s1.x : s1.y, s1.y};
     }
   }
   // the same rows as 16-bit PCM (x = pcm / 32768 on the way in, clamp(round(32768 x)) on the way out, as the wave-level
@@ -1092,12 +1094,13 @@ struct RowPair {
     } else {
       int o = m * C;
       asm volatile("" : "+v"(o));
-      float *p0 = a + o, *p1 = b + o;
-      p0[0] = v.x;
-      p0[C] = v.z;
+      float* p0 = a + o;
       if (has1) {
-        p1[0] = v.y;
-        p1[C] = v.w;
+        *reinterpret_cast<v2u_t*>(p0) = v2u_t{v.x, v.y};
+        *reinterpret_cast<v2u_t*>(p0 + C) = v2u_t{v.z, v.w};
+      } else {
+        p0[0] = v.x;
+        p0[C] = v.z;
       }
     }
   }
@@ -1135,7 +1138,7 @@ template <int NC, int NTC, int R0, int R1, int R2, int R3, int LAY, typename TX 
 static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k_fwd_wave_v(const TX* __restrict__ x, float* __restrict__ X,
                                                           const float* __restrict__ prev_block, const v4f_t* __restrict__ coefv,
                                                           const float* __restrict__ ctab, int Kin, int F, int N_rt, long long ntasks,
-                                                          int T, int nstrip, int B, int C, WavePlan wp) {
+                                                          int T, int nstrip, int B, int C, int adj, WavePlan wp) {
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int N = NC ? NC : N_rt, nt = NC ? NTC : wp.nt, gpw = (int)blockDim.x / nt, grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
   constexpr bool GRP = NTC > 64;   // one frame per workgroup of NTC lanes, transformed in place
@@ -1157,8 +1160,20 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
   const float scale = (float)(1.0 / ((double)N * 1.4142135623730951));
   const long long wg = (long long)blockIdx.x * gpw + grp;
   if (wg >= ntasks) return;
-  const int sp = (int)(wg % nstrip);
-  const long long pr = wg / nstrip;
+  // task -> (pair, strip); LAY 2 with several frames per workgroup (adj): the channel pairs of one signal and strip sit in one
+  // workgroup, so that the cache lines they share (a pair uses 8 of every 4 C bytes) come through one L1 (six channels,
+  // N = 120: 2.2 -> 3.4 TB/s; a frame per workgroup measured slower that way: pairs of a signal then stay far apart)
+  int sp;
+  long long pr;
+  if (LAY == 2 && adj) {
+    const int CP = (C + 1) / 2;
+    const long long rest = wg / CP;
+    sp = (int)(rest % nstrip);
+    pr = (rest / nstrip) * CP + (wg - rest * CP);
+  } else {
+    sp = (int)(wg % nstrip);
+    pr = wg / nstrip;
+  }
   const PairGeo gx = pair_geo<LAY>(pr, N, B, C, (size_t)Kin), gX = pair_geo<LAY>(pr, N, B, C, (size_t)F),
                 gp = pair_geo<LAY>(pr, N, B, C, 1);
   const RowPair<LAY> rp = {gx.has1, C};
@@ -1237,7 +1252,7 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
                                                           const float* __restrict__ tail_in, float* __restrict__ tail_out,
                                                           const v4f_t* __restrict__ coefv, const float* __restrict__ ctab, int Kp,
                                                           int nblk, int seg, int nseg, int N_rt, long long ntasks, int B,
-                                                          int C, WavePlan wp) {
+                                                          int C, int adj, WavePlan wp) {
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int N = NC ? NC : N_rt, nt = NC ? NTC : wp.nt, gpw = (int)blockDim.x / nt, grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
   constexpr bool GRP = NTC > 64;
@@ -1258,8 +1273,17 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
   cpair* Ap = reinterpret_cast<cpair*>(base + 4 * padded_len(h, ps));
   const long long wg = (long long)blockIdx.x * gpw + grp;
   if (wg >= ntasks) return;
-  const int sgm = (int)(wg % nseg);
-  const long long pr = wg / nseg;
+  int sgm;
+  long long pr;
+  if (LAY == 2 && adj) {   // (channel pairs of one signal and strip side by side: see k_fwd_wave_v)
+    const int CP = (C + 1) / 2;
+    const long long rest = wg / CP;
+    sgm = (int)(rest % nseg);
+    pr = (rest / nseg) * CP + (wg - rest * CP);
+  } else {
+    sgm = (int)(wg % nseg);
+    pr = wg / nseg;
+  }
   const PairGeo gX = pair_geo<LAY>(pr, N, B, C, (size_t)Kp), gx = pair_geo<LAY>(pr, N, B, C, (size_t)nblk);
   const RowPair<LAY> rp = {gx.has1, C};
   const v4f_t* cv = coefv + h;   // the synthesis half of the table
@@ -1959,7 +1983,7 @@ static int wave_v_layout(int C, std::initializer_list<const void*> ptrs) {
   uintptr_t bits = 0;
   for (const void* q : ptrs) bits |= reinterpret_cast<uintptr_t>(q);
   if (C == 2 && !(bits & 15)) return 0;
-  if (C == 1 && !(bits & 7)) return 1;
+  if (C == 1) return (bits & 7) ? -1 : 1;   // (a mono tensor off the 8-byte grid: the 8-byte kernels of the run-time forms)
   return 2;
 }
 // waves per workgroup, frames per workgroup and LDS bytes of the 16-byte kernels: the wave form packs frames as lds_wave_block
@@ -2016,6 +2040,7 @@ static int launch_fwd_wave_v(const ac_mdct_plan* p, const TX* x, float* X, const
   int w = 1, gpw = 1;
   wave_v_geometry(p->N, wp, &w, &gpw, &lds);
   const long long pairs = LAY == 0 ? (long long)B : LAY == 1 ? ((long long)B + 1) / 2 : (long long)B * ((C + 1) / 2);
+  const int adj = LAY == 2 && gpw >= (C + 1) / 2;   // (see the kernel: channel pairs of a signal in one workgroup)
   const int T = wave_strip(pairs, F, gpw, w, lds, p->cus, 0.25);   // (every strip reads one block more than it has frames)
   const int nstrip = (F + T - 1) / T;
   const long long ntasks = pairs * nstrip;
@@ -2032,7 +2057,7 @@ static int launch_fwd_wave_v(const ac_mdct_plan* p, const TX* x, float* X, const
     if (!st)                                                                                                                   \
       hipLaunchKernelGGL((k_fwd_wave_v<NC, NTC, R0, R1, R2, R3, LAY, TX>), dim3((unsigned)g), dim3(64 * w), lds, s, x, X,      \
                          prev_block, reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kin, F, p->N, ntasks, T, nstrip,   \
-                         B, C, wp);                                                                                            \
+                         B, C, adj, wp);                                                                                       \
   }
     AC_WAVE_PCM_SIZES
 #undef AC_WAVE_CT
@@ -2048,7 +2073,7 @@ static int launch_fwd_wave_v(const ac_mdct_plan* p, const TX* x, float* X, const
     if (!st)                                                                                                                   \
       hipLaunchKernelGGL((k_fwd_wave_v<NC, NTC, R0, R1, R2, R3, LAY>), dim3((unsigned)g), dim3(64 * w), lds, s, x, X,         \
                          prev_block, reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kin, F, p->N, ntasks, T, nstrip,   \
-                         B, C, wp);                                                                                            \
+                         B, C, adj, wp);                                                                                       \
   }
   AC_WAVE_CT_SIZES
 #undef AC_WAVE_CT
@@ -2056,7 +2081,7 @@ static int launch_fwd_wave_v(const ac_mdct_plan* p, const TX* x, float* X, const
     st = allow_lds(k_fwd_wave_v<0, 0, 0, 0, 0, 0, LAY>, lds);
     if (!st)
       hipLaunchKernelGGL((k_fwd_wave_v<0, 0, 0, 0, 0, 0, LAY>), dim3((unsigned)g), dim3(64 * w), lds, s, x, X, prev_block,
-                         reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kin, F, p->N, ntasks, T, nstrip, B, C, wp);
+                         reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kin, F, p->N, ntasks, T, nstrip, B, C, adj, wp);
   }
   if (st) return st;
   AC_HIP_CHECK(hipGetLastError());
@@ -2073,6 +2098,7 @@ static int launch_inv_wave_v(const ac_mdct_plan* p, const float* X, TX* x, const
   wave_v_geometry(p->N, wp, &w, &gpw, &lds);
   const int per_sig = nblk + (tail_out ? 1 : 0);
   const long long pairs = LAY == 0 ? (long long)B : LAY == 1 ? ((long long)B + 1) / 2 : (long long)B * ((C + 1) / 2);
+  const int adj = LAY == 2 && gpw >= (C + 1) / 2;
   const int seg = wave_strip(pairs, per_sig, gpw, w, lds, p->cus, 1.0);   // (every strip but a signal's first transforms one frame more)
   const int nseg = (per_sig + seg - 1) / seg;
   const long long ntasks = pairs * nseg;
@@ -2089,7 +2115,7 @@ static int launch_inv_wave_v(const ac_mdct_plan* p, const float* X, TX* x, const
     if (!st)                                                                                                                   \
       hipLaunchKernelGGL((k_inv_wave_v<NC, NTC, R0, R1, R2, R3, LAY, TX>), dim3((unsigned)g), dim3(64 * w), lds, s, X, x,      \
                          tail_in, tail_out, reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kp, nblk, seg, nseg, p->N,  \
-                         ntasks, B, C, wp);                                                                                    \
+                         ntasks, B, C, adj, wp);                                                                               \
   }
     AC_WAVE_PCM_SIZES
 #undef AC_WAVE_CT
@@ -2105,7 +2131,7 @@ static int launch_inv_wave_v(const ac_mdct_plan* p, const float* X, TX* x, const
     if (!st)                                                                                                                   \
       hipLaunchKernelGGL((k_inv_wave_v<NC, NTC, R0, R1, R2, R3, LAY>), dim3((unsigned)g), dim3(64 * w), lds, s, X, x,         \
                          tail_in, tail_out, reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kp, nblk, seg, nseg, p->N,  \
-                         ntasks, B, C, wp);                                                                                    \
+                         ntasks, B, C, adj, wp);                                                                               \
   }
   AC_WAVE_CT_SIZES
 #undef AC_WAVE_CT
@@ -2113,7 +2139,7 @@ static int launch_inv_wave_v(const ac_mdct_plan* p, const float* X, TX* x, const
     st = allow_lds(k_inv_wave_v<0, 0, 0, 0, 0, 0, LAY>, lds);
     if (!st)
       hipLaunchKernelGGL((k_inv_wave_v<0, 0, 0, 0, 0, 0, LAY>), dim3((unsigned)g), dim3(64 * w), lds, s, X, x, tail_in, tail_out,
-                         reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kp, nblk, seg, nseg, p->N, ntasks, B, C, wp);
+                         reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kp, nblk, seg, nseg, p->N, ntasks, B, C, adj, wp);
   }
   if (st) return st;
   AC_HIP_CHECK(hipGetLastError());
@@ -2163,7 +2189,7 @@ static int launch_fwd_wave(const ac_mdct_plan* p, const TIO* x, TIO* X, const TI
   if constexpr (std::is_same<TIO, float>::value)
     if (lds_wave_vec_ok(p, wp0, C)) {
       const int lay = wave_v_layout(C, {x, X, prev_block});
-      return lay == 0 ? launch_fwd_wave_v<0>(p, x, X, prev_block, B, Kin, F, 2, s)
+      if (lay >= 0) return lay == 0 ? launch_fwd_wave_v<0>(p, x, X, prev_block, B, Kin, F, 2, s)
              : lay == 1 ? launch_fwd_wave_mono(p, x, X, prev_block, B, Kin, F, s)
                         : launch_fwd_wave_strided(p, x, X, prev_block, B, Kin, F, C, s);
     }
@@ -2192,7 +2218,7 @@ static int launch_inv_wave(const ac_mdct_plan* p, const TIO* X, TIO* x, const fl
   if constexpr (std::is_same<TIO, float>::value)
     if (lds_wave_vec_ok(p, wp0, C)) {
       const int lay = wave_v_layout(C, {X, x});
-      return lay == 0 ? launch_inv_wave_v<0>(p, X, x, tail_in, tail_out, B, Kp, nblk, 2, s)
+      if (lay >= 0) return lay == 0 ? launch_inv_wave_v<0>(p, X, x, tail_in, tail_out, B, Kp, nblk, 2, s)
              : lay == 1 ? launch_inv_wave_mono(p, X, x, tail_in, tail_out, B, Kp, nblk, s)
                         : launch_inv_wave_strided(p, X, x, tail_in, tail_out, B, Kp, nblk, C, s);
     }
