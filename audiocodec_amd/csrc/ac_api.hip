@@ -525,7 +525,7 @@ int ac_tonality(const ac_psy_plan* p, const float* X, float* t, int B, int F, in
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
   if (p->fast && !g_force_generic) return launch_psy_fast(p, X, nullptr, t, nullptr, 0.f, B, F, C, s);
-  if (p->mid && !g_force_generic && C <= 2) return launch_psy_mid(p, X, nullptr, t, nullptr, 0.f, B, F, C, s);
+  if (p->mid && !g_force_generic) return launch_psy_mid(p, X, nullptr, t, nullptr, 0.f, B, F, C, s);
   return launch_tonality_generic(p, X, t, B, F, C, s);
 }
 
@@ -540,7 +540,7 @@ int ac_mask_threshold(const ac_psy_plan* p, const float* X, const float* t, floa
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
   if (p->fast && !g_force_generic) return launch_psy_fast(p, X, t, nullptr, thr, drown, B, F, C, s);
-  if (p->mid && !g_force_generic && C <= 2) return launch_psy_mid(p, X, t, nullptr, thr, drown, B, F, C, s);
+  if (p->mid && !g_force_generic) return launch_psy_mid(p, X, t, nullptr, thr, drown, B, F, C, s);
   return launch_threshold_generic(p, X, t, drown, thr, B, F, C, s);
 }
 
@@ -602,7 +602,7 @@ static int encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const 
   // un-fused composition for configurations the fused kernel does not cover: the transform, then tonality + threshold in
   // one wave-level pass over X where the general-layout masking kernels serve the plan, else the two generic kernels
   st = mdct_forward(mdct, x, pcm16, X, B, K, C, stream);
-  if (!st && psy->mid && !g_force_generic && C <= 2) return launch_psy_mid(psy, X, nullptr, t, thr, drown, B, K + 1, C, s);
+  if (!st && psy->mid && !g_force_generic) return launch_psy_mid(psy, X, nullptr, t, thr, drown, B, K + 1, C, s);
   if (!st) st = ac_tonality(psy, X, t, B, K + 1, C, stream);
   if (!st) st = ac_mask_threshold(psy, X, t, drown, thr, B, K + 1, C, stream);
   return st;
@@ -613,7 +613,7 @@ int ac_encode_launches(const ac_mdct_plan* mdct, const ac_psy_plan* psy, int C) 
   if (g_force_generic) return 3;
   if (mdct->fast && psy->fast) return (mdct->N == 2048 && C == 1) ? 2 : 1;   // (see encode_fused)
   if (mdct->fast && fast_multi_fuses(mdct, psy, C, 0, 1)) return 1;
-  return (psy->mid && C <= 2) ? 2 : 3;
+  return psy->mid ? 2 : 3;
 }
 
 int ac_encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr,
@@ -757,7 +757,7 @@ static int stream_analysis(ac_stream* s, const ac_psy_plan* psy, const float* x_
     // the same second step encode_fused takes for these configurations (so that chunked and one-shot results agree bit
     // for bit): tonality + threshold in one wave-level pass over X, or the two generic kernels
     if (fast && psy->fast) return launch_psy_fast(psy, X, nullptr, t, thr, drown, s->B, k, s->C, hs);
-    if (psy->mid && !g_force_generic && s->C <= 2) return launch_psy_mid(psy, X, nullptr, t, thr, drown, s->B, k, s->C, hs);
+    if (psy->mid && !g_force_generic) return launch_psy_mid(psy, X, nullptr, t, thr, drown, s->B, k, s->C, hs);
     st = ac_tonality(psy, X, t, s->B, k, s->C, stream);
     if (!st) st = ac_mask_threshold(psy, X, t, drown, thr, s->B, k, s->C, stream);
   }

@@ -17,6 +17,7 @@ namespace ac {
 namespace {
 
 using namespace mid;
+typedef float v2u __attribute__((ext_vector_type(2), aligned(4)));   // two floats on the 4-byte grid
 
 // Granule registers per lane from which the W_inv entries are read from global memory instead of the LDS image: from 8 (frames
 // above 512 bins), where the table is 15 ... 64 KB and keeping it out of LDS doubles the resident waves (B = 256 stereo, the
@@ -70,12 +71,35 @@ __global__ __launch_bounds__(256, (R >= 32 ? 1 : R >= 16 ? 2 : (WANT_THR && (FB 
       const long long task = task0 + (long long)(tt + fb) * nw;
       ok[fb] = tt + fb < a.T && task < a.ntasks;
       const long long tk = ok[fb] ? task : task0 + (long long)tt * nw;   // (a frame past the end re-reads the group's first row)
+      const size_t blk = (size_t)N * C;
+      if (CMODE == 1) {
+        // channels c, c + 1 of clip b (any channel count): rows strided by C, the pair's two values adjacent -- one 8-byte access
+        // on the 4-byte grid per bin; the half-empty last pair of an odd count reads (c - 1, c) and keeps the second value.
+        // The pairs of one frame are neighbouring tasks: the waves of a workgroup share the cache lines the pairs share.
+        const int CP = (C + 1) / 2;
+        const long long rest = tk / CP;
+        const int c = 2 * (int)(tk - rest * CP), f = (int)(rest % a.F);
+        const long long b = rest / a.F;
+        has1[fb] = c + 1 < C;
+        o0[fb] = ((size_t)b * a.F + (size_t)f) * blk + c;
+        o1[fb] = o0[fb];
+        t0[fb] = ((size_t)b * a.F + (size_t)f) * C + c;
+        t1[fb] = t0[fb] + 1;
+        const v2u* row = reinterpret_cast<const v2u*>(a.X + o0[fb] - (has1[fb] ? 0 : 1));
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          const int q = 64 * i + lane;
+          const v2u u = in(i) ? *reinterpret_cast<const v2u*>(reinterpret_cast<const float*>(row) + (size_t)(2 * q) * C) : v2u{0.f, 0.f};
+          const v2u w = in(i) ? *reinterpret_cast<const v2u*>(reinterpret_cast<const float*>(row) + (size_t)(2 * q + 1) * C) : v2u{0.f, 0.f};
+          xq[fb][i] = has1[fb] ? v4f{u.x, u.y, w.x, w.y} : v4f{u.y, u.y, w.y, w.y};
+        }
+        continue;
+      }
+      // the two signals of the wave: stereo = the two channels of clip p; mono = clips 2 p and 2 p + 1
       const int f = (int)(tk % a.F);
       const long long p = tk / a.F;
-      // the two signals of the wave: stereo = the two channels of clip p; mono = clips 2 p and 2 p + 1
       has1[fb] = CMODE == 0 ? true : (2 * p + 1 < a.nsig);
       const long long b0 = CMODE == 0 ? p : 2 * p, b1 = CMODE == 0 ? p : (has1[fb] ? 2 * p + 1 : 2 * p);
-      const size_t blk = (size_t)N * C;
       o0[fb] = ((size_t)b0 * a.F + (size_t)f) * blk;
       o1[fb] = ((size_t)b1 * a.F + (size_t)f) * blk;
       t0[fb] = ((size_t)b0 * a.F + (size_t)f) * C;
@@ -114,6 +138,15 @@ __global__ __launch_bounds__(256, (R >= 32 ? 1 : R >= 16 ? 2 : (WANT_THR && (FB 
       if (!ok[fb]) return;
       if (CMODE == 0) {
         __builtin_nontemporal_store(th, reinterpret_cast<v4f*>(a.thr + o0[fb]) + 64 * i + lane);
+      } else if (CMODE == 1) {
+        float* r0 = a.thr + o0[fb] + (size_t)(2 * (64 * i + lane)) * C;
+        if (has1[fb]) {
+          *reinterpret_cast<v2u*>(r0) = v2u{th.x, th.y};
+          *reinterpret_cast<v2u*>(r0 + C) = v2u{th.z, th.w};
+        } else {
+          r0[0] = th.x;
+          r0[C] = th.z;
+        }
       } else {
         __builtin_nontemporal_store(v2f{th.x, th.z}, reinterpret_cast<v2f*>(a.thr + o0[fb]) + 64 * i + lane);
         if (has1[fb]) __builtin_nontemporal_store(v2f{th.y, th.w}, reinterpret_cast<v2f*>(a.thr + o1[fb]) + 64 * i + lane);
@@ -268,10 +301,6 @@ int mid_psy_plan_init(ac_psy_plan* p) {
 int launch_psy_mid(const ac_psy_plan* p, const float* X, const float* t_in, float* t_out, float* thr, float drown, int B,
                    int F, int C, hipStream_t s) {
   if (B <= 0 || C <= 0 || F <= 0) return AC_OK;
-  if (C != 1 && C != 2) {
-    set_error("internal: the wave-level masking model serves mono and stereo tensors");
-    return AC_EUNSUPPORTED;
-  }
   // (the layout of the image was fixed when the plan was built: a launch only fills in arguments)
   MidLayout L;
   L.words = p->mid_words;
@@ -285,7 +314,7 @@ int launch_psy_mid(const ac_psy_plan* p, const float* X, const float* t_in, floa
   a.C = C;
   a.F = F;
   a.nsig = (long long)B * C;
-  a.ntasks = ((C == 2) ? (long long)B : (a.nsig + 1) / 2) * F;
+  a.ntasks = (C == 2 ? (long long)B : C == 1 ? (a.nsig + 1) / 2 : (long long)B * ((C + 1) / 2)) * F;   // pairs of rows x frames
   const bool want_t = t_out != nullptr, want_thr = thr != nullptr;
   const int R = mid_r(p->N);
   const int fb = mid_fb(R);
@@ -322,7 +351,13 @@ int launch_psy_mid(const ac_psy_plan* p, const float* X, const float* t_in, floa
   }
   const unsigned grid = (unsigned)g;
   int st;
-  if (C == 2) st = R == 1 ? launch_mid_R<1, 0>(a, want_t, want_thr, grid, nw, lds, s)
+  if (C > 2) st = R == 1 ? launch_mid_R<1, 1>(a, want_t, want_thr, grid, nw, lds, s)
+                 : R == 2 ? launch_mid_R<2, 1>(a, want_t, want_thr, grid, nw, lds, s)
+                 : R == 4 ? launch_mid_R<4, 1>(a, want_t, want_thr, grid, nw, lds, s)
+                 : R == 8 ? launch_mid_R<8, 1>(a, want_t, want_thr, grid, nw, lds, s)
+                 : R == 16 ? launch_mid_R<16, 1>(a, want_t, want_thr, grid, nw, lds, s)
+                           : launch_mid_R<32, 1>(a, want_t, want_thr, grid, nw, lds, s);
+  else if (C == 2) st = R == 1 ? launch_mid_R<1, 0>(a, want_t, want_thr, grid, nw, lds, s)
                  : R == 2 ? launch_mid_R<2, 0>(a, want_t, want_thr, grid, nw, lds, s)
                  : R == 4 ? launch_mid_R<4, 0>(a, want_t, want_thr, grid, nw, lds, s)
                  : R == 8 ? launch_mid_R<8, 0>(a, want_t, want_thr, grid, nw, lds, s)

@@ -162,7 +162,7 @@ AC_API int ac_mdct_plan_tier(const ac_mdct_plan* plan, int channels_n);
 AC_API int ac_psy_plan_is_fast(const ac_psy_plan* plan);
 /* Which kernels serve the masking model of a plan: 2 = the wave-level kernels fused into the encode (filter_bands_n 1024 /
  * 2048, 64 Bark bands, every bin in at most two adjacent bands); 1 = the wave-level kernels for general band layouts
- * (any even filter_bands_n up to 4096, up to 64 bands; mono / stereo tensors, other channel counts take the generic ones);
+ * (any even filter_bands_n up to 4096, up to 64 bands; any channel count);
  * 0 = the generic kernels (one workgroup per channel-frame). */
 AC_API int ac_psy_plan_tier(const ac_psy_plan* plan);
 

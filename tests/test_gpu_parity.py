@@ -1098,7 +1098,10 @@ def test_autograd_of_add_noise_and_db(path):
                                           (48000, 30, 8, 2, 2, 1), (48000, 1000, 64, 1, 3, 2),
                                           # above 1024 bins: 16 / 32 granule registers per lane, W_inv entries read from global memory
                                           (48000, 1920, 64, 2, 3, 2), (48000, 4096, 64, 1, 3, 2), (44100, 2048, 48, 2, 2, 1),
-                                          (48000, 1536, 48, 2, 2, 1), (96000, 4096, 64, 1, 2, 1), (48000, 2880, 64, 3, 2, 2)])
+                                          (48000, 1536, 48, 2, 2, 1), (96000, 4096, 64, 1, 2, 1), (48000, 2880, 64, 3, 2, 2),
+                                          # more than two channels: the pairs (c, c + 1), rows strided by the channel count
+                                          (48000, 960, 64, 2, 3, 3), (48000, 480, 64, 2, 4, 6), (44100, 512, 48, 3, 3, 5),
+                                          (48000, 1920, 64, 1, 2, 4), (48000, 120, 20, 2, 5, 7)])
 def test_masking_model_general_band_layouts(sr, N, M, B, F, C):
     """filter_bands_n other than 1024 / 2048 with 64 bands (256, 512, 960, 480 ...; 1024 with other band counts): the
     wave-level masking kernels for general band layouts
