@@ -388,7 +388,7 @@ static int psy_plan_build(int N, int M, double sample_rate, double alpha, int de
     st = fast_psy_plan_init(p);
     if (!st) p->fast = 1;
   }
-  if (!st && !p->fast && mid_psy_supported(p)) {
+  if (!st && mid_psy_supported(p)) {   // (beside the fused epilogue's tables where both apply: more than two channels, psy_mid_serves)
     st = mid_psy_plan_init(p);
     if (!st) p->mid = 1;
   }
@@ -449,8 +449,19 @@ int ac_psy_plan_tier(const ac_psy_plan* p) { return !p ? 0 : p->fast ? 2 : p->mi
 // whether the wave-level kernels take this call (plans at filters_n 512 / 256 serve a subset, see ac_internal.h)
 static bool wave_level(const ac_mdct_plan* p, int C, int iof, int blocks) {
   if (!p->fast || g_force_generic) return false;
+  // float32 tensors of more than two channels: the channel-pair instances of the LDS-FFT tier (2.2 - 3 TB/s) rather than
+  // the wave-level kernels' strided form (0.9 - 1.5); every float32 route -- one-shot, streaming, the encode -- asks here, so
+  // they stay bit-equal to each other.  16-bit PCM of more than two channels keeps the strided form.
+  if (iof == 0 && C > 2 && lds_fft_tier_of(p, C) == 2) return false;
   return fast_mdct_frames_per_wave(p->N) == 1 || fast_multi_serves(p, C, iof, blocks);
 }
+// Which masking-model kernels serve C channels of a plan: the general-layout ones (strided channel pairs) take more than
+// two channels off the fused epilogue's kernels too when the plan holds both forms and runs the default spreading product
+// (theirs: split bfloat16 on the matrix cores)
+static bool psy_mid_serves(const ac_psy_plan* p, int C) {
+  return p->mid && !g_force_generic && (!p->fast || (C > 2 && p->spread == AC_SPREAD_BF16X2_MFMA));
+}
+static bool psy_fast_serves(const ac_psy_plan* p, int C) { return p->fast && !g_force_generic && !psy_mid_serves(p, C); }
 
 int ac_mdct_plan_tier(const ac_mdct_plan* p, int C) {
   if (!p || C < 1) return -1;
@@ -524,8 +535,8 @@ int ac_tonality(const ac_psy_plan* p, const float* X, float* t, int B, int F, in
   AC_REQUIRE_ALIGNED(X);
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
-  if (p->fast && !g_force_generic) return launch_psy_fast(p, X, nullptr, t, nullptr, 0.f, B, F, C, s);
-  if (p->mid && !g_force_generic) return launch_psy_mid(p, X, nullptr, t, nullptr, 0.f, B, F, C, s);
+  if (psy_fast_serves(p, C)) return launch_psy_fast(p, X, nullptr, t, nullptr, 0.f, B, F, C, s);
+  if (psy_mid_serves(p, C)) return launch_psy_mid(p, X, nullptr, t, nullptr, 0.f, B, F, C, s);
   return launch_tonality_generic(p, X, t, B, F, C, s);
 }
 
@@ -539,8 +550,8 @@ int ac_mask_threshold(const ac_psy_plan* p, const float* X, const float* t, floa
   AC_REQUIRE_ALIGNED(X, thr);
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
-  if (p->fast && !g_force_generic) return launch_psy_fast(p, X, t, nullptr, thr, drown, B, F, C, s);
-  if (p->mid && !g_force_generic) return launch_psy_mid(p, X, t, nullptr, thr, drown, B, F, C, s);
+  if (psy_fast_serves(p, C)) return launch_psy_fast(p, X, t, nullptr, thr, drown, B, F, C, s);
+  if (psy_mid_serves(p, C)) return launch_psy_mid(p, X, t, nullptr, thr, drown, B, F, C, s);
   return launch_threshold_generic(p, X, t, drown, thr, B, F, C, s);
 }
 
@@ -586,7 +597,7 @@ static int encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const 
   AC_REQUIRE_ALIGNED(x, X, thr);
   DeviceGuard guard(mdct->device);
   hipStream_t s = (hipStream_t)stream;
-  if (mdct->fast && psy->fast && !g_force_generic) {
+  if (mdct->fast && psy->fast && !g_force_generic && wave_level(mdct, C, pcm16 ? 1 : 0, K) && psy_fast_serves(psy, C)) {
     // one fused launch, except at filters_n = 2048 for mono input and for 16-bit PCM with 3 or more channels, where the
     // fused kernel would spill registers (7 / 4 at the 256 budget): there two wave-level launches, the second computing
     // tonality and threshold in one pass over X
@@ -602,7 +613,7 @@ static int encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const 
   // un-fused composition for configurations the fused kernel does not cover: the transform, then tonality + threshold in
   // one wave-level pass over X where the general-layout masking kernels serve the plan, else the two generic kernels
   st = mdct_forward(mdct, x, pcm16, X, B, K, C, stream);
-  if (!st && psy->mid && !g_force_generic) return launch_psy_mid(psy, X, nullptr, t, thr, drown, B, K + 1, C, s);
+  if (!st && psy_mid_serves(psy, C)) return launch_psy_mid(psy, X, nullptr, t, thr, drown, B, K + 1, C, s);
   if (!st) st = ac_tonality(psy, X, t, B, K + 1, C, stream);
   if (!st) st = ac_mask_threshold(psy, X, t, drown, thr, B, K + 1, C, stream);
   return st;
@@ -611,9 +622,9 @@ static int encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const 
 int ac_encode_launches(const ac_mdct_plan* mdct, const ac_psy_plan* psy, int C) {
   if (!mdct || !psy || mdct->N != psy->N || mdct->device != psy->device || C < 1) return 0;
   if (g_force_generic) return 3;
-  if (mdct->fast && psy->fast) return (mdct->N == 2048 && C == 1) ? 2 : 1;   // (see encode_fused)
+  if (mdct->fast && psy->fast && wave_level(mdct, C, 0, 1) && psy_fast_serves(psy, C)) return (mdct->N == 2048 && C == 1) ? 2 : 1;   // (see encode_fused)
   if (mdct->fast && fast_multi_fuses(mdct, psy, C, 0, 1)) return 1;
-  return psy->mid ? 2 : 3;
+  return (psy_mid_serves(psy, C) || psy_fast_serves(psy, C)) ? 2 : 3;
 }
 
 int ac_encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr,
@@ -738,7 +749,7 @@ static int stream_analysis(ac_stream* s, const ac_psy_plan* psy, const float* x_
   const bool fast = wave_level(p, s->C, 0, k);
   // (filters_n = 2048 mono: the fused kernel is not instantiated, see encode_fused; filters_n 64 ... 512: the masking model
   // for general band layouts rides in the several-frames-per-wave kernels)
-  const bool fused = psy && fast && ((psy->fast && fast_mdct_frames_per_wave(p->N) == 1 && !(p->N == 2048 && s->C == 1)) ||
+  const bool fused = psy && fast && ((psy_fast_serves(psy, s->C) && fast_mdct_frames_per_wave(p->N) == 1 && !(p->N == 2048 && s->C == 1)) ||
                                      fast_multi_fuses(p, psy, s->C, 0, k));
   if (fast) {
     st = launch_fwd_fast(p, fused ? psy : nullptr, x_chunk, false, X, fused ? t : nullptr, fused ? thr : nullptr, drown,
@@ -756,8 +767,8 @@ static int stream_analysis(ac_stream* s, const ac_psy_plan* psy, const float* x_
   if (psy && !fused) {
     // the same second step encode_fused takes for these configurations (so that chunked and one-shot results agree bit
     // for bit): tonality + threshold in one wave-level pass over X, or the two generic kernels
-    if (fast && psy->fast) return launch_psy_fast(psy, X, nullptr, t, thr, drown, s->B, k, s->C, hs);
-    if (psy->mid && !g_force_generic) return launch_psy_mid(psy, X, nullptr, t, thr, drown, s->B, k, s->C, hs);
+    if (psy_fast_serves(psy, s->C)) return launch_psy_fast(psy, X, nullptr, t, thr, drown, s->B, k, s->C, hs);
+    if (psy_mid_serves(psy, s->C)) return launch_psy_mid(psy, X, nullptr, t, thr, drown, s->B, k, s->C, hs);
     st = ac_tonality(psy, X, t, s->B, k, s->C, stream);
     if (!st) st = ac_mask_threshold(psy, X, t, drown, thr, s->B, k, s->C, stream);
   }

@@ -155,7 +155,7 @@ AC_API int ac_psy_plan_spreading(const ac_psy_plan* plan);
  * runs the LDS-FFT middle tier (filters_n from 16 to 4096 with a 5-smooth half: 2^a 3^b 5^c; up to 8192 for float32
  * tensors with filters_n % 4 == 0) or the generic O(N^2) kernels. */
 AC_API int ac_mdct_plan_is_fast(const ac_mdct_plan* plan);
-/* Which kernels serve float32 tensors of `channels_n` channels: 3 = the wave-level kernels; 2 = a compile-time instance of the
+/* Which kernels serve float32 tensors of `channels_n` channels: 3 = the wave-level kernels (mono / stereo); 2 = a compile-time instance of the
  * LDS-FFT tier's 16-byte kernels (filters_n % 4 == 0 with a 5-smooth half, up to 8192); 1 = the tier's run-time forms;
  * 0 = the O(N^2) kernels; -1 = bad argument. */
 AC_API int ac_mdct_plan_tier(const ac_mdct_plan* plan, int channels_n);

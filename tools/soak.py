@@ -80,8 +80,9 @@ while time.time() < t_end:
     # 16-bit PCM where the wave-level kernels take it
     if codec.mdct.is_fast() and (N >= 1024 or C <= 2) and K > 0 and wt != "rect" and pre == "float64":
         pcm = torch.from_numpy(rng.integers(-32768, 32768, (B, K * N, C)).astype(np.int16)).cuda()
-        Xp = codec.encode(pcm)[0]
-        if not torch.equal(Xp, codec.encode(pcm.float() / 32768.0)[0]): fail(tag + " pcm16 encode")
+        Xp, Xq = codec.encode(pcm)[0], codec.encode(pcm.float() / 32768.0)[0]
+        # (more than two channels: PCM on the wave-level kernels' strided form, float32 on the channel-pair instances)
+        if not (torch.equal(Xp, Xq) if C <= 2 else float((Xp - Xq).abs().max()) <= 2e-6 * float(Xq.abs().max())): fail(tag + " pcm16 encode")
         if not torch.equal(codec.decode(Xp, pcm16=True)[:, N:-N], pcm): fail(tag + " pcm16 round trip")
     cases += 1
 print("soak: %d random cases in %.0f s, no mismatch" % (cases, budget))
