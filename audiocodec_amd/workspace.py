@@ -24,8 +24,8 @@ class Workspace:
     """``x [B, K*N, C]``, ``X [B, K+1, N, C]``, ``t [B, K+1, 1, C]``, ``thr`` like ``X``, ``xh [B, (K+2)*N, C]`` (float32).
 
     :param max_tries: allocations tried for (``thr``, ``xh``), at most 16; all but the chosen one are back with the driver
-                      when the constructor returns.  The search stops early at the first candidate that reaches the
-                      two-class rate, or once two candidates differ by the gap between the classes
+                      when the constructor returns.  The search stops at the first candidate that reaches the two-class
+                      rate on every copy; if none does, a second region A from further along is tried against them
     :param span_gib:  upper bound on the untouched spacer memory held for a moment between the tries (0: no spacers)
     :param tune:      False: one allocation each (``max_tries = 1``)
     """

@@ -11,7 +11,7 @@ out=gpurun_out/entry_points.txt
   echo; echo "== N = 960, B = 256 stereo, K = 499"; N=960 python tools/microbench.py 2>/dev/null | sed -n 1,6p
   echo; echo "== N = 960, B = 256 mono, K = 499"; N=960 C=1 python tools/microbench.py 2>/dev/null | sed -n 1,5p
   echo; echo "== N = 960, B = 84 clips of six channels, K = 499 (strided channel pairs)"; N=960 C=6 B=84 python tools/microbench.py 2>/dev/null | sed -n 1,5p
-  echo; echo "== N = 1024, B = 84 clips of six channels, K = 468 (the wave-level kernels' own strided form)"; N=1024 C=6 B=84 python tools/microbench.py 2>/dev/null | sed -n 1,5p
+  echo; echo "== N = 1024, B = 84 clips of six channels, K = 468 (channel-pair instances of the LDS-FFT tier + the general-layout masking kernels)"; N=1024 C=6 B=84 python tools/microbench.py 2>/dev/null | sed -n 1,5p
   echo; echo "== N = 1920 (LDS-FFT tier, two waves per frame; masking model with 16 granule registers), B = 256 stereo, K = 249"; N=1920 python tools/microbench.py 2>/dev/null | sed -n 1,6p
   echo; echo "== N = 4096 (four waves per frame; 32 granule registers), B = 256 stereo, K = 117"; N=4096 python tools/microbench.py 2>/dev/null | sed -n 1,6p
   echo; echo "== N = 512, B = 256 mono, K = 936"; N=512 C=1 python tools/microbench.py 2>/dev/null | sed -n 1,5p
