@@ -927,9 +927,7 @@ static __global__ __launch_bounds__(kThreads, 2) void k_fwd_wave(const TIO* __re
       }
     }
     wave_sync_lds();
-#ifndef AC_T_NODCT
     dct4_wave(v, Ap, Bp, tb, N, tid, nt, wp);
-#endif
     TIO* Xo = X + (((size_t)b * F + (size_t)n) * N) * C + c;
     for (int k = tid; k < N; k += nt) st2(Xo + (size_t)k * C, make_float2(v[k].x * scale, v[k].y * scale), C, has1);
     wave_sync_lds();   // v is read out before the next task folds into it
@@ -998,9 +996,7 @@ static __global__ __launch_bounds__(kThreads, 2) void k_inv_wave(const TIO* __re
       }
     }
     wave_sync_lds();
-#ifndef AC_T_NODCT
     if (has_n) dct4_wave(v, Ap, Bp, tb, N, tid, nt, wp);   // (the DCT-IV of a zero frame is zero)
-#endif
     if (t >= 0) {
       for (int j = tid; j < h; j += nt) {
         const float2 a = make_float2(v[h - 1 - j].x * scale, v[h - 1 - j].y * scale);   // u_n[h-1-j]
@@ -1229,11 +1225,9 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
     if (n + 1 < n1 && n + 1 < Kin)   // lands during the transform
       load_block(x + gx.off_a + (size_t)(n + 1) * gx.block_stride, x + gx.off_b + (size_t)(n + 1) * gx.block_stride);
     group_sync<NTC>();
-#ifndef AC_T_NODCT
     if constexpr (GRP) dct4_group_ct<NC, NTC, R0, R1, R2, R3>(v, Bp, tb, pre0, tid);
     else if constexpr (NC != 0) dct4_wave_ct<NC, NTC, R0, R1, R2, R3>(v, Ap, Bp, tb, tid);
     else dct4_wave(v, Ap, Bp, tb, N, tid, nt, wp);
-#endif
     float* Xa = X + gX.off_a + (size_t)n * gX.block_stride;
     float* Xb = X + gX.off_b + (size_t)n * gX.block_stride;
 #pragma unroll
@@ -1333,13 +1327,11 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
       if (tn < seg && n0 + tn < nlast && frame_ok(tn)) load_frame(tn);
     }
     group_sync<NTC>();
-#ifndef AC_T_NODCT
     if (has_n) {
       if constexpr (GRP) dct4_group_ct<NC, NTC, R0, R1, R2, R3>(v, Bp, tb, pre0, tid);
       else if constexpr (NC != 0) dct4_wave_ct<NC, NTC, R0, R1, R2, R3>(v, Ap, Bp, tb, tid);
       else dct4_wave(v, Ap, Bp, tb, N, tid, nt, wp);
     }
-#endif
     if (t >= 0) {
       if (n < nblk) {
         TX* xa = x + gx.off_a + (size_t)n * gx.block_stride;
