@@ -23,6 +23,7 @@ PROTOTYPES = {
     "ac_version": (c_int, []),
     "ac_last_error": (c_char_p, []),
     "ac_set_force_generic": (c_int, [c_int]),
+    "ac_testing_runs_image": (c_int, [c_int, c_int, c_double, c_double, c_int, POINTER(ctypes.c_uint32), c_int, POINTER(c_int)]),
     "ac_mdct_fold_coefficients_host": (c_int, [c_int, c_int, POINTER(c_double)]),
     "ac_mdct_dense_matrices_host": (c_int, [c_int, c_int, POINTER(c_float), POINTER(c_float)]),
     "ac_psy_tables_host": (c_int, [c_int, c_int, c_double, c_double, POINTER(c_float), POINTER(c_float),

@@ -67,6 +67,24 @@ int ac_set_force_generic(int on) {
   return AC_OK;
 }
 
+int ac_testing_runs_image(int N, int M, double sample_rate, double alpha, int precompute, unsigned* image, int cap, int* layout) {
+  AC_REQUIRE(N >= 2 && (N & 1) == 0 && M >= 1 && layout, "ac_testing_runs_image: bad arguments");
+  PsyTables t;
+  psy_tables(N, M, sample_rate, alpha, t, precompute);
+  std::vector<uint32_t> w;
+  RunsLayout L;
+  if (!build_runs(t, &w, &L)) {
+    set_error("tables without the run structure");
+    return AC_EUNSUPPORTED;
+  }
+  const int v[17] = {L.words, L.lw, L.kb, L.n4, L.n16, L.n64, L.o4, L.o16, L.o64, L.oz, L.slot,
+                     L.off_S, L.off_bc, L.off_bd, L.off_lst, L.off_bw, L.off_idx};
+  for (int i = 0; i < 17; ++i) layout[i] = v[i];
+  if (image)
+    for (int i = 0; i < L.words && i < cap; ++i) image[i] = w[(size_t)i];
+  return AC_OK;
+}
+
 // ---- host-only builders ------------------------------------------------------------------------
 
 #define AC_REQUIRE_PRE(d) AC_REQUIRE((d) == AC_F32 || (d) == AC_F64, "precompute = %d is not AC_F32 or AC_F64", (d))
@@ -391,6 +409,7 @@ static int psy_plan_build(int N, int M, double sample_rate, double alpha, int de
   if (!st && mid_psy_supported(p)) {   // (beside the fused epilogue's tables where both apply: more than two channels, psy_mid_serves)
     st = mid_psy_plan_init(p);
     if (!st) p->mid = 1;
+    if (!st && runs_psy_plan_init(p) == AC_EHIP) st = AC_EHIP;   // (tables without the run structure keep the band walk)
   }
   if (!st && spreading != AC_SPREAD_F32) {
     if (p->fast) {
@@ -434,6 +453,7 @@ int ac_psy_plan_destroy(ac_psy_plan* p) {
   (void)hipFree(p->d_beta64);
   (void)hipFree(p->d_fast);
   (void)hipFree(p->d_mid);
+  (void)hipFree(p->d_runs);
   delete p;
   return AC_OK;
 }

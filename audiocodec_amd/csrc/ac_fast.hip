@@ -32,6 +32,7 @@
 
 #include "ac_internal.h"
 #include "ac_psy_mid_dev.h"
+#include "ac_psy_runs_dev.h"
 
 namespace ac {
 namespace {
@@ -1958,11 +1959,11 @@ struct FwdMArgs {
   int cpp;           // chunks of NFR consecutive frames per signal pair: ceil(F / NFR)
   int T;             // chunks per wave: workgroup g owns chunks [g NW T, (g+1) NW T), wave w takes g NW T + w + NW t
   long long nsig, ntasks;   // B * C and npairs * cpp
-  // fused masking model (PSY kernels): tonality [B, F, 1, C], threshold [B, F, N, C], the image of ac_psy_plan::d_mid
+  // fused masking model (PSY kernels): tonality [B, F, 1, C], threshold [B, F, N, C], the image of ac_psy_plan::d_runs
   float* t;
   float* thr;
   const uint32_t* psy_img;
-  mid::MidParams mp;
+  runs::RunsParams rp;
 };
 
 // LDS of the several-frames-per-wave analysis kernels: [NW wave buffers | table image | masking-model image (PSY)].
@@ -1974,6 +1975,23 @@ template <int NFR, bool PSY> constexpr int multi_ts() { return PSY ? ((64 / NFR)
 template <int NFR, bool PSY> constexpr bool multi_pre_global() { return PSY && NFR == 2; }
 template <int NFR, bool PSY> constexpr int multi_tab_bytes() {   // (PRE_GLOBAL: fold coefficients and pre-twiddles both stay in global memory)
   return PSY ? (128 + (multi_pre_global<NFR, PSY>() ? 1 : 3) * 16 * multi_ts<NFR, PSY>()) * 4 : Geo<8>::TAB_LDS;
+}
+// The fused masking model (ac_psy_runs_dev.h) works on FB frames side by side, each in a slot of its own: intensities,
+// their partial sums, later G and the threshold entries.  multi_slot(): the largest slot build_runs lays out for
+// filters_n = FN (all four levels), a compile-time stride so that a frame's displacement is an immediate of its LDS
+// accesses.  Where a wave's NFR frames are one group (filters_n 512 / 256) the spectra are laid out straight into the slots
+// and the intensities overwrite them; below, the NFR spectra stay packed in the wave's first 8 KB and the FB slots follow.
+constexpr int multi_a16(int v) { return (v + 15) / 16 * 16; }
+template <int NFR> constexpr int multi_slot() {
+  constexpr int FN = 1024 / NFR;
+  return multi_a16(multi_a16(multi_a16(multi_a16((8 * FN > 1536 ? 8 * FN : 1536) + 8 * (FN / 4)) + 8 * (FN / 16)) + 8 * (FN / 64)) + 8);
+}
+template <int NFR> constexpr int multi_fb() { return (1024 / NFR) >= 512 ? 2 : 4; }
+template <int NFR> constexpr bool multi_in_slots() { return NFR == multi_fb<NFR>(); }
+template <int NFR, bool PSY> constexpr int multi_wave_bytes() {
+  if (!PSY) return WAVE_LDS;
+  const int need = multi_in_slots<NFR>() ? NFR * multi_slot<NFR>() : 8192 + multi_fb<NFR>() * multi_slot<NFR>();
+  return need > WAVE_LDS ? need : WAVE_LDS;
 }
 
 // analysis: the lanes of group f transform frame NFR c + f of the wave's signal pair (a group whose frame index is past
@@ -1993,10 +2011,11 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
   constexpr int TABB = multi_tab_bytes<NFR, PSY>();
   // (LDS offsets of the tables in floats: the global image's own when it is copied whole)
   constexpr int L_POST = PSY ? 128 : G::I_POST, L_COEF = PSY ? 128 + 16 * TS : G::I_COEF, L_PRE = PSY ? 128 + 32 * TS : G::I_PRE;
-  extern __shared__ __attribute__((aligned(16))) char lds[];   // NW * WAVE_LDS + TABB (+ the masking-model image)
+  constexpr int WSTR = multi_wave_bytes<NFR, PSY>();            // bytes of LDS per wave
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // NW * WSTR + TABB (+ the masking-model image)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if constexpr (PSY) {
-    float* dst = reinterpret_cast<float*>(lds + NW * WAVE_LDS);
+    float* dst = reinterpret_cast<float*>(lds + NW * WSTR);
     for (int i = threadIdx.x; i < 128; i += NW * 64) dst[G::I_P2 + i] = a.tab[G::I_P2 + i];
     for (int i = threadIdx.x; i < 8 * TS; i += NW * 64) {     // one period of every row of POST / COEF / PRE
       const int src = (i / TS) * 64 + (i % TS);
@@ -2006,15 +2025,19 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
         reinterpret_cast<v2f*>(dst + L_PRE)[i] = reinterpret_cast<const v2f*>(a.tab + G::I_PRE)[src];
       }
     }
-    uint4* pd = reinterpret_cast<uint4*>(lds + NW * WAVE_LDS + TABB);
-    for (int i = threadIdx.x; i < a.mp.img_words / 4; i += NW * 64) pd[i] = reinterpret_cast<const uint4*>(a.psy_img)[i];
+    uint4* pd = reinterpret_cast<uint4*>(lds + NW * WSTR + TABB);
+    for (int i = threadIdx.x; i < a.rp.lds_words / 4; i += NW * 64) pd[i] = reinterpret_cast<const uint4*>(a.psy_img)[i];
     __syncthreads();
   } else {
     load_tables<NW, WAVE_LDS, G::I_LDS, 0>(lds, a.tab, nullptr);
   }
-  char* buf = lds + wave * WAVE_LDS;
-  gtab_t tab = reinterpret_cast<const float*>(lds + NW * WAVE_LDS);
-  const uint32_t* pimg = reinterpret_cast<const uint32_t*>(lds + NW * WAVE_LDS + TABB);
+  char* buf = lds + wave * WSTR;
+  gtab_t tab = reinterpret_cast<const float*>(lds + NW * WSTR);
+  const uint32_t* pimg = reinterpret_cast<const uint32_t*>(lds + NW * WSTR + TABB);
+  // masking model: constants of band / edge bin `lane`, the lane's per-bin entry offsets (registers: at most four words)
+  constexpr int RPM = (1024 / NFR) >= 128 ? (1024 / NFR) / 128 : 1;
+  runs::RegIdx<RPM> ridx = {};
+  if constexpr (PSY) ridx.load(a.psy_img, a.rp, lane);
   const int tl = lane & (TS - 1);   // column of the lane in a table row
   v2f p1[8];
   load_p1<8>(a.tab, lane, p1);
@@ -2159,35 +2182,41 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
     }
     if constexpr (PSY) {
       constexpr int FN = 16 * LB;                      // filters_n
-      constexpr int RP = FN >= 128 ? FN / 128 : 1;     // granule registers per lane when 64 lanes share one frame
+      constexpr int RP = RPM;                          // granule registers per lane when 64 lanes share one frame
+      constexpr int FB = multi_fb<NFR>();              // frames side by side (ac_psy_runs_dev.h)
+      constexpr int SLOT = multi_slot<NFR>();
+      constexpr bool IN_SLOTS = multi_in_slots<NFR>(); // the spectra are laid out in the model's slots
+      constexpr int STG = IN_SLOTS ? SLOT : 8 * FN;    // bytes between the staged spectra of successive frames
+      char* slots = IN_SLOTS ? buf : buf + 8192;
       wave_sync();
       {
-        char* fb = buf + f * (8 * FN) + 16 * l;        // granule q = l + LB i of the group's frame at byte 16 q of its slot
+        char* fb = buf + f * STG + 16 * l;             // granule q = l + LB i of the group's frame at byte 16 q of its row
 #pragma unroll
         for (int i = 0; i < 8; ++i) *reinterpret_cast<v4f*>(fb + 16 * LB * i) = row[i];
       }
+      runs::slot_init(a.rp, slots, FB, SLOT, lane);    // (the FFT's exchanges run over the slots: the zero words again)
+      const runs::RunsLane lc = runs::load_lane(a.rp, pimg, lane);   // (per chunk: held across the FFT it would cost seven registers)
       wave_sync();
-      constexpr int FB = RP >= 4 ? 2 : 4;              // frames side by side (ac_psy_mid_dev.h)
 #pragma unroll 1
       for (int g0 = 0; g0 < NFR; g0 += FB) {
         if (c * NFR + g0 >= a.F) break;
-        char* ib = buf + g0 * (8 * FN);
+        const char* ib = buf + g0 * STG;
         v4f xq[FB][RP];
         bool ok[FB];
         size_t o0[FB], o1[FB];
 #pragma unroll
         for (int fb = 0; fb < FB; ++fb) {
           const int nn = c * NFR + g0 + fb;
-          ok[fb] = nn < a.F;   // (a slot past the last frame holds the zero spectrum of an idle group of lanes: computed, not stored)
+          ok[fb] = nn < a.F;   // (a row past the last frame holds the zero spectrum of an idle group of lanes: computed, not stored)
           o0[fb] = row_off(pq.b0, a.F, ok[fb] ? nn : 0, blk, pq.c0);
           o1[fb] = row_off(pq.b1, a.F, ok[fb] ? nn : 0, blk, pq.c1);
 #pragma unroll
           for (int i = 0; i < RP; ++i)
-            xq[fb][i] = mid::in_frame<RP>(a.mp, i, lane) ? *reinterpret_cast<const v4f*>(ib + fb * (8 * FN) + 16 * (64 * i + lane))
-                                                         : v4f{0.f, 0.f, 0.f, 0.f};
+            xq[fb][i] = runs::in_frame<RP>(a.rp, i, lane) ? *reinterpret_cast<const v4f*>(ib + fb * STG + 16 * (64 * i + lane))
+                                                          : v4f{0.f, 0.f, 0.f, 0.f};
         }
         v2f t[FB];
-        mid::tonality_frames<RP, FB>(xq, a.mp, lane, t);
+        runs::prep_frames<RP, FB, true, true>(xq, a.rp, slots, SLOT, lane, t);
 #pragma unroll
         for (int fb = 0; fb < FB; ++fb)
           if (ok[fb] && lane == 0) {
@@ -2195,7 +2224,8 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
             a.t[((size_t)pq.b0 * a.F + (size_t)nn) * C + pq.c0] = t[fb].x;
             if (pq.has1) a.t[((size_t)pq.b1 * a.F + (size_t)nn) * C + pq.c1] = t[fb].y;
           }
-        mid::threshold_frames<RP, FB>(xq, t, a.mp, pimg, reinterpret_cast<const uint4*>(pimg + a.mp.off_wi), ib, 8 * FN, lane, [&](int fb, int i, const v4f& th) {
+        wave_sync();
+        runs::threshold_frames<RP, FB>(t, a.rp, lc, pimg, slots, SLOT, lane, ridx, [&](int fb, int i, const v4f& th) {
           if (!ok[fb]) return;
           if (CMODE == 0) {
             __builtin_nontemporal_store(th, reinterpret_cast<v4f*>(a.thr + o0[fb]) + 64 * i + lane);
@@ -2204,8 +2234,8 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
             if (pq.has1) reinterpret_cast<v2f*>(a.thr + o1[fb])[64 * i + lane] = v2f{th.y, th.w};
           }
         });
+        wave_sync();   // the group's reads of its slots are done before the next group's intensities (or the next chunk's FFT) land
       }
-      wave_sync();   // the last group's reads of its slots are done before the next chunk's FFT writes the buffer
     }
   }
 }
@@ -2558,8 +2588,8 @@ bool fast_multi_serves(const ac_mdct_plan* p, int C, int iof, int blocks) {
 // the fused encode of the several-frames-per-wave kernels: float32 mono / stereo tensors, rotation fold blocks, and a
 // masking model the general-layout wave-level code serves at this size
 bool fast_multi_fuses(const ac_mdct_plan* p, const ac_psy_plan* psy, int C, int iof, int blocks) {
-  return psy != nullptr && psy->mid && !p->fold4 && iof == 0 && psy->N == p->N && fast_multi_serves(p, C, iof, blocks) &&
-         (size_t)AC_WAVES * WAVE_LDS + 12800 + (size_t)psy->mid_words * 4 <= 160 * 1024;
+  return psy != nullptr && psy->runs && !p->fold4 && iof == 0 && psy->N == p->N && fast_multi_serves(p, C, iof, blocks) &&
+         (size_t)AC_WAVES * 16384 + 12800 + (size_t)psy->runs_lay.off_idx * 4 <= 160 * 1024;
 }
 
 bool fast_mdct_supported(int N, const FoldCoef& c) {
@@ -2746,7 +2776,7 @@ static int launch_fwd_multi_N(const FwdMArgs& a, int iof, bool fold4, bool psy, 
     return AC_OK;
   };
   if (psy) {   // fused masking model: float32 tensors, rotation fold blocks (the caller checked)
-    const size_t lds = (size_t)AC_WAVES * WAVE_LDS + multi_tab_bytes<NFR, true>() + (size_t)a.mp.img_words * 4;
+    const size_t lds = (size_t)AC_WAVES * multi_wave_bytes<NFR, true>() + multi_tab_bytes<NFR, true>() + (size_t)a.rp.lds_words * 4;
     if (C == 2) return go(k_fwd_multi<NFR, 0, AC_WAVES, 0, false, true>, lds);
     return go(k_fwd_multi<NFR, 2, AC_WAVES, 0, false, true>, lds);
   }
@@ -2779,9 +2809,9 @@ static int launch_fwd_multi(const ac_mdct_plan* p, const ac_psy_plan* psy, const
   a.nsig = (long long)B * C;
   a.t = t;
   a.thr = thr;
-  a.psy_img = psy ? psy->d_mid : nullptr;
-  if (psy) a.mp = mid_params(psy, drown);
-  else a.mp = mid::MidParams{};
+  a.psy_img = psy ? psy->d_runs : nullptr;
+  if (psy) a.rp = runs_params(psy, drown, false);
+  else a.rp = runs::RunsParams{};
   const long long npairs = (C == 2) ? (long long)B : (a.nsig + 1) / 2;
   a.ntasks = npairs * a.cpp;
   // chunks per wave: the table copy (and the masking model's image) is paid once per workgroup

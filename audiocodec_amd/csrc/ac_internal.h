@@ -93,6 +93,14 @@ __device__ __forceinline__ float db_of(float v, int norm) {
 
 typedef __bf16 bf16_t;   // storage type of the AC_BF16 tensors (device code converts with v_cvt_pk_bf16_f32)
 
+// layout of the run-structured masking-model image and of its per-frame LDS slot (build_runs in ac_psy_mid.hip; the fields
+// are those of runs::RunsParams, ac_psy_runs_dev.h)
+struct RunsLayout {
+  int words = 0;
+  int lw = 0, kb = 0, n4 = 0, n16 = 0, n64 = 0, o4 = 0, o16 = 0, o64 = 0, oz = 0, slot = 0;
+  int off_S = 0, off_bc = 0, off_bd = 0, off_lst = 0, off_bw = 0, off_idx = 0;
+};
+
 }  // namespace ac
 
 // ---- plan objects ---------------------------------------------------------------------------
@@ -141,6 +149,11 @@ struct ac_psy_plan {
   uint32_t* d_mid = nullptr;
   int mid_words = 0;
   int mid_wi_w = 0, mid_off_S = 0, mid_off_band = 0, mid_off_wbe = 0, mid_off_wi = 0;   // layout of the image (build_mid)
+  // ... in its run-structured form (ac_psy_runs_dev.h): the form every kernel of that tier runs when the plan's tables have
+  // the structure (runs = 1; the band walk above stays for tables that do not)
+  int runs = 0;
+  uint32_t* d_runs = nullptr;
+  ac::RunsLayout runs_lay;
   int cus = 0;                 // compute units of the device (sizes the launches)
 };
 
@@ -224,6 +237,10 @@ bool mid_psy_supported(const ac_psy_plan* p);
 int mid_psy_plan_init(ac_psy_plan* p);
 int launch_psy_mid(const ac_psy_plan* p, const float* X, const float* t_in, float* t_out, float* thr, float drown, int B,
                    int F, int C, hipStream_t s);
+// the run-structured image of a model's tables, built on the host (no device needed): false when the tables lack the
+// structure (ac_psy_runs_dev.h); runs_psy_plan_init uploads it
+bool build_runs(const PsyTables& t, std::vector<uint32_t>* out, RunsLayout* lay);
+int runs_psy_plan_init(ac_psy_plan* p);
 
 int launch_tonality_bwd_generic(const ac_psy_plan* p, const float* X, const float* gt, float* gX, int accumulate, int B,
                                 int F, int C, hipStream_t s);

@@ -7,11 +7,14 @@
 // The per-frame arithmetic lives in ac_psy_mid_dev.h (shared with the fused encode of the several-frames-per-wave MDCT
 // kernels); this file holds the stand-alone kernel, the host-side image builder and the launcher.
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "ac_internal.h"
 #include "ac_psy_mid_dev.h"
+#include "ac_psy_runs_dev.h"
 
 namespace ac {
 namespace {
@@ -257,6 +260,225 @@ int launch_mid_R(const MidArgs& a, bool want_t, bool want_thr, unsigned grid, in
   return go(k_psy_mid<R, CMODE, true, false, mid_fb(R)>);
 }
 
+
+// ---- the run-structured form (ac_psy_runs_dev.h) -----------------------------------------------------------------------
+struct RunsArgs {
+  const float* X;
+  const float* t_in;
+  float* t_out;
+  float* thr;
+  const uint32_t* img;   // ac_psy_plan::d_runs
+  runs::RunsParams p;
+  int C, F;
+  int T;                 // frames per wave, as in MidArgs
+  long long nsig, ntasks;
+};
+
+// rows of FB tasks of a wave: offsets, flags and the granules (the loader of k_psy_mid, shared by both forms)
+template <int R, int CMODE, int FB>
+struct RowSet {
+  bool ok[FB], has1[FB];
+  size_t o0[FB], o1[FB], t0[FB], t1[FB];
+  template <class INF>
+  __device__ __forceinline__ void load(const float* X, int N, int C, int F, long long nsig, long long ntasks, long long task0, int tt, int T,
+                                       int nw, int lane, INF in, v4f (&xq)[FB][R]) {
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb) {
+      const long long task = task0 + (long long)(tt + fb) * nw;
+      ok[fb] = tt + fb < T && task < ntasks;
+      const long long tk = ok[fb] ? task : task0 + (long long)tt * nw;   // (a frame past the end re-reads the group's first row)
+      const size_t blk = (size_t)N * C;
+      if (CMODE == 1) {
+        const int CP = (C + 1) / 2;
+        const long long rest = tk / CP;
+        const int c = 2 * (int)(tk - rest * CP), f = (int)(rest % F);
+        const long long b = rest / F;
+        has1[fb] = c + 1 < C;
+        o0[fb] = ((size_t)b * F + (size_t)f) * blk + c;
+        o1[fb] = o0[fb];
+        t0[fb] = ((size_t)b * F + (size_t)f) * C + c;
+        t1[fb] = t0[fb] + 1;
+        const v2u* row = reinterpret_cast<const v2u*>(X + o0[fb] - (has1[fb] ? 0 : 1));
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          const int q = 64 * i + lane;
+          const v2u u = in(i) ? *reinterpret_cast<const v2u*>(reinterpret_cast<const float*>(row) + (size_t)(2 * q) * C) : v2u{0.f, 0.f};
+          const v2u w = in(i) ? *reinterpret_cast<const v2u*>(reinterpret_cast<const float*>(row) + (size_t)(2 * q + 1) * C) : v2u{0.f, 0.f};
+          xq[fb][i] = has1[fb] ? v4f{u.x, u.y, w.x, w.y} : v4f{u.y, u.y, w.y, w.y};
+        }
+        continue;
+      }
+      const int f = (int)(tk % F);
+      const long long p = tk / F;
+      has1[fb] = CMODE == 0 ? true : (2 * p + 1 < nsig);
+      const long long b0 = CMODE == 0 ? p : 2 * p, b1 = CMODE == 0 ? p : (has1[fb] ? 2 * p + 1 : 2 * p);
+      o0[fb] = ((size_t)b0 * F + (size_t)f) * blk;
+      o1[fb] = ((size_t)b1 * F + (size_t)f) * blk;
+      t0[fb] = ((size_t)b0 * F + (size_t)f) * C;
+      t1[fb] = CMODE == 0 ? t0[fb] + 1 : ((size_t)b1 * F + (size_t)f) * C;
+      if (CMODE == 0) {
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+          xq[fb][i] = in(i) ? reinterpret_cast<const v4f*>(X + o0[fb])[64 * i + lane] : v4f{0.f, 0.f, 0.f, 0.f};
+      } else {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          const v2f u = in(i) ? reinterpret_cast<const v2f*>(X + o0[fb])[64 * i + lane] : v2f{0.f, 0.f};
+          const v2f w = in(i) ? reinterpret_cast<const v2f*>(X + o1[fb])[64 * i + lane] : v2f{0.f, 0.f};
+          xq[fb][i] = v4f{u.x, w.x, u.y, w.y};
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void store_thr(float* thr, int C, int fb, int i, int lane, const v4f& th) const {
+    if (!ok[fb]) return;
+    if (CMODE == 0) {
+      __builtin_nontemporal_store(th, reinterpret_cast<v4f*>(thr + o0[fb]) + 64 * i + lane);
+    } else if (CMODE == 1) {
+      float* r0 = thr + o0[fb] + (size_t)(2 * (64 * i + lane)) * C;
+      if (has1[fb]) {
+        *reinterpret_cast<v2u*>(r0) = v2u{th.x, th.y};
+        *reinterpret_cast<v2u*>(r0 + C) = v2u{th.z, th.w};
+      } else {
+        r0[0] = th.x;
+        r0[C] = th.z;
+      }
+    } else {
+      __builtin_nontemporal_store(v2f{th.x, th.z}, reinterpret_cast<v2f*>(thr + o0[fb]) + 64 * i + lane);
+      if (has1[fb]) __builtin_nontemporal_store(v2f{th.y, th.w}, reinterpret_cast<v2f*>(thr + o1[fb]) + 64 * i + lane);
+    }
+  }
+};
+
+// the stand-alone kernel on the run-structured image: tasks, rows and the frame loop as in k_psy_mid; per wave FB slots of
+// a.p.slot bytes behind the image
+template <int R, int CMODE, bool WANT_T, bool WANT_THR, int FB>
+__global__ __launch_bounds__(256, (R >= 32 ? 1 : R >= 16 ? 2 : 3)) void k_psy_runs(RunsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  uint32_t* img = reinterpret_cast<uint32_t*>(smem);
+  const int slot = a.p.slot;
+  char* buf = smem + (size_t)a.p.lds_words * 4 + (size_t)wave * FB * slot;
+  constexpr bool IDX_REGS = R <= 8;   // (the launcher sizes lds_words to match)
+  if (WANT_THR) {
+    for (int i = threadIdx.x; i < a.p.lds_words / 4; i += blockDim.x)
+      reinterpret_cast<uint4*>(img)[i] = reinterpret_cast<const uint4*>(a.img)[i];
+    runs::slot_init(a.p, buf, FB, slot, lane);
+    __syncthreads();
+  }
+  runs::RunsLane lc = {};
+  runs::RegIdx<IDX_REGS ? R : 1> ridx = {};
+  if (WANT_THR) {
+    lc = runs::load_lane(a.p, img, lane);
+    if (IDX_REGS) ridx.load(a.img, a.p, lane);
+  }
+  const long long task0 = (long long)blockIdx.x * nw * a.T + wave;
+  for (int tt = 0; tt < a.T && task0 + (long long)tt * nw < a.ntasks; tt += FB) {   // (no workgroup barrier inside)
+    wave_sync();   // the previous group's reads of the wave's slots are done
+    RowSet<R, CMODE, FB> rs;
+    v4f xq[FB][R];
+    rs.load(a.X, a.p.N, a.C, a.F, a.nsig, a.ntasks, task0, tt, a.T, nw, lane, [&](int i) { return runs::in_frame<R>(a.p, i, lane); }, xq);
+    v2f t[FB];
+    runs::prep_frames<R, FB, WANT_T, WANT_THR>(xq, a.p, buf, slot, lane, t);
+    if (WANT_T) {
+#pragma unroll
+      for (int fb = 0; fb < FB; ++fb)
+        if (rs.ok[fb] && lane == 0) {
+          a.t_out[rs.t0[fb]] = t[fb].x;
+          if (rs.has1[fb]) a.t_out[rs.t1[fb]] = t[fb].y;
+        }
+    } else {
+#pragma unroll
+      for (int fb = 0; fb < FB; ++fb) t[fb] = v2f{a.t_in[rs.t0[fb]], rs.has1[fb] ? a.t_in[rs.t1[fb]] : 0.f};
+    }
+    if (!WANT_THR) continue;
+    wave_sync();
+    auto emit = [&](int fb, int i, const v4f& th) { rs.store_thr(a.thr, a.C, fb, i, lane, th); };
+    if constexpr (IDX_REGS) runs::threshold_frames<R, FB>(t, a.p, lc, img, buf, slot, lane, ridx, emit);
+    else runs::threshold_frames<R, FB>(t, a.p, lc, img, buf, slot, lane, runs::LdsIdx{img + a.p.off_idx + lane}, emit);
+  }
+}
+
+constexpr int runs_fb(int R) { return R >= 8 ? 1 : R == 4 ? 2 : 4; }
+
+template <int R, int CMODE>
+int launch_runs_R(const RunsArgs& a, bool want_t, bool want_thr, unsigned grid, int nw, size_t lds, hipStream_t s) {
+  const dim3 blk(64 * nw);
+  auto go = [&](auto kernel) -> int {
+    if (lds > 64 * 1024)
+      AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3(grid), blk, lds, s, a);
+    return AC_OK;
+  };
+  if (want_t && want_thr) return go(k_psy_runs<R, CMODE, true, true, runs_fb(R)>);
+  if (want_thr) return go(k_psy_runs<R, CMODE, false, true, runs_fb(R)>);
+  return go(k_psy_runs<R, CMODE, true, false, runs_fb(R)>);
+}
+
+int launch_psy_runs(const ac_psy_plan* p, const float* X, const float* t_in, float* t_out, float* thr, float drown, int B, int F,
+                    int C, hipStream_t s) {
+  RunsArgs a;
+  a.X = X;
+  a.t_in = t_in;
+  a.t_out = t_out;
+  a.thr = thr;
+  a.img = p->d_runs;
+  const int R = mid_r(p->N), fb = runs_fb(R);
+  a.p = runs_params(p, drown, R > 8);
+  a.C = C;
+  a.F = F;
+  a.nsig = (long long)B * C;
+  a.ntasks = (C == 2 ? (long long)B : C == 1 ? (a.nsig + 1) / 2 : (long long)B * ((C + 1) / 2)) * F;
+  const bool want_t = t_out != nullptr, want_thr = thr != nullptr;
+  // waves per workgroup: the size that leaves the most waves resident (image + FB slots per wave; 160 KB of LDS per CU, the
+  // kernels' register budget allows 12 / 8 / 4 waves per CU)
+  const int wave_cap = R >= 32 ? 4 : R >= 16 ? 8 : 12;
+  int nw = 4;
+  {
+    long best = -1;
+    for (int w : {4, 3, 2, 1}) {
+      const size_t b = (size_t)a.p.lds_words * 4 + (size_t)w * fb * a.p.slot;
+      if (b > 160 * 1024) continue;
+      const long res = std::min<long>((long)std::min<size_t>(8, 160 * 1024 / b) * w, wave_cap);
+      if (res > best) {
+        best = res;
+        nw = w;
+      }
+    }
+    if (best < 0) {
+      set_error("internal: masking-model slots too large for LDS");
+      return AC_EUNSUPPORTED;
+    }
+  }
+  const size_t lds = want_thr ? (size_t)a.p.lds_words * 4 + (size_t)nw * fb * a.p.slot : 0;
+  const int cus = p->cus > 0 ? p->cus : 256;
+  int T = want_thr ? 8 : fb;
+  while (T > fb && a.ntasks < (long long)nw * T * cus * 6) T >>= 1;
+  a.T = T;
+  const long long per = (long long)nw * T;
+  const long long g = (a.ntasks + per - 1) / per;
+  if (g > 2147483647ll) {
+    set_error("problem too large for one launch (%lld workgroups)", g);
+    return AC_EINVAL;
+  }
+  const unsigned grid = (unsigned)g;
+  int st;
+#define AC_RUNS_R(CM)                                                            \
+  (R == 1 ? launch_runs_R<1, CM>(a, want_t, want_thr, grid, nw, lds, s)          \
+   : R == 2 ? launch_runs_R<2, CM>(a, want_t, want_thr, grid, nw, lds, s)        \
+   : R == 4 ? launch_runs_R<4, CM>(a, want_t, want_thr, grid, nw, lds, s)        \
+   : R == 8 ? launch_runs_R<8, CM>(a, want_t, want_thr, grid, nw, lds, s)        \
+   : R == 16 ? launch_runs_R<16, CM>(a, want_t, want_thr, grid, nw, lds, s)      \
+             : launch_runs_R<32, CM>(a, want_t, want_thr, grid, nw, lds, s))
+  if (C > 2) st = AC_RUNS_R(1);
+  else if (C == 2) st = AC_RUNS_R(0);
+  else st = AC_RUNS_R(2);
+#undef AC_RUNS_R
+  if (st) return st;
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
 }  // namespace
 
 bool mid_psy_supported(const ac_psy_plan* p) { return build_mid(p, nullptr, nullptr); }
@@ -297,10 +519,214 @@ int mid_psy_plan_init(ac_psy_plan* p) {
   return AC_OK;
 }
 
+
+// The run-structured image (ac_psy_runs_dev.h).  Host only: nothing here touches the device.
+bool build_runs(const PsyTables& t, std::vector<uint32_t>* out, RunsLayout* lay) {
+  const int N = t.N, M = t.M;
+  if (N < 2 || N > 4096 || (N & 1) || M < 1 || M > 64) return false;
+  if ((int)t.g.size() != 2 * M) return false;
+  for (int i = 0; i < M; ++i)   // S is Toeplitz by construction; the kernel reads it through the prototype
+    for (int j = 0; j < M; ++j)
+      if ((float)t.S[(size_t)i * M + j] != (float)t.g[(size_t)(M - i + j)]) return false;
+  auto Wf = [&](int f, int j) { return (float)t.W[(size_t)f * M + j]; };
+  auto Vf = [&](int j, int f) { return (float)t.W_inv[(size_t)j * N + f]; };
+  // bands: one contiguous run of bins, interior weights exactly 1
+  std::vector<int> f0(M, -1), f1(M, -1);
+  for (int j = 0; j < M; ++j) {
+    for (int f = 0; f < N; ++f)
+      if (Wf(f, j) != 0.f) {
+        if (f0[j] < 0) f0[j] = f;
+        f1[j] = f;
+      }
+    if (f0[j] < 0) return false;
+    for (int f = f0[j]; f <= f1[j]; ++f) {
+      if (Wf(f, j) == 0.f) return false;
+      if (f > f0[j] && f < f1[j] && Wf(f, j) != 1.0f) return false;
+    }
+  }
+  RunsLayout L;
+  L.n4 = N / 4;
+  L.n16 = N / 16;
+  const int ipart = std::max(8 * N, 1536);
+  auto a16 = [](int v) { return (v + 15) / 16 * 16; };
+  L.o4 = ipart;
+  L.o16 = a16(L.o4 + 8 * L.n4);
+  // interior of band j as aligned runs of 64 (when use64) / 16 / 4 bins and single bins, greedily from the left
+  auto list_of = [&](int j, bool use64, int o64, int oz, std::vector<uint32_t>& lst) {
+    lst.clear();
+    (void)oz;
+    for (int f = f0[j] + 1; f <= f1[j] - 1;) {
+      if (use64 && (f & 63) == 0 && f + 63 <= f1[j] - 1) {
+        lst.push_back((uint32_t)(o64 + 8 * (f >> 6)));
+        f += 64;
+      } else if ((f & 15) == 0 && f + 15 <= f1[j] - 1) {
+        lst.push_back((uint32_t)(L.o16 + 8 * (f >> 4)));
+        f += 16;
+      } else if ((f & 3) == 0 && f + 3 <= f1[j] - 1) {
+        lst.push_back((uint32_t)(L.o4 + 8 * (f >> 2)));
+        f += 4;
+      } else {
+        lst.push_back((uint32_t)(8 * f));
+        f += 1;
+      }
+    }
+  };
+  const int o64c = a16(L.o16 + 8 * L.n16);
+  int lmax[2] = {0, 0};
+  std::vector<uint32_t> lst;
+  for (int u = 0; u < 2; ++u)
+    for (int j = 0; j < M; ++j) {
+      list_of(j, u == 1, o64c, 0, lst);
+      lmax[u] = std::max(lmax[u], (int)lst.size());
+    }
+  const bool use64 = lmax[1] + 2 <= lmax[0];   // a fourth level only where it shortens the longest list by a word
+  L.n64 = use64 ? N / 64 : 0;
+  L.o64 = o64c;
+  L.oz = use64 ? a16(L.o64 + 8 * L.n64) : o64c;
+  L.slot = a16(L.oz + 8);
+  if (L.slot > 65535) return false;
+  L.lw = (lmax[use64 ? 1 : 0] + 1) / 2;
+  // bins -> entries
+  std::vector<int> entry(N, -1), ej0(64, 0), ecnt(64, 0), ebin(64, -1);
+  std::vector<float> rho(M, 0.f);
+  std::vector<bool> have_rho(M, false);
+  int nb = 0, kb = 1;
+  for (int f = 0; f < N; ++f) {
+    int cnt = 0, jf = -1, jl = -1;
+    for (int j = 0; j < M; ++j)
+      if (Vf(j, f) != 0.f) {
+        if (cnt == 0) jf = j;
+        jl = j;
+        ++cnt;
+      }
+    if (cnt == 0 || jl - jf + 1 != cnt) return false;   // (a bin meets a run of consecutive bands)
+    if (cnt == 1) {
+      const float v = Vf(jf, f);
+      if (!have_rho[jf]) {
+        rho[jf] = v;
+        have_rho[jf] = true;
+      } else if (std::fabs(v - rho[jf]) > 1e-6f * rho[jf]) {
+        return false;
+      }
+      entry[f] = 512 + 16 * jf;
+    } else {
+      if (nb >= 64) return false;
+      ej0[nb] = jf;
+      ecnt[nb] = cnt;
+      ebin[nb] = f;
+      kb = std::max(kb, cnt);
+      entry[f] = 512 + 16 * nb + 8;
+      ++nb;
+    }
+  }
+  if (kb > 64) return false;
+  L.kb = kb;
+  const int R = mid_r(N);
+  L.off_S = 0;
+  L.off_bc = (2 * (MF_TAB_BYTES / 4) + 3) / 4 * 4;
+  L.off_bd = L.off_bc + 256;
+  L.off_lst = L.off_bd + 256;
+  L.off_bw = L.off_lst + 64 * L.lw;
+  L.off_idx = L.off_bw + 64 * L.kb;   // (every part a multiple of 64 words: 16-byte aligned)
+  L.words = (L.off_idx + 64 * R + 3) / 4 * 4;
+  std::vector<uint32_t> w((size_t)L.words, 0u);
+  auto putf = [&](int i, float v) { uint32_t u; memcpy(&u, &v, 4); w[(size_t)i] = u; };
+  {
+    auto gp = [&](int k) { const int d = k - 64; return (d > -M && d < M) ? (float)t.g[(size_t)(M + d)] : 0.f; };
+    auto bf16_rne = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+    auto bf16_val = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+    uint16_t* tb = reinterpret_cast<uint16_t*>(w.data() + L.off_S);
+    for (int c = 0; c < 4; ++c)
+      for (int y = 0; y < 132; ++y) {
+        const int m = y - c;
+        if (m < 1 || m > 127) continue;
+        const float v = gp(128 - m);
+        const uint16_t hi = bf16_rne(v);
+        tb[(c * MF_COPY_STRIDE) / 2 + y] = hi;
+        tb[(MF_TAB_BYTES + c * MF_COPY_STRIDE) / 2 + y] = bf16_rne(v - bf16_val(hi));
+      }
+  }
+  for (int l = 0; l < 64; ++l) {
+    const int bc = L.off_bc + 4 * l, bd = L.off_bd + 4 * l;
+    if (l < M) {
+      const bool two = f1[l] > f0[l];
+      w[(size_t)bc] = (uint32_t)(8 * f0[l]) | ((uint32_t)(two ? 8 * f1[l] : L.oz) << 16);
+      putf(bc + 1, Wf(f0[l], l));
+      putf(bc + 2, two ? Wf(f1[l], l) : 0.f);
+      putf(bc + 3, (float)t.quiet[l]);
+      putf(bd + 0, t.beta[l] + 9.0f);
+      putf(bd + 1, rho[l]);
+      list_of(l, use64, L.o64, L.oz, lst);
+    } else {
+      w[(size_t)bc] = (uint32_t)L.oz | ((uint32_t)L.oz << 16);
+      lst.clear();
+    }
+    lst.resize((size_t)2 * L.lw, (uint32_t)L.oz);
+    for (int k = 0; k < L.lw; ++k) w[(size_t)L.off_lst + 64 * k + l] = lst[2 * k] | (lst[2 * k + 1] << 16);
+    // edge bin l: its bands' G are read from a window of kb that stays inside the 64 G of the slot
+    if (l < nb) {
+      const int js = std::min(ej0[l], 64 - L.kb);
+      w[(size_t)bd + 2] = (uint32_t)(8 * js);
+      for (int k = 0; k < ecnt[l]; ++k) putf(L.off_bw + 64 * (ej0[l] - js + k) + l, Vf(ej0[l] + k, ebin[l]));
+    }
+  }
+  for (int l = 0; l < 64; ++l)
+    for (int i = 0; i < R; ++i) {
+      const int q = 64 * i + l;
+      if (2 * q + 1 < N) w[(size_t)L.off_idx + 64 * i + l] = (uint32_t)entry[2 * q] | ((uint32_t)entry[2 * q + 1] << 16);
+    }
+  if (out) *out = w;
+  if (lay) *lay = L;
+  return true;
+}
+
+bool runs_supported(const ac_psy_plan* p) { return p->runs != 0; }
+
+runs::RunsParams runs_params(const ac_psy_plan* p, float drown, bool idx_in_lds) {
+  const RunsLayout& L = p->runs_lay;
+  runs::RunsParams m;
+  m.img_words = L.words;
+  m.lds_words = idx_in_lds ? L.words : L.off_idx;   // (off_idx is a multiple of four words: build_runs)
+  m.N = p->N;
+  m.M = p->M;
+  m.lw = L.lw;
+  m.kb = L.kb;
+  m.n4 = L.n4;
+  m.n16 = L.n16;
+  m.n64 = L.n64;
+  m.o4 = L.o4;
+  m.o16 = L.o16;
+  m.o64 = L.o64;
+  m.oz = L.oz;
+  m.slot = L.slot;
+  m.off_S = L.off_S;
+  m.off_bc = L.off_bc;
+  m.off_bd = L.off_bd;
+  m.off_lst = L.off_lst;
+  m.off_bw = L.off_bw;
+  m.off_idx = L.off_idx;
+  m.alpha = (float)p->alpha;
+  m.inv_alpha = (float)(1.0 / p->alpha);
+  m.omd = 1.0f - drown;
+  m.inv_n = 1.0f / (float)p->N;
+  return m;
+}
+
+int runs_psy_plan_init(ac_psy_plan* p) {
+  std::vector<uint32_t> w;
+  if (!build_runs(p->host, &w, &p->runs_lay)) return AC_EUNSUPPORTED;   // (not an error: the plan keeps the band walk)
+  AC_HIP_CHECK(hipMalloc((void**)&p->d_runs, w.size() * sizeof(uint32_t)));
+  AC_HIP_CHECK(hipMemcpy(p->d_runs, w.data(), w.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  p->runs = 1;
+  return AC_OK;
+}
+
 // t_out != null: tonality (from X); thr != null: threshold (from t_out when given, else from t_in)
 int launch_psy_mid(const ac_psy_plan* p, const float* X, const float* t_in, float* t_out, float* thr, float drown, int B,
                    int F, int C, hipStream_t s) {
   if (B <= 0 || C <= 0 || F <= 0) return AC_OK;
+  static const bool no_runs = getenv("AC_NO_RUNS") != nullptr;   // (A/B hook: the band walk on a plan that has both forms)
+  if (p->runs && !no_runs) return launch_psy_runs(p, X, t_in, t_out, thr, drown, B, F, C, s);
   // (the layout of the image was fixed when the plan was built: a launch only fills in arguments)
   MidLayout L;
   L.words = p->mid_words;
