@@ -1979,18 +1979,13 @@ template <int NFR, bool PSY> constexpr int multi_tab_bytes() {   // (PRE_GLOBAL:
 // The fused masking model (ac_psy_runs_dev.h) works on FB frames side by side, each in a slot of its own: intensities,
 // their partial sums, later G and the threshold entries.  multi_slot(): the largest slot build_runs lays out for
 // filters_n = FN (all four levels), a compile-time stride so that a frame's displacement is an immediate of its LDS
-// accesses.  Where a wave's NFR frames are one group (filters_n 512 / 256) the spectra are laid out straight into the slots
-// and the intensities overwrite them; below, the NFR spectra stay packed in the wave's first 8 KB and the FB slots follow.
-constexpr int multi_a16(int v) { return (v + 15) / 16 * 16; }
-template <int NFR> constexpr int multi_slot() {
-  constexpr int FN = 1024 / NFR;
-  return multi_a16(multi_a16(multi_a16(multi_a16((8 * FN > 1536 ? 8 * FN : 1536) + 8 * (FN / 4)) + 8 * (FN / 16)) + 8 * (FN / 64)) + 8);
-}
+// accesses.  The wave lays the spectra of one group of FB frames at a time straight into the slots (the lanes of the later
+// groups keep theirs in registers meanwhile) and the intensities overwrite them: FB slots per wave, no staging area.
+template <int NFR> constexpr int multi_slot() { return runs::runs_slot_max(1024 / NFR); }
 template <int NFR> constexpr int multi_fb() { return (1024 / NFR) >= 512 ? 2 : 4; }
-template <int NFR> constexpr bool multi_in_slots() { return NFR == multi_fb<NFR>(); }
 template <int NFR, bool PSY> constexpr int multi_wave_bytes() {
   if (!PSY) return WAVE_LDS;
-  const int need = multi_in_slots<NFR>() ? NFR * multi_slot<NFR>() : 8192 + multi_fb<NFR>() * multi_slot<NFR>();
+  const int need = multi_fb<NFR>() * multi_slot<NFR>();
   return need > WAVE_LDS ? need : WAVE_LDS;
 }
 
@@ -2039,8 +2034,11 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
   runs::RegIdx<RPM> ridx = {};
   if constexpr (PSY) ridx.load(a.psy_img, a.rp, lane);
   const int tl = lane & (TS - 1);   // column of the lane in a table row
+  // the fused kernels whose later groups of frames wait in registers for the model (NFR > FB) fetch the pass-1 twiddles per
+  // chunk (L2-resident) instead of holding them across it: 14 registers less where the pressure peaks
+  constexpr bool P1_PER_CHUNK = PSY && NFR > multi_fb<NFR>();
   v2f p1[8];
-  load_p1<8>(a.tab, lane, p1);
+  if (!P1_PER_CHUNK) load_p1<8>(a.tab, lane, p1);
   const int f = lane / LB, l = lane & (LB - 1);
   const int C = a.C;
   const size_t blk = (size_t)(16 * LB) * C;   // floats per block / frame row over all channels
@@ -2048,6 +2046,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
   long long pair = task / a.cpp;          // (one 64-bit division per wave; the task index then advances without)
   int c = (int)(task - pair * a.cpp);
   for (int t = 0; t < a.T && task < a.ntasks; ++t, task += NW, c += NW) {
+    if (P1_PER_CHUNK) load_p1<8>(a.tab, (int)in_loop((uint32_t)lane), p1);
     while (c >= a.cpp) {
       c -= a.cpp;
       ++pair;
@@ -2185,22 +2184,21 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
       constexpr int RP = RPM;                          // granule registers per lane when 64 lanes share one frame
       constexpr int FB = multi_fb<NFR>();              // frames side by side (ac_psy_runs_dev.h)
       constexpr int SLOT = multi_slot<NFR>();
-      constexpr bool IN_SLOTS = multi_in_slots<NFR>(); // the spectra are laid out in the model's slots
-      constexpr int STG = IN_SLOTS ? SLOT : 8 * FN;    // bytes between the staged spectra of successive frames
-      char* slots = IN_SLOTS ? buf : buf + 8192;
-      wave_sync();
-      {
-        char* fb = buf + f * STG + 16 * l;             // granule q = l + LB i of the group's frame at byte 16 q of its row
-#pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<v4f*>(fb + 16 * LB * i) = row[i];
-      }
-      runs::slot_init(a.rp, slots, FB, SLOT, lane);    // (the FFT's exchanges run over the slots: the zero words again)
-      const runs::RunsLane lc = runs::load_lane(a.rp, pimg, lane);   // (per chunk: held across the FFT it would cost seven registers)
-      wave_sync();
+      static_assert(NFR % FB == 0, "whole groups");
+      const runs::RunsLane lc = runs::load_lane(pimg, lane);   // (per chunk: held across the FFT it would cost seven registers)
 #pragma unroll 1
       for (int g0 = 0; g0 < NFR; g0 += FB) {
         if (c * NFR + g0 >= a.F) break;
-        const char* ib = buf + g0 * STG;
+        wave_sync();   // the FFT's (or the previous group's) accesses of the slots are done
+        if (f >= g0 && f < g0 + FB) {
+          char* fb = buf + (f - g0) * SLOT + 16 * l;   // granule q = l + LB i of the group's frame at byte 16 q of its slot
+#pragma unroll
+          for (int i = 0; i < 8; ++i) *reinterpret_cast<v4f*>(fb + 16 * LB * i) = row[i];
+        }
+        wave_sync();
+        const char* ib = buf;
+        constexpr int STG = SLOT;
+        char* slots = buf;
         v4f xq[FB][RP];
         bool ok[FB];
         size_t o0[FB], o1[FB];
@@ -2225,7 +2223,7 @@ __global__ __launch_bounds__(NW * 64, AC_WPE) void k_fwd_multi(FwdMArgs a) {
             if (pq.has1) a.t[((size_t)pq.b1 * a.F + (size_t)nn) * C + pq.c1] = t[fb].y;
           }
         wave_sync();
-        runs::threshold_frames<RP, FB>(t, a.rp, lc, pimg, slots, SLOT, lane, ridx, [&](int fb, int i, const v4f& th) {
+        runs::threshold_frames<RP, FB, FN>(t, a.rp, lc, pimg, slots, SLOT, lane, ridx, [&](int fb, int i, const v4f& th) {
           if (!ok[fb]) return;
           if (CMODE == 0) {
             __builtin_nontemporal_store(th, reinterpret_cast<v4f*>(a.thr + o0[fb]) + 64 * i + lane);

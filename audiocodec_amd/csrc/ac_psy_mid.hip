@@ -363,13 +363,12 @@ __global__ __launch_bounds__(256, (R >= 32 ? 1 : R >= 16 ? 2 : 3)) void k_psy_ru
   if (WANT_THR) {
     for (int i = threadIdx.x; i < a.p.lds_words / 4; i += blockDim.x)
       reinterpret_cast<uint4*>(img)[i] = reinterpret_cast<const uint4*>(a.img)[i];
-    runs::slot_init(a.p, buf, FB, slot, lane);
     __syncthreads();
   }
   runs::RunsLane lc = {};
   runs::RegIdx<IDX_REGS ? R : 1> ridx = {};
   if (WANT_THR) {
-    lc = runs::load_lane(a.p, img, lane);
+    lc = runs::load_lane(img, lane);
     if (IDX_REGS) ridx.load(a.img, a.p, lane);
   }
   const long long task0 = (long long)blockIdx.x * nw * a.T + wave;
@@ -394,8 +393,8 @@ __global__ __launch_bounds__(256, (R >= 32 ? 1 : R >= 16 ? 2 : 3)) void k_psy_ru
     if (!WANT_THR) continue;
     wave_sync();
     auto emit = [&](int fb, int i, const v4f& th) { rs.store_thr(a.thr, a.C, fb, i, lane, th); };
-    if constexpr (IDX_REGS) runs::threshold_frames<R, FB>(t, a.p, lc, img, buf, slot, lane, ridx, emit);
-    else runs::threshold_frames<R, FB>(t, a.p, lc, img, buf, slot, lane, runs::LdsIdx{img + a.p.off_idx + lane}, emit);
+    if constexpr (IDX_REGS) runs::threshold_frames<R, FB, 0>(t, a.p, lc, img, buf, slot, lane, ridx, emit);
+    else runs::threshold_frames<R, FB, 0>(t, a.p, lc, img, buf, slot, lane, runs::LdsIdx{img + runs::off_idx(a.p.lw, a.p.kb) + lane}, emit);
   }
 }
 
@@ -545,12 +544,12 @@ bool build_runs(const PsyTables& t, std::vector<uint32_t>* out, RunsLayout* lay)
     }
   }
   RunsLayout L;
-  L.n4 = N / 4;
-  L.n16 = N / 16;
-  const int ipart = std::max(8 * N, 1536);
-  auto a16 = [](int v) { return (v + 15) / 16 * 16; };
-  L.o4 = ipart;
-  L.o16 = a16(L.o4 + 8 * L.n4);
+  const runs::RunsGeo geo = runs::runs_geo(N);   // (the kernels derive the same numbers from filter_bands_n)
+  auto a16 = [](int v) { return runs::a16(v); };
+  L.n4 = geo.n4;
+  L.n16 = geo.n16;
+  L.o4 = geo.o4;
+  L.o16 = geo.o16;
   // interior of band j as aligned runs of 64 (when use64) / 16 / 4 bins and single bins, greedily from the left
   auto list_of = [&](int j, bool use64, int o64, int oz, std::vector<uint32_t>& lst) {
     lst.clear();
@@ -571,7 +570,7 @@ bool build_runs(const PsyTables& t, std::vector<uint32_t>* out, RunsLayout* lay)
       }
     }
   };
-  const int o64c = a16(L.o16 + 8 * L.n16);
+  const int o64c = geo.o64;
   int lmax[2] = {0, 0};
   std::vector<uint32_t> lst;
   for (int u = 0; u < 2; ++u)
@@ -622,12 +621,14 @@ bool build_runs(const PsyTables& t, std::vector<uint32_t>* out, RunsLayout* lay)
   if (kb > 64) return false;
   L.kb = kb;
   const int R = mid_r(N);
-  L.off_S = 0;
-  L.off_bc = (2 * (MF_TAB_BYTES / 4) + 3) / 4 * 4;
-  L.off_bd = L.off_bc + 256;
-  L.off_lst = L.off_bd + 256;
-  L.off_bw = L.off_lst + 64 * L.lw;
-  L.off_idx = L.off_bw + 64 * L.kb;   // (every part a multiple of 64 words: 16-byte aligned)
+  L.off_S = runs::OFF_S;
+  L.off_bc = runs::OFF_BC;
+  L.off_bd = runs::OFF_BD;
+  L.off_lst = runs::OFF_LST;
+  L.off_bw = runs::off_bw(L.lw);
+  L.off_idx = runs::off_idx(L.lw, L.kb);   // (every part a multiple of 64 words: 16-byte aligned)
+  static_assert(runs::OFF_BC % 4 == 0, "16-byte rows");
+  if (L.slot > runs::runs_slot_max(N)) return false;   // (cannot happen: the compile-time strides of the fused kernels rely on it)
   L.words = (L.off_idx + 64 * R + 3) / 4 * 4;
   std::vector<uint32_t> w((size_t)L.words, 0u);
   auto putf = [&](int i, float v) { uint32_t u; memcpy(&u, &v, 4); w[(size_t)i] = u; };
@@ -653,9 +654,9 @@ bool build_runs(const PsyTables& t, std::vector<uint32_t>* out, RunsLayout* lay)
       w[(size_t)bc] = (uint32_t)(8 * f0[l]) | ((uint32_t)(two ? 8 * f1[l] : L.oz) << 16);
       putf(bc + 1, Wf(f0[l], l));
       putf(bc + 2, two ? Wf(f1[l], l) : 0.f);
-      putf(bc + 3, (float)t.quiet[l]);
       putf(bd + 0, t.beta[l] + 9.0f);
-      putf(bd + 1, rho[l]);
+      putf(bd + 1, (float)t.quiet[l]);
+      putf(bd + 2, rho[l]);
       list_of(l, use64, L.o64, L.oz, lst);
     } else {
       w[(size_t)bc] = (uint32_t)L.oz | ((uint32_t)L.oz << 16);
@@ -666,7 +667,7 @@ bool build_runs(const PsyTables& t, std::vector<uint32_t>* out, RunsLayout* lay)
     // edge bin l: its bands' G are read from a window of kb that stays inside the 64 G of the slot
     if (l < nb) {
       const int js = std::min(ej0[l], 64 - L.kb);
-      w[(size_t)bd + 2] = (uint32_t)(8 * js);
+      w[(size_t)bc + 3] = (uint32_t)(8 * js);
       for (int k = 0; k < ecnt[l]; ++k) putf(L.off_bw + 64 * (ej0[l] - js + k) + l, Vf(ej0[l] + k, ebin[l]));
     }
   }
@@ -685,26 +686,14 @@ bool runs_supported(const ac_psy_plan* p) { return p->runs != 0; }
 runs::RunsParams runs_params(const ac_psy_plan* p, float drown, bool idx_in_lds) {
   const RunsLayout& L = p->runs_lay;
   runs::RunsParams m;
-  m.img_words = L.words;
-  m.lds_words = idx_in_lds ? L.words : L.off_idx;   // (off_idx is a multiple of four words: build_runs)
   m.N = p->N;
   m.M = p->M;
+  m.lds_words = idx_in_lds ? L.words : L.off_idx;   // (off_idx is a multiple of four words: build_runs)
   m.lw = L.lw;
   m.kb = L.kb;
-  m.n4 = L.n4;
-  m.n16 = L.n16;
   m.n64 = L.n64;
-  m.o4 = L.o4;
-  m.o16 = L.o16;
-  m.o64 = L.o64;
   m.oz = L.oz;
   m.slot = L.slot;
-  m.off_S = L.off_S;
-  m.off_bc = L.off_bc;
-  m.off_bd = L.off_bd;
-  m.off_lst = L.off_lst;
-  m.off_bw = L.off_bw;
-  m.off_idx = L.off_idx;
   m.alpha = (float)p->alpha;
   m.inv_alpha = (float)(1.0 / p->alpha);
   m.omd = 1.0f - drown;

@@ -1,6 +1,6 @@
 // Device code of the wave-level masking model for general band layouts in its run-structured form (round 4): the model
 // of ac_psy_mid_dev.h with the structure every Bark mapping of the reference has (psychoacoustic.py:257-299) taken out of
-// the frame loop at plan time.  Shared by the stand-alone kernel (k_psy_mid, ac_psy_mid.hip), the fused encode of the
+// the frame loop at plan time.  Shared by the stand-alone kernel (k_psy_runs, ac_psy_mid.hip), the fused encode of the
 // several-frames-per-wave MDCT kernels (k_fwd_multi, ac_fast.hip) and the fused encode of the LDS-FFT tier (k_fwd_wave_v,
 // ac_generic.hip): ONE definition of the per-frame arithmetic, so the fused and the un-fused encode agree bit for bit.
 //
@@ -12,12 +12,18 @@
 //     longest band deciding the trip count of every lane).
 //   * W_inv (bands -> bins, :317-331): a bin inside one band sees G_j rho_j with one rho per band; a bin that holds a
 //     band edge is the only one with its combination.  There are at most M - 1 such bins, so a frame has at most 2 M
-//     distinct threshold values ("entries"): lane j forms the interior entry of band j and the entry of edge bin j --
-//     two square roots per lane -- and every bin then only looks its entry up (the old form summed <= wi_w weighted
-//     terms and took a square root per bin).
+//     distinct threshold values ("entries"): the interior entry of band j and the entry of edge bin j -- two square roots
+//     per band -- and every bin then only looks its entry up (the old form summed <= wi_w weighted terms and took a square
+//     root per bin).
 //   * T = max(eps, fac acc)^(1/alpha) with fac = 10^(-alpha O / 10) (:185-208) is evaluated in the log domain:
 //     exp2(max(log2 acc - alpha O log2(10) / 10, log2 eps) / alpha): one v_log + one v_exp per band and signal instead of
 //     three transcendentals.
+//   * the wave sums of the tonality (:102-120) of all the frames of a group are formed together: a reduction over lanes
+//     that halves the number of live registers with every exchange (4 FB values end as one register, lane & 15 = which
+//     value), one vector evaluation of the flatness formula for all of them.
+//   * the band x band product with the Toeplitz spreading matrix (:205-207, 223-228) runs as 16 v_mfma_f32_16x16x32_bf16 on
+//     split-bfloat16 operands for up to four frames at once (rows = frame x signal x {hi, lo}); the rest of the per-band
+//     arithmetic continues in the accumulator's layout.
 // gfx950 only.
 #pragma once
 #include "ac_psy_mid_dev.h"
@@ -32,61 +38,69 @@ using mid::wave_sync;
 using mid::log2v;
 using mid::exp2v;
 using mid::maxv;
+using mid::MF_COPY_STRIDE;
+using mid::MF_TAB_BYTES;
 
 // The per-frame LDS slot (byte offsets from its base; every list entry of the image is such an offset, 16 bits):
-//   [0, 8 N)            intensities, bin f at 8 f: (s0, s1)          -- later reused: G_j at 8 j (512 bytes), threshold
-//                       entries at 512 + 16 j: (interior entry of band j, entry of edge bin j), each (s0, s1)
+//   [0, ipart)          intensities, bin f at 8 f: (s0, s1); ipart = max(8 N, 1536) -- later reused: G_j at 8 j (512
+//                       bytes), threshold entries at 512 + 16 j: (interior entry of band j, entry of edge bin j), each (s0, s1)
 //   [o4, ...)           sums over aligned runs of 4 bins, 8 bytes each; then runs of 16; then (when the plan uses them) of 64
-//   [oz, oz + 8)        zeros: the padding target of the lists (written once per slot by runs::slot_init)
-// The first part is at least 1536 bytes (G and the entries need them when 8 N is less).
+//   [oz, oz + 8)        zeros: the padding target of the lists (runs::slot_init)
+// What depends on filter_bands_n alone is RunsGeo (a compile-time constant in the kernels that know the size):
+struct RunsGeo {
+  int n4, n16, o4, o16, o64;   // aligned runs per level; slot offsets of the levels (o64: where the third level starts if used)
+};
+__host__ __device__ constexpr int a16(int v) { return (v + 15) / 16 * 16; }
+__host__ __device__ constexpr RunsGeo runs_geo(int N) {
+  RunsGeo g = {N / 4, N / 16, (8 * N > 1536 ? 8 * N : 1536), 0, 0};
+  g.o16 = a16(g.o4 + 8 * g.n4);
+  g.o64 = a16(g.o16 + 8 * g.n16);
+  return g;
+}
+// the largest slot build_runs can lay out for a size (all levels): a compile-time stride for kernels that know the size
+__host__ __device__ constexpr int runs_slot_max(int N) { return a16(a16(runs_geo(N).o64 + 8 * (N / 64)) + 8); }
+
+// what depends on the plan
 struct RunsParams {
-  int img_words;                     // the whole image
-  int lds_words;                     // its part that is copied to LDS: all of it, or everything before the per-bin entry offsets
-                                     // (kernels with up to 8 granule registers per lane hold those in registers)
   int N, M;
+  int lds_words;                     // the part of the image that is copied to LDS: all of it, or everything before the per-bin
+                                     // entry offsets (kernels with up to 8 granule registers per lane hold those in registers)
   int lw;                            // list words per band (two 16-bit offsets each)
   int kb;                            // terms of an edge-bin entry (bands that meet in one bin)
-  int n4, n16, n64;                  // aligned runs per level (n64 = 0: level not used)
-  int o4, o16, o64, oz;              // slot offsets (bytes)
-  int slot;                          // bytes per slot (a multiple of 16)
-  int off_S, off_bc, off_bd, off_lst, off_bw, off_idx;   // word offsets inside the image
+  int n64;                           // aligned runs of 64 bins (0: level not used)
+  int oz;                            // slot offset of the zero word
+  int slot;                          // bytes per slot (a multiple of 16; <= runs_slot_max(N))
   float alpha, inv_alpha;
   float omd;                         // 1 - drown
   float inv_n;                       // 1 / N
 };
 // image (32-bit words):
-//   off_S:   bfloat16 tiles of the spreading matrix (mid::spread_tiles): hi table, lo table
-//   off_bc:  [64] x 4: {edge offsets lo | hi << 16, w0, w1, quiet}
-//   off_bd:  [64] x 4: {beta + 9, rho, byte offset of the first G of edge bin `lane`'s entry, 0}
-//   off_lst: [lw][64]: list words of band `lane`
+//   OFF_S:   bfloat16 tiles of the spreading matrix: four shifted copies of the reversed prototype rev[m] = gp[128 - m],
+//            gp[64 + d] = g[M + d] (0 where |d| >= M: S[i][j] = gp[64 + j - i]); hi parts (MF_TAB_BYTES) then lo parts
+//   OFF_BC:  [64] x 4: {edge offsets lo | hi << 16, w0, w1, byte offset of the first G of edge bin `lane`'s entry}
+//   OFF_BD:  [64] x 4: per band {beta + 9, quiet, rho, 0}
+//   OFF_LST: [lw][64]: list words of band `lane`
 //   off_bw:  [kb][64]: weights of edge bin `lane`'s entry (0 pads)
 //   off_idx: [R][64]:  byte offsets (lo | hi << 16) of the entries of the two bins of granule 64 i + lane
+constexpr int OFF_S = 0, OFF_BC = 2 * (MF_TAB_BYTES / 4), OFF_BD = OFF_BC + 256, OFF_LST = OFF_BD + 256;
+__host__ __device__ constexpr int off_bw(int lw) { return OFF_LST + 64 * lw; }
+__host__ __device__ constexpr int off_idx(int lw, int kb) { return OFF_LST + 64 * (lw + kb); }
 
 constexpr float kLog2Eps = -46.506993328423076f;    // log2(1e-14)
 constexpr float kLog2_10_10 = 0.33219280948873623f; // log2(10) / 10
 
-// constants of band / edge bin `lane`, loop-invariant
+// constants of band / edge bin `lane` for the list walk and the edge entries
 struct RunsLane {
   uint32_t edge;
-  float w0, w1, quiet;
-  float c1, rho;
+  float w0, w1;
   uint32_t goff;
 };
-__device__ __forceinline__ RunsLane load_lane(const RunsParams& a, const uint32_t* img, int lane) {
-  const uint4 bc = reinterpret_cast<const uint4*>(img + a.off_bc)[lane];
-  const uint4 bd = reinterpret_cast<const uint4*>(img + a.off_bd)[lane];
-  RunsLane c;
-  c.edge = bc.x;
-  c.w0 = __uint_as_float(bc.y);
-  c.w1 = __uint_as_float(bc.z);
-  c.quiet = __uint_as_float(bc.w);
-  c.c1 = __uint_as_float(bd.x);
-  c.rho = __uint_as_float(bd.y);
-  c.goff = bd.z;
-  return c;
+__device__ __forceinline__ RunsLane load_lane(const uint32_t* img, int lane) {
+  const uint4 bc = reinterpret_cast<const uint4*>(img + OFF_BC)[lane];
+  return RunsLane{bc.x, __uint_as_float(bc.y), __uint_as_float(bc.z), bc.w};
 }
 
-// once per slot, before its first frame (the zero word is never written again)
+// the zero word of each slot (threshold_frames writes them anew for every group: the A image of spread16 runs over them)
 __device__ __forceinline__ void slot_init(const RunsParams& a, char* slot0, int nslots, int slot_bytes, int lane) {
   if (lane < nslots) *reinterpret_cast<v2f*>(slot0 + lane * slot_bytes + a.oz) = v2f{0.f, 0.f};
 }
@@ -94,15 +108,55 @@ __device__ __forceinline__ void slot_init(const RunsParams& a, char* slot0, int 
 template <int R>
 __device__ __forceinline__ bool in_frame(const RunsParams& a, int i, int lane) { return R * 128 == a.N || 64 * i + lane < (a.N >> 1); }
 
-// tonality of FB frames (psychoacoustic.py:102-120; the arithmetic of mid::tonality_frames) and, STORE_I, their
-// intensities into the slots (the squares are formed once for both)
+// ---- wave totals of V = 4, 8 or 16 values at once -------------------------------------------------------------------------
+// Four exchanges inside a row of 16 lanes -- partners lane ^ 15 (row_mirror), ^ 7 (row_half_mirror), ^ 3 and ^ 1 (quad_perm) --
+// then the four rows.  While more than one register is live an exchange halves them: a lane keeps the value its bit of the
+// exchange selects, hands the other to its partner and adds what it is handed.  Every value meets the same partners in the
+// same order whatever V and whichever register it started in, so a frame's sums do not depend on the group it shares.
+// Afterwards v[0] of lane l holds the total of value number l & 15 (V = 16), (l >> 1) & 7 (V = 8) or (l >> 2) & 3 (V = 4).
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL, int N>
+__device__ __forceinline__ void exchange(float (&v)[16], bool sel) {   // N live registers -> N / 2 (N == 1: stays one)
+  if constexpr (N == 1) {
+    v[0] += dpp_get<CTRL>(v[0]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+      const float keep = sel ? v[i + N / 2] : v[i], give = sel ? v[i] : v[i + N / 2];
+      v[i] = keep + dpp_get<CTRL>(give);
+    }
+  }
+}
+template <int V>
+__device__ __forceinline__ float wave_totals(float (&v)[16], int lane) {
+  static_assert(V == 4 || V == 8 || V == 16, "4 values per frame, 1 / 2 / 4 frames");
+  exchange<0x140, V>(v, (lane & 8) != 0);                       // row_mirror
+  exchange<0x141, (V >= 2 ? V / 2 : 1)>(v, (lane & 4) != 0);    // row_half_mirror
+  exchange<0x1B, (V >= 4 ? V / 4 : 1)>(v, (lane & 2) != 0);     // quad_perm [3, 2, 1, 0]
+  exchange<0xB1, (V >= 8 ? V / 8 : 1)>(v, (lane & 1) != 0);     // quad_perm [1, 0, 3, 2]
+  // rows: v_permlane32_swap(x, x) = (lanes 0..31 twice, lanes 32..63 twice); v_permlane16_swap(y, y) = (even rows twice, odd
+  // rows twice)
+  const unsigned x = __float_as_uint(v[0]);
+  const auto h = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  const float y = __uint_as_float(h[0]) + __uint_as_float(h[1]);
+  const unsigned yu = __float_as_uint(y);
+  const auto r = __builtin_amdgcn_permlane16_swap(yu, yu, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// tonality of FB frames (psychoacoustic.py:102-120) and, STORE_I, their intensities into the slots (the squares are formed
+// once for both).  Value number of (frame fb, kind = 0 sum of logs / 1 sum of squares, signal ch) in wave_totals:
+// FB = 4: 4 fb + 2 kind + ch; FB = 2: 4 fb + 2 ch + kind; FB = 1: 2 kind + ch -- so that the lane holding a frame's sum of logs
+// finds the matching sum of squares at lane ^ 2 (FB = 4, 2: quad_perm) or lane ^ 8 (FB = 1: row_ror 8).
 template <int R, int FB, bool WANT_T, bool STORE_I>
 __device__ __forceinline__ void prep_frames(const v4f (&xq)[FB][R], const RunsParams& a, char* slot0, int slot_bytes, int lane, v2f (&t)[FB]) {
-  v2f slog[FB], ssq[FB];
+  float v[16];
 #pragma unroll
   for (int fb = 0; fb < FB; ++fb) {
-    slog[fb] = v2f{0.f, 0.f};
-    ssq[fb] = v2f{0.f, 0.f};
+    v2f slog = {0.f, 0.f}, ssq = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       v4f I = xq[fb][i] * xq[fb][i];
@@ -110,26 +164,34 @@ __device__ __forceinline__ void prep_frames(const v4f (&xq)[FB][R], const RunsPa
       if (STORE_I && in_frame<R>(a, i, lane)) *reinterpret_cast<v4f*>(slot0 + fb * slot_bytes + 16 * (64 * i + lane)) = I;
       if (WANT_T) {
         const v2f ie = v2f{I.x, I.y}, io = v2f{I.z, I.w};
-        ssq[fb] += ie + io;
+        ssq += ie + io;
         const v2f lg = log2v(maxv(ie, kEps) * maxv(io, kEps));
-        slog[fb] += in_frame<R>(a, i, lane) ? lg : v2f{0.f, 0.f};
+        slog += in_frame<R>(a, i, lane) ? lg : v2f{0.f, 0.f};
+      }
+    }
+    if (WANT_T) {
+      if (FB == 4) {
+        v[4 * fb + 0] = slog.x, v[4 * fb + 1] = slog.y, v[4 * fb + 2] = ssq.x, v[4 * fb + 3] = ssq.y;
+      } else if (FB == 2) {
+        v[4 * fb + 0] = slog.x, v[4 * fb + 1] = ssq.x, v[4 * fb + 2] = slog.y, v[4 * fb + 3] = ssq.y;
+      } else {
+        v[0] = slog.x, v[1] = slog.y, v[2] = ssq.x, v[3] = ssq.y;
       }
     }
   }
   if (!WANT_T) return;
+  const float tot = wave_totals<4 * FB>(v, lane);
+  // in the lanes that hold a sum of logs: the frame's sum of squares from the partner lane, then
+  // sfm = 10 log10(gm / am) = 10 log10(2) (mean log2 I - log2 am), t = min(sfm / -60, 1)   (the other lanes compute on without use)
+  const float sq = FB == 1 ? dpp_get<0x128>(tot) : dpp_get<0x4E>(tot);   // row_ror 8 | quad_perm [2, 3, 0, 1]
+  const float am = sq * a.inv_n + kEps;
+  const float sfm = 3.0102999566398120f * (tot * a.inv_n - __builtin_amdgcn_logf(am));
+  const float tt = fminf(sfm * (-1.0f / 60.0f), 1.0f);
 #pragma unroll
   for (int fb = 0; fb < FB; ++fb) {
-    slog[fb].x = mid::wave_sum(slog[fb].x);
-    slog[fb].y = mid::wave_sum(slog[fb].y);
-    ssq[fb].x = mid::wave_sum(ssq[fb].x);
-    ssq[fb].y = mid::wave_sum(ssq[fb].y);
-  }
-#pragma unroll
-  for (int fb = 0; fb < FB; ++fb) {
-    const v2f am = ssq[fb] * a.inv_n + kEps;
-    const v2f sfm = 3.0102999566398120f * (slog[fb] * a.inv_n - log2v(am));
-    const v2f tt = sfm * (-1.0f / 60.0f);
-    t[fb] = v2f{fminf(tt.x, 1.0f), fminf(tt.y, 1.0f)};
+    const int l0 = FB == 4 ? 4 * fb : FB == 2 ? 8 * fb : 0, l1 = FB == 4 ? 4 * fb + 1 : FB == 2 ? 8 * fb + 4 : 4;
+    t[fb] = v2f{__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tt), l0)),
+                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tt), l1))};
   }
 }
 
@@ -150,10 +212,6 @@ __device__ __forceinline__ void level_sums(char* slot0, int slot_bytes, int src,
   }
 }
 
-// masking thresholds of FB frames whose intensities are in their slots (prep_frames, or the caller's own stores: bin f
-// at 8 f); emit(fb, i, th) receives the thresholds of granule 64 i + lane of frame fb (lanes with in_frame(i) only).
-// img: the LDS copy of the image.  The caller orders its stores of the intensities before the call (wave_sync) and its
-// next use of the slots after it.
 // idx(i): the entry-offset word of granule 64 i + lane (LdsIdx: read from the LDS image; or the caller's registers)
 struct LdsIdx {
   const uint32_t* p;   // img + off_idx + lane
@@ -164,33 +222,96 @@ struct RegIdx {
   uint32_t w[R];
   __device__ __forceinline__ void load(const uint32_t* gimg, const RunsParams& a, int lane) {   // gimg: the image in global memory
 #pragma unroll
-    for (int i = 0; i < R; ++i) w[i] = gimg[a.off_idx + 64 * i + lane];
+    for (int i = 0; i < R; ++i) w[i] = gimg[off_idx(a.lw, a.kb) + 64 * i + lane];
   }
   __device__ __forceinline__ uint32_t operator()(int i) const { return w[i]; }
 };
-template <int R, int FB, class IDX, class EMIT>
-__device__ __forceinline__ void threshold_frames(const v2f (&t)[FB], const RunsParams& a, const RunsLane& c, const uint32_t* img,
-                                                 char* slot0, int slot_bytes, int lane, const IDX& idx, EMIT emit) {
-  // partial sums over aligned runs of 4, 16 (64) bins
-  level_sums<FB>(slot0, slot_bytes, 0, a.o4, a.n4, lane);
+
+// ---- band x band product on the matrix cores, up to four frames at once -----------------------------------------------------
+//   acc_j = sum_i Q_i S[i, j],  S[i, j] = gp[64 + j - i]
+// as D = A B with v_mfma_f32_16x16x32_bf16: rows of A = (frame fb, part, signal) -- row 4 fb + 2 part + ch, part 0 = Q rounded to
+// bfloat16, part 1 = the remainder Q - hi -- K = band i (two steps of 32), columns = band j (four tiles of 16); S = hi + lo
+// likewise (two B tables), the four partial products meet in float32 accumulators: ~16 mantissa bits, thresholds within 1e-5 of
+// an all-float32 product.  A goes through LDS once (lane = band writes its rows' entries, 2 bytes each; lane l reads
+// A[row l & 15][k = 8 (l >> 4) .. + 7] as 16 bytes, rows of 160 bytes: conflict-free); with fewer than four frames the rows
+// repeat (row mod 4 FB), so every group of 16 lanes gets a copy of the result.  B[k][col] for lane (g = l >> 4, n = l & 15),
+// tile c, step s is rev[m0 .. m0 + 7], m0 = 64 - 16 c + 32 s - n + 8 g: eight consecutive entries of the reversed prototype,
+// 8-byte aligned in copy n & 3 of the table; tiles with equal 2 s - c are the same registers.
+// D of tile c: lane (g, n), register 2 part + ch = row 4 g + 2 part + ch, column 16 c + n.
+typedef __bf16 v8b __attribute__((ext_vector_type(8)));
+constexpr int A_ROW = 160;                 // bytes per row of the A image
+constexpr int A_BYTES = 16 * A_ROW;        // it takes the head of the group's slots once their intensities are done with
+template <int FB>
+__device__ __forceinline__ void spread16(const v2f (&Q)[FB], const uint32_t* img, char* abuf, int lane, v4f (&D)[4]) {
+#pragma unroll
+  for (int fb = 0; fb < FB; ++fb) {
+    const uint32_t whi = mid::pk_bf16(Q[fb].x, Q[fb].y);
+    const float hx = __uint_as_float(whi << 16), hy = __uint_as_float(whi & 0xffff0000u);
+    const uint32_t wlo = mid::pk_bf16(Q[fb].x - hx, Q[fb].y - hy);
+    char* w = abuf + (4 * fb) * A_ROW + 2 * lane;
+    *reinterpret_cast<uint16_t*>(w) = (uint16_t)whi;
+    *reinterpret_cast<uint16_t*>(w + A_ROW) = (uint16_t)(whi >> 16);
+    *reinterpret_cast<uint16_t*>(w + 2 * A_ROW) = (uint16_t)wlo;
+    *reinterpret_cast<uint16_t*>(w + 3 * A_ROW) = (uint16_t)(wlo >> 16);
+  }
   wave_sync();
-  level_sums<FB>(slot0, slot_bytes, a.o4, a.o16, a.n16, lane);
+  const int g = lane >> 4, n = lane & 15;
+  const char* ar = abuf + ((lane & 15) & (4 * FB - 1)) * A_ROW + 16 * g;
+  const v8b a0 = *reinterpret_cast<const v8b*>(ar), a1 = *reinterpret_cast<const v8b*>(ar + 64);
+  const char* bt = reinterpret_cast<const char*>(img + OFF_S) + (n & 3) * MF_COPY_STRIDE + 2 * (64 - (n & ~3) + 8 * g);
+  auto btile = [&](int d, int lo) {   // d = 2 s - c
+    const char* p = bt + lo * MF_TAB_BYTES + 32 * d;
+    typedef short s4v __attribute__((ext_vector_type(4)));
+    const s4v u0 = *reinterpret_cast<const s4v*>(p), u1 = *reinterpret_cast<const s4v*>(p + 8);
+    typedef short s8v __attribute__((ext_vector_type(8)));
+    const s8v u = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+    return __builtin_bit_cast(v8b, u);
+  };
+#pragma unroll
+  for (int c = 0; c < 4; ++c) D[c] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int d = -3; d <= 2; ++d) {   // tiles in the order of their B registers
+    const v8b bh = btile(d, 0), bl = btile(d, 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int c = 2 * s - d;
+      if (c < 0 || c > 3) continue;
+      D[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(s ? a1 : a0, bh, D[c], 0, 0, 0);
+      D[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(s ? a1 : a0, bl, D[c], 0, 0, 0);
+    }
+  }
+}
+
+// masking thresholds of FB frames whose intensities are in their slots (prep_frames, or the caller's own stores: bin f
+// at 8 f); emit(fb, i, th) receives the thresholds of granule 64 i + lane of frame fb (lanes with in_frame(i) only).
+// img: the LDS copy of the image.  NC: filter_bands_n where the kernel knows it at compile time (0: a.N).  The caller orders
+// its stores of the intensities before the call (wave_sync) and its next use of the slots after it.
+template <int R, int FB, int NC, class IDX, class EMIT>
+__device__ __forceinline__ void threshold_frames(const v2f (&t)[FB], const RunsParams& a, const RunsLane& lc, const uint32_t* img,
+                                                 char* slot0, int slot_bytes, int lane, const IDX& idx, EMIT emit) {
+  static_assert(FB == 1 || FB == 2 || FB == 4, "frames side by side");
+  const RunsGeo geo = runs_geo(NC ? NC : a.N);
+  slot_init(a, slot0, FB, slot_bytes, lane);   // (the A image of the group before, or the caller's own use, ran over the zero words)
+  // partial sums over aligned runs of 4, 16 (64) bins
+  level_sums<FB>(slot0, slot_bytes, 0, geo.o4, geo.n4, lane);
+  wave_sync();
+  level_sums<FB>(slot0, slot_bytes, geo.o4, geo.o16, geo.n16, lane);
   if (a.n64 > 0) {
     wave_sync();
-    level_sums<FB>(slot0, slot_bytes, a.o16, a.o64, a.n64, lane);
+    level_sums<FB>(slot0, slot_bytes, geo.o16, geo.o64, a.n64, lane);
   }
   wave_sync();
   // P_j = sum_f I_f W[f, j]  (:312-313): lane = band; two weighted edge bins, the interior through the list
   v2f P0[FB], P1[FB];
   {
-    const uint32_t e0 = c.edge & 0xffffu, e1 = c.edge >> 16;
+    const uint32_t e0 = lc.edge & 0xffffu, e1 = lc.edge >> 16;
 #pragma unroll
     for (int fb = 0; fb < FB; ++fb) {
       const char* s = slot0 + fb * slot_bytes;
-      P0[fb] = *reinterpret_cast<const v2f*>(s + e0) * c.w0;
-      P1[fb] = *reinterpret_cast<const v2f*>(s + e1) * c.w1;
+      P0[fb] = *reinterpret_cast<const v2f*>(s + e0) * lc.w0;
+      P1[fb] = *reinterpret_cast<const v2f*>(s + e1) * lc.w1;
     }
-    const uint32_t* lst = img + a.off_lst + lane;
+    const uint32_t* lst = img + OFF_LST + lane;
     for (int k = 0; k < a.lw; ++k) {
       const uint32_t w = lst[64 * k];
       const uint32_t u0 = w & 0xffffu, u1 = w >> 16;
@@ -208,34 +329,55 @@ __device__ __forceinline__ void threshold_frames(const v2f (&t)[FB], const RunsP
     const v2f q = exp2v(a.alpha * log2v(maxv(P0[fb] + P1[fb], kEps)));
     Q[fb] = lane < a.M ? q : v2f{0.f, 0.f};
   }
-  v2f acc[FB];   // sum_i Q_i S[i, j] on the matrix cores, offset factor outside the sum  (:185-208)
-  mid::spread_tiles<FB>(Q, reinterpret_cast<const char*>(img + a.off_S), lane, acc);
-  wave_sync();   // every lane is done with the intensities and their sums: the head of each slot takes G and the entries
-  v2f G[FB];
+  wave_sync();   // every lane is done with the intensities and their sums: the head of the slots takes A, then G and the entries
+  v4f D[4];      // sum_i Q_i S[i, j] on the matrix cores, offset factor outside the sum  (:185-208)
+  spread16<FB>(Q, img, slot0, lane, D);
+  wave_sync();
+  // the rest of the per-band arithmetic in the accumulator's layout: lane (g, n) holds frame g % FB, bands 16 c + n of the FB
+  // tiles c = (g / FB) FB + ci
+  {
+    const int g = lane >> 4, n = lane & 15;
+    const int f = g & (FB - 1), cg = (g / FB) * FB;
+    // the frame's tonality (each candidate through an opaque copy: left alone the compiler turns the selection into an indexed
+    // load of t[] from scratch)
+    auto opaque = [](v2f x) { asm("" : "+v"(x)); return x; };
+    v2f tg = t[0];
+    if (FB >= 2) tg = (f & 1) ? opaque(t[1 % FB]) : tg;
+    if (FB == 4) tg = f == 2 ? opaque(t[2 % FB]) : f == 3 ? opaque(t[3 % FB]) : tg;
+    char* sf = slot0 + f * slot_bytes;
 #pragma unroll
-  for (int fb = 0; fb < FB; ++fb) {
-    const v2f offset = a.omd * (t[fb] * c.c1 + 5.5f);                                          // (1 - drown) (t beta + 9 t + 5.5)
-    const v2f y = maxv(log2v(acc[fb]) - (a.alpha * kLog2_10_10) * offset, kLog2Eps);           // log2 max(eps, fac acc)
-    G[fb] = maxv(exp2v(a.inv_alpha * y), c.quiet);                                             // (:208, :144)
-    *reinterpret_cast<v2f*>(slot0 + fb * slot_bytes + 8 * lane) = G[fb];
+    for (int ci = 0; ci < FB; ++ci) {
+      v4f d;
+      if (FB == 4) d = D[ci];
+      else if (FB == 2) d = cg ? D[2 + ci] : D[ci];
+      else d = g == 0 ? D[0] : g == 1 ? D[1] : g == 2 ? D[2] : D[3];
+      const v2f acc = v2f{d.x + d.z, d.y + d.w};
+      const int b = 16 * (cg + ci) + n;
+      const v4f bd = reinterpret_cast<const v4f*>(img + OFF_BD)[b];                              // {beta + 9, quiet, rho}
+      const v2f offset = a.omd * (tg * bd.x + 5.5f);                                            // (1 - drown) (t beta + 9 t + 5.5)
+      const v2f y = maxv(log2v(acc) - (a.alpha * kLog2_10_10) * offset, kLog2Eps);              // log2 max(eps, fac acc)
+      const v2f G = maxv(exp2v(a.inv_alpha * y), bd.y);                                         // (:208, :144)
+      const v2f A0 = maxv(G * bd.z, kEps);                                                      // interior bins of band b  (:330-331)
+      *reinterpret_cast<v2f*>(sf + 8 * b) = G;
+      *reinterpret_cast<v2f*>(sf + 512 + 16 * b) = v2f{__builtin_amdgcn_sqrtf(A0.x), __builtin_amdgcn_sqrtf(A0.y)};
+    }
   }
   wave_sync();
-  // entries: interior bins of band `lane` sqrt(max(eps, G rho)); edge bin `lane` sqrt(max(eps, sum_k G_{j0+k} u_k))  (:330-331)
+  // edge bin `lane`: sqrt(max(eps, sum_k G_{j0+k} u_k))  (:330-331)
   {
     v2f s[FB];
 #pragma unroll
     for (int fb = 0; fb < FB; ++fb) s[fb] = v2f{0.f, 0.f};
-    const float* bw = reinterpret_cast<const float*>(img + a.off_bw) + lane;
+    const float* bw = reinterpret_cast<const float*>(img + off_bw(a.lw)) + lane;
     for (int k = 0; k < a.kb; ++k) {
       const float u = bw[64 * k];
 #pragma unroll
-      for (int fb = 0; fb < FB; ++fb) s[fb] += *reinterpret_cast<const v2f*>(slot0 + fb * slot_bytes + c.goff + 8 * k) * u;
+      for (int fb = 0; fb < FB; ++fb) s[fb] += *reinterpret_cast<const v2f*>(slot0 + fb * slot_bytes + lc.goff + 8 * k) * u;
     }
 #pragma unroll
     for (int fb = 0; fb < FB; ++fb) {
-      const v2f A0 = maxv(G[fb] * c.rho, kEps), A1 = maxv(s[fb], kEps);
-      *reinterpret_cast<v4f*>(slot0 + fb * slot_bytes + 512 + 16 * lane) =
-          v4f{__builtin_amdgcn_sqrtf(A0.x), __builtin_amdgcn_sqrtf(A0.y), __builtin_amdgcn_sqrtf(A1.x), __builtin_amdgcn_sqrtf(A1.y)};
+      const v2f A1 = maxv(s[fb], kEps);
+      *reinterpret_cast<v2f*>(slot0 + fb * slot_bytes + 512 + 16 * lane + 8) = v2f{__builtin_amdgcn_sqrtf(A1.x), __builtin_amdgcn_sqrtf(A1.y)};
     }
   }
   wave_sync();

@@ -76,7 +76,7 @@ def thresholds(L, img, N, M, alpha, X, t, g, drown=0.0):
         for i in range(M):
             acc[j] += Q[i] * float(g[M - i + j])
     for lane in range(64):
-        quiet = float(fimg[L["off_bc"] + 4 * lane + 3])
+        quiet = float(fimg[L["off_bd"] + 4 * lane + 1])
         c1 = float(fimg[L["off_bd"] + 4 * lane])
         offset = (1.0 - drown) * (float(t) * c1 + 5.5)
         with np.errstate(divide="ignore"):
@@ -86,8 +86,8 @@ def thresholds(L, img, N, M, alpha, X, t, g, drown=0.0):
         put(8 * lane, G[lane])
     entries = np.zeros((64, 2), dtype=np.float64)
     for lane in range(64):
-        rho = float(fimg[L["off_bd"] + 4 * lane + 1])
-        goff = int(img[L["off_bd"] + 4 * lane + 2])
+        rho = float(fimg[L["off_bd"] + 4 * lane + 2])
+        goff = int(img[L["off_bc"] + 4 * lane + 3])
         s = 0.0
         for k in range(L["kb"]):
             assert goff + 8 * k < 512
