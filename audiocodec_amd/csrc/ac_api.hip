@@ -630,6 +630,9 @@ static int encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const 
   // filters_n 64 ... 512: the several-frames-per-wave kernels with the general-layout masking model in the same launch
   if (!g_force_generic && mdct->fast && fast_multi_fuses(mdct, psy, C, pcm16 ? 1 : 0, K))
     return launch_fwd_fast(mdct, psy, x, 0, X, t, thr, drown, nullptr, B, K, K + 1, C, s);
+  // the LDS-FFT tier's instances with the masking model on the frame while it is in LDS
+  if (!pcm16 && !wave_level(mdct, C, 0, K) && K >= 1 && wave_encode_fuses(mdct, psy, C, x, X, thr))
+    return launch_enc_wave(mdct, psy, static_cast<const float*>(x), X, t, thr, drown, nullptr, B, K, K + 1, C, s);
   // un-fused composition for configurations the fused kernel does not cover: the transform, then tonality + threshold in
   // one wave-level pass over X where the general-layout masking kernels serve the plan, else the two generic kernels
   st = mdct_forward(mdct, x, pcm16, X, B, K, C, stream);
@@ -644,6 +647,7 @@ int ac_encode_launches(const ac_mdct_plan* mdct, const ac_psy_plan* psy, int C) 
   if (g_force_generic) return 3;
   if (mdct->fast && psy->fast && wave_level(mdct, C, 0, 1) && psy_fast_serves(psy, C)) return (mdct->N == 2048 && C == 1) ? 2 : 1;   // (see encode_fused)
   if (mdct->fast && fast_multi_fuses(mdct, psy, C, 0, 1)) return 1;
+  if (!wave_level(mdct, C, 0, 1) && wave_encode_fuses(mdct, psy, C, nullptr, nullptr, nullptr)) return 1;   // (tensors on the 16-byte grid)
   return (psy_mid_serves(psy, C) || psy_fast_serves(psy, C)) ? 2 : 3;
 }
 

@@ -8,6 +8,7 @@
 #include <utility>
 
 #include "ac_internal.h"
+#include "ac_psy_runs_dev.h"
 
 namespace ac {
 
@@ -348,7 +349,7 @@ __device__ __forceinline__ void wave_sync_lds() {
 #define AC_PAD_SHIFT 4
 static inline __host__ __device__ constexpr int pad_shift_ct(int N) { return N == 120 || N == 36 ? 2 : AC_PAD_SHIFT; }
 __device__ __forceinline__ int pad16(int i, int ps = AC_PAD_SHIFT) { return i + (i >> ps); }
-static inline __host__ __device__ int padded_len(int n, int ps = AC_PAD_SHIFT) { return n + (n >> ps) + 1; }
+static inline __host__ __device__ constexpr int padded_len(int n, int ps = AC_PAD_SHIFT) { return n + (n >> ps) + 1; }
 
 // compile-time cos / sin of 2 pi e / R (Taylor series on the angle reduced to [-pi, pi])
 constexpr double c_series(double x, bool sine) {
@@ -704,8 +705,8 @@ __device__ __forceinline__ void dct4_group_ct(float2* v, cpair* buf, const WaveT
 }
 
 // LDS floats per frame of the wave form: Bp (= v) and Ap, padded; of the in-place form above: one buffer
-static inline __host__ __device__ int wave_floats_per_group(int N, int ps = AC_PAD_SHIFT) { return 2 * 4 * padded_len(N / 2, ps); }
-static inline __host__ __device__ int group_floats_per_frame(int N, int ps = AC_PAD_SHIFT) { return 4 * padded_len(N / 2, ps); }
+static inline __host__ __device__ constexpr int wave_floats_per_group(int N, int ps = AC_PAD_SHIFT) { return 2 * 4 * padded_len(N / 2, ps); }
+static inline __host__ __device__ constexpr int group_floats_per_frame(int N, int ps = AC_PAD_SHIFT) { return 4 * padded_len(N / 2, ps); }
 
 // the FFT's twiddles exp(-2 pi i k / (N/2)), k < N/2, once per workgroup into LDS (every thread takes part; the caller
 // synchronises before the first use)
@@ -1236,6 +1237,313 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
       if (i < h) rp.store2(Xa, Xb, 2 * i, *reinterpret_cast<const v4f_t*>(v + 2 * i) * scale);
     }
     group_sync<NTC>();
+  }
+}
+
+// ---- the fused encode of the LDS-FFT tier: k_fwd_wave_v with the masking model (run-structured form, ac_psy_runs_dev.h) in
+// the same launch -- X is not read back from HBM; same device code on the same values as the stand-alone kernel (k_psy_runs),
+// so X, tonality and threshold equal transform -> tonality -> threshold bit for bit.  In two phases per strip of frames:
+//   1. frame by frame, while the spectrum is in LDS: X out, the intensities in its place (bin f at 8 f: the model's slot, the
+//      partial sums where the transform's second buffer was), tonality and the 64 band intensities P_j -- the part of the model
+//      that needs every bin.  t goes to its tensor, P to the head of the frame's (not yet written) threshold row: 512 bytes that
+//      come back from L2 in phase 2.
+//   2. after the strip's last frame, when the transform's registers are dead: four frames at a time side by side -- P and t back
+//      in, spreading product on the matrix cores, threshold entries, and every bin's look-up straight into the threshold rows.
+// The transform's loop keeps its registers and occupancy; the per-band arithmetic runs where it interleaves four frames.
+//   up to 64 lanes per frame: the wave works on its 64 / NTC frames (one strip each) together -- it needs all 64 lanes (= bands)
+//     on every frame, so every group of lanes walks the same number of steps;
+//   a frame on NTC / 64 waves (filters_n above 1024): all waves store X, square and form the partial sums and their share of the
+//     tonality sums (one interleaved accumulator each: runs::tonality_ways); the first wave finishes t and P; in phase 2 the
+//     waves take groups of four frames in turn.
+struct WaveEncArgs {
+  const uint32_t* img;   // ac_psy_plan::d_runs
+  runs::RunsParams rp;
+  float* t;              // [B, F, 1, C]
+  float* thr;            // as X
+};
+static inline __host__ __device__ constexpr int enc_r(int N) { return N <= 128 ? 1 : N <= 256 ? 2 : N <= 512 ? 4 : N <= 1024 ? 8 : N <= 2048 ? 16 : 32; }
+constexpr int kEncSlot2 = 1536;   // bytes per frame in phase 2: G (512) + the threshold entries (1024)
+// floats of LDS per frame: what the transform needs, or the model's largest slot; a frame on several waves: and room for every
+// wave's four slots of phase 2
+static inline __host__ __device__ constexpr int enc_floats_per_frame(int N, int nt, int ps) {
+  const int fft = nt > 64 ? group_floats_per_frame(N, ps) : wave_floats_per_group(N, ps), slot = runs::runs_slot_max(N) / 4;
+  const int ph2 = nt > 64 ? (nt / 64) * 4 * kEncSlot2 / 4 : 0;
+  const int m = fft > slot ? fft : slot;
+  return m > ph2 ? m : ph2;
+}
+template <int NC, int NTC, int R0, int R1, int R2, int R3, int LAY>
+static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k_enc_wave_v(const float* __restrict__ x, float* __restrict__ X,
+                                                          const float* __restrict__ prev_block, const v4f_t* __restrict__ coefv,
+                                                          const float* __restrict__ ctab, int Kin, int F, long long ntasks,
+                                                          int T, int nstrip, int B, WaveEncArgs pa) {
+  static_assert(NC != 0 && LAY <= 1, "instances only; stereo or mono rows");
+  using runs::v2f;
+  using runs::v4f;
+  float* smem = reinterpret_cast<float*>(smem_raw);
+  constexpr int N = NC, nt = NTC;
+  constexpr bool GRP = NTC > 64;   // one frame per workgroup of NTC lanes, transformed in place
+  constexpr int ps = pad_shift_ct(NC);
+  constexpr int per = enc_floats_per_frame(NC, NTC, ps), h = N >> 1, q = N >> 2;
+  constexpr int RQ = enc_r(NC);                                  // granule registers per lane of a 64-lane pass over a frame
+  constexpr int FPW = GRP ? 1 : 64 / NTC;                        // frames per wave
+  constexpr int NW = GRP ? NTC / 64 : 1;                         // waves per frame
+  constexpr int FB = GRP ? 1 : (NTC == 64 ? 1 : NTC == 32 ? 2 : 4);   // frames side by side in phase 1
+  static_assert(!GRP || NW == runs::tonality_ways(RQ), "a wave per tonality accumulator");
+  const int gpw = (int)blockDim.x / nt, grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
+  const int lane = threadIdx.x & 63;
+  float2* tw = reinterpret_cast<float2*>(smem + (size_t)gpw * per);
+  for (int k = threadIdx.x; k < h; k += blockDim.x) {
+    tw[k] = cis_neg(ctab, 16 * k, N);
+    tw[h + k] = cis_neg(ctab, 4 * k, N);
+    if constexpr (!GRP) tw[2 * h + k] = cis_neg(ctab, 4 * k + 1, N);
+  }
+  uint32_t* pimg = reinterpret_cast<uint32_t*>(tw + (GRP ? 2 : 3) * h);   // the masking model's image (without the per-bin entry offsets)
+  for (int i = threadIdx.x; i < pa.rp.lds_words / 4; i += blockDim.x) reinterpret_cast<uint4*>(pimg)[i] = reinterpret_cast<const uint4*>(pa.img)[i];
+  __syncthreads();
+  const WaveTabs tb = {tw, tw + 2 * h, tw + h};   // (the in-place form has no pre-twiddle table)
+  const float2 pre0 = cis_neg(ctab, 1, N);        // exp(-i pi / (4 N))
+  float* base = smem + (size_t)grp * per;
+  float2* v = reinterpret_cast<float2*>(base);
+  cpair* Bp = reinterpret_cast<cpair*>(base);
+  cpair* Ap = reinterpret_cast<cpair*>(base + 4 * padded_len(h, ps));
+  const float scale = (float)(1.0 / ((double)N * 1.4142135623730951));
+  const long long wg0 = (long long)blockIdx.x * gpw + grp;
+  // (a group past the last task stays: its lanes are bands of the wave's other frames; it works on task 0 and stores nothing)
+  const bool live = wg0 < ntasks;
+  if (GRP && !live) return;
+  const long long wg = live ? wg0 : 0;
+  const int sp = (int)(wg % nstrip);
+  const long long pr = wg / nstrip;
+  const PairGeo gx = pair_geo<LAY>(pr, N, B, LAY == 0 ? 2 : 1, (size_t)Kin), gX = pair_geo<LAY>(pr, N, B, LAY == 0 ? 2 : 1, (size_t)F),
+                gp = pair_geo<LAY>(pr, N, B, LAY == 0 ? 2 : 1, 1);
+  const RowPair<LAY> rp = {gx.has1, LAY == 0 ? 2 : 1};
+  const int n0 = sp * T, n1 = live ? min(n0 + T, F) : n0;
+  const size_t t_a = LAY == 0 ? (size_t)pr * F * 2 : (size_t)(2 * pr) * F, t_step = LAY == 0 ? 2 : 1;   // tonality of frame n, signal 0
+  const size_t t_b = LAY == 0 ? 1 : (size_t)F;                                                           // ... signal 1, from there
+  v4f_t d0[kWaveVSteps], d1[kWaveVSteps], cy[kWaveVSteps];
+  auto load_block = [&](auto xa, auto xb) {
+#pragma unroll
+    for (int s = 0; s < kWaveVSteps; ++s) {
+      const int i = tid + s * nt;
+      if (i < q) {
+        d0[s] = rp.load2(xa, xb, 2 * i);           // samples 2 i, 2 i + 1
+        d1[s] = rp.load2(xa, xb, N - 2 - 2 * i);   // samples N - 2 - 2 i, N - 1 - 2 i
+      }
+    }
+  };
+  auto fold2 = [](float a, float x, float b, float y) { return __builtin_fmaf(a, x, b * y); };   // (one rounding order: see k_fwd_wave_v)
+  auto carry_of = [&](int s, int i) {   // (v[h - 2 - 2 i], v[h - 1 - 2 i]) of the NEXT frame
+    const v4f_t g = coefv[2 * i + 1];
+    return v4f_t{fold2(g.z, d0[s].z, g.w, d1[s].x), fold2(g.z, d0[s].w, g.w, d1[s].y), fold2(g.x, d0[s].x, g.y, d1[s].z),
+                 fold2(g.x, d0[s].y, g.y, d1[s].w)};
+  };
+  {
+    const bool have = n0 >= 1 || prev_block != nullptr;
+    if (n0 >= 1) load_block(x + gx.off_a + (size_t)(n0 - 1) * gx.block_stride, x + gx.off_b + (size_t)(n0 - 1) * gx.block_stride);
+    else if (prev_block) load_block(prev_block + gp.off_a, prev_block + gp.off_b);
+#pragma unroll
+    for (int s = 0; s < kWaveVSteps; ++s) {
+      const int i = tid + s * nt;
+      cy[s] = (have && i < q) ? carry_of(s, i) : v4f_t{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  if (n0 < Kin) load_block(x + gx.off_a + (size_t)n0 * gx.block_stride, x + gx.off_b + (size_t)n0 * gx.block_stride);
+  // the wave's first frame region = its first slot; a frame's region is its slot (bytes `per` * 4 apart)
+  char* wslot0 = reinterpret_cast<char*>(smem + (size_t)(GRP ? grp : (threadIdx.x >> 6) * FPW) * per);
+  char* myslot = reinterpret_cast<char*>(base);
+  constexpr int SLOT = per * 4;
+  const runs::RunsGeo geo = runs::runs_geo(NC);
+  // ---- phase 1
+  for (int it = 0; it < T; ++it) {   // (every group of a wave walks T steps: the model needs all 64 lanes on each)
+    const int n = n0 + it;
+    const bool fr = n < n1;          // this group has a frame in this step
+    if (GRP && !fr) break;
+    const bool has_cur = n < Kin;
+#pragma unroll
+    for (int s = 0; s < kWaveVSteps; ++s) {
+      const int i = tid + s * nt;
+      if (i < q) {
+        v4f_t hi = {0.f, 0.f, 0.f, 0.f};
+        if (has_cur) {
+          const v4f_t f = coefv[2 * i];
+          hi = v4f_t{fold2(f.x, d0[s].x, f.y, d1[s].z), fold2(f.x, d0[s].y, f.y, d1[s].w), fold2(f.z, d0[s].z, f.w, d1[s].x),
+                     fold2(f.z, d0[s].w, f.w, d1[s].y)};
+        }
+        *reinterpret_cast<v4f_t*>(v + h + 2 * i) = hi;
+        *reinterpret_cast<v4f_t*>(v + h - 2 - 2 * i) = cy[s];
+        if (has_cur) cy[s] = carry_of(s, i);
+      }
+    }
+    if (n + 1 < n1 && n + 1 < Kin)   // lands during the transform (issued after it: 0.758 -> 0.808 ms at 960, 0.864 -> 0.950 at 4096)
+      load_block(x + gx.off_a + (size_t)(n + 1) * gx.block_stride, x + gx.off_b + (size_t)(n + 1) * gx.block_stride);
+    group_sync<NTC>();
+    if constexpr (GRP) dct4_group_ct<NC, NTC, R0, R1, R2, R3>(v, Bp, tb, pre0, tid);
+    else dct4_wave_ct<NC, NTC, R0, R1, R2, R3>(v, Ap, Bp, tb, tid);
+    const size_t nn = fr ? (size_t)n : 0;
+    float* Xa = X + gX.off_a + nn * gX.block_stride;
+    float* Xb = X + gX.off_b + nn * gX.block_stride;
+    float* Ta = pa.thr + gX.off_a + nn * gX.block_stride;
+    float* Tb = pa.thr + gX.off_b + nn * gX.block_stride;
+    // X out; the frame's intensities take its place (bin f at 8 f: the model's slot).  One wave per frame: the lane's granules
+    // tid + 64 s are the ones the tonality sums take from it, so their intensities stay in registers for that
+    v4f Ireg[NTC == 64 ? 2 * kWaveVSteps : 1];
+#pragma unroll
+    for (int s = 0; s < 2 * kWaveVSteps; ++s) {
+      const int i = tid + s * nt;
+      v4f I = {0.f, 0.f, 0.f, 0.f};
+      if (i < h) {
+        const v4f_t r = *reinterpret_cast<const v4f_t*>(v + 2 * i) * scale;
+        if (fr) rp.store2(Xa, Xb, 2 * i, r);
+        I = runs::squares(r);
+        *reinterpret_cast<v4f*>(v + 2 * i) = I;
+      }
+      if constexpr (NTC == 64) Ireg[s] = I;
+    }
+    group_sync<NTC>();
+    auto isrc_of = [&](const char* slot) {
+      return [=](int i) {
+        return (RQ * 128 == NC || 64 * i + lane < h) ? *reinterpret_cast<const v4f*>(slot + 16 * (64 * i + lane)) : v4f{0.f, 0.f, 0.f, 0.f};
+      };
+    };
+    if constexpr (GRP) {
+      // a wave per tonality accumulator; the partial sums of 4, 16 (64) bins by all lanes
+      const int w = tid >> 6;
+      const v4f part = runs::lane_sums<RQ, 4>(isrc_of(myslot), pa.rp, lane, w, NW);
+      runs::level_sums<1>(myslot, SLOT, 0, geo.o4, geo.n4, tid, nt);
+      __syncthreads();
+      runs::level_sums<1>(myslot, SLOT, geo.o4, geo.o16, geo.n16, tid, nt);
+      if (pa.rp.n64 > 0) {
+        __syncthreads();
+        runs::level_sums<1>(myslot, SLOT, geo.o16, geo.o64, pa.rp.n64, tid, nt);
+      }
+      // the accumulators of waves 1 .. NW - 1 meet the first wave's behind the image (the launcher sizes it)
+      v4f* xch = reinterpret_cast<v4f*>(pimg + pa.rp.lds_words);   // [NW - 1][64] v4f behind the image (the launcher sizes it)
+      if (w > 0) xch[(w - 1) * 64 + lane] = part;
+      __syncthreads();
+      if (w == 0) {
+        v4f acc1[1] = {part};
+#pragma unroll
+        for (int k = 1; k < NW; ++k) acc1[0] += xch[(k - 1) * 64 + lane];
+        v2f t1[1], P1[1];
+        runs::tonality_finish<1>(acc1, pa.rp, lane, t1);
+        runs::band_sums<1>(pa.rp, runs::load_lane(pimg, lane), pimg, myslot, SLOT, lane, P1);
+        if (lane == 0) {
+          pa.t[t_a + nn * t_step] = t1[0].x;
+          if (rp.has1) pa.t[t_a + nn * t_step + t_b] = t1[0].y;
+        }
+        // P_j as "bin j" of the threshold row: lanes j, j + 1 (j even) make one 16-byte granule
+        const float px = __shfl_down(P1[0].x, 1, 64), py = __shfl_down(P1[0].y, 1, 64);
+        if ((lane & 1) == 0) rp.store2(Ta, Tb, lane, v4f_t{P1[0].x, P1[0].y, px, py});
+      }
+    } else {
+#pragma unroll 1
+      for (int g0 = 0; g0 < FPW; g0 += FB) {
+        char* slots = wslot0 + g0 * SLOT;
+        v2f tf[FB], Pf[FB];
+        if constexpr (NTC == 64) {
+          static_assert(RQ == 2 * kWaveVSteps, "eight granules per lane");
+          runs::tonality_from<RQ, FB, 0>([&](int, int i) { return Ireg[i]; }, pa.rp, lane, tf);
+        } else {
+          runs::tonality_from<RQ, FB, 4>([&](int fb, int i) { return isrc_of(slots + fb * SLOT)(i); }, pa.rp, lane, tf);
+        }
+        runs::level_sums<FB>(slots, SLOT, 0, geo.o4, geo.n4, lane);
+        wave_sync_lds();
+        runs::level_sums<FB>(slots, SLOT, geo.o4, geo.o16, geo.n16, lane);
+        if (pa.rp.n64 > 0) {
+          wave_sync_lds();
+          runs::level_sums<FB>(slots, SLOT, geo.o16, geo.o64, pa.rp.n64, lane);
+        }
+        runs::band_sums<FB>(pa.rp, runs::load_lane(pimg, lane), pimg, slots, SLOT, lane, Pf);
+        // P (lane = band) and t of frame fb to the lanes of its group: through the head of its slot (the intensities are done with)
+        wave_sync_lds();
+#pragma unroll
+        for (int fb = 0; fb < FB; ++fb) {
+          *reinterpret_cast<v2f*>(slots + fb * SLOT + 8 * lane) = Pf[fb];
+          if (lane == 0) *reinterpret_cast<v2f*>(slots + fb * SLOT + 512) = tf[fb];
+        }
+      }
+      wave_sync_lds();
+      if (fr) {
+        if (tid == 0) {
+          const v2f tm = *reinterpret_cast<const v2f*>(myslot + 512);
+          pa.t[t_a + nn * t_step] = tm.x;
+          if (rp.has1) pa.t[t_a + nn * t_step + t_b] = tm.y;
+        }
+        for (int i = tid; i < 32; i += nt) rp.store2(Ta, Tb, 2 * i, *reinterpret_cast<const v4f_t*>(myslot + 16 * i));   // P_j as "bin j" of the threshold row
+      }
+    }
+    group_sync<NTC>();
+  }
+  // ---- phase 2: the strip's frames four at a time -- slots of kEncSlot2 bytes at the head of the wave's region
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores of P and t have landed (L2) before anything reads them back
+    if constexpr (GRP) __syncthreads();
+    const runs::RunsLane lc = runs::load_lane(pimg, lane);
+    const int total = GRP ? n1 - n0 : T * FPW;         // frames of the wave (of the workgroup: GRP), in the order m = step * FPW + group
+    const int w = GRP ? (tid >> 6) : 0;
+    char* slots2 = GRP ? myslot + w * (4 * kEncSlot2) : wslot0;
+    const int mygroup = GRP ? 0 : lane / NTC;
+    // entry-offset words of the granules this lane stores: i = tid + s nt (a frame on several waves: i = lane + 64 s, read per use)
+    uint32_t ew[GRP ? 1 : 2 * kWaveVSteps];
+    if constexpr (!GRP) {
+#pragma unroll
+      for (int s = 0; s < 2 * kWaveVSteps; ++s) {
+        const int i = tid + s * nt;
+        ew[s] = i < h ? pa.img[runs::off_idx(pa.rp.lw, pa.rp.kb) + i] : 0u;
+      }
+    }
+    for (int m0 = 4 * w; m0 < total; m0 += 4 * NW) {
+      wave_sync_lds();   // the look-ups of the four frames before are done
+      // P and t back in: the lanes of a frame's group read its row's head (L2) into the frame's slot.  A slot without a frame --
+      // past the strip, or a group without a task -- keeps what it held: finite stand-ins (a frame's arithmetic touches only its
+      // own rows of the matrix product and its own slot), nothing of it is stored
+      bool mine[4];
+      float* Ta[4];
+      float* Tb[4];
+#pragma unroll
+      for (int fb = 0; fb < 4; ++fb) {
+        const int m = m0 + fb, g = GRP ? 0 : m % FPW, n = n0 + (GRP ? m : m / FPW);
+        mine[fb] = g == mygroup && m < total && n < n1;
+        const size_t nn = mine[fb] ? (size_t)n : 0;
+        Ta[fb] = pa.thr + gX.off_a + nn * gX.block_stride;
+        Tb[fb] = pa.thr + gX.off_b + nn * gX.block_stride;
+        char* sl = slots2 + fb * kEncSlot2;
+        if (mine[fb]) {
+          const int l = GRP ? lane : tid;
+          for (int i = l; i < 32; i += (GRP ? 64 : nt)) *reinterpret_cast<v4f_t*>(sl + 16 * i) = rp.load2(Ta[fb], Tb[fb], 2 * i);
+          if (l == 0) *reinterpret_cast<v2f*>(sl + 512) = v2f{pa.t[t_a + nn * t_step], rp.has1 ? pa.t[t_a + nn * t_step + t_b] : 0.f};
+        }
+      }
+      wave_sync_lds();
+      v2f P4[4], t4[4];
+#pragma unroll
+      for (int fb = 0; fb < 4; ++fb) {
+        const char* sl = slots2 + fb * kEncSlot2;
+        P4[fb] = *reinterpret_cast<const v2f*>(sl + 8 * lane);
+        t4[fb] = *reinterpret_cast<const v2f*>(sl + 512);
+      }
+      runs::band_tail<4>(P4, t4, pa.rp, lc, pimg, slots2, kEncSlot2, lane);
+      wave_sync_lds();
+      if constexpr (GRP) {
+#pragma unroll 2
+        for (int i = lane; i < h; i += 64) {
+          const uint32_t wi = pa.img[runs::off_idx(pa.rp.lw, pa.rp.kb) + i];
+#pragma unroll
+          for (int fb = 0; fb < 4; ++fb)
+            if (mine[fb]) rp.store2(Ta[fb], Tb[fb], 2 * i, runs::entry_lookup(slots2 + fb * kEncSlot2, wi));
+        }
+      } else {
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) {
+          if (!mine[fb]) continue;
+#pragma unroll
+          for (int s = 0; s < 2 * kWaveVSteps; ++s) {
+            const int i = tid + s * nt;
+            if (i < h) rp.store2(Ta[fb], Tb[fb], 2 * i, runs::entry_lookup(slots2 + fb * kEncSlot2, ew[s]));
+          }
+        }
+      }
+    }
   }
 }
 
@@ -2140,10 +2448,103 @@ static int launch_inv_wave_v(const ac_mdct_plan* p, const float* X, TX* x, const
 }
 
 #ifdef AC_WAVE_ROWS_TU
-// ---- this file compiled again as ac_wave_rows.hip (AC_WAVE_ROWS_TU = 1: mono rows) and ac_wave_rows2.hip (= 2: channel
-// pairs of any channel count): only the instances of the 16-byte kernels for that row layout and their two launchers (the
-// instances of one layout take a minute to compile: translation units of their own)
-#if AC_WAVE_ROWS_TU == 1
+// ---- this file compiled again as ac_wave_rows.hip (AC_WAVE_ROWS_TU = 1: mono rows), ac_wave_rows2.hip (= 2: channel
+// pairs of any channel count) and ac_wave_enc.hip (= 3: the fused encode): only the instances of the 16-byte kernels for
+// that row layout / form and their launchers (the instances of one layout take a minute to compile: translation units of
+// their own)
+#if AC_WAVE_ROWS_TU == 3
+// the fused encode (k_enc_wave_v): sizes with an instance whose frame region holds a slot of the model -- filters_n 108 ...
+// 4096 (the masking model's range ends there; below 108 a frame's LDS is smaller than the model's smallest slot)
+static bool enc_size(int N) { return N >= 108 && N <= 4096 && lds_wave_ct_size(N); }
+// ... and where the one launch measured faster than transform + masking kernel on an MI355X (ratio <= 0.98 over B = 256 stereo
+// clips of 10 s, profiles/r4/lds_fft_fused_encode_sweep.txt: 0.74 - 0.98; the instances left out ran 1.0 - 1.33 x -- the ones
+// that spill registers, and the small sizes, where the per-frame part of the model outweighs the second read of X)
+static bool enc_pays(int N) {
+  static const int sizes[] = {500, 540, 600, 640, 648, 720, 768, 800, 864, 960, 1296, 1440, 1500, 1536, 1728, 2160, 2304, 2400, 2500,
+                              2560, 2592, 2700, 2880, 2916, 3000, 3072, 3200, 3456, 4096};
+  for (int n : sizes)
+    if (n == N) return true;
+  return false;
+}
+template <int LAY>
+static int launch_enc_wave_v(const ac_mdct_plan* p, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr,
+                             float drown, const float* prev_block, int B, int Kin, int F, hipStream_t s) {
+  const WavePlan wp = lds_wave_plan(p->N);
+  const int N = p->N, ps = pad_shift_ct(N);
+  WaveEncArgs pa;
+  pa.img = psy->d_runs;
+  pa.rp = runs_params(psy, drown, false);
+  pa.t = t;
+  pa.thr = thr;
+  const int per = enc_floats_per_frame(N, wp.nt, ps);
+  const size_t fixed = ((size_t)(wp.nt > 64 ? 2 : 3) * N + (size_t)pa.rp.lds_words) * sizeof(float) +
+                       (wp.nt > 64 ? (size_t)(wp.nt / 64 - 1) * 1024 : 0);   // (... and the tonality accumulators of a frame's other waves)
+  int w = 1, gpw = 1;
+  size_t lds = 0;
+  if (wp.nt > 64) {
+    w = wp.nt / 64;
+    lds = (size_t)per * sizeof(float) + fixed;
+  } else {   // waves per workgroup that leave the most waves resident (the tables are paid per workgroup)
+    long best = -1;
+    for (int ww = 1; ww <= 4; ++ww) {
+      const size_t b = (size_t)(64 / wp.nt) * ww * per * sizeof(float) + fixed;
+      const long res = b > 160 * 1024 ? -1 : (long)std::min<size_t>(8 / ww, 160 * 1024 / b) * ww;
+      if (res >= best) {
+        best = res;
+        w = ww;
+        lds = b;
+      }
+    }
+    if (best < 0) return AC_EUNSUPPORTED;
+    gpw = w * (64 / wp.nt);
+  }
+  if (lds > 160 * 1024) return AC_EUNSUPPORTED;
+  const long long pairs = LAY == 0 ? (long long)B : ((long long)B + 1) / 2;
+  const int T = wave_strip(pairs, F, gpw, w, lds, p->cus, 0.25);
+  const int nstrip = (F + T - 1) / T;
+  const long long ntasks = pairs * nstrip;
+  const long long g = (ntasks + gpw - 1) / gpw;
+  const int st2 = check_grid(g);
+  if (st2) return st2 < 0 ? st2 : AC_OK;
+  int st = AC_OK;
+  bool done = false;
+#define AC_WAVE_CT(NC, NTC, R0, R1, R2, R3)                                                                                   \
+  if constexpr (NC >= 108 && NC <= 4096) {                                                                                     \
+    if (!done && N == NC) {                                                                                                    \
+      done = true;                                                                                                             \
+      st = allow_lds(k_enc_wave_v<NC, NTC, R0, R1, R2, R3, LAY>, lds);                                                         \
+      if (!st)                                                                                                                 \
+        hipLaunchKernelGGL((k_enc_wave_v<NC, NTC, R0, R1, R2, R3, LAY>), dim3((unsigned)g), dim3(64 * w), lds, s, x, X,        \
+                           prev_block, reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kin, F, ntasks, T, nstrip, B, pa); \
+    }                                                                                                                          \
+  }
+  AC_WAVE_CT_SIZES
+#undef AC_WAVE_CT
+  if (!done) {
+    set_error("internal: no fused-encode instance for filters_n = %d", N);
+    return AC_EUNSUPPORTED;
+  }
+  if (st) return st;
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+// whether encode() on these tensors is the one fused launch of the LDS-FFT tier: float32 mono / stereo rows on the 8- / 16-byte
+// grid, a size with an instance, a masking model with the run structure
+bool wave_encode_fuses(const ac_mdct_plan* p, const ac_psy_plan* psy, int C, const void* x, const void* X, const void* thr) {
+  const char* e = getenv("AC_LDS_WAVE_NOFUSE");   // (A/B measurements: read per call, so that one process can time both forms)
+  const int off = e ? atoi(e) : 0;
+  if (off == 1 || g_force_generic || !p || !psy || !psy->runs || p->N != psy->N || !enc_size(p->N) || wave_ct_off()) return false;
+  if (off != 2 && !enc_pays(p->N)) return false;   // (2: every instance, as the tests run them)
+  if (C < 1 || C > 2 || !lds_wave_vec_ok(p, lds_wave_plan(p->N), C)) return false;
+  const int lay = wave_v_layout(C, {x, X, thr});
+  return lay == 0 || lay == 1;
+}
+int launch_enc_wave(const ac_mdct_plan* p, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr, float drown,
+                    const float* prev_block, int B, int Kin, int F, int C, hipStream_t s) {
+  return C == 2 ? launch_enc_wave_v<0>(p, psy, x, X, t, thr, drown, prev_block, B, Kin, F, s)
+                : launch_enc_wave_v<1>(p, psy, x, X, t, thr, drown, prev_block, B, Kin, F, s);
+}
+#elif AC_WAVE_ROWS_TU == 1
 int launch_fwd_wave_mono(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin, int F,
                          hipStream_t s) {
   return launch_fwd_wave_v<1>(p, x, X, prev_block, B, Kin, F, 1, s);

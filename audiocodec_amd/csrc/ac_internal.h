@@ -188,6 +188,11 @@ int launch_fwd_lds_pcm16(const ac_mdct_plan* p, const int16_t* x, float* X, int 
 int launch_inv_lds_pcm16(const ac_mdct_plan* p, const float* X, int16_t* x, int B, int Kp, int C, hipStream_t s);
 int launch_fwd_wave_mono_pcm16(const ac_mdct_plan* p, const int16_t* x, float* X, int B, int Kin, int F, hipStream_t s);
 int launch_inv_wave_mono_pcm16(const ac_mdct_plan* p, const float* X, int16_t* x, int B, int Kp, int nblk, hipStream_t s);
+// the fused encode of the LDS-FFT tier (ac_wave_enc.hip): the 16-byte analysis kernels with the run-structured masking model
+// on the frame while it is in LDS; filters_n 108 ... 4096 with an instance, float32 mono / stereo
+bool wave_encode_fuses(const ac_mdct_plan* p, const ac_psy_plan* psy, int C, const void* x, const void* X, const void* thr);
+int launch_enc_wave(const ac_mdct_plan* p, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr, float drown,
+                    const float* prev_block, int B, int Kin, int F, int C, hipStream_t s);
 // ... and on channel pairs of any channel count / rows off the 16-byte grid (ac_wave_rows2.hip)
 int launch_fwd_wave_strided(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin, int F,
                             int C, hipStream_t s);

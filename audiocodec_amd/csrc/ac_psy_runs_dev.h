@@ -151,35 +151,44 @@ __device__ __forceinline__ float wave_totals(float (&v)[16], int lane) {
 // once for both).  Value number of (frame fb, kind = 0 sum of logs / 1 sum of squares, signal ch) in wave_totals:
 // FB = 4: 4 fb + 2 kind + ch; FB = 2: 4 fb + 2 ch + kind; FB = 1: 2 kind + ch -- so that the lane holding a frame's sum of logs
 // finds the matching sum of squares at lane ^ 2 (FB = 4, 2: quad_perm) or lane ^ 8 (FB = 1: row_ror 8).
-template <int R, int FB, bool WANT_T, bool STORE_I>
-__device__ __forceinline__ void prep_frames(const v4f (&xq)[FB][R], const RunsParams& a, char* slot0, int slot_bytes, int lane, v2f (&t)[FB]) {
+// ISRC: isrc(fb, i) = the intensities of granule 64 i + lane of frame fb, (I[2q], I[2q+1]) x (s0, s1), zero past the frame
+// (squares formed in registers, or read back where a kernel keeps them in LDS).  A lane adds its granules in tonality_ways(R)
+// interleaved accumulators (i = way, way + ways, ...: one accumulator up to 1024 bins, two up to 2048, four above), the
+// accumulators in order, then the lanes (wave_totals): one association for every kernel that calls this, whatever holds the
+// spectrum -- and one that the waves of a frame dealt to two or four waves can form side by side (a wave per accumulator).
+__host__ __device__ constexpr int tonality_ways(int R) { return R >= 32 ? 4 : R >= 16 ? 2 : 1; }
+// one accumulator of a lane: {sum of log2, s0 | s1, sum of squares, s0 | s1} over the granules i = first, first + step, ... < R.
+// CHUNK (0: none): a scheduling fence after every CHUNK granules -- for sources that read LDS, where the compiler would otherwise
+// issue all the reads ahead and hold four registers each.
+template <int R, int CHUNK, class ISRC1>
+__device__ __forceinline__ v4f lane_sums(ISRC1 isrc1, const RunsParams& a, int lane, int first, int step) {
+  v2f slog = {0.f, 0.f}, ssq = {0.f, 0.f};
+  int k = 0;
+#pragma unroll
+  for (int i = first; i < R; i += step, ++k) {
+    if (CHUNK > 0 && k > 0 && k % CHUNK == 0) __builtin_amdgcn_sched_barrier(0);
+    const v4f I = isrc1(i);
+    const v2f ie = v2f{I.x, I.y}, io = v2f{I.z, I.w};
+    ssq += ie + io;
+    const v2f lg = log2v(maxv(ie, kEps) * maxv(io, kEps));
+    slog += in_frame<R>(a, i, lane) ? lg : v2f{0.f, 0.f};
+  }
+  return v4f{slog.x, slog.y, ssq.x, ssq.y};
+}
+// from the lanes' sums {slog.x, slog.y, ssq.x, ssq.y} of FB frames to their tonalities
+template <int FB>
+__device__ __forceinline__ void tonality_finish(const v4f (&acc)[FB], const RunsParams& a, int lane, v2f (&t)[FB]) {
   float v[16];
 #pragma unroll
   for (int fb = 0; fb < FB; ++fb) {
-    v2f slog = {0.f, 0.f}, ssq = {0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-      v4f I = xq[fb][i] * xq[fb][i];
-      asm("" : "+v"(I));   // the squares stay rounded products (see psy_stage in ac_fast.hip)
-      if (STORE_I && in_frame<R>(a, i, lane)) *reinterpret_cast<v4f*>(slot0 + fb * slot_bytes + 16 * (64 * i + lane)) = I;
-      if (WANT_T) {
-        const v2f ie = v2f{I.x, I.y}, io = v2f{I.z, I.w};
-        ssq += ie + io;
-        const v2f lg = log2v(maxv(ie, kEps) * maxv(io, kEps));
-        slog += in_frame<R>(a, i, lane) ? lg : v2f{0.f, 0.f};
-      }
-    }
-    if (WANT_T) {
-      if (FB == 4) {
-        v[4 * fb + 0] = slog.x, v[4 * fb + 1] = slog.y, v[4 * fb + 2] = ssq.x, v[4 * fb + 3] = ssq.y;
-      } else if (FB == 2) {
-        v[4 * fb + 0] = slog.x, v[4 * fb + 1] = ssq.x, v[4 * fb + 2] = slog.y, v[4 * fb + 3] = ssq.y;
-      } else {
-        v[0] = slog.x, v[1] = slog.y, v[2] = ssq.x, v[3] = ssq.y;
-      }
+    if (FB == 4) {
+      v[4 * fb + 0] = acc[fb].x, v[4 * fb + 1] = acc[fb].y, v[4 * fb + 2] = acc[fb].z, v[4 * fb + 3] = acc[fb].w;
+    } else if (FB == 2) {
+      v[4 * fb + 0] = acc[fb].x, v[4 * fb + 1] = acc[fb].z, v[4 * fb + 2] = acc[fb].y, v[4 * fb + 3] = acc[fb].w;
+    } else {
+      v[0] = acc[fb].x, v[1] = acc[fb].y, v[2] = acc[fb].z, v[3] = acc[fb].w;
     }
   }
-  if (!WANT_T) return;
   const float tot = wave_totals<4 * FB>(v, lane);
   // in the lanes that hold a sum of logs: the frame's sum of squares from the partner lane, then
   // sfm = 10 log10(gm / am) = 10 log10(2) (mean log2 I - log2 am), t = min(sfm / -60, 1)   (the other lanes compute on without use)
@@ -194,13 +203,50 @@ __device__ __forceinline__ void prep_frames(const v4f (&xq)[FB][R], const RunsPa
                 __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tt), l1))};
   }
 }
+template <int R, int FB, int CHUNK = 0, class ISRC>
+__device__ __forceinline__ void tonality_from(ISRC isrc, const RunsParams& a, int lane, v2f (&t)[FB]) {
+  constexpr int WAYS = tonality_ways(R);
+  v4f acc[FB];
+#pragma unroll
+  for (int fb = 0; fb < FB; ++fb) {
+    acc[fb] = lane_sums<R, CHUNK>([&](int i) { return isrc(fb, i); }, a, lane, 0, WAYS);
+#pragma unroll
+    for (int w = 1; w < WAYS; ++w) acc[fb] += lane_sums<R, CHUNK>([&](int i) { return isrc(fb, i); }, a, lane, w, WAYS);
+  }
+  tonality_finish<FB>(acc, a, lane, t);
+}
+// the intensities of a granule: rounded products (left to -ffp-contract=fast the compiler fuses one of the two squares of
+// ie + io into the sum of squares -- which one differs between instantiations; see psy_stage in ac_fast.hip)
+__device__ __forceinline__ v4f squares(v4f x) {
+  v4f I = x * x;
+  asm("" : "+v"(I));
+  return I;
+}
+// on a spectrum in registers: xq[fb][i] = granule 64 i + lane of frame fb, (X[2q], X[2q+1]) x (s0, s1), zero past the frame
+template <int R, int FB, bool WANT_T, bool STORE_I>
+__device__ __forceinline__ void prep_frames(const v4f (&xq)[FB][R], const RunsParams& a, char* slot0, int slot_bytes, int lane, v2f (&t)[FB]) {
+  if (WANT_T) {
+    tonality_from<R, FB, 0>([&](int fb, int i) {
+      const v4f I = squares(xq[fb][i]);
+      if (STORE_I && in_frame<R>(a, i, lane)) *reinterpret_cast<v4f*>(slot0 + fb * slot_bytes + 16 * (64 * i + lane)) = I;
+      return I;
+    }, a, lane, t);
+  } else if (STORE_I) {
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb)
+#pragma unroll
+      for (int i = 0; i < R; ++i)
+        if (in_frame<R>(a, i, lane)) *reinterpret_cast<v4f*>(slot0 + fb * slot_bytes + 16 * (64 * i + lane)) = squares(xq[fb][i]);
+  }
+}
 
 // one level of partial sums: n runs, run c = the sum of the 32 bytes (four v2f) at src + 32 c, written to dst + 8 c.
 // The lane's two 16-byte reads are taken in the order that keeps a group of 16 lanes on 16 different bank quads
 // ((c >> 3) & 1 picks the half read first; the sum is the same either way).
+// tid / nt: the lane's number among the nt lanes that share the work (one wave: lane / 64; more where several waves hold a frame)
 template <int FB>
-__device__ __forceinline__ void level_sums(char* slot0, int slot_bytes, int src, int dst, int n, int lane) {
-  for (int c = lane; c < n; c += 64) {
+__device__ __forceinline__ void level_sums(char* slot0, int slot_bytes, int src, int dst, int n, int tid, int nt = 64) {
+  for (int c = tid; c < n; c += nt) {
     const int first = ((c >> 3) & 1) * 16;
 #pragma unroll
     for (int fb = 0; fb < FB; ++fb) {
@@ -286,20 +332,15 @@ __device__ __forceinline__ void spread16(const v2f (&Q)[FB], const uint32_t* img
 // at 8 f); emit(fb, i, th) receives the thresholds of granule 64 i + lane of frame fb (lanes with in_frame(i) only).
 // img: the LDS copy of the image.  NC: filter_bands_n where the kernel knows it at compile time (0: a.N).  The caller orders
 // its stores of the intensities before the call (wave_sync) and its next use of the slots after it.
-template <int R, int FB, int NC, class IDX, class EMIT>
-__device__ __forceinline__ void threshold_frames(const v2f (&t)[FB], const RunsParams& a, const RunsLane& lc, const uint32_t* img,
-                                                 char* slot0, int slot_bytes, int lane, const IDX& idx, EMIT emit) {
+// The per-band part, in two steps (a kernel may keep the band intensities between them: the fused encode of the LDS-FFT tier
+// forms them frame by frame and finishes four frames at a time):
+// band_sums: P_j of FB frames whose intensities and partial sums are in their slots -- lane = band.  One wave.  The caller
+// orders the partial sums before the call (wave_sync, or a workgroup barrier where other waves formed them).
+template <int FB>
+__device__ __forceinline__ void band_sums(const RunsParams& a, const RunsLane& lc, const uint32_t* img, char* slot0, int slot_bytes, int lane,
+                                          v2f (&P)[FB]) {
   static_assert(FB == 1 || FB == 2 || FB == 4, "frames side by side");
-  const RunsGeo geo = runs_geo(NC ? NC : a.N);
   slot_init(a, slot0, FB, slot_bytes, lane);   // (the A image of the group before, or the caller's own use, ran over the zero words)
-  // partial sums over aligned runs of 4, 16 (64) bins
-  level_sums<FB>(slot0, slot_bytes, 0, geo.o4, geo.n4, lane);
-  wave_sync();
-  level_sums<FB>(slot0, slot_bytes, geo.o4, geo.o16, geo.n16, lane);
-  if (a.n64 > 0) {
-    wave_sync();
-    level_sums<FB>(slot0, slot_bytes, geo.o16, geo.o64, a.n64, lane);
-  }
   wave_sync();
   // P_j = sum_f I_f W[f, j]  (:312-313): lane = band; two weighted edge bins, the interior through the list
   v2f P0[FB], P1[FB];
@@ -323,10 +364,20 @@ __device__ __forceinline__ void threshold_frames(const v2f (&t)[FB], const RunsP
       }
     }
   }
+#pragma unroll
+  for (int fb = 0; fb < FB; ++fb) P[fb] = P0[fb] + P1[fb];
+}
+
+// band_tail: from the band intensities to the threshold entries -- afterwards slot fb holds its frame's entries (the interior
+// entry of band j at 512 + 16 j, the entry of edge bin j at 512 + 16 j + 8); the slots need 1536 bytes each (FB = 1: 2560, the
+// A image of spread16), nothing in them is read.  One wave; the caller orders the look-ups after the call.
+template <int FB>
+__device__ __forceinline__ void band_tail(const v2f (&P)[FB], const v2f (&t)[FB], const RunsParams& a, const RunsLane& lc, const uint32_t* img,
+                                          char* slot0, int slot_bytes, int lane) {
   v2f Q[FB];   // max(eps, P)^alpha (:206); lanes beyond the M bands keep 0: the rows of S they would meet do not exist
 #pragma unroll
   for (int fb = 0; fb < FB; ++fb) {
-    const v2f q = exp2v(a.alpha * log2v(maxv(P0[fb] + P1[fb], kEps)));
+    const v2f q = exp2v(a.alpha * log2v(maxv(P[fb], kEps)));
     Q[fb] = lane < a.M ? q : v2f{0.f, 0.f};
   }
   wave_sync();   // every lane is done with the intensities and their sums: the head of the slots takes A, then G and the entries
@@ -380,18 +431,45 @@ __device__ __forceinline__ void threshold_frames(const v2f (&t)[FB], const RunsP
       *reinterpret_cast<v2f*>(slot0 + fb * slot_bytes + 512 + 16 * lane + 8) = v2f{__builtin_amdgcn_sqrtf(A1.x), __builtin_amdgcn_sqrtf(A1.y)};
     }
   }
+}
+template <int FB>
+__device__ __forceinline__ void band_stage(const v2f (&t)[FB], const RunsParams& a, const RunsLane& lc, const uint32_t* img, char* slot0,
+                                           int slot_bytes, int lane) {
+  v2f P[FB];
+  band_sums<FB>(a, lc, img, slot0, slot_bytes, lane, P);
+  band_tail<FB>(P, t, a, lc, img, slot0, slot_bytes, lane);
+}
+
+// the threshold of granule q (bins 2 q, 2 q + 1) of the frame in `slot` from its entries; w = the granule's entry-offset word
+__device__ __forceinline__ v4f entry_lookup(const char* slot, uint32_t w) {
+  const v2f a0 = *reinterpret_cast<const v2f*>(slot + (w & 0xffffu)), a1 = *reinterpret_cast<const v2f*>(slot + (w >> 16));
+  return v4f{a0.x, a0.y, a1.x, a1.y};
+}
+
+// masking thresholds of FB frames whose intensities are in their slots (prep_frames, or the caller's own stores: bin f
+// at 8 f); emit(fb, i, th) receives the thresholds of granule 64 i + lane of frame fb (lanes with in_frame(i) only).
+// img: the LDS copy of the image.  NC: filter_bands_n where the kernel knows it at compile time (0: a.N).  The caller orders
+// its stores of the intensities before the call (wave_sync) and its next use of the slots after it.
+template <int R, int FB, int NC, class IDX, class EMIT>
+__device__ __forceinline__ void threshold_frames(const v2f (&t)[FB], const RunsParams& a, const RunsLane& lc, const uint32_t* img,
+                                                 char* slot0, int slot_bytes, int lane, const IDX& idx, EMIT emit) {
+  const RunsGeo geo = runs_geo(NC ? NC : a.N);
+  // partial sums over aligned runs of 4, 16 (64) bins
+  level_sums<FB>(slot0, slot_bytes, 0, geo.o4, geo.n4, lane);
+  wave_sync();
+  level_sums<FB>(slot0, slot_bytes, geo.o4, geo.o16, geo.n16, lane);
+  if (a.n64 > 0) {
+    wave_sync();
+    level_sums<FB>(slot0, slot_bytes, geo.o16, geo.o64, a.n64, lane);
+  }
+  band_stage<FB>(t, a, lc, img, slot0, slot_bytes, lane);
   wave_sync();
 #pragma unroll
   for (int i = 0; i < R; ++i) {
     if (in_frame<R>(a, i, lane)) {
       const uint32_t w = idx(i);
-      const uint32_t u0 = w & 0xffffu, u1 = w >> 16;
 #pragma unroll
-      for (int fb = 0; fb < FB; ++fb) {
-        const char* s = slot0 + fb * slot_bytes;
-        const v2f a0 = *reinterpret_cast<const v2f*>(s + u0), a1 = *reinterpret_cast<const v2f*>(s + u1);
-        emit(fb, i, v4f{a0.x, a0.y, a1.x, a1.y});
-      }
+      for (int fb = 0; fb < FB; ++fb) emit(fb, i, entry_lookup(slot0 + fb * slot_bytes, w));
     }
   }
 }

@@ -460,11 +460,11 @@ def test_codec_golden_beside_the_powers_of_two(golden, path, N):
             thr = host(codec.psy.global_masking_threshold(Xp, dev(t_ref.astype(np.float32)), drown))
             assert rel_elem(thr, g["thr_%s_d%02d_ref64" % (name, int(drown * 10))]) <= TOL
     # the codec's encode on the fixture's PCM: same spectrum, thresholds of its own spectrum within the bar of the model.
-    # At 512 / 128 that is ONE launch (the masking model rides in the several-frames-per-wave kernels), at 960 two
+    # ONE launch: at 512 / 128 the masking model rides in the several-frames-per-wave kernels, at 960 in the LDS-FFT instance
     Xe, te, thre = codec.encode(dev(g["x"]))
     assert rel_peak(host(Xe), g["X_ref64"]) <= TOL
     if path == "auto":
-        assert codec.encode_launches(2) == (2 if N == 960 else 1)
+        assert codec.encode_launches(2) == 1   # (960: the fused encode of the LDS-FFT tier, where it measured faster)
     # the fixture's interior frames are frames 1..3 of that spectrum (Xp_rand = X_ref32[:, 1:4]): reference-produced
     # tonality / thresholds of the reference's float32 spectrum against the fused kernel's own spectrum -- the spectra
     # agree to 1e-6 of the frame peak, which the thresholds feel at a few 1e-5
@@ -474,6 +474,38 @@ def test_codec_golden_beside_the_powers_of_two(golden, path, N):
     X64 = host(Xe).astype(np.float64)
     t64 = o.tonality(X64)
     assert tonality_err(host(te), t64) <= 1.0 and rel_elem(host(thre), o.global_masking_threshold(X64, t64)) <= TOL
+
+
+@pytest.mark.parametrize("N", [108, 120, 240, 480, 500, 576, 768, 960, 1000, 1080, 1536, 1920, 2304, 3240, 4096])
+@pytest.mark.parametrize("C", [2, 1])
+def test_fused_encode_of_the_lds_fft_tier_equals_the_unfused_calls(N, C, monkeypatch):
+    """k_enc_wave_v (ac_generic.hip): the LDS-FFT instances with the masking model in the same launch -- tonality and the band
+    intensities frame by frame while the spectrum is in LDS, the rest four frames at a time after the strip -- against
+    transform -> tonality -> global_masking_threshold (psychoacoustic.py:102-148 on mdctransformer.py:62-125): bit for bit (one
+    definition of the arithmetic), every instance forced on (AC_LDS_WAVE_NOFUSE=2: the product fuses where it measured faster),
+    one / several frames per wave and a frame on two / four waves, short and ragged strips, a batch that leaves lanes without
+    a task; thresholds against the oracle at the bar."""
+    monkeypatch.setenv("AC_LDS_WAVE_NOFUSE", "2")
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    assert codec.mdct.tier(C) == 2 and codec.psy.tier() == 1
+    for (B, K) in ((3, 5), (1, 1), (2, 37)):
+        x = (torch.rand((B, K * N, C), device="cuda") * 2 - 1) * torch.rand((B, 1, C), device="cuda")
+        assert codec.encode_launches(C) == 1
+        X, t, thr = codec.encode(x)
+        monkeypatch.setenv("AC_LDS_WAVE_NOFUSE", "1")
+        assert codec.encode_launches(C) == 2
+        X2 = codec.mdct.transform(x)
+        t2 = codec.psy.tonality(X2)
+        thr2 = codec.psy.global_masking_threshold(X2, t2)
+        X3, t3, thr3 = codec.encode(x)
+        monkeypatch.setenv("AC_LDS_WAVE_NOFUSE", "2")
+        for a, b in ((X, X2), (t, t2), (thr, thr2), (X, X3), (t, t3), (thr, thr3)):
+            assert torch.equal(a, b)
+        if (B, K) == (3, 5):
+            o = PsychoOracle(48000, N, 64, compute_dtype=np.float64)
+            X64 = host(X).astype(np.float64)
+            t64 = o.tonality(X64)
+            assert tonality_err(host(t), t64) <= 1.0 and rel_elem(host(thr), o.global_masking_threshold(X64, t64)) <= TOL
 
 
 @pytest.mark.parametrize("N,C,sr", [(512, 2, 48000), (512, 1, 48000), (256, 2, 48000), (256, 1, 44100), (128, 2, 48000), (128, 1, 48000),
