@@ -60,6 +60,7 @@ PROTOTYPES = {
     "ac_workspace_destroy": (c_int, [c_void_p]),
     "ac_workspace_alloc_dlpack": (c_void_p, [c_void_p, c_int, c_int, POINTER(ctypes.c_int64), c_void_p]),
     "ac_workspace_live": (ctypes.c_long, [c_void_p]),
+    "ac_workspace_record_stream": (c_int, [c_void_p, c_void_p, c_void_p]),
     "ac_probe_placement": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p), c_int, c_int, c_int,
                                    c_int, c_void_p, POINTER(c_int), POINTER(c_float)]),
     "ac_encode_fused_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_int,

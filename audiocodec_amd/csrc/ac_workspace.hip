@@ -23,12 +23,18 @@
 // enqueueing is the order of execution (the rule torch's caching allocator applies to its blocks)
 struct ac_extent {
   size_t bytes;
-  void* stream;
+  void* stream;                    // the stream its last tenant was allocated for; kFreshExtent: never handed out
+  std::vector<hipEvent_t> wait;    // recorded at release on the OTHER streams the tenant was used on (ac_workspace_record_stream):
+                                   // the next tenant's stream waits for them before the extent is written again
 };
+// (not nullptr: that is the handle of the default stream, where most tenants run -- an extent released after default-stream
+// work must not look fresh to a request on a side stream)
+static void* const kFreshExtent = reinterpret_cast<void*>(~(uintptr_t)0);
 
 struct ac_workspace {
   std::mutex mu;
   std::map<size_t, ac_extent> free_ext[2];   // region 0 = A, 1 = B
+  std::map<const void*, void*> live_blocks;  // data pointer -> PoolBlock of the tensors handed out (ac_workspace_record_stream)
   long live = 0;          // tensors handed out and not yet released
   bool closed = false;    // ac_workspace_destroy was called: the last release frees the regions
   bool pooled = false;    // ac_workspace_alloc_dlpack has been used: the fixed tensors of ac_workspace_buffers are not valid any more
@@ -102,6 +108,7 @@ int ac_workspace_create(const ac_mdct_plan* mdct, const ac_psy_plan* psy, int B,
     return st;
   };
   if (hipMalloc(&w->a, w->bytes_a) != hipSuccess) {
+    (void)hipGetLastError();   // (or the next launch's error check reports this allocation's failure)
     set_error("workspace: %zu bytes for region A not available", w->bytes_a);
     w->a = nullptr;
     return fail(AC_ENOMEM);
@@ -184,37 +191,45 @@ int ac_workspace_create(const ac_mdct_plan* mdct, const ac_psy_plan* psy, int B,
     w->spacer_gib += spacer_gib;
   }
   w->chosen = (int)(std::min_element(w->ms, w->ms + w->tries) - w->ms);
-  if (cands.size() >= 2 && enc_bytes / (w->ms[w->chosen] * 1e-3) < good_rate) {
-    // no candidate pairs well with region A where it is (one process in eight on the bench box: A itself sits across two
-    // classes): a second region A from further along (the spacers are still held), tried against the candidates at hand
+  // no candidate pairs well with region A where it is (one process in eight on the bench box: A itself sits across two
+  // classes): another region A -- first from further along (the spacers are still held), then, if that one pairs no better,
+  // from the hole a spacer in the middle of the row leaves -- each tried against the candidates at hand
+  for (int attempt = 0; attempt < 2 && cands.size() >= 2 && enc_bytes / (w->ms[w->chosen] * 1e-3) < good_rate; ++attempt) {
+    if (attempt == 1) {
+      if (spacers.size() < 2) break;
+      const size_t mid = spacers.size() / 2;
+      (void)hipFree(spacers[mid]);
+      spacers.erase(spacers.begin() + (long)mid);
+    }
     void* a2 = nullptr;
-    if (hipMalloc(&a2, w->bytes_a) == hipSuccess) {
-      hipLaunchKernelGGL(k_fill_noise, dim3(4096), dim3(256), 0, hs, reinterpret_cast<float*>((char*)a2 + w->off_x),
-                         (size_t)B * K * N * C, 0x5eedull);
-      int best_j = -1;
-      float best = w->ms[w->chosen];
-      for (size_t j = 0; j < cands.size() && !st; ++j) {
-        const float sc = time_pair(a2, cands[j]);
-        if (!st && sc < best) {
-          best = sc;
-          best_j = (int)j;
-        }
-      }
-      if (st) {
-        (void)hipFree(a2);
-        if (st == AC_EHIP) set_error("workspace: a HIP call failed while timing a candidate");
-        return fail(st);
-      }
-      if (best_j >= 0) {
-        (void)hipFree(w->a);
-        w->a = a2;
-        w->chosen = best_j;
-        w->ms[best_j] = best;
-      } else {
-        (void)hipFree(a2);
-      }
-    } else {
+    if (hipMalloc(&a2, w->bytes_a) != hipSuccess) {
       (void)hipGetLastError();
+      break;
+    }
+    hipLaunchKernelGGL(k_fill_noise, dim3(4096), dim3(256), 0, hs, reinterpret_cast<float*>((char*)a2 + w->off_x),
+                       (size_t)B * K * N * C, 0x5eedull);
+    int best_j = -1;
+    float best = w->ms[w->chosen];
+    for (size_t j = 0; j < cands.size() && !st; ++j) {
+      const float sc = time_pair(a2, cands[j]);
+      if (!st && sc < best) {
+        best = sc;
+        best_j = (int)j;
+      }
+      if (!st && enc_bytes / (sc * 1e-3) >= good_rate) break;   // (a two-class pair: no need to time the rest)
+    }
+    if (st) {
+      (void)hipFree(a2);
+      if (st == AC_EHIP) set_error("workspace: a HIP call failed while timing a candidate");
+      return fail(st);
+    }
+    if (best_j >= 0) {
+      (void)hipFree(w->a);
+      w->a = a2;
+      w->chosen = best_j;
+      w->ms[best_j] = best;
+    } else {
+      (void)hipFree(a2);
     }
   }
   w->b = cands[(size_t)w->chosen];
@@ -230,6 +245,7 @@ int ac_workspace_create(const ac_mdct_plan* mdct, const ac_psy_plan* psy, int B,
 int ac_workspace_buffers(const ac_workspace* w, int copy, float** x, float** X, float** t, float** thr, float** xhat) {
   AC_REQUIRE(w != nullptr, "workspace is NULL");
   AC_REQUIRE(copy >= 0 && copy < w->copies, "copy %d of %d", copy, w->copies);
+  AC_REQUIRE(!w->pooled, "the workspace is a pool of tensors now (ac_workspace_alloc_dlpack): its fixed buffers are not valid any more");
   const size_t N = (size_t)w->N;
   auto up2 = [](size_t v) { return up(v); };
   const size_t nX = up2((size_t)w->B * (w->K + 1) * N * w->C * 4), nt = up2((size_t)w->B * (w->K + 1) * w->C * 4),
@@ -296,6 +312,7 @@ struct PoolBlock {
   int region;
   size_t offset, bytes;
   void* stream;
+  std::vector<void*> also;   // other streams the tensor was used on (ac_workspace_record_stream)
   int64_t shape[8];
 };
 
@@ -303,14 +320,30 @@ void pool_release(DLManagedTensor* m) {
   PoolBlock* b = reinterpret_cast<PoolBlock*>(m);
   ac_workspace* w = b->ws;
   bool last = false;
+  // work on other streams may still be reading (or writing) the tensor: an event on each of them, for the extent's next
+  // tenant to wait on (what torch's allocator does with the streams of Tensor.record_stream)
+  std::vector<hipEvent_t> wait;
+  if (!b->also.empty()) {
+    DeviceGuard guard(w->device);
+    for (void* s2 : b->also) {
+      hipEvent_t ev = nullptr;
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+        if (hipEventRecord(ev, (hipStream_t)s2) == hipSuccess) wait.push_back(ev);
+        else (void)hipEventDestroy(ev);
+      }
+      (void)hipGetLastError();
+    }
+  }
   {
     std::lock_guard<std::mutex> lock(w->mu);
+    w->live_blocks.erase(b->mt.dl_tensor.data);
     auto& fr = w->free_ext[b->region];
     size_t off = b->offset, n = b->bytes;
-    // coalesce with neighbours that were last used on the same stream
+    // coalesce with neighbours that were last used on the same stream (their pending events go along)
     auto nx = fr.lower_bound(off);
     if (nx != fr.end() && nx->first == off + n && nx->second.stream == b->stream) {
       n += nx->second.bytes;
+      wait.insert(wait.end(), nx->second.wait.begin(), nx->second.wait.end());
       nx = fr.erase(nx);
     }
     if (nx != fr.begin()) {
@@ -318,10 +351,11 @@ void pool_release(DLManagedTensor* m) {
       if (pv->first + pv->second.bytes == off && pv->second.stream == b->stream) {
         off = pv->first;
         n += pv->second.bytes;
+        wait.insert(wait.end(), pv->second.wait.begin(), pv->second.wait.end());
         fr.erase(pv);
       }
     }
-    fr[off] = ac_extent{n, b->stream};
+    fr[off] = ac_extent{n, b->stream, wait};
     last = --w->live == 0 && w->closed;
   }
   delete b;
@@ -341,21 +375,28 @@ void* ac_workspace_alloc_dlpack(ac_workspace* w, int region, int ndim, const int
   if (w->closed) return nullptr;
   if (!w->pooled) {   // first use: both regions are one free extent each (no stream yet: fresh memory)
     w->pooled = true;
-    w->free_ext[0][0] = ac_extent{w->bytes_a, nullptr};
-    w->free_ext[1][0] = ac_extent{w->bytes_b, nullptr};
+    w->free_ext[0][0] = ac_extent{w->bytes_a, kFreshExtent, {}};
+    w->free_ext[1][0] = ac_extent{w->bytes_b, kFreshExtent, {}};
   }
   auto& fr = w->free_ext[region];
   for (auto it = fr.begin(); it != fr.end(); ++it) {
-    if (it->second.bytes < need || (it->second.stream != nullptr && it->second.stream != stream)) continue;
+    if (it->second.bytes < need || (it->second.stream != kFreshExtent && it->second.stream != stream)) continue;
+    PoolBlock* b = new (std::nothrow) PoolBlock();
+    if (!b) return nullptr;
     const size_t off = it->first, rest = it->second.bytes - need;
     void* tag = it->second.stream;
+    std::vector<hipEvent_t> wait;
+    wait.swap(it->second.wait);
     fr.erase(it);
-    if (rest) fr[off + need] = ac_extent{rest, tag};
-    PoolBlock* b = new (std::nothrow) PoolBlock();
-    if (!b) {
-      fr[off] = ac_extent{need + rest, tag};
-      return nullptr;
+    if (!wait.empty()) {   // the extent's earlier tenants were used on other streams too: this tenant's stream waits for that work
+      DeviceGuard guard(w->device);
+      for (hipEvent_t ev : wait) {
+        (void)hipStreamWaitEvent((hipStream_t)stream, ev, 0);
+        (void)hipEventDestroy(ev);   // (released once it has completed)
+      }
+      (void)hipGetLastError();
     }
+    if (rest) fr[off + need] = ac_extent{rest, tag, {}};   // (the remainder was covered by the same waits: nothing left pending on it)
     b->ws = w, b->region = region, b->offset = off, b->bytes = need, b->stream = stream;
     for (int i = 0; i < ndim; ++i) b->shape[i] = shape[i];
     b->mt.dl_tensor.data = (char*)(region == 0 ? w->a : w->b) + off;
@@ -368,9 +409,20 @@ void* ac_workspace_alloc_dlpack(ac_workspace* w, int region, int ndim, const int
     b->mt.manager_ctx = b;
     b->mt.deleter = pool_release;
     ++w->live;
+    w->live_blocks[b->mt.dl_tensor.data] = b;
     return &b->mt;
   }
   return nullptr;   // no room (or only extents last used on other streams): the caller allocates elsewhere
+}
+
+int ac_workspace_record_stream(ac_workspace* w, const void* data, void* stream) {
+  AC_REQUIRE(w != nullptr && data != nullptr, "workspace / tensor is NULL");
+  std::lock_guard<std::mutex> lock(w->mu);
+  auto it = w->live_blocks.find(data);
+  AC_REQUIRE(it != w->live_blocks.end(), "not the start of a tensor of this workspace's pool");
+  PoolBlock* b = reinterpret_cast<PoolBlock*>(it->second);
+  if (stream != b->stream && std::find(b->also.begin(), b->also.end(), stream) == b->also.end()) b->also.push_back(stream);
+  return AC_OK;
 }
 
 long ac_workspace_live(ac_workspace* w) {

@@ -12,9 +12,22 @@ return -- the library decides, once per process and device:
   kernel on at most 8 candidate allocations (untouched 12 GiB spacers between the tries, every loser and every spacer back
   with the driver before the call returns; ~0.1 s, once);
 * from then on results are carved out of the two regions (``ac_workspace_alloc_dlpack``: DLPack tensors that own their
-  extent and give it back when the last view dies; an extent is reused only for work on the stream it was last used on, the
-  rule torch's caching allocator applies to its blocks); a request the regions have no room for gets a plain
-  ``torch.empty`` -- never an error, never a copy.
+  extent and give it back when the last view dies; an extent is reused only for work on the stream its last tenant was
+  allocated for, the rule torch's caching allocator applies to its blocks); a request the regions have no room for gets a
+  plain ``torch.empty`` -- never an error, never a copy.
+
+Two things torch's allocator does for its own blocks and a DLPack tensor's storage does not get from it:
+
+* **other streams**: ``Tensor.record_stream`` does not reach these tensors.  A consumer that uses a result on ANOTHER stream
+  and may drop its last reference before that work has run calls ``placement.record_stream(tensor, stream)`` instead (the
+  same contract: the pool makes the extent's next tenant wait for that stream's work);
+* **graph capture**: under ``torch.cuda.graph`` nothing is carved out of the pool (a captured address must stay valid for
+  every replay, and building the pool synchronises the device): results are plain ``torch.empty`` tensors from the capture's
+  private pool, as before this module existed.
+
+The pool is built only for the configuration its effect was measured on -- float32 mono / stereo through the fused
+wave-level encode (filters_n 1024 / 2048); every other configuration gets plain allocations (``audiocodec_amd.Workspace``
+remains for callers who want to probe theirs explicitly).
 
 Memory held: the two regions, sized for two generations of the first large request (so that a loop that rebinds its
 results never runs dry), capped at ``AC_PLACEMENT_MAX_GIB`` (default 16) -- ``report()`` states it, ``release()`` gives it
@@ -87,7 +100,11 @@ def pool(device):
 
 def ensure(codec, x_shape, device):
     """Called by ``AudioCodec.encode``: creates the device's pool on the first request large enough to need one."""
-    if not enabled() or codec.compute_dtype != torch.float32:
+    if not enabled() or codec.compute_dtype != torch.float32 or torch.cuda.is_current_stream_capturing():
+        return None
+    # (only where the class effect was measured: the fused wave-level encode on mono / stereo rows; elsewhere the search's stop
+    # criterion -- a rate of THAT kernel -- can never be met and the probe would run its full length inside a user's call)
+    if x_shape[2] > 2 or not (codec.mdct.is_fast(device) and codec.psy.is_fast(device)):
         return None
     idx = device.index if device.index is not None else torch.cuda.current_device()
     p = _pools.get(idx)
@@ -131,13 +148,26 @@ def ensure(codec, x_shape, device):
 
 def empty(region, shape, dtype, device):
     """A tensor for a result of the library: from the device's pool when there is one with room, else ``torch.empty``."""
-    if dtype == torch.float32:
+    if dtype == torch.float32 and not torch.cuda.is_current_stream_capturing():
         p = pool(device)
         if p is not None:
             t = p.alloc(region, shape)
             if t is not None:
                 return t
     return torch.empty(shape, dtype=dtype, device=device)
+
+
+def record_stream(tensor, stream):
+    """The pool's ``Tensor.record_stream``: ``tensor`` (a result of the library, or a view that starts where it starts) is
+    also used by work on ``stream``; its memory will not be rewritten before that work has run.  A tensor that does not come
+    from the pool gets torch's own ``record_stream``."""
+    p = pool(tensor.device) if tensor.is_cuda else None
+    sp = stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream)
+    if p is not None:
+        st = _lib.load().ac_workspace_record_stream(p.handle, ctypes.c_void_p(tensor.untyped_storage().data_ptr()), ctypes.c_void_p(sp))
+        if st == _lib.AC_OK:
+            return
+    tensor.record_stream(stream)
 
 
 def report(device=None):

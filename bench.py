@@ -16,9 +16,12 @@ N = 2, 4, 8).  Clips are independent (reference mdctransformer.py:292-295 folds 
 batch axis is sharded and there is no data-path collective; RCCL carries the barrier, the max-over-ranks time and the
 reduction of frame counts / checksums / round-trip error.
 
-All tensors are plain torch allocations (what a caller of the reference API gets).  Prints ONE JSON line on rank 0.
-value = frames/s over all GPUs, a frame being one 1024-sample hop of one channel, encode + decode both done
-(20 484 algorithmic bytes per frame).
+The timed step is the call shape of the reference's classes: X, t, thr = codec.encode(x); x^ = codec.decode(X) -- the
+library allocates (and places, audiocodec_amd/placement.py) what it returns, as mdctransformer.py:62-125 and
+psychoacoustic.py:102-148 return new tensors.  The same step on caller-owned plain torch tensors (encode_into /
+decode_into: what a C-ABI caller that brings its own buffers gets) is reported beside it (caller_owned_*).  Prints ONE
+JSON line on rank 0.  value = frames/s over all GPUs, a frame being one 1024-sample hop of one channel, encode + decode
+both done (20 484 algorithmic bytes per frame).
 """
 
 import argparse
@@ -57,8 +60,7 @@ def parse_args(argv=None):
                          "has idled runs the first ~30 ms of load at reduced clocks (reported as settle_ms / settle_steps; "
                          "cold_start in the same line is the same measurement without it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-encode-api", action="store_true",
-                    help="skip the side measurement of the same step through the allocating API (AudioCodec.encode / decode)")
+    ap.add_argument("--no-encode-api", action="store_true", help="(accepted for old command lines: the allocating API is the headline now)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the side measurements (f32 spreading, "
                     "K = 46, configs[3] / configs[4])")
     ap.add_argument("--no-smi", action="store_true", help="do not sample the GPU's clocks / power from a side process")
@@ -171,20 +173,28 @@ def cpu_baseline(seconds=12.0):
         r = json.loads(out.strip().splitlines()[-1])
         rate += r["frames"] / r["seconds"]
         frames += r["frames"]
-    # the reference-shaped flavour (dense [2,N,N] polyphase products, 2N-point DCT-III, dense Bark einsums,
-    # materialised 5-D masking tensor) on one core, for scale
-    out = subprocess.run(cmd[:-1] + ["3", "--dense"], cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True,
-                         timeout=600).stdout
-    d = json.loads(out.strip().splitlines()[-1])
+    # the reference-shaped flavour (dense [2,N,N] polyphase products, 2N-point DCT-III, dense Bark einsums, materialised
+    # 5-D masking tensor: the op sequence the reference hands to TensorFlow) on the same cores
+    dense_s = 8.0
+    dprocs = [subprocess.Popen(cmd[:-1] + [str(dense_s), "--dense", "--seed", str(i)], cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+              for i in range(procs_n)]
+    drate, dframes, dsec = 0.0, 0, 0.0
+    for p in dprocs:
+        out, _ = p.communicate(timeout=dense_s * 10 + 300)
+        r = json.loads(out.strip().splitlines()[-1])
+        drate += r["frames"] / r["seconds"]
+        dframes += r["frames"]
+        dsec = max(dsec, r["seconds"])
     return {
         "value": rate, "unit": "frames/s", "cores": procs_n, "kind": "port",
         "host_cpus": host_cpus, "usable_cpus": usable, "processes": procs_n, "threads_per_process": 1,
         "cores_bound": share["bound"], "cgroup_cpu_quota": share["cgroup_cpu_quota"], "visible_gpus": share["visible_gpus"],
         "sample": "%d single-threaded processes x %.0f s of (B=2 stereo clips, K=46 blocks, N=%d) encode+decode, "
                   "closed-form numpy/scipy oracle; %d frames in total" % (procs_n, seconds, N, frames),
-        "reference_shaped_value_per_core": d["frames"] / d["seconds"],
-        "reference_shaped_sample": "1 process, dense polyphase / DCT-III / einsum restatement of the reference's op "
-                                   "sequence, %.1f s" % d["seconds"],
+        "reference_shaped_value": drate, "reference_shaped_cores": procs_n,
+        "reference_shaped_value_per_core": drate / procs_n,
+        "reference_shaped_sample": "%d single-threaded processes x %.1f s, dense polyphase / DCT-III / einsum restatement of the "
+                                   "reference's op sequence on the same clips; %d frames in total" % (procs_n, dsec, dframes),
     }
 
 
@@ -363,10 +373,11 @@ def timed_loop(torch, codec, x, X, t, thr, xh, steps, warmup, barrier=None, sett
     return elapsed, enc, dec, w0, w1, settled
 
 
-def encode_api_step(torch, np, codec, x, steps, warmup, settle_ms):
-    """The step through the allocating API, as a user of the reference's classes calls it: X, t, thr = codec.encode(x);
-    x^ = codec.decode(X) -- the library allocates (and places) what it returns.  Same settle / warm-up / timed region as
-    the headline; event times per launch."""
+def timed_loop_api(torch, codec, x, steps, warmup, barrier=None, settle_ms=0.0):
+    """The step as a user of the reference's classes calls it -- X, t, thr = codec.encode(x); x^ = codec.decode(X): the library
+    allocates (and places, audiocodec_amd/placement.py) what it returns (mdctransformer.py:62-125, psychoacoustic.py:102-148
+    return new tensors).  Device settle, `warmup` untimed steps, then exactly `steps` steps between synchronisations; per-launch
+    times by events.  Returns (elapsed_s, encode_ms list, decode_ms list, t0, t1 wall clock, settle steps, last outputs)."""
     def step(ev=None):
         if ev:
             ev[0].record()
@@ -388,20 +399,20 @@ def encode_api_step(torch, np, codec, x, steps, warmup, settle_ms):
         step()
     torch.cuda.synchronize()
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+    if barrier is not None:
+        barrier()
+    torch.cuda.synchronize()
+    w0 = time.time()
     t0 = time.perf_counter()
+    out = None
     for i in range(steps):
         out = step(evs[i])
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    B, S, C = x.shape
-    frames = B * C * (S // N)
-    err = float((out[3][:, N:-N] - x).abs().max())
-    rep = getattr(codec, "placement_report", None)
-    return {"value": frames * steps / el, "ms_per_step": el / steps * 1e3,
-            "encode_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in evs])),
-            "decode_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in evs])),
-            "round_trip_max_abs_err": err, "settle_steps": n_settle,
-            "placement": rep(x.device) if callable(rep) else None}
+    w1 = time.time()
+    enc = [e[0].elapsed_time(e[1]) for e in evs]
+    dec = [e[1].elapsed_time(e[2]) for e in evs]
+    return el, enc, dec, w0, w1, n_settle, out
 
 
 def other_configs(torch, np, audiocodec_amd, dev, steps, warmup, settle_ms):
@@ -679,8 +690,14 @@ def main():
                 "encode_ms": float(np.mean(ce)), "decode_ms": float(np.mean(cd)),
                 "encode_ms_per_step": [round(v, 4) for v in ce[:32]],
                 "note": "the same %d + %d steps started 250 ms after the device went idle, no settle phase" % (args.warmup, args.steps)}
-    elapsed, enc_all, dec_all, w0, w1, settled = timed_loop(torch, codec, x, X, t, thr, xh, args.steps, args.warmup, barrier,
-                                                            args.settle_ms)
+    # the step on caller-owned plain tensors (encode_into / decode_into: what a C-ABI caller with its own buffers gets), beside
+    # the headline
+    co_el, co_enc, co_dec, _, _, _ = timed_loop(torch, codec, x, X, t, thr, xh, args.steps, args.warmup, None, args.settle_ms)
+    err_co = float((xh[:, N:-N] - x).abs().max()) if K > 0 else 0.0
+    # THE HEADLINE: the step through the API of the reference's classes (the library allocates what it returns)
+    elapsed, enc_all, dec_all, w0, w1, settled, outs = timed_loop_api(torch, codec, x, args.steps, args.warmup, barrier,
+                                                                     args.settle_ms)
+    X, t, thr, xh = outs
     elapsed_max, = acd.reduce_scalars([elapsed], "max", device=dev)   # also the closing barrier
     # parity guard on the benchmark data itself + the cross-rank aggregates of SURVEY 8(e): frames, checksums of
     # X / thr / PCM (float64 sums), maximum round-trip error (<= 1 LSB of int16)
@@ -715,28 +732,25 @@ def main():
                         "step_frac_of_achievable_6290_GBs": (ENC_BYTES + DEC_BYTES) * (value / world) / 6.29e12,
                         "step_read_share_of_hbm_peak": 2 * 4 * N * (value / world) / (HBM_PEAK_GBS * 1e9)},
             "workload": "BASELINE %s: batch=%d stereo 48 kHz clips per GPU, N=1024, K=%d blocks (%.1f s), fused MDCT+tonality+"
-                        "masking encode then IMDCT decode, plain torch allocations; clips split across ranks, no data-path "
-                        "collective" % (cfg, B, K, K * N / 48000.0),
+                        "masking encode then IMDCT decode through codec.encode() / decode() (the library allocates its results, as "
+                        "the reference's API does); clips split across ranks, no data-path collective" % (cfg, B, K, K * N / 48000.0),
         }
         if cold is not None:
             side["cold_start"] = cold
         if smi is not None:
             pr = torch.cuda.get_device_properties(dev)
             side["gpu_state"] = smi.finish(w0, w1, "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id))
-        flat = {}
-        if world == 1 and not args.no_encode_api:
-            # the same step through the allocating API (AudioCodec.encode / decode: the library places the tensors it
-            # returns, audiocodec_amd/placement.py) beside the headline on caller-owned plain tensors
-            try:
-                ea = encode_api_step(torch, np, codec, x, args.steps, args.warmup, args.settle_ms)
-                side["encode_api"] = ea
-                flat["encode_api_value"] = ea["value"]
-                flat["encode_api_encode_ms"] = ea["encode_ms"]
-            except Exception as e:
-                side["encode_api"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        flat = {"caller_owned_value": frames_rank * args.steps / co_el, "caller_owned_encode_ms": float(np.mean(co_enc)),
+                "caller_owned_decode_ms": float(np.mean(co_dec))}
+        side["caller_owned"] = {"value_rank0": flat["caller_owned_value"], "ms_per_step": co_el / args.steps * 1e3,
+                                "encode_ms_per_step": [round(v, 4) for v in co_enc[:64]], "round_trip_max_abs_err": err_co,
+                                "note": "the same step on caller-owned plain torch allocations (encode_into / decode_into)"}
+        rep = getattr(codec, "placement_report", None)
+        side["placement"] = rep(dev) if callable(rep) else None
         if not args.no_workspace and world == 1:
             # the same step on tensors placed by audiocodec_amd.Workspace (DESIGN_LOG.md 9a), beside the headline
             try:
+                del X, t, thr, xh, outs
                 ws = audiocodec_amd.Workspace(codec, B, K, C, device=dev)
                 ws.x.copy_(x)
                 el, e2, d2, _, _, _ = timed_loop(torch, codec, ws.x, ws.X, ws.t, ws.thr, ws.xh, args.steps, args.warmup,
@@ -752,7 +766,7 @@ def main():
         if cpu is not None:
             side["cpu_baseline"] = cpu
         if world == 1 and not args.no_other_configs:
-            del x, X, t, thr, xh
+            del x
             try:
                 oc = other_configs(torch, np, audiocodec_amd, dev, min(args.steps, 50), args.warmup, args.settle_ms)
                 side["other_configs"] = oc
@@ -779,8 +793,8 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE %s: %d stereo 48 kHz clips/GPU x %d blocks, N=1024, fused encode + decode, plain "
-                                   "allocations" % (cfg, B, K),
+            "config": {"workload": "BASELINE %s: %d stereo 48 kHz clips/GPU x %d blocks, N=1024, codec.encode() + decode() (library-"
+                                   "allocated results)" % (cfg, B, K),
                        "clips_per_gpu": B, "clips_total": B * world, "channels": C, "blocks": K, "filters_n": N,
                        "sharding": "clips", "backend": backend_seen, "devices": min(world, ndev)},
             "roofline": {"bound": "hbm", "kernel": "k_fwd_fast<8,0,true,4,0,%d> fused encode, %s spreading"
@@ -789,7 +803,8 @@ def main():
                          "traffic": traffic,
                          "traffic_source": ("%s (committed PMC pass, not this run)" % tr[1]) if tr else None,
                          "bytes_per_frame": ENC_BYTES, "frames_per_launch": frames_rank, "avg_launch_ms": enc_ms},
-            "cpu_baseline": ({k: cpu[k] for k in ("value", "unit", "cores", "kind", "cores_bound", "host_cpus")} if cpu else None),
+            "cpu_baseline": ({k: cpu[k] for k in ("value", "unit", "cores", "kind", "cores_bound", "host_cpus", "reference_shaped_value",
+                                                  "reference_shaped_cores")} if cpu else None),
             "timed_region_s": elapsed_max, "settle_ms": args.settle_ms, "settle_steps": settled,
             "encode_ms": enc_ms, "decode_ms": dec_ms,
             "reduced_over_ranks": {"frames_per_step": int(sums[0]), "checksum_X": sums[1], "checksum_thr": sums[2],
@@ -797,7 +812,8 @@ def main():
                                    "round_trip_max_abs_err": err_max},
         }
         if cpu:
-            out["cpu_baseline"]["sample"] = "%d procs x 12 s of B=2 K=46 stereo encode+decode, numpy oracle" % cpu["processes"]
+            out["cpu_baseline"]["sample"] = ("%d procs x 12 s of B=2 K=46 stereo encode+decode, numpy oracle (closed form: value; "
+                                              "reference-shaped dense ops, 8 s: reference_shaped_value)" % cpu["processes"])
         out.update(flat)
 
         def trim(o):   # seven significant digits are plenty for a rate or a time (checksums keep all of theirs)

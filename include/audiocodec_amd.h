@@ -314,9 +314,15 @@ AC_API int ac_workspace_destroy(ac_workspace* ws);
  * only for work on the stream its last tenant was allocated for (same-stream order is execution order).  NULL when the
  * region has no room: the caller then allocates elsewhere.  Once used, the fixed tensors of ac_workspace_buffers overlap
  * the pool's and must not be used; ac_workspace_destroy defers freeing the regions until the last tensor is released.
- * ac_workspace_live: tensors handed out and not yet released. */
+ * ac_workspace_live: tensors handed out and not yet released.
+ * ac_workspace_record_stream: the pool's counterpart of torch's Tensor.record_stream (which a DLPack tensor's storage does not
+ * reach): tells the pool that the tensor starting at `data` is also used by work on `stream`.  When the tensor dies, the pool
+ * records an event on every such stream and the extent's next tenant -- whatever stream it is allocated for -- waits for them
+ * first, so a consumer on a side stream that drops its last reference early cannot have the memory rewritten under it.
+ * AC_EINVAL when `data` is not the start of a live tensor of this pool. */
 AC_API void* ac_workspace_alloc_dlpack(ac_workspace* ws, int region, int ndim, const int64_t* shape, void* stream);
 AC_API long ac_workspace_live(ac_workspace* ws);
+AC_API int ac_workspace_record_stream(ac_workspace* ws, const void* data, void* stream);
 
 /* The probe on its own: runs ac_encode_fused with each of the n caller-owned candidate threshold buffers (x, X, t fixed;
  * contents of X, t and the candidates are overwritten), times every candidate with HIP events (median of three launches

@@ -1955,6 +1955,73 @@ def test_library_allocated_results_are_placed_without_changing_them():
     assert placement.report() is None
 
 
+def test_pool_streams_and_graph_capture():
+    """What torch's allocator does for its own blocks and the pool has to do itself: (1) an extent released
+    after work on the DEFAULT stream -- whose handle is a null pointer -- is not "fresh" to a request on a side stream;
+    (2) placement.record_stream: a consumer on a side stream that drops its reference early does not get the memory
+    rewritten under it by the extent's next tenant; (3) under torch.cuda.graph nothing is carved out of the pool and no
+    pool is built (captured addresses must stay valid for the replays); (4) no pool outside the configuration its effect
+    was measured on."""
+    from audiocodec_amd import placement
+    placement.release()
+    N, B, K, C = 1024, 80, 234, 2
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    x = torch.rand(B, K * N, C, device="cuda") * 2 - 1
+    # (4) a configuration without the fused wave-level encode: plain allocations, no probe inside the user's call
+    c960 = audiocodec_amd.AudioCodec(48000, 960)
+    c960.encode(torch.rand(160, 117 * 960, 2, device="cuda"))
+    assert placement.report() is None
+    # (3) capture before any pool exists: none is built
+    xs = x[:4].contiguous()
+    codec.encode(xs)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        Xg, tg, thrg = codec.encode(x)
+    assert placement.report() is None
+    gr.replay()
+    torch.cuda.synchronize()
+    X, t, thr = codec.encode(x)                            # builds the pool
+    assert torch.equal(X, Xg) and torch.equal(thr, thrg)
+    pl = placement.pool(x.device)
+    assert pl is not None and placement.report()["live_tensors"] == 2
+    gr2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr2):                            # ... and with a pool: the capture's tensors are torch's own
+        Xh, th, thrh = codec.encode(x)
+    assert placement.report()["live_tensors"] == 2
+    gr2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(Xh, X) and torch.equal(thrh, thr)
+    del Xg, tg, thrg, Xh, th, thrh, gr, gr2
+    # (1) default stream, then a side stream
+    shape = tuple(thr.shape)
+    p0 = thr.data_ptr()
+    del thr                                                # released after default-stream work
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        a = placement.empty(placement.REGION_OTHER, shape, torch.float32, x.device)
+    assert a.data_ptr() != p0                              # the freed extent waits for a request on ITS stream
+    b = placement.empty(placement.REGION_OTHER, shape, torch.float32, x.device)
+    assert b.data_ptr() == p0
+    del a
+    # (2) record_stream
+    b.fill_(1.0)
+    ev = torch.cuda.Event()
+    ev.record()
+    with torch.cuda.stream(side):
+        side.wait_event(ev)
+        torch.cuda._sleep(200_000_000)                     # ~0.1 s: the consumer's read is still queued when the producer moves on
+        got = b[:2].sum()
+    placement.record_stream(b, side)
+    del b
+    c = placement.empty(placement.REGION_OTHER, shape, torch.float32, x.device)   # the same extent again (default stream)
+    assert c.data_ptr() == p0
+    c.fill_(2.0)
+    torch.cuda.synchronize()
+    assert float(got) == float(2 * shape[1] * shape[2] * shape[3])
+    del c, X, t
+    placement.release()
+
+
 def test_workspace_c_abi():
     """ac_workspace_* through ctypes alone (what a C caller has): placed buffers, fixed tensors of two copies, report."""
     import ctypes
@@ -2016,9 +2083,10 @@ def test_bench_contract_line_on_a_small_workload():
                    "--no-other-configs", "--no-workspace")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "reduced_over_ranks", "settle_ms",
-              "timed_region_s", "cold_start_value", "encode_ms", "decode_ms"):
+              "timed_region_s", "cold_start_value", "encode_ms", "decode_ms", "caller_owned_value", "caller_owned_encode_ms"):
         assert k in d, k
-    assert "cold_start" in d["_side"] and "kernels" in d["_side"]
+    assert "cold_start" in d["_side"] and "kernels" in d["_side"] and "caller_owned" in d["_side"]
+    assert "codec.encode()" in d["config"]["workload"]   # the headline is the reference's call shape: the library allocates its results
     assert abs(d["timed_region_s"] / (d["ms_per_step"] * d["steps"] * 1e-3) - 1.0) < 1e-5 and d["config"]["backend"] is None
     assert d["metric"].startswith("MDCT frames/s") and d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 5
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["higher_is_better"] is True and d["vs_baseline"] is None
@@ -2052,9 +2120,10 @@ def test_bench_one_rank_over_rccl():
     torch.distributed.run; its barrier, max-over-ranks time, checksum reductions and the closing barrier(device_ids=...) /
     destroy_process_group go through RCCL on the device -- the code the 1 / 2 / 4 / 8 curve depends on
     (no data-path collective: clips are independent, mdctransformer.py:292-295).  Same results bit for bit, and the same
-    rate as the plain run on BASELINE configs[1] itself: within 10 % on library-placed tensors (AudioCodec.encode / decode),
-    within 20 % on caller-owned plain ones (two processes: where the allocator puts X and thr moves the step by up to 11 %
-    on its own, and RCCL's own buffers shift every later allocation)."""
+    rate as the plain run on BASELINE configs[1] itself: the headline (library-placed results of codec.encode / decode)
+    within 5 % -- two processes differ by up to 4 % on their own; the caller-owned figure is printed, not asserted (where
+    the allocator puts X and thr moves that step by up to 11 % between two processes, and RCCL's own buffers shift every
+    later allocation)."""
     common = ("--steps", 60, "--warmup", 5, "--no-cpu-baseline", "--no-other-configs", "--no-workspace", "--no-smi")
     nccl = _run_bench("--gpus", 1, "--dist", "nccl", *common)
     plain = _run_bench("--gpus", 1, *common)
@@ -2064,13 +2133,9 @@ def test_bench_one_rank_over_rccl():
     assert a["frames_per_step"] == b["frames_per_step"] == 256 * 2 * 468
     for k in ("checksum_X", "checksum_thr", "checksum_pcm", "checksum_tonality", "round_trip_max_abs_err"):
         assert a[k] == b[k], (k, a[k], b[k])
-    print("one rank over RCCL %.1f M frames/s (library-placed tensors %.1f M), plain %.1f M (%.1f M)"
-          % (nccl["value"] / 1e6, nccl["encode_api_value"] / 1e6, plain["value"] / 1e6, plain["encode_api_value"] / 1e6))
-    # caller-owned plain tensors: where the allocator puts X and thr moves the step by up to 11 % between two processes
-    # (254 ... 283 M measured), so the like-for-like comparison is the one on library-placed tensors
-    # (library-placed: 276 ... 287 M over the round's runs, 4 % between two processes on their own)
-    assert abs(nccl["value"] / plain["value"] - 1.0) < 0.20, (nccl["value"], plain["value"])
-    assert abs(nccl["encode_api_value"] / plain["encode_api_value"] - 1.0) < 0.10, (nccl["encode_api_value"], plain["encode_api_value"])
+    print("one rank over RCCL %.1f M frames/s (caller-owned tensors %.1f M), plain %.1f M (%.1f M)"
+          % (nccl["value"] / 1e6, nccl["caller_owned_value"] / 1e6, plain["value"] / 1e6, plain["caller_owned_value"] / 1e6))
+    assert abs(nccl["value"] / plain["value"] - 1.0) < 0.05, (nccl["value"], plain["value"])
     # the driver's own form of the same thing: torch.distributed.run --nproc-per-node 1 bench.py --gpus 1
     import json
     import os
