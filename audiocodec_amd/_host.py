@@ -29,18 +29,21 @@ def as_torch_dtype(dtype):
     raise TypeError("unsupported dtype %r" % (dtype,))
 
 
-# AC_F32 / AC_F64 / AC_BF16 of include/audiocodec_amd.h
+# AC_F32 / AC_F64 / AC_BF16 of include/audiocodec_amd.h (AC_F16 = 3: the filter bank only, MDCT_DTYPE_IDS)
 DTYPE_IDS = {torch.float32: 0, torch.float64: 1, torch.bfloat16: 2}
+MDCT_DTYPE_IDS = {**DTYPE_IDS, torch.float16: 3}
 
 
-def require_hip_compute_dtype(compute_dtype, who):
+def require_hip_compute_dtype(compute_dtype, who, filter_bank=False):
     """float32 (wave-level / LDS-FFT / generic kernels), float64 (float64 kernels and constants) and bfloat16
-    (bfloat16 tensors, float32 arithmetic) have HIP kernels; anything else is refused."""
-    if compute_dtype not in DTYPE_IDS:
+    (bfloat16 tensors, float32 arithmetic) have HIP kernels; the filter bank also takes float16 tensors (float32 arithmetic),
+    as the reference's does (mdctransformer.py:327-344); anything else is refused."""
+    ids = MDCT_DTYPE_IDS if filter_bank else DTYPE_IDS
+    if compute_dtype not in ids:
         raise NotImplementedError(
-            "%s: the HIP kernels serve compute_dtype float32, float64 and bfloat16 (got %s); "
-            "there is no CPU or other-precision fallback" % (who, compute_dtype))
-    return DTYPE_IDS[compute_dtype]
+            "%s: the HIP kernels serve compute_dtype float32, float64 and bfloat16%s (got %s); "
+            "there is no CPU or other-precision fallback" % (who, ", float16" if filter_bank else "", compute_dtype))
+    return ids[compute_dtype]
 
 
 def precompute_id(precompute_dtype, who):

@@ -978,9 +978,11 @@ int ac_probe_placement(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const f
 
 // ---- compute_dtype variants ---------------------------------------------------------------------
 #define AC_REQUIRE_DTYPE(d) AC_REQUIRE((d) == AC_F32 || (d) == AC_F64 || (d) == AC_BF16, "dtype = %d is not one of AC_F32, AC_F64, AC_BF16", (d))
+// the filter bank also takes float16 tensors (mdctransformer.py:327-344); the masking model does not (psychoacoustic.py:42-43)
+#define AC_REQUIRE_DTYPE_MDCT(d) AC_REQUIRE((d) == AC_F32 || (d) == AC_F64 || (d) == AC_BF16 || (d) == AC_F16, "dtype = %d is not one of AC_F32, AC_F64, AC_BF16, AC_F16", (d))
 
 int ac_mdct_forward_typed(const ac_mdct_plan* p, const void* x, void* X, int dtype, int B, int K, int C, void* stream) {
-  AC_REQUIRE_DTYPE(dtype);
+  AC_REQUIRE_DTYPE_MDCT(dtype);
   if (dtype == AC_F32) return ac_mdct_forward(p, static_cast<const float*>(x), static_cast<float*>(X), B, K, C, stream);
   AC_REQUIRE(p != nullptr, "plan is NULL");
   int st = check_dims(B, K, C);
@@ -991,13 +993,14 @@ int ac_mdct_forward_typed(const ac_mdct_plan* p, const void* x, void* X, int dty
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == AC_F64) return launch_fwd_f64(p, static_cast<const double*>(x), static_cast<double*>(X), B, K, K + 1, C, s);
+  if (dtype == AC_F16) return launch_fwd_f16(p, static_cast<const f16_t*>(x), static_cast<f16_t*>(X), B, K, K + 1, C, s);
   if (wave_level(p, C, 2, K) && C <= 2)   // bfloat16 on the wave-level kernels (stereo / mono)
     return launch_fwd_fast(p, nullptr, x, 2, static_cast<float*>(X), nullptr, nullptr, 0.f, nullptr, B, K, K + 1, C, s);
   return launch_fwd_bf16(p, static_cast<const bf16_t*>(x), static_cast<bf16_t*>(X), B, K, K + 1, C, s);
 }
 
 int ac_mdct_inverse_typed(const ac_mdct_plan* p, const void* X, void* x, int dtype, int B, int Kp, int C, void* stream) {
-  AC_REQUIRE_DTYPE(dtype);
+  AC_REQUIRE_DTYPE_MDCT(dtype);
   if (dtype == AC_F32) return ac_mdct_inverse(p, static_cast<const float*>(X), static_cast<float*>(x), B, Kp, C, stream);
   AC_REQUIRE(p != nullptr, "plan is NULL");
   int st = check_dims(B, Kp, C);
@@ -1008,6 +1011,7 @@ int ac_mdct_inverse_typed(const ac_mdct_plan* p, const void* X, void* x, int dty
   DeviceGuard guard(p->device);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == AC_F64) return launch_inv_f64(p, static_cast<const double*>(X), static_cast<double*>(x), B, Kp, Kp + 1, C, s);
+  if (dtype == AC_F16) return launch_inv_f16(p, static_cast<const f16_t*>(X), static_cast<f16_t*>(x), B, Kp, Kp + 1, C, s);
   if (wave_level(p, C, 2, Kp) && C <= 2)
     return launch_inv_fast(p, static_cast<const float*>(X), x, 2, nullptr, nullptr, B, Kp, Kp + 1, C, s);
   return launch_inv_bf16(p, static_cast<const bf16_t*>(X), static_cast<bf16_t*>(x), B, Kp, Kp + 1, C, s);

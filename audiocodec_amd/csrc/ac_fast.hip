@@ -724,7 +724,9 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[R], char* lds0, char* 
     // sfm = 10 log10(gm / am) with gm = exp(mean ln I)  ==  10 log10(2) (mean log2 I - log2 am)
     const v2f sfm = 3.0102999566398120f * (slog * (1.0f / P::FN) - log2v(am));
     const v2f tt = sfm * (-1.0f / 60.0f);
-    t = v2f{fminf(tt.x, 1.0f), fminf(tt.y, 1.0f)};
+    // a frame with a NaN or an infinite intensity has a NaN tonality, as tf.maximum / reduce_mean / tf.minimum make it
+    // (psychoacoustic.py:113-118): its sum of squares is not finite (v_max / v_min alone would return the other operand)
+    t = v2f{(ssq.x - ssq.x == 0.0f) ? fminf(tt.x, 1.0f) : __builtin_nanf(""), (ssq.y - ssq.y == 0.0f) ? fminf(tt.y, 1.0f) : __builtin_nanf("")};
     if (T_BF16) {   // bfloat16 tensors: the threshold is computed from the tonality the caller gets
       const s2 e = Bf16Fmt::enc2(t.x, t.y);
       t = v2f{Bf16Fmt::dec(e.x), Bf16Fmt::dec(e.y)};
@@ -773,7 +775,10 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[R], char* lds0, char* 
     }
   }
   const v2f Pj = P0 + P1;
-  const v2f Q = exp2v(pp.alpha * log2v(maxv(Pj, kEps)));   // max(eps, P)^alpha  (:206)
+  v2f Q = exp2v(pp.alpha * log2v(maxv(Pj, kEps)));   // max(eps, P)^alpha  (:206)
+  // a band with a NaN intensity stays NaN (tf.maximum): through the band x band product it poisons every band of its frame and
+  // signal, as the reference's dense einsum does (:205-207)
+  Q = v2f{Pj.x == Pj.x ? Q.x : Pj.x, Pj.y == Pj.y ? Q.y : Pj.y};
   v2f acc;
   if (SPREAD == 0) {
     wave_sync();
@@ -796,7 +801,11 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[R], char* lds0, char* 
   const v2f offset = (1.0f - pp.drown) * (t * bc1.x + 9.0f * t + 5.5f);                        // (:185-191)
   const v2f fac = exp2v(offset * (-pp.alpha * 0.33219280948873623f));                          // 10^(-alpha O / 10)
   const v2f T = exp2v(pp.inv_alpha * log2v(maxv(fac * acc, kEps)));                             // (:208)
-  const v2f G = maxv(T, pc.bc0[0].w);                                                           // (:144)
+  v2f G = maxv(T, pc.bc0[0].w);                                                                 // (:144)
+  {   // NaN where the reference has NaN: a poisoned product or a NaN tonality (the clamps -- v_max -- would drop it)
+    const float px = acc.x + t.x, py = acc.y + t.y;
+    G = v2f{px == px ? G.x : px, py == py ? G.y : py};
+  }
   v2f Gn;
   Gn.x = __shfl_down(G.x, 1, 64);   // G of band j + 1
   Gn.y = __shfl_down(G.y, 1, 64);
@@ -805,8 +814,9 @@ __device__ __forceinline__ void psy_stage(const v4f (&xq)[R], char* lds0, char* 
   const v2f A0 = maxv(G * bc1.y, kEps), A1 = maxv(G * bc1.z + Gn * bc1.w, kEps);
   wave_sync();
   // v_sqrt_f32 (1 ulp); arguments are >= 1e-14, far from the denormal range
-  *reinterpret_cast<v4f*>(buf + 16 * lane) = v4f{__builtin_amdgcn_sqrtf(A0.x), __builtin_amdgcn_sqrtf(A0.y),
-                                                 __builtin_amdgcn_sqrtf(A1.x), __builtin_amdgcn_sqrtf(A1.y)};   // entry e at byte 8 e
+  // (a poisoned frame: every band's G is NaN, and so is every entry)
+  *reinterpret_cast<v4f*>(buf + 16 * lane) = v4f{G.x == G.x ? __builtin_amdgcn_sqrtf(A0.x) : G.x, G.y == G.y ? __builtin_amdgcn_sqrtf(A0.y) : G.y,
+                                                 G.x == G.x ? __builtin_amdgcn_sqrtf(A1.x) : G.x, G.y == G.y ? __builtin_amdgcn_sqrtf(A1.y) : G.y};   // entry e at byte 8 e
   wave_sync();
   emit.begin();
 #pragma unroll

@@ -23,9 +23,11 @@ template <> struct Compute<double> { using type = double; };
 __device__ __forceinline__ float ldv(const float* p) { return *p; }
 __device__ __forceinline__ double ldv(const double* p) { return *p; }
 __device__ __forceinline__ float ldv(const bf16_t* p) { return (float)*p; }
+__device__ __forceinline__ float ldv(const f16_t* p) { return (float)*p; }
 __device__ __forceinline__ void stv(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stv(double* p, double v) { *p = v; }
 __device__ __forceinline__ void stv(bf16_t* p, float v) { *p = (bf16_t)v; }   // round to nearest even
+__device__ __forceinline__ void stv(f16_t* p, float v) { *p = (f16_t)v; }     // round to nearest even (overflow: infinity, as a cast)
 extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
 // ------------------------------------------------------------------------------------------------
@@ -208,6 +210,24 @@ __device__ __forceinline__ void st2(bf16_t* p, float2 v, int C, bool has1) {
   }
   p[0] = (bf16_t)v.x;
   if (has1) p[1] = (bf16_t)v.y;
+}
+// float16 storage (MDCTransformer(compute_dtype=float16): mdctransformer.py:327-344 up-casts such tensors to float32 inside
+// the DCT-IV; here all the arithmetic is float32)
+typedef f16_t f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 ld2(const f16_t* p, int C, bool has1) {
+  if (C == 2) {
+    const f2v v = __builtin_convertvector(*reinterpret_cast<const f16x2_t*>(p), f2v);
+    return make_float2(v.x, v.y);
+  }
+  return make_float2((float)p[0], has1 ? (float)p[1] : 0.f);
+}
+__device__ __forceinline__ void st2(f16_t* p, float2 v, int C, bool has1) {
+  if (C == 2) {
+    *reinterpret_cast<f16x2_t*>(p) = __builtin_convertvector(f2v{v.x, v.y}, f16x2_t);
+    return;
+  }
+  p[0] = (f16_t)v.x;
+  if (has1) p[1] = (f16_t)v.y;
 }
 
 __device__ __forceinline__ cpair cadd(cpair a, cpair b) { return {unpk(pk(a.re) + pk(b.re)), unpk(pk(a.im) + pk(b.im))}; }
@@ -1704,10 +1724,12 @@ __device__ __forceinline__ float m_pow(float x, float y) { return powf(x, y); }
 __device__ __forceinline__ double m_pow(double x, double y) { return pow(x, y); }
 __device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
-__device__ __forceinline__ float m_max(float a, float b) { return fmaxf(a, b); }
-__device__ __forceinline__ double m_max(double a, double b) { return fmax(a, b); }
-__device__ __forceinline__ float m_min(float a, float b) { return fminf(a, b); }
-__device__ __forceinline__ double m_min(double a, double b) { return fmin(a, b); }
+// maximum / minimum as tf.maximum / tf.minimum (psychoacoustic.py:113-116, 205-208, 331): a NaN operand gives NaN (fmax / fmin
+// would return the other operand and turn a poisoned frame into finite numbers)
+__device__ __forceinline__ float m_max(float a, float b) { return (a != a || b != b) ? a + b : fmaxf(a, b); }
+__device__ __forceinline__ double m_max(double a, double b) { return (a != a || b != b) ? a + b : fmax(a, b); }
+__device__ __forceinline__ float m_min(float a, float b) { return (a != a || b != b) ? a + b : fminf(a, b); }
+__device__ __forceinline__ double m_min(double a, double b) { return (a != a || b != b) ? a + b : fmin(a, b); }
 
 template <typename TIO, typename TC = typename Compute<TIO>::type>
 static __global__ __launch_bounds__(kThreads) void k_tonality_generic(const TIO* __restrict__ X, TIO* __restrict__ t,
@@ -2843,12 +2865,14 @@ int launch_inv_f64(const ac_mdct_plan* p, const double* X, double* x, int B, int
   return AC_OK;
 }
 
-int launch_fwd_bf16(const ac_mdct_plan* p, const bf16_t* x, bf16_t* X, int B, int Kin, int F, int C, hipStream_t s) {
+// 2-byte tensors (bfloat16, float16), float32 arithmetic: the 8-byte wave kernels / the workgroup form of the LDS-FFT tier, else O(N^2)
+template <typename T16>
+static int launch_fwd_16(const ac_mdct_plan* p, const T16* x, T16* X, int B, int Kin, int F, int C, hipStream_t s) {
   const long long nwg = (long long)B * C * F;
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
   if (lds_wave_ok(p->N, false, C, false) && !g_force_generic) {
-    const int r = launch_fwd_wave<bf16_t>(p, x, X, (const bf16_t*)nullptr, B, Kin, F, C, s);
+    const int r = launch_fwd_wave<T16>(p, x, X, (const T16*)nullptr, B, Kin, F, C, s);
     if (r != kWaveDeclined) return r;
   }
   if (lds_fft_ok(p->N) && !g_force_generic) {
@@ -2856,32 +2880,33 @@ int launch_fwd_bf16(const ac_mdct_plan* p, const bf16_t* x, bf16_t* X, int B, in
     const long long ntasks = (long long)B * CP * F;
     const size_t lds2 = ((size_t)gpw * lds_fwd_floats_per_group(p->N) + p->N) * sizeof(float);
     const bool alias = lds_fwd_floats_per_group(p->N) == 4 * p->N;
-    const int st2 = alias ? allow_lds(k_fwd_lds<bf16_t, true>, lds2) : allow_lds(k_fwd_lds<bf16_t, false>, lds2);
+    const int st2 = alias ? allow_lds(k_fwd_lds<T16, true>, lds2) : allow_lds(k_fwd_lds<T16, false>, lds2);
     if (st2) return st2;
     const dim3 grid((unsigned)((ntasks + gpw - 1) / gpw));
     if (alias)
-      hipLaunchKernelGGL((k_fwd_lds<bf16_t, true>), grid, dim3(kThreads), lds2, s, x, X, (const bf16_t*)nullptr, p->d_coef,
+      hipLaunchKernelGGL((k_fwd_lds<T16, true>), grid, dim3(kThreads), lds2, s, x, X, (const T16*)nullptr, p->d_coef,
                          p->d_ctab, Kin, F, C, CP, p->N, ntasks);
     else
-      hipLaunchKernelGGL((k_fwd_lds<bf16_t, false>), grid, dim3(kThreads), lds2, s, x, X, (const bf16_t*)nullptr, p->d_coef,
+      hipLaunchKernelGGL((k_fwd_lds<T16, false>), grid, dim3(kThreads), lds2, s, x, X, (const T16*)nullptr, p->d_coef,
                          p->d_ctab, Kin, F, C, CP, p->N, ntasks);
     AC_HIP_CHECK(hipGetLastError());
     return AC_OK;
   }
   const size_t lds = (size_t)p->N * sizeof(float);
   AC_REQUIRE(lds <= 64 * 1024, "filters_n = %d too large for the generic kernel", p->N);
-  hipLaunchKernelGGL((k_fwd_generic<bf16_t, float>), dim3((unsigned)nwg), dim3(kThreads), lds, s, x, X,
-                     (const bf16_t*)nullptr, p->d_coef, p->d_ctab, Kin, F, C, p->N);
+  hipLaunchKernelGGL((k_fwd_generic<T16, float>), dim3((unsigned)nwg), dim3(kThreads), lds, s, x, X,
+                     (const T16*)nullptr, p->d_coef, p->d_ctab, Kin, F, C, p->N);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }
 
-int launch_inv_bf16(const ac_mdct_plan* p, const bf16_t* X, bf16_t* x, int B, int Kp, int nblk, int C, hipStream_t s) {
+template <typename T16>
+static int launch_inv_16(const ac_mdct_plan* p, const T16* X, T16* x, int B, int Kp, int nblk, int C, hipStream_t s) {
   const long long nwg = (long long)B * C * nblk;
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
   if (lds_wave_ok(p->N, true, C, false) && !g_force_generic) {
-    const int r = launch_inv_wave<bf16_t>(p, X, x, nullptr, nullptr, B, Kp, nblk, C, s);
+    const int r = launch_inv_wave<T16>(p, X, x, nullptr, nullptr, B, Kp, nblk, C, s);
     if (r != kWaveDeclined) return r;
   }
   if (lds_fft_ok(p->N) && !g_force_generic) {
@@ -2889,9 +2914,9 @@ int launch_inv_bf16(const ac_mdct_plan* p, const bf16_t* X, bf16_t* x, int B, in
     const int nseg = (nblk + seg - 1) / seg;
     const long long ntasks = (long long)B * CP * nseg;
     const size_t lds2 = ((size_t)gpw * 7 * p->N + p->N) * sizeof(float);
-    const int st2 = allow_lds(k_inv_lds<bf16_t>, lds2);
+    const int st2 = allow_lds(k_inv_lds<T16>, lds2);
     if (st2) return st2;
-    hipLaunchKernelGGL(k_inv_lds<bf16_t>, dim3((unsigned)((ntasks + gpw - 1) / gpw)), dim3(kThreads), lds2, s, X, x,
+    hipLaunchKernelGGL(k_inv_lds<T16>, dim3((unsigned)((ntasks + gpw - 1) / gpw)), dim3(kThreads), lds2, s, X, x,
                        (const float*)nullptr, (float*)nullptr, p->d_coef, p->d_ctab, Kp, nblk, seg, nseg, C, CP, p->N,
                        ntasks);
     AC_HIP_CHECK(hipGetLastError());
@@ -2899,10 +2924,23 @@ int launch_inv_bf16(const ac_mdct_plan* p, const bf16_t* X, bf16_t* x, int B, in
   }
   const size_t lds = 2 * (size_t)p->N * sizeof(float);
   AC_REQUIRE(lds <= 64 * 1024, "filters_n = %d too large for the generic kernel", p->N);
-  hipLaunchKernelGGL((k_inv_generic<bf16_t, float>), dim3((unsigned)nwg), dim3(kThreads), lds, s, X, x,
+  hipLaunchKernelGGL((k_inv_generic<T16, float>), dim3((unsigned)nwg), dim3(kThreads), lds, s, X, x,
                      (const float*)nullptr, (float*)nullptr, p->d_coef, p->d_ctab, Kp, nblk, nblk, C, p->N);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
+}
+
+int launch_fwd_bf16(const ac_mdct_plan* p, const bf16_t* x, bf16_t* X, int B, int Kin, int F, int C, hipStream_t s) {
+  return launch_fwd_16<bf16_t>(p, x, X, B, Kin, F, C, s);
+}
+int launch_inv_bf16(const ac_mdct_plan* p, const bf16_t* X, bf16_t* x, int B, int Kp, int nblk, int C, hipStream_t s) {
+  return launch_inv_16<bf16_t>(p, X, x, B, Kp, nblk, C, s);
+}
+int launch_fwd_f16(const ac_mdct_plan* p, const f16_t* x, f16_t* X, int B, int Kin, int F, int C, hipStream_t s) {
+  return launch_fwd_16<f16_t>(p, x, X, B, Kin, F, C, s);
+}
+int launch_inv_f16(const ac_mdct_plan* p, const f16_t* X, f16_t* x, int B, int Kp, int nblk, int C, hipStream_t s) {
+  return launch_inv_16<f16_t>(p, X, x, B, Kp, nblk, C, s);
 }
 
 template <typename TIO>

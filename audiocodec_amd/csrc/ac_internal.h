@@ -92,6 +92,7 @@ __device__ __forceinline__ float db_of(float v, int norm) {
 #endif
 
 typedef __bf16 bf16_t;   // storage type of the AC_BF16 tensors (device code converts with v_cvt_pk_bf16_f32)
+typedef _Float16 f16_t;  // storage type of the AC_F16 tensors (filter bank only)
 
 // layout of the run-structured masking-model image and of its per-frame LDS slot (build_runs in ac_psy_mid.hip; the fields
 // are those of runs::RunsParams, ac_psy_runs_dev.h)
@@ -260,6 +261,8 @@ int launch_fwd_f64(const ac_mdct_plan* p, const double* x, double* X, int B, int
 int launch_inv_f64(const ac_mdct_plan* p, const double* X, double* x, int B, int Kp, int nblk, int C, hipStream_t s);
 int launch_fwd_bf16(const ac_mdct_plan* p, const bf16_t* x, bf16_t* X, int B, int Kin, int F, int C, hipStream_t s);
 int launch_inv_bf16(const ac_mdct_plan* p, const bf16_t* X, bf16_t* x, int B, int Kp, int nblk, int C, hipStream_t s);
+int launch_fwd_f16(const ac_mdct_plan* p, const f16_t* x, f16_t* X, int B, int Kin, int F, int C, hipStream_t s);
+int launch_inv_f16(const ac_mdct_plan* p, const f16_t* X, f16_t* x, int B, int Kp, int nblk, int C, hipStream_t s);
 int launch_tonality_f64(const ac_psy_plan* p, const double* X, double* t, int B, int F, int C, hipStream_t s);
 int launch_tonality_bf16(const ac_psy_plan* p, const bf16_t* X, bf16_t* t, int B, int F, int C, hipStream_t s);
 int launch_threshold_f64(const ac_psy_plan* p, const double* X, const double* t, double drown, double* thr, int B, int F,

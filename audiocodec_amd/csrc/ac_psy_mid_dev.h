@@ -176,7 +176,8 @@ __device__ __forceinline__ void tonality_frames(const v4f (&xq)[FB][R], const Mi
     const v2f am = ssq[fb] * a.inv_n + kEps;
     const v2f sfm = 3.0102999566398120f * (slog[fb] * a.inv_n - log2v(am));
     const v2f tt = sfm * (-1.0f / 60.0f);
-    t[fb] = v2f{fminf(tt.x, 1.0f), fminf(tt.y, 1.0f)};
+    // (a NaN or an infinite intensity: NaN, as the reference's tf.maximum / tf.minimum propagate it)
+    t[fb] = v2f{(ssq[fb].x - ssq[fb].x == 0.0f) ? fminf(tt.x, 1.0f) : __builtin_nanf(""), (ssq[fb].y - ssq[fb].y == 0.0f) ? fminf(tt.y, 1.0f) : __builtin_nanf("")};
   }
 }
 
@@ -231,7 +232,11 @@ __device__ __forceinline__ void threshold_frames(const v4f (&xq)[FB][R], const v
       }
     }
 #pragma unroll
-    for (int fb = 0; fb < FB; ++fb) Q[fb] = exp2v(a.alpha * log2v(maxv(P0[fb] + P1[fb], kEps)));   // max(eps, P)^alpha  (:206)
+    for (int fb = 0; fb < FB; ++fb) {
+      const v2f Pj = P0[fb] + P1[fb];
+      const v2f q = exp2v(a.alpha * log2v(maxv(Pj, kEps)));   // max(eps, P)^alpha  (:206); a NaN intensity stays NaN (tf.maximum)
+      Q[fb] = v2f{Pj.x == Pj.x ? q.x : Pj.x, Pj.y == Pj.y ? q.y : Pj.y};
+    }
   }
   wave_sync();   // every lane is done with the intensities: the head of each slot takes the frame's G
   v2f acc[FB];   // sum_i Q_i S[i, j] on the matrix cores, offset factor outside the sum  (:185-208)
@@ -241,7 +246,9 @@ __device__ __forceinline__ void threshold_frames(const v4f (&xq)[FB][R], const v
     const v2f offset = (1.0f - a.drown) * (t[fb] * beta + 9.0f * t[fb] + 5.5f);
     const v2f fac = exp2v(offset * (-a.alpha * 0.33219280948873623f));                 // 10^(-alpha O / 10)
     const v2f T = exp2v(a.inv_alpha * log2v(maxv(fac * acc[fb], kEps)));                // (:208)
-    reinterpret_cast<v2f*>(ibuf + fb * istride)[lane] = maxv(T, quiet);                 // (:144)
+    const v2f Gq = maxv(T, quiet);                                                       // (:144)
+    const float px = acc[fb].x + t[fb].x, py = acc[fb].y + t[fb].y;                      // NaN where the reference has NaN
+    reinterpret_cast<v2f*>(ibuf + fb * istride)[lane] = v2f{px == px ? Gq.x : px, py == py ? Gq.y : py};
   }
   wave_sync();
   // thr_f = sqrt(max(eps, sum_j G_j W_inv[j, f]))  (:330-331)
@@ -275,7 +282,8 @@ __device__ __forceinline__ void threshold_frames(const v4f (&xq)[FB][R], const v
 #pragma unroll
       for (int fb = 0; fb < FB; ++fb) {
         const v2f u0 = maxv(s0[fb], kEps), u1 = maxv(s1[fb], kEps);
-        emit(fb, i, v4f{__builtin_amdgcn_sqrtf(u0.x), __builtin_amdgcn_sqrtf(u0.y), __builtin_amdgcn_sqrtf(u1.x), __builtin_amdgcn_sqrtf(u1.y)});
+        emit(fb, i, v4f{s0[fb].x == s0[fb].x ? __builtin_amdgcn_sqrtf(u0.x) : s0[fb].x, s0[fb].y == s0[fb].y ? __builtin_amdgcn_sqrtf(u0.y) : s0[fb].y,
+                        s1[fb].x == s1[fb].x ? __builtin_amdgcn_sqrtf(u1.x) : s1[fb].x, s1[fb].y == s1[fb].y ? __builtin_amdgcn_sqrtf(u1.y) : s1[fb].y});
       }
     }
   }

@@ -195,7 +195,9 @@ __device__ __forceinline__ void tonality_finish(const v4f (&acc)[FB], const Runs
   const float sq = FB == 1 ? dpp_get<0x128>(tot) : dpp_get<0x4E>(tot);   // row_ror 8 | quad_perm [2, 3, 0, 1]
   const float am = sq * a.inv_n + kEps;
   const float sfm = 3.0102999566398120f * (tot * a.inv_n - __builtin_amdgcn_logf(am));
-  const float tt = fminf(sfm * (-1.0f / 60.0f), 1.0f);
+  // a frame with a NaN or an infinite intensity has a NaN tonality, as tf.maximum / reduce_mean / tf.minimum make it
+  // (psychoacoustic.py:113-118): its sum of squares is not finite (v_max / v_min alone would return the other operand)
+  const float tt = (sq - sq == 0.0f) ? fminf(sfm * (-1.0f / 60.0f), 1.0f) : __builtin_nanf("");
 #pragma unroll
   for (int fb = 0; fb < FB; ++fb) {
     const int l0 = FB == 4 ? 4 * fb : FB == 2 ? 8 * fb : 0, l1 = FB == 4 ? 4 * fb + 1 : FB == 2 ? 8 * fb + 4 : 4;
@@ -377,7 +379,10 @@ __device__ __forceinline__ void band_tail(const v2f (&P)[FB], const v2f (&t)[FB]
   v2f Q[FB];   // max(eps, P)^alpha (:206); lanes beyond the M bands keep 0: the rows of S they would meet do not exist
 #pragma unroll
   for (int fb = 0; fb < FB; ++fb) {
-    const v2f q = exp2v(a.alpha * log2v(maxv(P[fb], kEps)));
+    v2f q = exp2v(a.alpha * log2v(maxv(P[fb], kEps)));
+    // a band with a NaN intensity stays NaN (tf.maximum): through the matrix product it poisons every band of its frame and
+    // signal, as the reference's dense einsum does (psychoacoustic.py:205-207)
+    q = v2f{P[fb].x == P[fb].x ? q.x : P[fb].x, P[fb].y == P[fb].y ? q.y : P[fb].y};
     Q[fb] = lane < a.M ? q : v2f{0.f, 0.f};
   }
   wave_sync();   // every lane is done with the intensities and their sums: the head of the slots takes A, then G and the entries
@@ -407,10 +412,14 @@ __device__ __forceinline__ void band_tail(const v2f (&P)[FB], const v2f (&t)[FB]
       const v4f bd = reinterpret_cast<const v4f*>(img + OFF_BD)[b];                              // {beta + 9, quiet, rho}
       const v2f offset = a.omd * (tg * bd.x + 5.5f);                                            // (1 - drown) (t beta + 9 t + 5.5)
       const v2f y = maxv(log2v(acc) - (a.alpha * kLog2_10_10) * offset, kLog2Eps);              // log2 max(eps, fac acc)
-      const v2f G = maxv(exp2v(a.inv_alpha * y), bd.y);                                         // (:208, :144)
+      v2f G = maxv(exp2v(a.inv_alpha * y), bd.y);                                               // (:208, :144)
+      // NaN where the reference has NaN: a poisoned product (above) or a NaN tonality (the clamps -- v_max -- would drop it)
+      const float poison_x = acc.x + tg.x, poison_y = acc.y + tg.y;
+      G = v2f{poison_x == poison_x ? G.x : poison_x, poison_y == poison_y ? G.y : poison_y};
       const v2f A0 = maxv(G * bd.z, kEps);                                                      // interior bins of band b  (:330-331)
       *reinterpret_cast<v2f*>(sf + 8 * b) = G;
-      *reinterpret_cast<v2f*>(sf + 512 + 16 * b) = v2f{__builtin_amdgcn_sqrtf(A0.x), __builtin_amdgcn_sqrtf(A0.y)};
+      *reinterpret_cast<v2f*>(sf + 512 + 16 * b) =
+          v2f{G.x == G.x ? __builtin_amdgcn_sqrtf(A0.x) : G.x, G.y == G.y ? __builtin_amdgcn_sqrtf(A0.y) : G.y};
     }
   }
   wave_sync();
@@ -428,7 +437,8 @@ __device__ __forceinline__ void band_tail(const v2f (&P)[FB], const v2f (&t)[FB]
 #pragma unroll
     for (int fb = 0; fb < FB; ++fb) {
       const v2f A1 = maxv(s[fb], kEps);
-      *reinterpret_cast<v2f*>(slot0 + fb * slot_bytes + 512 + 16 * lane + 8) = v2f{__builtin_amdgcn_sqrtf(A1.x), __builtin_amdgcn_sqrtf(A1.y)};
+      *reinterpret_cast<v2f*>(slot0 + fb * slot_bytes + 512 + 16 * lane + 8) =
+          v2f{s[fb].x == s[fb].x ? __builtin_amdgcn_sqrtf(A1.x) : s[fb].x, s[fb].y == s[fb].y ? __builtin_amdgcn_sqrtf(A1.y) : s[fb].y};
     }
   }
 }

@@ -61,8 +61,10 @@ class MDCTransformer:
         :param window_type:      'sine', 'vorbis' (default); any other string or None selects the
                                  rectangular window (``:199-211``; the reference crashes on None)
         :param compute_dtype:    dtype of inputs and outputs: float32 (the wave-level kernels), float64 (everything in
-                                 float64, constants included: the on-device float64 cross-check) or bfloat16 (bfloat16 tensors,
-                                 float32 arithmetic inside); autograd and streaming are float32 only
+                                 float64, constants included: the on-device float64 cross-check), bfloat16 or float16 (2-byte
+                                 tensors, float32 arithmetic inside: the reference up-casts them inside its DCT-IV, ``:327-344``;
+                                 float16 results beyond 65504 become infinity as a cast makes them); autograd and streaming
+                                 are float32 only
         :param precompute_dtype: arithmetic type the window / fold constants are computed in on the host before they are
                                  cast to float32 tables (``:14,31-35,58-59``): float64 (default) or float32 -- the latter
                                  reproduces the reference's float32 rounding, including the cancellation at ``:218-221``
@@ -74,7 +76,7 @@ class MDCTransformer:
         self.window_type = window_type
         self.compute_dtype = _host.as_torch_dtype(compute_dtype)
         self.precompute_dtype, self._pre_id = _host.precompute_id(precompute_dtype, "MDCTransformer")
-        self._dtype_id = _host.require_hip_compute_dtype(self.compute_dtype, "MDCTransformer")
+        self._dtype_id = _host.require_hip_compute_dtype(self.compute_dtype, "MDCTransformer", filter_bank=True)
         self._window = _lib.window_id(window_type)
         self._lib = _lib.load()
         self._H = None

@@ -64,7 +64,7 @@ enum {
 enum { AC_WINDOW_VORBIS = 0, AC_WINDOW_SINE = 1, AC_WINDOW_RECT = 2 };
 
 /* element types: `dtype` of the *_typed entry points (compute_dtype) and `precompute` of the *_pre ones (precompute_dtype) */
-enum { AC_F32 = 0, AC_F64 = 1, AC_BF16 = 2 };
+enum { AC_F32 = 0, AC_F64 = 1, AC_BF16 = 2, AC_F16 = 3 };   /* AC_F16: ac_mdct_forward_typed / ac_mdct_inverse_typed only */
 
 typedef struct ac_mdct_plan ac_mdct_plan;
 typedef struct ac_psy_plan ac_psy_plan;
@@ -343,6 +343,19 @@ AC_API int ac_probe_placement(const ac_mdct_plan* mdct, const ac_psy_plan* psy, 
  *            X and the tonality to bfloat16 before the masking model uses them, so fused and un-fused calls agree),
  *            else the LDS-FFT kernels for filters_n from 16 to 4096 with a 5-smooth half and the O(N^2) kernels; results carry
  *            bfloat16's output rounding (2^-9 relative) -- more accurate than the reference's all-bfloat16 op sequence.
+ *   AC_F16   float16 tensors, float32 arithmetic inside; the filter bank only (ac_mdct_forward_typed / ac_mdct_inverse_typed:
+ *            MDCTransformer accepts it and up-casts inside its DCT-IV, mdctransformer.py:327-344; PsychoacousticModel refuses it
+ *            by name, psychoacoustic.py:42-43 -- the masking entry points return AC_EINVAL): the 8-byte LDS-FFT kernels for
+ *            filters_n from 16 to 4096 with a 5-smooth half, else the O(N^2) kernels; results carry float16's rounding
+ *            (2^-11 relative) and range (a coefficient beyond 65504 becomes infinity, as a cast makes it).
+ *
+ * Non-finite inputs (all dtypes): the filter bank is linear arithmetic -- a NaN or infinite sample makes every coefficient
+ * of the two frames that contain it NaN (as the reference's dense products do).  The masking model follows tf.maximum /
+ * tf.minimum, which propagate NaN (psychoacoustic.py:113-116, 205-208, 331): a frame and signal with a NaN or infinite
+ * intensity has a NaN tonality, and a NaN intensity or a NaN tonality makes the whole threshold row of that frame and signal
+ * NaN; every other frame and the other signal are untouched.  One corner differs: intensities that overflow float32
+ * (|X| > 1.8e19) with a caller-supplied finite tonality give NaN thresholds where the reference has infinities.  Denormal
+ * inputs are ordinary numbers (nothing is flushed on the way in; intensities below 1e-14 meet the model's floor).
  * Streaming (ac_stream_*_typed) serves AC_F32 at every size and AC_BF16 where the wave-level kernels do (filters_n 1024 /
  * 2048, mono / stereo; the state stays float32, chunked results equal the one-shot calls bit for bit); no backward passes
  * for AC_F64 / AC_BF16.

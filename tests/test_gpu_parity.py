@@ -1636,6 +1636,83 @@ def test_bfloat16_filter_bank(path, N, wt, C):
         assert np.max(np.abs(xh[:, N:-N] - x)) <= 2e-2       # round trip through bfloat16 coefficients
 
 
+@pytest.mark.parametrize("N,wt,C", [(1024, "vorbis", 2), (960, "vorbis", 2), (256, "sine", 1), (12, "vorbis", 3), (4096, "vorbis", 2), (64, "rect", 3)])
+def test_float16_filter_bank(path, N, wt, C):
+    """compute_dtype = float16 (the reference's filter bank accepts it and up-casts inside its DCT-IV, mdctransformer.py:
+    327-344): float16 tensors, float32 arithmetic.  Tolerance: the output rounding of float16 (2^-11 of each value) on top of
+    the float32 kernels' own error -- 1e-3 of the frame's peak; the masking model refuses the type (psychoacoustic.py:42-43)."""
+    rng = np.random.default_rng(N)
+    x = torch.from_numpy(rng.uniform(-1, 1, (2, 5 * N, C))).to(torch.float16)
+    x64 = x.double().numpy()
+    m = audiocodec_amd.MDCTransformer(N, window_type=wt, compute_dtype=torch.float16)
+    o = MDCTOracle(N, wt, np.float64)
+    X = m.transform(x.cuda())
+    assert X.dtype == torch.float16
+    assert rel_peak(host(X.double()), o.transform(x64)) <= 1e-3
+    xh = host(m.inverse_transform(X).double())
+    ref = o.inverse_transform(host(X.double()))              # the oracle on the very coefficients the kernel read
+    assert np.max(np.abs(xh - ref)) <= 1e-3 * max(1.0, np.max(np.abs(ref)))
+    if wt != "rect":
+        assert np.max(np.abs(xh[:, N:-N] - x64)) <= 5e-3     # round trip through float16 coefficients
+    with pytest.raises(TypeError):
+        audiocodec_amd.PsychoacousticModel(48000, N, compute_dtype=torch.float16)
+    with pytest.raises(ValueError):
+        m.transform(x.cuda().float())                        # inputs must carry compute_dtype (mdctransformer.py:22-23)
+
+
+@pytest.mark.parametrize("N", [1024, 2048, 512, 64, 960, 1920, 100])
+def test_non_finite_and_denormal_inputs(path, N):
+    """NaN / infinite / denormal samples against the oracle, whose np.maximum / np.minimum propagate NaN as tf.maximum /
+    tf.minimum do (psychoacoustic.py:113-116, 205-208, 331): the two frames that contain a NaN or infinite sample have NaN
+    coefficients, a NaN tonality and an all-NaN threshold row FOR THAT SIGNAL; every other frame, and the other signal, meet
+    the oracle at the usual bar -- through the fused encode of every tier and through the three separate calls (which, given
+    a finite tonality for a poisoned spectrum, still return the NaN row).  Denormal samples are ordinary numbers."""
+    import warnings
+    C, K = 2, 8
+    rng = np.random.default_rng(N)
+    x = rng.uniform(-1, 1, (3, K * N, C)).astype(np.float32)
+    x[0, 2 * N + 5, 0] = np.nan                  # clip 0, signal 0: frames 2 and 3
+    x[1, 5 * N + N // 2, 1] = np.inf             # clip 1, signal 1: frames 5 and 6
+    x[2, 3 * N:4 * N, :] = 1e-40                 # clip 2: a block of denormals
+    codec = audiocodec_amd.AudioCodec(48000, N)
+    X, t, thr = codec.encode(dev(x))
+    o_m, o_p = MDCTOracle(N, "vorbis", np.float64), PsychoOracle(48000, N, 64, compute_dtype=np.float64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        Xo = o_m.transform(x.astype(np.float64))
+        to = o_p.tonality(Xo)
+        thro = o_p.global_masking_threshold(Xo, to)
+    Xh, th, thrh = host(X), host(t), host(thr)
+    # the same coefficients are not finite (an infinite sample: infinities and NaNs, which of the two an FFT leaves where is the
+    # algorithm's business -- the reference's dense products make them all NaN); the same tonalities and thresholds are NaN
+    assert np.array_equal(np.isfinite(Xh), np.isfinite(Xo)) and np.array_equal(np.isnan(th), np.isnan(to))
+    assert np.array_equal(np.isnan(thrh), np.isnan(thro))
+    assert np.isnan(Xh[0, 2:4, :, 0]).all() and np.isfinite(Xh[0, 2:4, :, 1]).all() and np.isnan(th[0, 2:4, 0, 0]).all()
+    assert np.isnan(thrh[0, 2:4, :, 0]).all() and np.isnan(thrh[1, 5:7, :, 1]).all() and np.isfinite(thrh[2]).all()
+    ok = ~np.isnan(thro)
+    okX = np.isfinite(Xo)
+    # ... and the rest meets the oracle (coefficients: per-frame peak metric over the finite frames)
+    Xc, Xoc = np.where(okX, Xh, 0.0), np.where(okX, Xo, 0.0)
+    assert rel_peak(Xc, Xoc) <= TOL
+    X64 = np.where(okX, Xh.astype(np.float64), np.nan)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        t64 = o_p.tonality(X64)
+        thr64 = o_p.global_masking_threshold(X64, t64)
+    okt = ~np.isnan(t64)
+    assert tonality_err(th[okt], t64[okt]) <= 1.0
+    assert float(np.max(np.abs(thrh[ok] - thr64[ok]) / thr64[ok])) <= TOL
+    # the separate calls: same values; a finite tonality handed in for a poisoned spectrum does not un-poison the row (a NaN
+    # sample: NaN, as the reference; an infinite one: not finite -- infinities where the coefficients are all infinite and the
+    # reference has them, NaN where the matrix-core product met them)
+    t2 = codec.psy.tonality(X)
+    assert torch.equal(torch.nan_to_num(t2, nan=-7.0), torch.nan_to_num(t, nan=-7.0))
+    thr2 = host(codec.psy.global_masking_threshold(X, torch.nan_to_num(t, nan=0.5)))
+    assert np.array_equal(np.isnan(thr2[0]), np.isnan(thro[0])) and np.array_equal(np.isfinite(thr2[1]), np.isfinite(thro[1]))
+    fin = ~np.isnan(thro[0])
+    assert rel_elem(thr2[2], thrh[2]) <= 1e-5 and rel_elem(thr2[0][fin], thrh[0][fin]) <= 1e-5   # (bit-equal below 1024; one rounding apart there)
+
+
 @pytest.mark.parametrize("N,C", [(1024, 2), (1024, 1), (2048, 2), (2048, 1)])
 def test_bfloat16_streaming(N, C):
     """Streaming overlap-add on bfloat16 tensors (ac_stream_*_typed: the wave-level kernels, state kept in float32): chunk

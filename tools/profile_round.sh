@@ -3,14 +3,16 @@
 #   bench_driver_style.json     python bench.py --steps 20 --warmup 5   (how the driver runs it; cpu_baseline, other_configs, workspace)
 #   bench.json                  python bench.py   (defaults: 200 steps, 10 warmup)
 #   bench_kernel_stats.csv      rocprofv3 --kernel-trace --stats of the driver-style command (without the side measurements)
-#   bench_kernel_stats_timed_region.csv   the same trace restricted to the `steps` timed dispatches of each kernel
+#   bench_kernel_stats_api_timed_region.csv   the same trace restricted to the `steps` timed dispatches of the HEADLINE loop
+#                               (codec.encode() / decode(), library-placed results) and of the caller-owned loop before it
+#   placement_12_runs.txt       twelve fresh driver-style processes: encode ms of the headline loop in each
 #   pmc_encode.txt, pmc_decode.txt   rocprofv3 --pmc, separate passes (tools/pmc.sh)
 #   traffic.json                FETCH_SIZE (doubled: gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE per launch
 #   pmc_short_frames_n256.txt   the same counters for transform / inverse / threshold at filters_n = 256
 #   lds_fft_tier_sizes.txt      the LDS-FFT tier over its sizes (stereo, mono, three channels; the A/B forms of the kernels)
 #   entry_points.txt            every entry point on bench-sized workloads (tools/entry_points.sh)
 # Copy the directory's files into profiles/rNN afterwards.
-r=${1:-r3}
+r=${1:-r4}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 make -s -C audiocodec_amd/csrc || exit 1   # never build under the profiler
 out=gpurun_out/profile_$r
@@ -32,17 +34,34 @@ for f in glob.glob(out + "/trace/*/*kernel_trace.csv"):
         if "ac::" in r["Kernel_Name"]:
             name = r["Kernel_Name"].replace("void ac::(anonymous namespace)::", "").split("(")[0]
             rows[name].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
-with open(out + "/bench_kernel_stats_timed_region.csv", "w") as fh:
-    fh.write("Name,Calls,AverageNs,MinNs,MaxNs,note\n")
+api_len = line["settle_steps"] + line["warmup"] + steps   # dispatches of the headline loop: settle, warm-up, timed
+with open(out + "/bench_kernel_stats_api_timed_region.csv", "w") as fh:
+    fh.write("Name,Loop,Calls,AverageNs,MinNs,MaxNs,note\n")
     for name, v in rows.items():
         v.sort()
         d = [x[1] for x in v]
-        timed = d[-steps:]      # nothing launches these kernels after the timed loop (side measurements switched off)
-        fh.write("%s,%d,%.1f,%d,%d,timed region of bench.py (the last %d of %d dispatches; events in the same run: encode %.4f ms decode %.4f ms)\n"
-                 % (name, len(timed), sum(timed) / len(timed), min(timed), max(timed), steps, len(d),
-                    line["encode_ms"], line["decode_ms"]))
-print(open(out + "/bench_kernel_stats_timed_region.csv").read())
+        timed = d[-steps:]      # nothing launches these kernels after the headline loop (side measurements switched off)
+        fh.write("%s,codec.encode()/decode() (headline),%d,%.1f,%d,%d,the last %d of %d dispatches; events in the same run: encode %.4f ms decode %.4f ms\n"
+                 % (name, len(timed), sum(timed) / len(timed), min(timed), max(timed), steps, len(d), line["encode_ms"], line["decode_ms"]))
+        co = d[-api_len - steps:-api_len]   # the caller-owned loop's timed dispatches: the `steps` right before the headline loop's settle phase
+        if len(co) == steps:
+            fh.write("%s,encode_into()/decode_into() (caller-owned),%d,%.1f,%d,%d,events in the same run: encode %.4f ms decode %.4f ms\n"
+                     % (name, len(co), sum(co) / len(co), min(co), max(co), line["caller_owned_encode_ms"], line["caller_owned_decode_ms"]))
+print(open(out + "/bench_kernel_stats_api_timed_region.csv").read())
 PY
+{
+  echo "# twelve fresh processes of: python bench.py --steps 20 --warmup 5 (side measurements off): the headline loop's encode / decode ms,"
+  echo "# value in M frames/s, and what the placement search did (tries, encode ms by try)"
+  for i in 1 2 3 4 5 6 7 8 9 10 11 12; do
+    python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-workspace --no-smi 2>/dev/null | python -c "
+import json, sys
+ls = [l for l in sys.stdin.read().splitlines() if l.startswith('{')]
+d = json.loads(ls[-1]); s = json.loads(ls[0])['bench_side'] if len(ls) > 1 else {}
+p = s.get('placement') or {}
+print('run %2d  encode %.4f ms  decode %.4f ms  value %.1f M  caller-owned %.1f M (encode %.4f ms)  tries %s chosen %s by try %s' % ($i, d['encode_ms'], d['decode_ms'], d['value'] / 1e6, d['caller_owned_value'] / 1e6, d['caller_owned_encode_ms'], p.get('tries'), p.get('chosen_try'), p.get('encode_ms_by_try')))"
+  done
+} > $out/placement_12_runs.txt
+cat $out/placement_12_runs.txt
 tools/pmc.sh encode ${r}_enc > /dev/null 2>&1 && cp gpurun_out/pmc_${r}_enc.txt $out/pmc_encode.txt || exit 1
 echo "pmc encode done"
 tools/pmc.sh inverse ${r}_dec > /dev/null 2>&1 && cp gpurun_out/pmc_${r}_dec.txt $out/pmc_decode.txt || exit 1
@@ -89,6 +108,11 @@ echo "pmc short frames done"
     N=512 tools/pmc.sh $what ${r}_n512_$what > /dev/null 2>&1
     echo "== filters_n = 512, B = 256 stereo, K = 936: fused $what (algorithmic bytes per launch: $((6148 * 256 * 2 * 936)))"
     cat gpurun_out/pmc_${r}_n512_$what.txt
+  done
+  for what in encode; do
+    N=960 tools/pmc.sh $what ${r}_n960_$what > /dev/null 2>&1
+    echo "== filters_n = 960 (LDS-FFT tier, fused encode k_enc_wave_v), B = 256 stereo, K = 500: $what (algorithmic bytes per launch: $((11524 * 256 * 2 * 500)))"
+    cat gpurun_out/pmc_${r}_n960_$what.txt
   done
   for what in transform inverse; do
     N=960 B=64 tools/pmc.sh $what ${r}_n960_$what > /dev/null 2>&1
