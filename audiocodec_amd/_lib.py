@@ -52,6 +52,9 @@ PROTOTYPES = {
     "ac_tonality_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ac_mask_threshold_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_int, c_int, c_int, c_int,
                                         c_void_p]),
+    "ac_tonality_backward_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ac_mask_threshold_backward_typed": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                                 c_int, c_void_p]),
     "ac_workspace_create": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_void_p, POINTER(c_void_p)]),
     "ac_workspace_buffers": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                      POINTER(c_void_p)]),

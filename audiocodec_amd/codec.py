@@ -215,9 +215,9 @@ class StreamingMDCT:
     """
 
     def __init__(self, mdct: MDCTransformer, batches_n, channels_n, device=None, psy: PsychoacousticModel = None):
-        if mdct.compute_dtype not in (torch.float32, torch.bfloat16):
-            raise NotImplementedError("streaming overlap-add serves compute_dtype float32 (every size) and bfloat16 (the "
-                                      "wave-level kernels: filters_n 1024 / 2048, mono / stereo); got %s" % mdct.compute_dtype)
+        if mdct.compute_dtype not in (torch.float32, torch.float64, torch.bfloat16):
+            raise NotImplementedError("streaming overlap-add serves compute_dtype float32 and float64 (every size) and bfloat16 "
+                                      "(the wave-level kernels: filters_n 1024 / 2048, mono / stereo); got %s" % mdct.compute_dtype)
         if psy is not None:
             if psy.compute_dtype != mdct.compute_dtype:
                 raise ValueError("psy.compute_dtype (%s) != mdct.compute_dtype (%s)" % (psy.compute_dtype, mdct.compute_dtype))
@@ -321,7 +321,7 @@ class StreamingMDCT:
         addresses, shapes and arguments) are seen, and replayed from then on -- the gaps between the dependent launches
         go (one stereo clip in chunks of 256 blocks: 7.9 us per chunk against 11.9).  A replay reads the CURRENT contents
         of the same input buffers and overwrites the output tensors of the first call, which are returned again."""
-        _host.require_float32(self.mdct.compute_dtype, "StreamingMDCT.run (use the chunk calls for bfloat16 streams)")
+        _host.require_float32(self.mdct.compute_dtype, "StreamingMDCT.run (use the chunk calls for bfloat16 / float64 streams)")
         if graph:
             return self._run_graph(x, blocks_per_chunk, masking, synthesis, drown)
         k, N = int(blocks_per_chunk), self.mdct.filters_n

@@ -388,16 +388,22 @@ static int psy_plan_build(int N, int M, double sample_rate, double alpha, int de
   {
     // the same constants in float64 (AC_F64 entry points): W / W_inv entries in CSR order, S, quiet, and the offset
     // grid linspace(0, max_bark, M) evaluated in float64 (psychoacoustic.py:187-189 with compute_dtype = float64)
-    std::vector<double> wbv(wb.idx.size()), wiv(wi.idx.size()), beta64(M);
+    std::vector<double> wbv(wb.idx.size()), wiv(wi.idx.size()), wfv(wf.idx.size()), vbv(vb.idx.size()), beta64(M);
     for (int j = 0; j < M; ++j)
       for (int e = wb.ptr[j]; e < wb.ptr[j + 1]; ++e) wbv[e] = p->host.W[(size_t)wb.idx[e] * M + j];
     for (int f = 0; f < N; ++f)
       for (int e = wi.ptr[f]; e < wi.ptr[f + 1]; ++e) wiv[e] = p->host.W_inv[(size_t)wi.idx[e] * N + f];
+    for (int f = 0; f < N; ++f)   // the transposed walks (backward passes): W by bin, W_inv by band
+      for (int e = wf.ptr[f]; e < wf.ptr[f + 1]; ++e) wfv[e] = p->host.W[(size_t)f * M + wf.idx[e]];
+    for (int j = 0; j < M; ++j)
+      for (int e = vb.ptr[j]; e < vb.ptr[j + 1]; ++e) vbv[e] = p->host.W_inv[(size_t)j * N + vb.idx[e]];
     const double stop = p->host.max_bark, step = (M > 1) ? stop / (double)(M - 1) : 0.0;
     for (int j = 0; j < M; ++j) beta64[j] = step * (double)j;
     if (M > 1) beta64[M - 1] = stop;
     if (!st) st = upload(wbv, &p->d_wb_val64);
     if (!st) st = upload(wiv, &p->d_wi_val64);
+    if (!st) st = upload(wfv, &p->d_wf_val64);
+    if (!st) st = upload(vbv, &p->d_vb_val64);
     if (!st) st = upload(p->host.S, &p->d_S64);
     if (!st) st = upload(p->host.quiet, &p->d_quiet64);
     if (!st) st = upload(beta64, &p->d_beta64);
@@ -448,6 +454,8 @@ int ac_psy_plan_destroy(ac_psy_plan* p) {
   (void)hipFree(p->d_beta);
   (void)hipFree(p->d_wb_val64);
   (void)hipFree(p->d_wi_val64);
+  (void)hipFree(p->d_wf_val64);
+  (void)hipFree(p->d_vb_val64);
   (void)hipFree(p->d_S64);
   (void)hipFree(p->d_quiet64);
   (void)hipFree(p->d_beta64);
@@ -738,6 +746,8 @@ int ac_stream_reset(ac_stream* s, void* stream) {
   const size_t nt = (size_t)s->B * s->C * (s->N / 2) * sizeof(float);
   AC_HIP_CHECK(hipMemsetAsync(s->d_prev_block, 0, nb, (hipStream_t)stream));
   AC_HIP_CHECK(hipMemsetAsync(s->d_tail, 0, nt, (hipStream_t)stream));
+  if (s->d_prev64) AC_HIP_CHECK(hipMemsetAsync(s->d_prev64, 0, 2 * nb, (hipStream_t)stream));
+  if (s->d_tail64) AC_HIP_CHECK(hipMemsetAsync(s->d_tail64, 0, 2 * nt, (hipStream_t)stream));
   return AC_OK;
 }
 
@@ -748,6 +758,9 @@ int ac_stream_destroy(ac_stream* s) {
   (void)hipFree(s->d_prev_tmp);
   (void)hipFree(s->d_tail);
   (void)hipFree(s->d_tail_tmp);
+  (void)hipFree(s->d_prev64);
+  (void)hipFree(s->d_tail64);
+  (void)hipFree(s->d_tail64_tmp);
   delete s;
   return AC_OK;
 }
@@ -1087,13 +1100,31 @@ int ac_encode_fused_typed(const ac_mdct_plan* mdct, const ac_psy_plan* psy, cons
 // ---- streaming on bfloat16 tensors: the wave-level kernels (filters_n 1024 / 2048, mono / stereo) with the conversion in
 // their loads and stores; the state stays float32 (a bfloat16 block is exact in it, the aliased half is kept unrounded),
 // so chunked results equal the one-shot *_typed calls bit for bit
+// float64 streams: the state in double (allocated by the first float64 call), the float64 kernels (O(N^2), any even size)
+static int stream_state64(ac_stream* s) {
+  if (s->d_prev64) return AC_OK;
+  const size_t nb = (size_t)s->B * s->N * s->C * sizeof(double), nt = (size_t)s->B * s->C * (s->N / 2) * sizeof(double);
+  hipError_t e = hipMalloc((void**)&s->d_prev64, nb);
+  if (e == hipSuccess) e = hipMalloc((void**)&s->d_tail64, nt);
+  if (e == hipSuccess) e = hipMalloc((void**)&s->d_tail64_tmp, nt);
+  if (e == hipSuccess) e = hipMemset(s->d_prev64, 0, nb);
+  if (e == hipSuccess) e = hipMemset(s->d_tail64, 0, nt);
+  if (e == hipSuccess) e = hipMemset(s->d_tail64_tmp, 0, nt);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("float64 stream state allocation failed: %s", hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? AC_ENOMEM : AC_EHIP;
+  }
+  return AC_OK;
+}
 static int stream_typed_check(const ac_stream* s, int dtype, int k) {
   AC_REQUIRE(s != nullptr, "stream is NULL");
   AC_REQUIRE_DTYPE(dtype);
   AC_REQUIRE(k >= 0, "negative chunk length %d", k);
-  if (dtype == AC_F64 || !(s->plan->fast && fast_mdct_frames_per_wave(s->N) == 1 && s->C <= 2 && !g_force_generic)) {
-    set_error("streaming on %s tensors is served by the wave-level kernels only (filters_n 1024 / 2048, mono / stereo, "
-              "bfloat16); float32 streams take every size", dtype == AC_F64 ? "float64" : "bfloat16");
+  if (dtype == AC_F64) return AC_OK;
+  if (!(s->plan->fast && fast_mdct_frames_per_wave(s->N) == 1 && s->C <= 2 && !g_force_generic)) {
+    set_error("streaming on bfloat16 tensors is served by the wave-level kernels only (filters_n 1024 / 2048, mono / stereo); "
+              "float32 and float64 streams take every size");
     return AC_EUNSUPPORTED;
   }
   return AC_OK;
@@ -1116,10 +1147,25 @@ int ac_stream_encode_typed(ac_stream* s, const ac_psy_plan* psy, const void* x_c
   if (psy) {
     AC_REQUIRE(t != nullptr && thr != nullptr, "NULL tensor pointer");
     AC_REQUIRE(p->N == psy->N && p->device == psy->device, "plans do not belong together");
-    AC_REQUIRE(psy->fast, "internal: the masking model of this size has no bfloat16 wave-level kernels");
+    AC_REQUIRE(dtype == AC_F64 || psy->fast, "internal: the masking model of this size has no bfloat16 wave-level kernels");
   }
   DeviceGuard guard(s->device);
   hipStream_t hs = (hipStream_t)stream;
+  if (dtype == AC_F64) {   // analysis with the stored block -1, the new state = the chunk's last block, the model on the chunk
+    st = stream_state64(s);
+    if (st) return st;
+    const double* xd = static_cast<const double*>(x_chunk);
+    st = launch_fwd_f64_stream(p, xd, static_cast<double*>(X), s->d_prev64, s->B, k, k, s->C, hs);
+    if (st) return st;
+    const size_t row = (size_t)p->N * s->C * sizeof(double);
+    AC_HIP_CHECK(hipMemcpy2DAsync(s->d_prev64, row, xd + (size_t)(k - 1) * p->N * s->C, row * k, row, (size_t)s->B, hipMemcpyDeviceToDevice, hs));
+    if (psy) {
+      st = launch_tonality_f64(psy, static_cast<const double*>(X), static_cast<double*>(t), s->B, k, s->C, hs);
+      if (!st) st = launch_threshold_f64(psy, static_cast<const double*>(X), static_cast<const double*>(t), drown, static_cast<double*>(thr),
+                                         s->B, k, s->C, hs);
+    }
+    return st;
+  }
   const bool fused = psy && !(p->N == 2048 && s->C == 1);   // (as ac_encode_fused_typed)
   st = launch_fwd_fast(p, fused ? psy : nullptr, x_chunk, 2, static_cast<float*>(X), fused ? static_cast<float*>(t) : nullptr,
                        fused ? static_cast<float*>(thr) : nullptr, (float)drown, s->d_prev_block, s->B, k, k, s->C, hs, s->d_prev_tmp);
@@ -1140,6 +1186,14 @@ int ac_stream_inverse_typed(ac_stream* s, const void* X_chunk, void* x, int dtyp
   AC_REQUIRE(X_chunk != nullptr && x != nullptr, "NULL tensor pointer");
   AC_REQUIRE_ALIGNED(X_chunk, x);
   DeviceGuard guard(s->device);
+  if (dtype == AC_F64) {
+    st = stream_state64(s);
+    if (!st) st = launch_inv_f64_stream(s->plan, static_cast<const double*>(X_chunk), static_cast<double*>(x), s->d_tail64, s->d_tail64_tmp,
+                                        s->B, k, k, s->C, (hipStream_t)stream);
+    if (st) return st;
+    std::swap(s->d_tail64, s->d_tail64_tmp);
+    return AC_OK;
+  }
   st = launch_inv_fast(s->plan, static_cast<const float*>(X_chunk), x, 2, s->d_tail, s->d_tail_tmp, s->B, k, k, s->C, (hipStream_t)stream);
   if (st) return st;
   std::swap(s->d_tail, s->d_tail_tmp);
@@ -1151,6 +1205,35 @@ int ac_amplitude_to_db_typed(const void* a, void* out, size_t n, int norm, int d
   if (dtype == AC_F32) return ac_amplitude_to_db(static_cast<const float*>(a), static_cast<float*>(out), n, norm, stream);
   AC_REQUIRE(n == 0 || (a != nullptr && out != nullptr), "NULL tensor pointer");
   return launch_db_typed(a, out, n, norm, dtype, (hipStream_t)stream);
+}
+
+int ac_tonality_backward_typed(const ac_psy_plan* p, const void* X, const void* grad_t, void* grad_X, int dtype, int B, int F, int C,
+                               void* stream) {
+  AC_REQUIRE_DTYPE(dtype);
+  if (dtype == AC_F32)
+    return ac_tonality_backward(p, static_cast<const float*>(X), static_cast<const float*>(grad_t), static_cast<float*>(grad_X), 0, B, F, C, stream);
+  AC_REQUIRE(p != nullptr, "plan is NULL");
+  int st = check_dims(B, F, C);
+  if (st) return st;
+  if (B == 0 || C == 0 || F == 0) return AC_OK;
+  AC_REQUIRE(X != nullptr && grad_t != nullptr && grad_X != nullptr, "NULL tensor pointer");
+  DeviceGuard guard(p->device);
+  return launch_tonality_bwd_typed(p, X, grad_t, grad_X, dtype, B, F, C, (hipStream_t)stream);
+}
+
+int ac_mask_threshold_backward_typed(const ac_psy_plan* p, const void* X, const void* t, double drown, const void* grad_thr, void* grad_X,
+                                     void* grad_t, int dtype, int B, int F, int C, void* stream) {
+  AC_REQUIRE_DTYPE(dtype);
+  if (dtype == AC_F32)
+    return ac_mask_threshold_backward(p, static_cast<const float*>(X), static_cast<const float*>(t), (float)drown,
+                                      static_cast<const float*>(grad_thr), static_cast<float*>(grad_X), static_cast<float*>(grad_t), B, F, C, stream);
+  AC_REQUIRE(p != nullptr, "plan is NULL");
+  int st = check_dims(B, F, C);
+  if (st) return st;
+  if (B == 0 || C == 0 || F == 0) return AC_OK;
+  AC_REQUIRE(X != nullptr && t != nullptr && grad_thr != nullptr && grad_X != nullptr && grad_t != nullptr, "NULL tensor pointer");
+  DeviceGuard guard(p->device);
+  return launch_threshold_bwd_typed(p, X, t, drown, grad_thr, grad_X, grad_t, dtype, B, F, C, (hipStream_t)stream);
 }
 
 int ac_add_noise_typed(const void* X, const void* thr, void* out, size_t n, uint64_t seed, int dtype, void* stream) {

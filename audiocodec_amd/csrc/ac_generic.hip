@@ -1810,33 +1810,36 @@ static __global__ __launch_bounds__(kThreads) void k_threshold_generic(
 // ------------------------------------------------------------------------------------------------
 // t = min(c' [mean_f ln max(eps, I_f) - ln(mean_f I_f + eps)], 1), c' = (10 / ln 10) / (-60), I_f = X_f^2:
 // d t / d X_f = c' (1/N) ([I_f > eps] / I_f - 1 / (mean I + eps)) 2 X_f   where the clamp is inactive
-static __global__ __launch_bounds__(kThreads) void k_tonality_bwd_generic(const float* __restrict__ X,
-                                                                   const float* __restrict__ gt,
-                                                                   float* __restrict__ gX, int accumulate, int C,
+// TIO: the tensors' element type (float, double, bfloat16); TC: the arithmetic and the constant tables (float, double)
+template <typename TIO, typename TC = typename Compute<TIO>::type>
+static __global__ __launch_bounds__(kThreads) void k_tonality_bwd_generic(const TIO* __restrict__ X,
+                                                                   const TIO* __restrict__ gt,
+                                                                   TIO* __restrict__ gX, int accumulate, int C,
                                                                    int N) {
-  __shared__ float red[kThreads / 64];
+  __shared__ TC red[kThreads / 64];
+  const TC eps = (TC)1e-14;
   const long long wg = blockIdx.x;   // (b*F + f)*C + c
   const int c = (int)(wg % C);
   const long long bf = wg / C;
-  const float* Xi = X + (size_t)bf * N * C + c;
-  float* gi = gX + (size_t)bf * N * C + c;
-  float slog = 0.f, ssq = 0.f;
+  const TIO* Xi = X + (size_t)bf * N * C + c;
+  TIO* gi = gX + (size_t)bf * N * C + c;
+  TC slog = 0, ssq = 0;
   for (int k = threadIdx.x; k < N; k += kThreads) {
-    const float a = Xi[(size_t)k * C];
-    slog += logf(fmaxf(kEps, a * a));
+    const TC a = ldv(Xi + (size_t)k * C);
+    slog += m_log(a * a > eps ? a * a : eps);
     ssq += a * a;
   }
   slog = block_sum(slog, red);
   ssq = block_sum(ssq, red);
-  const float am = ssq / (float)N + kEps;
-  const float cc = (10.f / 2.302585092994046f) / -60.f;
-  const float tt = cc * (slog / (float)N - logf(am));
-  const float g = (tt < 1.f) ? gt[wg] * cc / (float)N : 0.f;
+  const TC am = ssq / (TC)N + eps;
+  const TC cc = ((TC)10 / (TC)2.302585092994046) / (TC)-60;
+  const TC tt = cc * (slog / (TC)N - m_log(am));
+  const TC g = (tt < (TC)1) ? (TC)ldv(gt + wg) * cc / (TC)N : (TC)0;
   for (int k = threadIdx.x; k < N; k += kThreads) {
-    const float a = Xi[(size_t)k * C];
-    const float I = a * a;
-    const float d = g * ((I > kEps ? 1.f / I : 0.f) - 1.f / am) * 2.f * a;
-    gi[(size_t)k * C] = accumulate ? gi[(size_t)k * C] + d : d;
+    const TC a = ldv(Xi + (size_t)k * C);
+    const TC I = a * a;
+    const TC d = g * ((I > eps ? (TC)1 / I : (TC)0) - (TC)1 / am) * (TC)2 * a;
+    stv(gi + (size_t)k * C, accumulate ? (TC)ldv(gi + (size_t)k * C) + d : d);
   }
 }
 
@@ -1844,115 +1847,120 @@ static __global__ __launch_bounds__(kThreads) void k_tonality_bwd_generic(const 
 // Y_j = fac_j A_j, A_j = sum_i Q_i S[i,j], Q_i = max(eps, P_i)^alpha, P_i = sum_f X_f^2 W[f,i],
 // fac_j = 10^(-alpha O_j / 10), O_j = (1 - drown)(t beta_j + 9 t + 5.5).  The adjoint walks the chain backwards;
 // every max() passes the gradient to its active branch.
+template <typename TIO, typename TC = typename Compute<TIO>::type>
 static __global__ __launch_bounds__(kThreads) void k_threshold_bwd_generic(
-    const float* __restrict__ X, const float* __restrict__ t, const float* __restrict__ gthr, float* __restrict__ gX,
-    float* __restrict__ gt, float drown, float alpha,
-    const int32_t* __restrict__ wb_ptr, const int32_t* __restrict__ wb_idx, const float* __restrict__ wb_val,
-    const int32_t* __restrict__ wi_ptr, const int32_t* __restrict__ wi_idx, const float* __restrict__ wi_val,
-    const int32_t* __restrict__ wf_ptr, const int32_t* __restrict__ wf_idx, const float* __restrict__ wf_val,
-    const int32_t* __restrict__ vb_ptr, const int32_t* __restrict__ vb_idx, const float* __restrict__ vb_val,
-    const float* __restrict__ S, const float* __restrict__ quiet, const float* __restrict__ beta, int C, int N,
+    const TIO* __restrict__ X, const TIO* __restrict__ t, const TIO* __restrict__ gthr, TIO* __restrict__ gX,
+    TIO* __restrict__ gt, TC drown, TC alpha,
+    const int32_t* __restrict__ wb_ptr, const int32_t* __restrict__ wb_idx, const TC* __restrict__ wb_val,
+    const int32_t* __restrict__ wi_ptr, const int32_t* __restrict__ wi_idx, const TC* __restrict__ wi_val,
+    const int32_t* __restrict__ wf_ptr, const int32_t* __restrict__ wf_idx, const TC* __restrict__ wf_val,
+    const int32_t* __restrict__ vb_ptr, const int32_t* __restrict__ vb_idx, const TC* __restrict__ vb_val,
+    const TC* __restrict__ S, const TC* __restrict__ quiet, const TC* __restrict__ beta, int C, int N,
     int M, int s_in_lds) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ float red[kThreads / 64];
-  float* xs = smem;        // [N] X
-  float* gE = xs + N;      // [N] d L / d E
-  float* P = gE + N;       // [M]
-  float* Q = P + M;        // [M]
-  float* A = Q + M;        // [M]
-  float* G = A + M;        // [M]
-  float* gA = G + M;       // [M]
-  float* gP = gA + M;      // [M]
-  float* part = gP + M;    // [4][M] partial sums of the band x band products
-  float* Ss = part + 4 * M;   // [M][M] spreading matrix (when it fits)
+  TC* smem = reinterpret_cast<TC*>(smem_raw);
+  __shared__ TC red[kThreads / 64];
+  const TC kEps = (TC)1e-14;
+  TC* xs = smem;        // [N] X
+  TC* gE = xs + N;      // [N] d L / d E
+  TC* P = gE + N;       // [M]
+  TC* Q = P + M;        // [M]
+  TC* A = Q + M;        // [M]
+  TC* G = A + M;        // [M]
+  TC* gA = G + M;       // [M]
+  TC* gP = gA + M;      // [M]
+  TC* part = gP + M;    // [4][M] partial sums of the band x band products
+  TC* Ss = part + 4 * M;   // [M][M] spreading matrix (when it fits)
   const long long wg = blockIdx.x;
   const int c = (int)(wg % C);
   const long long bf = wg / C;
-  const float* Xi = X + (size_t)bf * N * C + c;
-  const float* gi = gthr + (size_t)bf * N * C + c;
-  for (int k = threadIdx.x; k < N; k += kThreads) xs[k] = Xi[(size_t)k * C];
+  const TIO* Xi = X + (size_t)bf * N * C + c;
+  const TIO* gi = gthr + (size_t)bf * N * C + c;
+  for (int k = threadIdx.x; k < N; k += kThreads) xs[k] = ldv(Xi + (size_t)k * C);
   if (s_in_lds)
     for (int k = threadIdx.x; k < M * M; k += kThreads) Ss[k] = S[k];
-  const float* Sm = s_in_lds ? Ss : S;
+  const TC* Sm = s_in_lds ? Ss : S;
   __syncthreads();
   // the band loops run on four groups of 64 threads: group q takes every fourth term, partial sums meet in LDS
   const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
   for (int j0 = 0; j0 < M; j0 += 64) {
     const int j = j0 + l;
-    float p = 0.f;
+    TC p = 0.f;
     if (j < M)
       for (int e = wb_ptr[j] + q; e < wb_ptr[j + 1]; e += 4) p += xs[wb_idx[e]] * xs[wb_idx[e]] * wb_val[e];
     if (j < M) part[q * M + j] = p;
   }
   __syncthreads();
   for (int j = threadIdx.x; j < M; j += kThreads) {
-    const float p = (part[j] + part[M + j]) + (part[2 * M + j] + part[3 * M + j]);
+    const TC p = (part[j] + part[M + j]) + (part[2 * M + j] + part[3 * M + j]);
     P[j] = p;
-    Q[j] = powf(fmaxf(kEps, p), alpha);
+    Q[j] = m_pow(p > kEps ? p : kEps, alpha);
   }
   __syncthreads();
   for (int j0 = 0; j0 < M; j0 += 64) {
     const int j = j0 + l;
-    float acc = 0.f;
+    TC acc = 0.f;
     if (j < M)
       for (int i = q; i < M; i += 4) acc += Q[i] * Sm[(size_t)i * M + j];
     if (j < M) part[q * M + j] = acc;
   }
   __syncthreads();
-  const float tt = t[wg];
+  const TC tt = t[wg];
   for (int j = threadIdx.x; j < M; j += kThreads) {
-    const float acc = (part[j] + part[M + j]) + (part[2 * M + j] + part[3 * M + j]);
-    const float fac = powf(10.f, -alpha * (1.f - drown) * (tt * beta[j] + 9.f * tt + 5.5f) / 10.f);
+    const TC acc = (part[j] + part[M + j]) + (part[2 * M + j] + part[3 * M + j]);
+    const TC fac = m_pow((TC)10, -alpha * ((TC)1 - drown) * (tt * beta[j] + (TC)9 * tt + (TC)5.5) / (TC)10);
     A[j] = acc;
-    G[j] = fmaxf(powf(fmaxf(kEps, fac * acc), 1.f / alpha), quiet[j]);
+    {
+      const TC Tj = m_pow(fac * acc > kEps ? fac * acc : kEps, (TC)1 / alpha);
+      G[j] = Tj > quiet[j] ? Tj : quiet[j];
+    }
   }
   __syncthreads();
   for (int k = threadIdx.x; k < N; k += kThreads) {
-    float E = 0.f;
+    TC E = 0.f;
     for (int e = wi_ptr[k]; e < wi_ptr[k + 1]; ++e) E += G[wi_idx[e]] * wi_val[e];
-    gE[k] = (E > kEps) ? gi[(size_t)k * C] * 0.5f / sqrtf(E) : 0.f;
+    gE[k] = (E > kEps) ? (TC)ldv(gi + (size_t)k * C) * (TC)0.5 / m_sqrt(E) : (TC)0;
   }
   __syncthreads();
   for (int j0 = 0; j0 < M; j0 += 64) {
     const int j = j0 + l;
-    float gG = 0.f;
+    TC gG = 0.f;
     if (j < M)
       for (int e = vb_ptr[j] + q; e < vb_ptr[j + 1]; e += 4) gG += gE[vb_idx[e]] * vb_val[e];
     if (j < M) part[q * M + j] = gG;
   }
   __syncthreads();
-  float gt_part = 0.f;
+  TC gt_part = 0.f;
   for (int j = threadIdx.x; j < M; j += kThreads) {
-    const float gG = (part[j] + part[M + j]) + (part[2 * M + j] + part[3 * M + j]);
-    const float fac = powf(10.f, -alpha * (1.f - drown) * (tt * beta[j] + 9.f * tt + 5.5f) / 10.f);
-    const float Y = fac * A[j];
-    const float T = powf(fmaxf(kEps, Y), 1.f / alpha);
-    const float gT = (T > quiet[j]) ? gG : 0.f;
-    const float gY = (Y > kEps) ? gT * T / (alpha * Y) : 0.f;
+    const TC gG = (part[j] + part[M + j]) + (part[2 * M + j] + part[3 * M + j]);
+    const TC fac = m_pow((TC)10, -alpha * ((TC)1 - drown) * (tt * beta[j] + (TC)9 * tt + (TC)5.5) / (TC)10);
+    const TC Y = fac * A[j];
+    const TC T = m_pow(Y > kEps ? Y : kEps, (TC)1 / alpha);
+    const TC gT = (T > quiet[j]) ? gG : (TC)0;
+    const TC gY = (Y > kEps) ? gT * T / (alpha * Y) : (TC)0;
     gA[j] = gY * fac;
     // d fac / d t = fac (-alpha ln 10 / 10) (1 - drown) (beta_j + 9)
-    gt_part += gY * A[j] * fac * (-alpha * 0.2302585092994046f) * (1.f - drown) * (beta[j] + 9.f);
+    gt_part += gY * A[j] * fac * (-alpha * (TC)0.2302585092994046) * ((TC)1 - drown) * (beta[j] + (TC)9);
   }
   gt_part = block_sum(gt_part, red);   // (contains the barriers that publish gA)
-  if (threadIdx.x == 0) gt[wg] = gt_part;
+  if (threadIdx.x == 0) stv(gt + wg, gt_part);
   for (int i0 = 0; i0 < M; i0 += 64) {
     const int i = i0 + l;
-    float gQ = 0.f;
+    TC gQ = 0.f;
     if (i < M)
       for (int j = q; j < M; j += 4) gQ += Sm[(size_t)i * M + j] * gA[j];
     if (i < M) part[q * M + i] = gQ;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < M; i += kThreads) {
-    const float gQ = (part[i] + part[M + i]) + (part[2 * M + i] + part[3 * M + i]);
-    gP[i] = (P[i] > kEps) ? gQ * alpha * Q[i] / P[i] : 0.f;
+    const TC gQ = (part[i] + part[M + i]) + (part[2 * M + i] + part[3 * M + i]);
+    gP[i] = (P[i] > kEps) ? gQ * alpha * Q[i] / P[i] : (TC)0;
   }
   __syncthreads();
-  float* go = gX + (size_t)bf * N * C + c;
+  TIO* go = gX + (size_t)bf * N * C + c;
   for (int k = threadIdx.x; k < N; k += kThreads) {
-    float gI = 0.f;
+    TC gI = 0.f;
     for (int e = wf_ptr[k]; e < wf_ptr[k + 1]; ++e) gI += gP[wf_idx[e]] * wf_val[e];
-    go[(size_t)k * C] = 2.f * xs[k] * gI;
+    stv(go + (size_t)k * C, (TC)2 * xs[k] * gI);
   }
 }
 
@@ -2774,32 +2782,59 @@ int launch_threshold_generic(const ac_psy_plan* p, const float* X, const float* 
   return AC_OK;
 }
 
-int launch_tonality_bwd_generic(const ac_psy_plan* p, const float* X, const float* gt, float* gX, int accumulate, int B,
-                                int F, int C, hipStream_t s) {
+template <typename TIO>
+static int launch_tonality_bwd_T(const ac_psy_plan* p, const TIO* X, const TIO* gt, TIO* gX, int accumulate, int B, int F, int C,
+                                 hipStream_t s) {
   const long long nwg = (long long)B * F * C;
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
-  hipLaunchKernelGGL(k_tonality_bwd_generic, dim3((unsigned)nwg), dim3(kThreads), 0, s, X, gt, gX, accumulate, C, p->N);
+  hipLaunchKernelGGL((k_tonality_bwd_generic<TIO>), dim3((unsigned)nwg), dim3(kThreads), 0, s, X, gt, gX, accumulate, C, p->N);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }
+int launch_tonality_bwd_generic(const ac_psy_plan* p, const float* X, const float* gt, float* gX, int accumulate, int B,
+                                int F, int C, hipStream_t s) {
+  return launch_tonality_bwd_T<float>(p, X, gt, gX, accumulate, B, F, C, s);
+}
 
-int launch_threshold_bwd_generic(const ac_psy_plan* p, const float* X, const float* t, float drown, const float* gthr,
-                                 float* gX, float* gt, int B, int F, int C, hipStream_t s) {
+// TC tables of the plan: float (float32 / bfloat16 tensors) or the float64 set
+template <typename TIO, typename TC>
+static int launch_threshold_bwd_T(const ac_psy_plan* p, const TIO* X, const TIO* t, TC drown, const TIO* gthr, TIO* gX, TIO* gt,
+                                  const TC* wb_val, const TC* wi_val, const TC* wf_val, const TC* vb_val, const TC* S, const TC* quiet,
+                                  const TC* beta, int B, int F, int C, hipStream_t s) {
   const long long nwg = (long long)B * F * C;
   const int st = check_grid(nwg);
   if (st) return st < 0 ? st : AC_OK;
-  size_t lds = (2 * (size_t)p->N + 10 * (size_t)p->M) * sizeof(float);
+  size_t lds = (2 * (size_t)p->N + 10 * (size_t)p->M) * sizeof(TC);
   AC_REQUIRE(lds <= 64 * 1024, "filter_bands_n = %d / bark_bands_n = %d too large for the backward kernel", p->N, p->M);
-  const size_t with_s = lds + (size_t)p->M * p->M * sizeof(float);
+  const size_t with_s = lds + (size_t)p->M * p->M * sizeof(TC);
   const int s_in_lds = with_s <= 64 * 1024;
   if (s_in_lds) lds = with_s;
-  hipLaunchKernelGGL(k_threshold_bwd_generic, dim3((unsigned)nwg), dim3(kThreads), lds, s, X, t, gthr, gX, gt, drown,
-                     (float)p->alpha, p->d_wb_ptr, p->d_wb_idx, p->d_wb_val, p->d_wi_ptr, p->d_wi_idx, p->d_wi_val,
-                     p->d_wf_ptr, p->d_wf_idx, p->d_wf_val, p->d_vb_ptr, p->d_vb_idx, p->d_vb_val, p->d_S, p->d_quiet,
-                     p->d_beta, C, p->N, p->M, s_in_lds);
+  hipLaunchKernelGGL((k_threshold_bwd_generic<TIO, TC>), dim3((unsigned)nwg), dim3(kThreads), lds, s, X, t, gthr, gX, gt, drown,
+                     (TC)p->alpha, p->d_wb_ptr, p->d_wb_idx, wb_val, p->d_wi_ptr, p->d_wi_idx, wi_val, p->d_wf_ptr, p->d_wf_idx,
+                     wf_val, p->d_vb_ptr, p->d_vb_idx, vb_val, S, quiet, beta, C, p->N, p->M, s_in_lds);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
+}
+int launch_threshold_bwd_generic(const ac_psy_plan* p, const float* X, const float* t, float drown, const float* gthr,
+                                 float* gX, float* gt, int B, int F, int C, hipStream_t s) {
+  return launch_threshold_bwd_T<float, float>(p, X, t, drown, gthr, gX, gt, p->d_wb_val, p->d_wi_val, p->d_wf_val, p->d_vb_val, p->d_S,
+                                              p->d_quiet, p->d_beta, B, F, C, s);
+}
+// compute_dtype float64 (everything in double) / bfloat16 (bfloat16 tensors, float32 arithmetic and tables)
+int launch_tonality_bwd_typed(const ac_psy_plan* p, const void* X, const void* gt, void* gX, int dtype, int B, int F, int C, hipStream_t s) {
+  if (dtype == AC_F64) return launch_tonality_bwd_T<double>(p, (const double*)X, (const double*)gt, (double*)gX, 0, B, F, C, s);
+  return launch_tonality_bwd_T<bf16_t>(p, (const bf16_t*)X, (const bf16_t*)gt, (bf16_t*)gX, 0, B, F, C, s);
+}
+int launch_threshold_bwd_typed(const ac_psy_plan* p, const void* X, const void* t, double drown, const void* gthr, void* gX, void* gt,
+                               int dtype, int B, int F, int C, hipStream_t s) {
+  if (dtype == AC_F64)
+    return launch_threshold_bwd_T<double, double>(p, (const double*)X, (const double*)t, drown, (const double*)gthr, (double*)gX, (double*)gt,
+                                                  p->d_wb_val64, p->d_wi_val64, p->d_wf_val64, p->d_vb_val64, p->d_S64, p->d_quiet64,
+                                                  p->d_beta64, B, F, C, s);
+  return launch_threshold_bwd_T<bf16_t, float>(p, (const bf16_t*)X, (const bf16_t*)t, (float)drown, (const bf16_t*)gthr, (bf16_t*)gX,
+                                               (bf16_t*)gt, p->d_wb_val, p->d_wi_val, p->d_wf_val, p->d_vb_val, p->d_S, p->d_quiet,
+                                               p->d_beta, B, F, C, s);
 }
 
 int launch_db(const float* a, float* out, size_t n, int norm, hipStream_t s) {
@@ -2861,6 +2896,32 @@ int launch_inv_f64(const ac_mdct_plan* p, const double* X, double* x, int B, int
   AC_REQUIRE(lds <= 64 * 1024, "filters_n = %d too large for the float64 kernel", p->N);
   hipLaunchKernelGGL((k_inv_generic<double, double>), dim3((unsigned)nwg), dim3(kThreads), lds, s, X, x,
                      (const double*)nullptr, (double*)nullptr, p->d_coef64, p->d_ctab64, Kp, nblk, nblk, C, p->N);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+
+int launch_fwd_f64_stream(const ac_mdct_plan* p, const double* x, double* X, const double* prev_block, int B, int Kin, int F, int C,
+                          hipStream_t s) {
+  const long long nwg = (long long)B * C * F;
+  const int st = check_grid(nwg);
+  if (st) return st < 0 ? st : AC_OK;
+  const size_t lds = (size_t)p->N * sizeof(double);
+  AC_REQUIRE(lds <= 64 * 1024, "filters_n = %d too large for the float64 kernel", p->N);
+  hipLaunchKernelGGL((k_fwd_generic<double, double>), dim3((unsigned)nwg), dim3(kThreads), lds, s, x, X, prev_block, p->d_coef64,
+                     p->d_ctab64, Kin, F, C, p->N);
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+int launch_inv_f64_stream(const ac_mdct_plan* p, const double* X, double* x, const double* tail_in, double* tail_out, int B, int Kp,
+                          int nblk, int C, hipStream_t s) {
+  const int per_sig = nblk + (tail_out ? 1 : 0);
+  const long long nwg = (long long)B * C * per_sig;
+  const int st = check_grid(nwg);
+  if (st) return st < 0 ? st : AC_OK;
+  const size_t lds = 2 * (size_t)p->N * sizeof(double);
+  AC_REQUIRE(lds <= 64 * 1024, "filters_n = %d too large for the float64 kernel", p->N);
+  hipLaunchKernelGGL((k_inv_generic<double, double>), dim3((unsigned)nwg), dim3(kThreads), lds, s, X, x, tail_in, tail_out,
+                     p->d_coef64, p->d_ctab64, Kp, nblk, per_sig, C, p->N);
   AC_HIP_CHECK(hipGetLastError());
   return AC_OK;
 }

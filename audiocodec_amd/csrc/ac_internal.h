@@ -141,6 +141,7 @@ struct ac_psy_plan {
   float* d_beta = nullptr;     // [M]
   // float64 constants (AC_F64 entry points): CSR values, S, quiet, beta = linspace(0, max_bark, M) in float64
   double* d_wb_val64 = nullptr; double* d_wi_val64 = nullptr;
+  double* d_wf_val64 = nullptr; double* d_vb_val64 = nullptr;   // ... of the transposed walks (backward in float64)
   double* d_S64 = nullptr; double* d_quiet64 = nullptr; double* d_beta64 = nullptr;
   // fast-path tables (ac_fast.hip)
   float* d_fast = nullptr;
@@ -171,6 +172,10 @@ struct ac_stream {
   // state where a later replay will find it
   float* d_prev_home = nullptr;
   float* d_tail_home = nullptr;
+  // float64 streams (AC_F64 through ac_stream_*_typed): the same state in double, allocated by the first float64 call
+  double* d_prev64 = nullptr;      // [B, N, C]
+  double* d_tail64 = nullptr;      // [B, C, N/2]
+  double* d_tail64_tmp = nullptr;
 };
 
 // ---- kernel launchers (each returns an AC_* status) -----------------------------------------
@@ -259,6 +264,11 @@ int launch_psy_bwd_fast(const ac_psy_plan* p, const float* X, const float* t, fl
 // compute_dtype variants (ac_generic.hip)
 int launch_fwd_f64(const ac_mdct_plan* p, const double* x, double* X, int B, int Kin, int F, int C, hipStream_t s);
 int launch_inv_f64(const ac_mdct_plan* p, const double* X, double* x, int B, int Kp, int nblk, int C, hipStream_t s);
+// ... with the streaming state (block -1 of every signal / the aliased half of the frame before frame 0 in, of the last one out)
+int launch_fwd_f64_stream(const ac_mdct_plan* p, const double* x, double* X, const double* prev_block, int B, int Kin, int F, int C,
+                          hipStream_t s);
+int launch_inv_f64_stream(const ac_mdct_plan* p, const double* X, double* x, const double* tail_in, double* tail_out, int B, int Kp,
+                          int nblk, int C, hipStream_t s);
 int launch_fwd_bf16(const ac_mdct_plan* p, const bf16_t* x, bf16_t* X, int B, int Kin, int F, int C, hipStream_t s);
 int launch_inv_bf16(const ac_mdct_plan* p, const bf16_t* X, bf16_t* x, int B, int Kp, int nblk, int C, hipStream_t s);
 int launch_fwd_f16(const ac_mdct_plan* p, const f16_t* x, f16_t* X, int B, int Kin, int F, int C, hipStream_t s);
@@ -269,6 +279,9 @@ int launch_threshold_f64(const ac_psy_plan* p, const double* X, const double* t,
                          int C, hipStream_t s);
 int launch_threshold_bf16(const ac_psy_plan* p, const bf16_t* X, const bf16_t* t, float drown, bf16_t* thr, int B, int F,
                           int C, hipStream_t s);
+int launch_tonality_bwd_typed(const ac_psy_plan* p, const void* X, const void* gt, void* gX, int dtype, int B, int F, int C, hipStream_t s);
+int launch_threshold_bwd_typed(const ac_psy_plan* p, const void* X, const void* t, double drown, const void* gthr, void* gX, void* gt,
+                               int dtype, int B, int F, int C, hipStream_t s);
 int launch_db_typed(const void* a, void* out, size_t n, int norm, int dtype, hipStream_t s);
 int launch_add_noise_typed(const void* X, const void* thr, void* out, size_t n, uint64_t seed, int dtype, hipStream_t s);
 int launch_db(const float* a, float* out, size_t n, int norm, hipStream_t s);

@@ -63,8 +63,9 @@ class MDCTransformer:
         :param compute_dtype:    dtype of inputs and outputs: float32 (the wave-level kernels), float64 (everything in
                                  float64, constants included: the on-device float64 cross-check), bfloat16 or float16 (2-byte
                                  tensors, float32 arithmetic inside: the reference up-casts them inside its DCT-IV, ``:327-344``;
-                                 float16 results beyond 65504 become infinity as a cast makes them); autograd and streaming
-                                 are float32 only
+                                 float16 results beyond 65504 become infinity as a cast makes them).  ``transform`` and
+                                 ``inverse_transform`` are differentiable in every one of them (the reference's op chain is,
+                                 ``:31-35``); streaming: float32, float64, bfloat16
         :param precompute_dtype: arithmetic type the window / fold constants are computed in on the host before they are
                                  cast to float32 tables (``:14,31-35,58-59``): float64 (default) or float32 -- the latter
                                  reproduces the reference's float32 rounding, including the cancellation at ``:218-221``
@@ -139,8 +140,7 @@ class MDCTransformer:
         :return:  ``[batches_n, blocks_n + 1, filters_n, channels_n]`` amplitudes in ]-1, 1[
         """
         if isinstance(x, torch.Tensor) and x.requires_grad and torch.is_grad_enabled():
-            _host.require_float32(self.compute_dtype, "the backward pass of transform")
-            return _TransformFn.apply(x, self)
+            return _TransformFn.apply(x, self)   # (every compute_dtype: the adjoint plan runs the same typed kernels)
         return self._transform(x)
 
     def _transform(self, x, adjoint=False):
@@ -164,7 +164,6 @@ class MDCTransformer:
         :return:                ``[batches_n, (blocks_n + 1) * filters_n, channels_n]``
         """
         if isinstance(mdct_amplitudes, torch.Tensor) and mdct_amplitudes.requires_grad and torch.is_grad_enabled():
-            _host.require_float32(self.compute_dtype, "the backward pass of inverse_transform")
             return _InverseFn.apply(mdct_amplitudes, self)
         return self._inverse(mdct_amplitudes)
 

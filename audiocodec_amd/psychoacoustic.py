@@ -219,8 +219,7 @@ class PsychoacousticModel:
     def tonality(self, mdct_amplitudes):
         """``tonality`` (``psychoacoustic.py:102-120``): [B, K, N, C] -> [B, K, 1, C] in [0, 1]."""
         if isinstance(mdct_amplitudes, torch.Tensor) and mdct_amplitudes.requires_grad and torch.is_grad_enabled():
-            _host.require_float32(self.compute_dtype, "the backward pass of tonality")
-            return _TonalityFn.apply(mdct_amplitudes, self)
+            return _TonalityFn.apply(mdct_amplitudes, self)   # (every compute_dtype: ac_tonality_backward_typed)
         return self._tonality(mdct_amplitudes)
 
     def _tonality(self, mdct_amplitudes):
@@ -237,15 +236,14 @@ class PsychoacousticModel:
         B, F, N, C = X.shape
         gX = torch.empty_like(X)
         with _host.on_device(X.device):
-            _lib.check(self._lib.ac_tonality_backward(self._plans.get(X.device), _host.ptr(X), _host.ptr(gt),
-                                                      _host.ptr(gX), 0, B, F, C, _host.stream_ptr(X.device)))
+            _lib.check(self._lib.ac_tonality_backward_typed(self._plans.get(X.device), _host.ptr(X), _host.ptr(gt), _host.ptr(gX),
+                                                            self._dtype_id, B, F, C, _host.stream_ptr(X.device)))
         return gX
 
     def global_masking_threshold(self, mdct_amplitudes, tonality_per_block, drown=0.0):
         """``global_masking_threshold`` (``psychoacoustic.py:122-148``): -> [B, K, N, C], strictly positive."""
         needs_grad = any(isinstance(v, torch.Tensor) and v.requires_grad for v in (mdct_amplitudes, tonality_per_block))
         if needs_grad and torch.is_grad_enabled():
-            _host.require_float32(self.compute_dtype, "the backward pass of global_masking_threshold")
             return _ThresholdFn.apply(mdct_amplitudes, tonality_per_block, self, float(drown))
         return self._threshold(mdct_amplitudes, tonality_per_block, drown)
 
@@ -256,9 +254,9 @@ class PsychoacousticModel:
         gX = torch.empty_like(X)
         gt = torch.empty_like(t)
         with _host.on_device(X.device):
-            _lib.check(self._lib.ac_mask_threshold_backward(self._plans.get(X.device), _host.ptr(X), _host.ptr(t),
-                                                            float(drown), _host.ptr(gthr), _host.ptr(gX), _host.ptr(gt),
-                                                            B, F, C, _host.stream_ptr(X.device)))
+            _lib.check(self._lib.ac_mask_threshold_backward_typed(self._plans.get(X.device), _host.ptr(X), _host.ptr(t),
+                                                                  float(drown), _host.ptr(gthr), _host.ptr(gX), _host.ptr(gt),
+                                                                  self._dtype_id, B, F, C, _host.stream_ptr(X.device)))
         return gX, gt
 
     def _threshold(self, mdct_amplitudes, tonality_per_block, drown=0.0):

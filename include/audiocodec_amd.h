@@ -356,15 +356,23 @@ AC_API int ac_probe_placement(const ac_mdct_plan* mdct, const ac_psy_plan* psy, 
  * NaN; every other frame and the other signal are untouched.  One corner differs: intensities that overflow float32
  * (|X| > 1.8e19) with a caller-supplied finite tonality give NaN thresholds where the reference has infinities.  Denormal
  * inputs are ordinary numbers (nothing is flushed on the way in; intensities below 1e-14 meet the model's floor).
- * Streaming (ac_stream_*_typed) serves AC_F32 at every size and AC_BF16 where the wave-level kernels do (filters_n 1024 /
- * 2048, mono / stereo; the state stays float32, chunked results equal the one-shot calls bit for bit); no backward passes
- * for AC_F64 / AC_BF16.
+ * Streaming (ac_stream_*_typed) serves AC_F32 and AC_F64 at every size (float64: a state of its own in double, the float64
+ * kernels) and AC_BF16 where the wave-level kernels do (filters_n 1024 / 2048, mono / stereo; the state stays float32);
+ * chunked results equal the one-shot calls bit for bit.  Backward passes: the filter bank through ac_mdct_plan_adjoint and
+ * the typed forward entry points in every dtype; the masking model through the *_backward_typed entry points below.
  * ---------------------------------------------------------------------------------------- */
 AC_API int ac_mdct_forward_typed(const ac_mdct_plan* plan, const void* x, void* X, int dtype, int B, int K, int C, void* stream);
 AC_API int ac_mdct_inverse_typed(const ac_mdct_plan* plan, const void* X, void* x, int dtype, int B, int Kp, int C, void* stream);
 AC_API int ac_tonality_typed(const ac_psy_plan* plan, const void* X, void* t, int dtype, int B, int F, int C, void* stream);
 AC_API int ac_mask_threshold_typed(const ac_psy_plan* plan, const void* X, const void* t, double drown, void* thr, int dtype,
                             int B, int F, int C, void* stream);
+/* the adjoints of the two (ac_tonality_backward / ac_mask_threshold_backward on tensors of `dtype`: the reference's op chain is
+ * differentiable in every dtype it accepts, psychoacoustic.py:311): AC_F64 in float64 throughout, AC_BF16 bfloat16 tensors with
+ * float32 arithmetic; grad_X is overwritten (no accumulate form) */
+AC_API int ac_tonality_backward_typed(const ac_psy_plan* plan, const void* X, const void* grad_t, void* grad_X, int dtype, int B, int F,
+                                      int C, void* stream);
+AC_API int ac_mask_threshold_backward_typed(const ac_psy_plan* plan, const void* X, const void* t, double drown, const void* grad_thr,
+                                            void* grad_X, void* grad_t, int dtype, int B, int F, int C, void* stream);
 AC_API int ac_encode_fused_typed(const ac_mdct_plan* mdct, const ac_psy_plan* psy, const void* x, void* X, void* t, void* thr,
                           double drown, int dtype, int B, int K, int C, void* stream);
 /* ac_stream_forward / ac_stream_encode (psy may be NULL: then t, thr are ignored) and ac_stream_inverse on tensors of `dtype` */

@@ -1348,6 +1348,112 @@ def test_autograd_where_the_synthesis_bank_is_not_the_transpose(path, N, wt, pre
     assert np.max(np.abs(host(Xv.grad) - gX_ref)) <= 1e-4 * max(1.0, np.max(np.abs(gX_ref)))
 
 
+@pytest.mark.parametrize("dt", ["float64", "bfloat16", "float16"])
+@pytest.mark.parametrize("N,wt,C", [(64, "vorbis", 2), (96, "rect", 3), (1024, "vorbis", 2), (960, "sine", 1)])
+def test_autograd_of_the_filter_bank_in_every_dtype(N, wt, C, dt):
+    """Backward of transform / inverse_transform for float64, bfloat16 and float16 tensors (the reference's op chain is
+    differentiable in every dtype it accepts, mdctransformer.py:31-35): the transposed bank (ac_mdct_plan_adjoint) through the
+    typed kernels.  Reference = the ORACLE's linear maps assembled from unit impulses in float64 (N <= 96), and the
+    inner-product identity <T x, g> = <x, T^T g> with T x from the oracle at every size -- no self-comparison.  Tolerances: the
+    storage type's rounding (float64 1e-10; bfloat16 2^-8, float16 2^-10 of the gradient's peak, plus its accumulation)."""
+    tdt = getattr(torch, dt)
+    tol = {"float64": 1e-10, "bfloat16": 1.2e-2, "float16": 2e-3}[dt]
+    K, B = 3, 2
+    m = audiocodec_amd.MDCTransformer(N, window_type=wt, compute_dtype=tdt)
+    o = MDCTOracle(N, wt, np.float64)
+    g = torch.Generator(device="cuda").manual_seed(N + C)
+    x = (torch.rand(B, K * N, C, device="cuda", generator=g, dtype=torch.float64) * 2 - 1).to(tdt).requires_grad_(True)
+    gX = torch.randn(B, K + 1, N, C, device="cuda", generator=g, dtype=torch.float64).to(tdt)
+    X = m.transform(x)
+    (X * gX).sum().backward()
+    assert x.grad.dtype == tdt
+    x64, gX64 = host(x.detach().double()), host(gX.double())
+    lhs = float(np.sum(o.transform(x64) * gX64))                       # <T x, g> with the oracle's T x
+    rhs = float(np.sum(x64 * host(x.grad.double())))                   # <x, T^T g> with the kernels' T^T g
+    assert abs(lhs - rhs) <= 40 * tol * max(1.0, float(np.sqrt(np.sum(gX64 ** 2) * np.sum(o.transform(x64) ** 2))) / 10)
+    Xv = torch.randn(B, K, N, C, device="cuda", generator=g, dtype=torch.float64).to(tdt).requires_grad_(True)
+    gy = torch.randn(B, (K + 1) * N, C, device="cuda", generator=g, dtype=torch.float64).to(tdt)
+    y = m.inverse_transform(Xv)
+    (y * gy).sum().backward()
+    assert Xv.grad.dtype == tdt
+    if N > 96:
+        return
+    eye = np.eye(K * N).reshape(K * N, K * N, 1)
+    T = o.transform(eye).reshape(K * N, (K + 1) * N)
+    gx_ref = np.einsum("if,bfc->bic", T, gX64.reshape(B, (K + 1) * N, C))
+    assert np.max(np.abs(host(x.grad.double()) - gx_ref)) <= tol * max(1.0, np.max(np.abs(gx_ref)))
+    eyeX = np.eye(K * N).reshape(K * N, K, N, 1)
+    S = o.inverse_transform(eyeX).reshape(K * N, (K + 1) * N)
+    gX_ref = np.einsum("is,bsc->bic", S, host(gy.double())).reshape(B, K, N, C)
+    assert np.max(np.abs(host(Xv.grad.double()) - gX_ref)) <= 4 * tol * max(1.0, np.max(np.abs(gX_ref)))
+
+
+@pytest.mark.parametrize("dt", ["float64", "bfloat16"])
+@pytest.mark.parametrize("sr,N,M,C,drown", [(48000, 1024, 64, 2, 0.0), (44100, 256, 48, 3, 0.3), (48000, 960, 64, 1, 0.0)])
+def test_autograd_of_the_masking_model_in_other_dtypes(sr, N, M, C, drown, dt):
+    """Backward of tonality / global_masking_threshold for float64 and bfloat16 tensors (psychoacoustic.py:311: the reference's
+    op chain is differentiable in the dtypes the model accepts) against torch.autograd on the float64 restatement of the
+    reference's formulas -- evaluated at the very (rounded) inputs the kernels saw.  float64: 1e-8 of the gradient's norm;
+    bfloat16: its output rounding (2^-8) on top of the float32 kernels' own bar."""
+    tdt = getattr(torch, dt)
+    tol = 1e-8 if dt == "float64" else 2e-2
+    B, F = 2, 3
+    g = torch.Generator(device="cuda").manual_seed(5)
+    env = torch.logspace(-3, 0, N, device="cuda", dtype=torch.float64).reshape(1, 1, N, 1)
+    X = ((torch.rand(B, F, N, C, device="cuda", generator=g, dtype=torch.float64) * 2 - 1) * env).to(tdt).requires_grad_(True)
+    p = audiocodec_amd.PsychoacousticModel(sr, filter_bands_n=N, bark_bands_n=M, compute_dtype=tdt)
+    w = (torch.rand(B, F, N, C, device="cuda", generator=g, dtype=torch.float64) + 0.5).to(tdt)
+    t = p.tonality(X)
+    thr = p.global_masking_threshold(X, t, drown)
+    (thr * w).sum().backward()
+    assert X.grad.dtype == tdt
+    Xd = X.detach().double().requires_grad_(True)
+    td = _torch_tonality_reference(Xd)
+    if dt == "bfloat16":
+        td = td + (t.detach().double() - td).detach()      # the threshold kernel saw the ROUNDED tonality; its gradient path is td's
+    thrd = _torch_psy_reference(p, Xd, td, drown)
+    (thrd * w.double()).sum().backward()
+    gref = Xd.grad
+    assert float(torch.linalg.vector_norm(X.grad.double() - gref) / torch.linalg.vector_norm(gref)) <= tol
+    # threshold alone, tonality as an independent differentiable input
+    X2 = X.detach().clone().requires_grad_(True)
+    t2 = t.detach().clone().requires_grad_(True)
+    (p.global_masking_threshold(X2, t2, drown) * w).sum().backward()
+    Xd2 = X.detach().double().requires_grad_(True)
+    td2 = t.detach().double().requires_grad_(True)
+    (_torch_psy_reference(p, Xd2, td2, drown) * w.double()).sum().backward()
+    assert float((t2.grad.double() - td2.grad).abs().max()) <= 2 * tol * float(td2.grad.abs().max())
+    assert float(torch.linalg.vector_norm(X2.grad.double() - Xd2.grad) / torch.linalg.vector_norm(Xd2.grad)) <= tol
+
+
+@pytest.mark.parametrize("N,C", [(64, 2), (960, 1), (1024, 3)])
+def test_float64_streaming(N, C):
+    """Streaming overlap-add on float64 tensors (ac_stream_*_typed with AC_F64: a state of its own in double, the float64
+    kernels): chunk by chunk -- ragged chunk lengths -- spectra, tonality, thresholds and the synthesised PCM equal the
+    one-shot float64 calls bit for bit, which the float64 ORACLE confirms at 1e-12 / 1e-10 (mdctransformer.py:62-153)."""
+    B, K = 2, 7
+    rng = np.random.default_rng(N + C)
+    x = rng.uniform(-1, 1, (B, K * N, C))
+    xd = dev(x)
+    codec = audiocodec_amd.AudioCodec(48000, N, compute_dtype=torch.float64)
+    X, t, thr = codec.encode(xd, drown=0.1)
+    xh = codec.decode(X)
+    st = codec.stream(B, C)
+    cuts = ((0, 1), (1, 4), (4, 7))
+    parts = [st.encode_chunk(xd[:, a * N:b * N].contiguous(), drown=0.1) for a, b in cuts]
+    for i, ref in enumerate((X, t, thr)):
+        assert torch.equal(torch.cat([p_[i] for p_ in parts], dim=1), ref[:, :K])
+    back = torch.cat([st.inverse_chunk(p_[0]) for p_ in parts], dim=1)
+    assert back.dtype == torch.float64 and torch.equal(back, xh[:, :K * N])
+    st.reset()
+    again = torch.cat([st.transform_chunk(xd[:, a * N:b * N].contiguous()) for a, b in cuts], dim=1)
+    assert torch.equal(again, X[:, :K])
+    o = MDCTOracle(N, "vorbis", np.float64)
+    assert rel_peak(host(X), o.transform(x)) <= 1e-12
+    assert np.max(np.abs(host(back)[:, N:] - x[:, :-N])) <= 1e-12
+    st.close()
+
+
 def test_tensors_beyond_4_gib():
     """Offsets are 64-bit: a batch whose tensors exceed 4 GiB gives, clip for clip, the bits of a small batch."""
     N, B, K, C = 1024, 1200, 468, 2                       # x: 4.6 GB, X / thr: 4.6 GB each
@@ -1380,7 +1486,9 @@ def _torch_psy_reference(p, X, t, drown):
     P = torch.einsum("nbic,ij->nbjc", I, W)
     Q = torch.clamp(P, min=eps) ** alpha
     A = torch.einsum("nbic,ij->nbjc", Q, S)
-    beta = torch.linspace(0.0, float(p.max_bark), M, dtype=torch.float32).double().cuda().reshape(1, 1, M, 1)
+    # (the reference evaluates linspace in compute_dtype, psychoacoustic.py:187-189: float32 unless the model is float64)
+    bdt = torch.float64 if p.compute_dtype == torch.float64 else torch.float32
+    beta = torch.linspace(0.0, float(p.max_bark), M, dtype=bdt).double().cuda().reshape(1, 1, M, 1)
     O = (1.0 - drown) * (t * beta + 9.0 * t + 5.5)
     fac = 10.0 ** (-alpha * O / 10.0)
     T = torch.clamp(fac * A, min=eps) ** (1.0 / alpha)
@@ -1554,8 +1662,7 @@ def test_float64_filter_bank_vs_oracle(N, wt, C):
         assert np.max(np.abs(xh[:, N:-N] - x)) <= 1e-12
     with pytest.raises(ValueError):
         m.transform(dev(x.astype(np.float32)))              # no implicit cast, as in the reference
-    with pytest.raises(NotImplementedError):
-        m.transform(dev(x).requires_grad_())
+    assert m.transform(dev(x).requires_grad_()).requires_grad   # (differentiable in every dtype: test_autograd_of_the_filter_bank_in_every_dtype)
 
 
 @pytest.mark.parametrize("sr,N,M,C", [(48000, 1024, 64, 2), (44100, 256, 48, 1), (48000, 2048, 64, 3)])
@@ -1804,14 +1911,12 @@ def test_codec_in_other_compute_dtypes(dtype):
     xh = codec.decode(X)
     assert xh.dtype == dtype
     assert float((xh[:, N:-N] - x).double().abs().max()) <= (1e-12 if dtype == torch.float64 else 2e-2)
-    if dtype == torch.float64:                      # (bfloat16 streams exist where the wave-level kernels serve them: N = 1024 / 2048)
-        with pytest.raises(NotImplementedError):
-            audiocodec_amd.StreamingMDCT(codec.mdct, 2, 2)
-    else:
+    if dtype == torch.float64:                      # (float64 streams: every size, test_float64_streaming)
+        assert audiocodec_amd.StreamingMDCT(codec.mdct, 2, 2).transform_chunk(x[:, :N].contiguous()).dtype == torch.float64
+    else:                                           # (bfloat16 streams exist where the wave-level kernels serve them: N = 1024 / 2048)
         with pytest.raises(_lib.AudioCodecError):
             audiocodec_amd.StreamingMDCT(codec.mdct, 2, 2).transform_chunk(x[:, :N].contiguous())
-    with pytest.raises(NotImplementedError):
-        codec.psy.tonality(X.clone().requires_grad_())
+    assert codec.psy.tonality(X.clone().requires_grad_()).requires_grad   # (test_autograd_of_the_masking_model_in_other_dtypes)
 
 
 def test_fuzz_wave_kernels_against_the_generic_kernels():
