@@ -470,7 +470,8 @@ struct WaveTabs {
 };
 template <int R1, int R2, bool first, bool last_to_v, bool CT = false>
 __device__ __forceinline__ void wave_pass(const cpair* __restrict__ src, cpair* __restrict__ dst, float2* v, int N, int L, int H,
-                                          const WaveTabs& tb, int tid, int nt, int ps = AC_PAD_SHIFT) {
+                                          const WaveTabs& tb, int tid, int nt, int ps = AC_PAD_SHIFT, int ps_dst = -1) {
+  if (ps_dst < 0) ps_dst = ps;   // (ps: the padding of src; ps_dst: of dst, when the two buffers are padded differently)
   constexpr int R = R1 * R2;
   const int m = H / (R * L), nb = H / R;
   const unsigned invL = 0xFFFFFFFFu / (unsigned)L + 1u;   // j / L for j < 2^16 as a multiply-high
@@ -496,7 +497,7 @@ __device__ __forceinline__ void wave_pass(const cpair* __restrict__ src, cpair* 
         v[2 * k] = r.re;
         v[N - 1 - 2 * k] = make_float2(-r.im.x, -r.im.y);
       } else {
-        dst[pad16(k, ps)] = val;
+        dst[pad16(k, ps_dst)] = val;
       }
     };
     if constexpr (R2 == 1) {
@@ -610,19 +611,29 @@ __device__ __forceinline__ void dct4_wave_ct(float2* v, cpair* Ap, cpair* Bp, co
   static_assert(R0 * (R1 ? R1 : 1) * (R2 ? R2 : 1) * (R3 ? R3 : 1) == H, "the super-radices multiply to N / 2");
   constexpr bool even = (NP & 1) == 0;
   constexpr int PS = pad_shift_ct(NC);
+  // The first pass writes its outputs R0 elements apart from lane to lane.  One element of padding per 16 spreads a stride
+  // that is a multiple of four over the banks; a stride of 5, 6, 9 or 10 elements already visits all sixteen 16-byte bank
+  // groups in eight consecutive lanes, and the padding only folds them onto each other (filters_n = 960, R0 = 10: lanes
+  // 0 .. 7 land on groups 0, 10, 5, 15, 10, 5, 15, 10).  So buffer A -- the first pass's target -- is padded only where the
+  // first radix asks for it; buffer B (and the later passes' writes: runs of R0 consecutive elements) keeps the padding.
+  // Measured (128 stereo clips of 10 s, base -> this): filters_n 600 transform 0.249 -> 0.212 ms, 540 0.244 -> 0.216, 648
+  // 0.218 -> 0.200, 360 inverse 0.220 -> 0.202, the other sizes of 32 and 64 lanes per frame within the noise; the frames
+  // of 8 and 16 lanes (108, 160) lost 8-15 % on the inverse and keep the padding.  LDS bank-conflict cycles at 960: 35 % of
+  // the LDS-active cycles -> 26 %.
+  constexpr int PSA = (R0 % 4 == 0 || PS != AC_PAD_SHIFT || NTC < 32) ? PS : 30, PSB = PS;
   // pass 1: v -> Ap; then Ap -> Bp -> Ap ...; an even count ends in v (= Bp's bytes) in final form
-  wave_pass<RadixSplit<R0>::A, RadixSplit<R0>::B, true, false, true>(Bp, Ap, v, NC, 1, H, tb, tid, NTC, PS);
+  wave_pass<RadixSplit<R0>::A, RadixSplit<R0>::B, true, false, true>(Bp, Ap, v, NC, 1, H, tb, tid, NTC, PSB, PSA);
   wave_sync_lds();
   if constexpr (NP >= 2) {
-    wave_pass<RadixSplit<R1>::A, RadixSplit<R1>::B, false, NP == 2, true>(Ap, Bp, v, NC, R0, H, tb, tid, NTC, PS);
+    wave_pass<RadixSplit<R1>::A, RadixSplit<R1>::B, false, NP == 2, true>(Ap, Bp, v, NC, R0, H, tb, tid, NTC, PSA, PSB);
     wave_sync_lds();
   }
   if constexpr (NP >= 3) {
-    wave_pass<RadixSplit<R2>::A, RadixSplit<R2>::B, false, false, true>(Bp, Ap, v, NC, R0 * R1, H, tb, tid, NTC, PS);
+    wave_pass<RadixSplit<R2>::A, RadixSplit<R2>::B, false, false, true>(Bp, Ap, v, NC, R0 * R1, H, tb, tid, NTC, PSB, PSA);
     wave_sync_lds();
   }
   if constexpr (NP >= 4) {
-    wave_pass<RadixSplit<R3>::A, RadixSplit<R3>::B, false, true, true>(Ap, Bp, v, NC, R0 * R1 * R2, H, tb, tid, NTC, PS);
+    wave_pass<RadixSplit<R3>::A, RadixSplit<R3>::B, false, true, true>(Ap, Bp, v, NC, R0 * R1 * R2, H, tb, tid, NTC, PSA, PSB);
     wave_sync_lds();
   }
   if constexpr (!even) {
@@ -630,7 +641,7 @@ __device__ __forceinline__ void dct4_wave_ct(float2* v, cpair* Ap, cpair* Bp, co
     for (int rd = 0; rd < (H + NTC - 1) / NTC; ++rd) {
       const int k = tid + rd * NTC;
       if (k < H) {
-        const cpair r = cmulw(Ap[pad16(k, PS)], tb.post[k]);
+        const cpair r = cmulw(Ap[pad16(k, PSA)], tb.post[k]);
         v[2 * k] = r.re;
         v[NC - 1 - 2 * k] = make_float2(-r.im.x, -r.im.y);
       }
