@@ -1712,6 +1712,343 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
   }
 }
 
+// ---- the 16-byte kernels for channel counts other than one and two ("team" form): whole cache lines on both sides ---------
+// A row of [filters_n, C] floats interleaves the channels; a channel pair's 8 bytes per sample are a third of each cache line
+// at six channels, and the strided form above (LAY 2) pays for it at the L1's request rate (2 - 3 TB/s).  Here the CP = ceil(C / 2)
+// groups of lanes that transform the channel pairs of ONE signal and strip form a team: the team moves whole rows between HBM
+// and LDS in 16-byte pieces, consecutive lanes on consecutive addresses, and every group picks its pair's samples out of (puts
+// them into) the row image in LDS -- the image takes the bytes of the team's transform buffers, which are dead between frames:
+//   block n + 1: global -> registers while frame n transforms (as the stereo kernel's prefetch), registers -> row image,
+//                barrier, (channel pair, sample pair) reads into the fold's registers, barrier, fold into the group's buffer;
+//   spectrum n:  group's buffer -> registers, barrier, 8-byte writes into the row image, barrier, 16-byte reads -> global, barrier.
+// The arithmetic is the strided form's on the same values: results equal it bit for bit.  A workgroup holds TPW teams that
+// step through their strips together (the barriers are the workgroup's; a team past its last frame idles through them).
+constexpr int kTeamDeclined = -12346;   // launch_*_wave_team: the shape has no team form, the caller takes the strided one
+constexpr int kTeamChunks = 8;   // 16-byte pieces of a row per lane: N C / (4 CP lanes per frame) <= 4 C / CP <= 8
+template <int NC, int NTC>
+struct TeamIO {
+  float* stage;     // the team's row image on the way in (and transform buffers)
+  float* stage_out; // ... on the way out: behind the other where the team's buffers hold two images (the wave form), else the same
+  int C, c0, u, TL, NCH, NCHL;   // NCH: 16-byte pieces of a row (0: a group outside every team), NCHL: the same for the loads
+  bool has1, member;   // member: the group belongs to a team (the groups a workgroup has left over after its last whole team do not)
+  v4f_t raw[kTeamChunks];
+  // (a lane's offsets are formed where they are used: hoisted out of the frame loop -- they are loop invariant -- they spill)
+  static __device__ __forceinline__ int here(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+  }
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int k = 0; k < kTeamChunks; ++k) raw[k] = v4f_t{0.f, 0.f, 0.f, 0.f};
+  }
+  // (no branch around a load: at the join the wave would wait for the loads before it -- the row would come in one piece at a
+  // time; a lane past the row's end reads its last piece again)
+  __device__ __forceinline__ void load_row(const float* row) {
+    const int u0 = here(u), last = NCHL - 1;
+#pragma unroll
+    for (int k = 0; k < kTeamChunks; ++k) {
+      const int j = min(u0 + k * TL, last);
+      raw[k] = *reinterpret_cast<const v4f_t*>(row + 4 * (size_t)j);
+    }
+  }
+  __device__ __forceinline__ void row_to_image() const {
+    const int u0 = here(u);
+#pragma unroll
+    for (int k = 0; k < kTeamChunks; ++k) {
+      const int j = u0 + k * TL;
+      if (j < NCH) *reinterpret_cast<v4f_t*>(stage + 4 * j) = raw[k];
+    }
+  }
+  __device__ __forceinline__ void image_to_global(float* row, bool act) const {
+    const int u0 = here(u);
+#pragma unroll
+    for (int k = 0; k < kTeamChunks; ++k) {
+      const int j = u0 + k * TL;
+      if (j < NCH && act) __builtin_nontemporal_store(*reinterpret_cast<const v4f_t*>(stage_out + 4 * j), reinterpret_cast<v4f_t*>(row + 4 * (size_t)j));
+    }
+  }
+  // samples m, m + 1 of the group's channel pair: (c0[m], c1[m], c0[m+1], c1[m+1]); a half-empty pair carries its one channel twice
+  __device__ __forceinline__ v4f_t get2(int m) const {
+    const float* p = stage + here(m * C + c0);
+    const v2u_t a = *reinterpret_cast<const v2u_t*>(p), b = *reinterpret_cast<const v2u_t*>(p + C);
+    return v4f_t{a.x, has1 ? a.y : a.x, b.x, has1 ? b.y : b.x};
+  }
+  __device__ __forceinline__ void put2(int m, v4f_t o) const {
+    float* p = stage_out + here(m * C + c0);
+    if (!member) return;
+    if (has1) {
+      *reinterpret_cast<v2u_t*>(p) = v2u_t{o.x, o.y};
+      *reinterpret_cast<v2u_t*>(p + C) = v2u_t{o.z, o.w};
+    } else {
+      p[0] = o.x;
+      p[C] = o.z;
+    }
+  }
+};
+template <int NC, int NTC, int R0, int R1, int R2, int R3>
+static __global__ __launch_bounds__(512, 2) void k_fwd_wave_c(const float* __restrict__ x, float* __restrict__ X,
+                                                          const float* __restrict__ prev_block, const v4f_t* __restrict__ coefv,
+                                                          const float* __restrict__ ctab, int Kin, int F, long long nteams, int T,
+                                                          int nstrip, int C, int CP, int TPW) {
+  float* smem = reinterpret_cast<float*>(smem_raw);
+  constexpr int N = NC, nt = NTC, ps = pad_shift_ct(NC), h = N >> 1, q = N >> 2;
+  constexpr bool GRP = NTC > 64;
+  constexpr int per = GRP ? group_floats_per_frame(N, ps) : wave_floats_per_group(N, ps);
+  const int gpw = (int)blockDim.x / nt, grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
+  float2* tw = reinterpret_cast<float2*>(smem + (size_t)gpw * per);
+  for (int k = threadIdx.x; k < h; k += blockDim.x) {
+    tw[k] = cis_neg(ctab, 16 * k, N);
+    tw[h + k] = cis_neg(ctab, 4 * k, N);
+    if constexpr (!GRP) tw[2 * h + k] = cis_neg(ctab, 4 * k + 1, N);
+  }
+  __syncthreads();
+  const WaveTabs tb = {tw, tw + 2 * h, tw + h};
+  const float2 pre0 = cis_neg(ctab, 1, N);
+  float* base = smem + (size_t)grp * per;
+  float2* v = reinterpret_cast<float2*>(base);
+  cpair* Bp = reinterpret_cast<cpair*>(base);
+  cpair* Ap = reinterpret_cast<cpair*>(base + 4 * padded_len(h, ps));
+  const float scale = (float)(1.0 / ((double)N * 1.4142135623730951));
+  const int team = min(grp / CP, max(TPW - 1, 0)), gi = grp - (grp / CP) * CP;
+  const long long tk = (long long)blockIdx.x * TPW + grp / CP;
+  const bool valid = grp / CP < TPW && tk < nteams;   // (no early exit: every lane takes part in the workgroup's barriers)
+  const int sp = valid ? (int)(tk % nstrip) : 0;
+  const long long b0 = valid ? tk / nstrip : 0;
+  const size_t RS = (size_t)N * C;   // floats per row
+  const float* xs = x + (size_t)b0 * Kin * RS;
+  float* Xs = X + (size_t)b0 * F * RS;
+  TeamIO<NC, NTC> io;
+  io.stage = smem + (size_t)team * CP * per;
+  io.stage_out = io.stage + (GRP ? 0 : (CP * per / 2) & ~3);   // (two images of N C <= 2 N CP floats in CP per >= 4.25 N CP)
+  io.C = C;
+  io.c0 = 2 * gi;
+  io.has1 = io.c0 + 1 < C;
+  io.member = grp / CP < TPW;
+  io.NCH = io.member ? N * C / 4 : 0;
+  io.u = gi * nt + tid;
+  io.TL = CP * nt;
+  io.NCHL = N * C / 4;
+  io.clear();
+  const int n0 = sp * T, n1 = valid ? min(n0 + T, F) : n0;
+  v4f_t d0[kWaveVSteps], d1[kWaveVSteps], cy[kWaveVSteps];
+  auto image_to_d = [&]() {
+#pragma unroll
+    for (int s = 0; s < kWaveVSteps; ++s) {
+      const int i = tid + s * nt;
+      if (i < q) {
+        d0[s] = io.get2(2 * i);
+        d1[s] = io.get2(N - 2 - 2 * i);
+      }
+    }
+  };
+  auto fold2 = [](float a, float x, float b, float y) { return __builtin_fmaf(a, x, b * y); };   // (as k_fwd_wave_v)
+  auto carry_of = [&](int s, int i) {
+    const v4f_t g = coefv[2 * i + 1];
+    return v4f_t{fold2(g.z, d0[s].z, g.w, d1[s].x), fold2(g.z, d0[s].w, g.w, d1[s].y), fold2(g.x, d0[s].x, g.y, d1[s].z),
+                 fold2(g.x, d0[s].y, g.y, d1[s].w)};
+  };
+  {
+    const bool have = valid && (n0 >= 1 || prev_block != nullptr);
+    if (have) io.load_row(n0 >= 1 ? xs + (size_t)(n0 - 1) * RS : prev_block + (size_t)b0 * RS);
+    io.row_to_image();
+    __syncthreads();
+    image_to_d();
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kWaveVSteps; ++s) {
+      const int i = tid + s * nt;
+      cy[s] = (have && i < q) ? carry_of(s, i) : v4f_t{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  if (valid && n0 < Kin) io.load_row(xs + (size_t)n0 * RS);
+  for (int it = 0; it < T; ++it) {
+    const int n = n0 + it;
+    const bool act = n < n1, has_cur = act && n < Kin;
+    io.row_to_image();
+    __syncthreads();
+    image_to_d();
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kWaveVSteps; ++s) {
+      const int i = tid + s * nt;
+      if (i < q) {
+        v4f_t hi = {0.f, 0.f, 0.f, 0.f};
+        if (has_cur) {
+          const v4f_t f = coefv[2 * i];
+          hi = v4f_t{fold2(f.x, d0[s].x, f.y, d1[s].z), fold2(f.x, d0[s].y, f.y, d1[s].w), fold2(f.z, d0[s].z, f.w, d1[s].x),
+                     fold2(f.z, d0[s].w, f.w, d1[s].y)};
+        }
+        *reinterpret_cast<v4f_t*>(v + h + 2 * i) = hi;
+        *reinterpret_cast<v4f_t*>(v + h - 2 - 2 * i) = cy[s];
+        if (has_cur) cy[s] = carry_of(s, i);
+      }
+    }
+    if (n + 1 < n1 && n + 1 < Kin) io.load_row(xs + (size_t)(n + 1) * RS);   // lands during the transform
+    group_sync<NTC>();
+    if (act) {   // (a frame on several waves: TPW = 1, so `act` is the workgroup's)
+      if constexpr (GRP) dct4_group_ct<NC, NTC, R0, R1, R2, R3>(v, Bp, tb, pre0, tid);
+      else dct4_wave_ct<NC, NTC, R0, R1, R2, R3>(v, Ap, Bp, tb, tid);
+    }
+    v4f_t o[2 * kWaveVSteps];
+#pragma unroll
+    for (int s = 0; s < 2 * kWaveVSteps; ++s) {
+      const int i = tid + s * nt;
+      if (i < h) o[s] = *reinterpret_cast<const v4f_t*>(v + 2 * i) * scale;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2 * kWaveVSteps; ++s) {
+      const int i = tid + s * nt;
+      if (i < h) io.put2(2 * i, o[s]);
+    }
+    __syncthreads();
+    io.image_to_global(Xs + (size_t)n * RS, act);
+    if constexpr (GRP) __syncthreads();   // (the wave form's two images are apart: the next row may come in while this one goes out)
+  }
+}
+template <int NC, int NTC, int R0, int R1, int R2, int R3>
+static __global__ __launch_bounds__(512, 2) void k_inv_wave_c(const float* __restrict__ X, float* __restrict__ x,
+                                                          const float* __restrict__ tail_in, float* __restrict__ tail_out,
+                                                          const v4f_t* __restrict__ coefv, const float* __restrict__ ctab, int Kp,
+                                                          int nblk, int seg, int nseg, long long nteams, int C, int CP, int TPW) {
+  float* smem = reinterpret_cast<float*>(smem_raw);
+  constexpr int N = NC, nt = NTC, ps = pad_shift_ct(NC), h = N >> 1, q = N >> 2;
+  constexpr bool GRP = NTC > 64;
+  constexpr int per = GRP ? group_floats_per_frame(N, ps) : wave_floats_per_group(N, ps);
+  const int gpw = (int)blockDim.x / nt, grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
+  float2* tw = reinterpret_cast<float2*>(smem + (size_t)gpw * per);
+  for (int k = threadIdx.x; k < h; k += blockDim.x) {
+    tw[k] = cis_neg(ctab, 16 * k, N);
+    tw[h + k] = cis_neg(ctab, 4 * k, N);
+    if constexpr (!GRP) tw[2 * h + k] = cis_neg(ctab, 4 * k + 1, N);
+  }
+  __syncthreads();
+  const WaveTabs tb = {tw, tw + 2 * h, tw + h};
+  const float2 pre0 = cis_neg(ctab, 1, N);
+  float* base = smem + (size_t)grp * per;
+  float2* v = reinterpret_cast<float2*>(base);
+  cpair* Bp = reinterpret_cast<cpair*>(base);
+  cpair* Ap = reinterpret_cast<cpair*>(base + 4 * padded_len(h, ps));
+  const int team = min(grp / CP, max(TPW - 1, 0)), gi = grp - (grp / CP) * CP;
+  const long long tk = (long long)blockIdx.x * TPW + grp / CP;
+  const bool valid = grp / CP < TPW && tk < nteams;
+  const int sgm = valid ? (int)(tk % nseg) : 0;
+  const long long b0 = valid ? tk / nseg : 0;
+  const size_t RS = (size_t)N * C;
+  const float* Xs = X + (size_t)b0 * Kp * RS;
+  float* xs = x + (size_t)b0 * nblk * RS;
+  TeamIO<NC, NTC> io;
+  io.stage = smem + (size_t)team * CP * per;
+  io.stage_out = io.stage + (GRP ? 0 : (CP * per / 2) & ~3);   // (two images of N C <= 2 N CP floats in CP per >= 4.25 N CP)
+  io.C = C;
+  io.c0 = 2 * gi;
+  io.has1 = io.c0 + 1 < C;
+  io.member = grp / CP < TPW;
+  io.NCH = io.member ? N * C / 4 : 0;
+  io.u = gi * nt + tid;
+  io.TL = CP * nt;
+  io.NCHL = N * C / 4;
+  io.clear();
+  const v4f_t* cv = coefv + h;
+  const float scale = 2.0f * 1.4142135623730951f;
+  const int nlast = nblk + (tail_out ? 1 : 0);
+  const int n0 = sgm * seg;
+  const size_t ts = (size_t)(b0 * C + io.c0) * h;   // stream state rows of the pair: ts, ts + h
+  v4f_t um[kWaveVSteps];
+#pragma unroll
+  for (int s = 0; s < kWaveVSteps; ++s) {
+    const int i = tid + s * nt;
+    um[s] = v4f_t{0.f, 0.f, 0.f, 0.f};
+    if (valid && n0 == 0 && tail_in && i < q) {
+      um[s].x = tail_in[ts + 2 * i];
+      um[s].z = tail_in[ts + 2 * i + 1];
+      if (io.has1) {
+        um[s].y = tail_in[ts + h + 2 * i];
+        um[s].w = tail_in[ts + h + 2 * i + 1];
+      }
+    }
+  }
+  auto frame_ok = [&](int t) { const int n = n0 + t; return t < 0 || (n < Kp && n < nblk); };
+  // every team walks t = -1 ... seg - 1 (the barriers are the workgroup's); a signal's first strip idles through t = -1
+  auto runs_at = [&](int t) { return valid && (t >= 0 ? n0 + t < nlast : n0 >= 1); };
+  if (runs_at(-1) && frame_ok(-1)) io.load_row(Xs + (size_t)(n0 - 1) * RS);
+  else if (runs_at(0) && n0 == 0 && frame_ok(0)) io.load_row(Xs + (size_t)n0 * RS);
+  for (int t = -1; t < seg; ++t) {
+    const int n = n0 + t;
+    const bool act = runs_at(t), has_n = act && frame_ok(t);
+    v4f_t r[2 * kWaveVSteps];
+    io.row_to_image();
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2 * kWaveVSteps; ++s) {
+      const int i = tid + s * nt;
+      if (i < h) r[s] = io.get2(2 * i);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2 * kWaveVSteps; ++s) {
+      const int i = tid + s * nt;
+      if (i < h) *reinterpret_cast<v4f_t*>(v + 2 * i) = has_n ? r[s] : v4f_t{0.f, 0.f, 0.f, 0.f};
+    }
+    {
+      const int tn = t + 1;
+      // (a first strip's frame 0 was loaded before the loop and passes through t = -1 in the registers)
+      if (tn < seg && runs_at(tn) && frame_ok(tn) && !(t == -1 && n0 == 0)) io.load_row(Xs + (size_t)(n0 + tn) * RS);
+    }
+    group_sync<NTC>();
+    if (has_n) {
+      if constexpr (GRP) dct4_group_ct<NC, NTC, R0, R1, R2, R3>(v, Bp, tb, pre0, tid);
+      else dct4_wave_ct<NC, NTC, R0, R1, R2, R3>(v, Ap, Bp, tb, tid);
+    }
+    const bool out = act && t >= 0 && n < nblk;
+    v4f_t o0[kWaveVSteps], o1[kWaveVSteps];
+#pragma unroll
+    for (int s = 0; s < kWaveVSteps; ++s) {
+      const int i = tid + s * nt;
+      if (i < q) {
+        const v4f_t A = *reinterpret_cast<const v4f_t*>(v + h - 2 - 2 * i) * scale;
+        const v4f_t Bm = um[s];
+        const v4f_t c0 = cv[2 * i], c1 = cv[2 * i + 1];
+        o0[s] = v4f_t{c0.x * A.z + c0.y * Bm.x, c0.x * A.w + c0.y * Bm.y, c0.z * A.x + c0.w * Bm.z, c0.z * A.y + c0.w * Bm.w};
+        o1[s] = v4f_t{c1.z * A.x + c1.w * Bm.z, c1.z * A.y + c1.w * Bm.w, c1.x * A.z + c1.y * Bm.x, c1.x * A.w + c1.y * Bm.y};
+      }
+    }
+    if (act && t >= 0 && n >= nblk && tail_out) {
+#pragma unroll
+      for (int s = 0; s < kWaveVSteps; ++s) {
+        const int i = tid + s * nt;
+        if (i < q) {
+          tail_out[ts + 2 * i] = um[s].x;
+          tail_out[ts + 2 * i + 1] = um[s].z;
+          if (io.has1) {
+            tail_out[ts + h + 2 * i] = um[s].y;
+            tail_out[ts + h + 2 * i + 1] = um[s].w;
+          }
+        }
+      }
+    }
+    if (act) {
+#pragma unroll
+      for (int s = 0; s < kWaveVSteps; ++s) {
+        const int i = tid + s * nt;
+        if (i < q) um[s] = *reinterpret_cast<const v4f_t*>(v + h + 2 * i) * scale;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kWaveVSteps; ++s) {
+      const int i = tid + s * nt;
+      if (i < q) {
+        io.put2(2 * i, o0[s]);
+        io.put2(N - 2 - 2 * i, o1[s]);
+      }
+    }
+    __syncthreads();
+    io.image_to_global(xs + (size_t)n * RS, out);
+    if constexpr (GRP) __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // tonality (psychoacoustic.py:102-120), one workgroup per (b, frame, c)
 // ------------------------------------------------------------------------------------------------
@@ -2123,6 +2460,7 @@ static bool lds_wave_ok(int N, bool synthesis, int C, bool f32) {
 // rectangular window and, below 1024, more than two channels; the plan the search below would pick, with lanes >= N / 16).  Strides, round counts and buffer offsets fold into immediates: 960 runs 0.156 -> 0.103 ms against the run-time form of
 // the same kernel.  lds_wave_plan returns these plans, so the launch geometry and the instance agree by construction; any
 // other size runs the run-time form.
+#ifndef AC_WAVE_CT_SIZES   // (a build for inspection may bring a shorter list)
 #define AC_WAVE_CT_SIZES \
   AC_WAVE_CT(16, 4, 8, 0, 0, 0) \
   AC_WAVE_CT(20, 4, 10, 0, 0, 0) \
@@ -2230,6 +2568,7 @@ static bool lds_wave_ok(int N, bool synthesis, int C, bool f32) {
   AC_WAVE_CT(512, 32, 8, 8, 4, 0) \
   AC_WAVE_CT(1024, 64, 8, 8, 8, 0) \
   AC_WAVE_CT(2048, 128, 8, 8, 8, 2)
+#endif
 static bool lds_wave_ct_size(int N) {
 #define AC_WAVE_CT(NC, NTC, R0, R1, R2, R3) \
   if (N == NC) return true;
@@ -2600,6 +2939,123 @@ int launch_fwd_wave_mono_pcm16(const ac_mdct_plan* p, const int16_t* x, float* X
 int launch_inv_wave_mono_pcm16(const ac_mdct_plan* p, const float* X, int16_t* x, int B, int Kp, int nblk, hipStream_t s) {
   return launch_inv_wave_v<1, int16_t>(p, X, x, nullptr, nullptr, B, Kp, nblk, 1, s);
 }
+#elif AC_WAVE_ROWS_TU == 4
+// the team form (k_fwd_wave_c / k_inv_wave_c): waves per workgroup, teams per workgroup and LDS bytes that keep the most channel
+// pairs resident per CU; false when the shape has no place in it (a team is at most a workgroup of 1024 lanes; a lane moves at
+// most kTeamChunks 16-byte pieces of a row)
+// ... and where it measured faster than the strided channel pairs on an MI355X (geometric mean over C = 3, 4, 6 of team /
+// strided <= 0.97, profiles/r4/lds_fft_team_sweep.txt: 0.57 - 0.97; the sizes left out ran 0.97 - 1.33 x -- the team form moves
+// every byte once (PMC: reads 0.65 x, writes 0.62 x of the strided form's) but keeps six or eight waves per CU where the
+// strided form keeps eight or nine, and the tier is bound by latency per wave, not by the memory side)
+static bool team_pays(int N, bool inverse) {
+  static const int fwd[] = {64, 80, 96, 100, 108, 120, 128, 144, 160, 180, 192, 200, 216, 240, 256, 324, 384, 400, 432, 480, 500, 512,
+                            576, 600, 640, 648, 720, 768, 800, 864, 900, 960, 972, 1000, 1024, 1152, 1200, 1280, 1296, 1440, 1500, 1536,
+                            1600, 1620, 1728, 1800, 1920, 2000, 2048, 3072, 3456, 3840, 3888, 4096};
+  static const int inv[] = {64, 80, 96, 120, 128, 144, 160, 180, 192, 200, 240, 256, 320, 384, 432, 512, 640, 720, 768, 800, 1024, 1280,
+                            1536, 2048, 3072, 4096};
+  if (inverse) {
+    for (int n : inv)
+      if (n == N) return true;
+  } else {
+    for (int n : fwd)
+      if (n == N) return true;
+  }
+  return false;
+}
+static bool team_geometry(int N, const WavePlan& wp, int C, bool inverse, int* w, int* tpw, size_t* lds) {
+  const char* e = getenv("AC_LDS_WAVE_NOTEAM");   // (read per call -- A/B measurements, tests: 1 never, 2 wherever the shape fits)
+  const int mode = e ? atoi(e) : 0;
+  const int CP = (C + 1) / 2, ps = pad_shift_ct(N);
+  if (mode == 1 || C < 3 || wave_ct_off() || !lds_wave_ct_size(N)) return false;
+  if (mode != 2 && !team_pays(N, inverse)) return false;
+  if ((long long)N * C > (long long)4 * kTeamChunks * CP * wp.nt) return false;
+  if (wp.nt > 64) {
+    if (CP * wp.nt > 512) return false;   // (the kernels' launch bound)
+    *w = CP * wp.nt / 64;
+    *tpw = 1;
+    *lds = ((size_t)CP * group_floats_per_frame(N, ps) + 2 * (size_t)N) * sizeof(float);
+    return *lds <= 160 * 1024;
+  }
+  const int gw = 64 / wp.nt;
+  long best = 0;
+  for (int ww = 1; ww <= 8; ++ww) {
+    const int gpw = ww * gw, teams = gpw / CP;
+    const size_t bytes = ((size_t)gpw * wave_floats_per_group(N, ps) + 3 * (size_t)N) * sizeof(float);
+    if (teams < 1 || bytes > 160 * 1024) continue;
+    const long resident = std::min<long>(160 * 1024 / (long)bytes, 8 / ww);   // (two waves per SIMD: the kernels take ~200 registers)
+    const long useful = resident * teams * CP;
+    if (useful > best) {
+      best = useful;
+      *w = ww;
+      *tpw = teams;
+      *lds = bytes;
+    }
+  }
+  return best > 0;
+}
+int launch_fwd_wave_team(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin, int F, int C,
+                         hipStream_t s) {
+  const WavePlan wp = lds_wave_plan(p->N);
+  size_t lds = 0;
+  int w = 1, tpw = 1;
+  if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(prev_block)) & 15) ||
+      !team_geometry(p->N, wp, C, false, &w, &tpw, &lds))
+    return kTeamDeclined;
+  const int CP = (C + 1) / 2;
+  const int T = wave_strip((long long)B * CP, F, tpw * CP, w, lds, p->cus, 0.25);
+  const int nstrip = (F + T - 1) / T;
+  const long long nteams = (long long)B * nstrip, g = (nteams + tpw - 1) / tpw;
+  const int st2 = check_grid(g);
+  if (st2) return st2 < 0 ? st2 : AC_OK;
+  int st = AC_OK;
+  bool done = false;
+#define AC_WAVE_CT(NC, NTC, R0, R1, R2, R3)                                                                                   \
+  if (!done && p->N == NC) {                                                                                                   \
+    done = true;                                                                                                               \
+    st = allow_lds(k_fwd_wave_c<NC, NTC, R0, R1, R2, R3>, lds);                                                                \
+    if (!st)                                                                                                                   \
+      hipLaunchKernelGGL((k_fwd_wave_c<NC, NTC, R0, R1, R2, R3>), dim3((unsigned)g), dim3(64 * w), lds, s, x, X, prev_block,   \
+                         reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kin, F, nteams, T, nstrip, C, CP, tpw);        \
+  }
+  AC_WAVE_CT_SIZES
+#undef AC_WAVE_CT
+  if (!done) return kTeamDeclined;
+  if (st) return st;
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
+int launch_inv_wave_team(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out, int B, int Kp,
+                         int nblk, int C, hipStream_t s) {
+  const WavePlan wp = lds_wave_plan(p->N);
+  size_t lds = 0;
+  int w = 1, tpw = 1;
+  if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(X)) & 15) || !team_geometry(p->N, wp, C, true, &w, &tpw, &lds))
+    return kTeamDeclined;
+  const int CP = (C + 1) / 2;
+  const int per_sig = nblk + (tail_out ? 1 : 0);
+  const int seg = wave_strip((long long)B * CP, per_sig, tpw * CP, w, lds, p->cus, 1.0);
+  const int nseg = (per_sig + seg - 1) / seg;
+  const long long nteams = (long long)B * nseg, g = (nteams + tpw - 1) / tpw;
+  const int st2 = check_grid(g);
+  if (st2) return st2 < 0 ? st2 : AC_OK;
+  int st = AC_OK;
+  bool done = false;
+#define AC_WAVE_CT(NC, NTC, R0, R1, R2, R3)                                                                                   \
+  if (!done && p->N == NC) {                                                                                                   \
+    done = true;                                                                                                               \
+    st = allow_lds(k_inv_wave_c<NC, NTC, R0, R1, R2, R3>, lds);                                                                \
+    if (!st)                                                                                                                   \
+      hipLaunchKernelGGL((k_inv_wave_c<NC, NTC, R0, R1, R2, R3>), dim3((unsigned)g), dim3(64 * w), lds, s, X, x, tail_in,      \
+                         tail_out, reinterpret_cast<const v4f_t*>(p->d_coefv), p->d_ctab, Kp, nblk, seg, nseg, nteams, C, CP,  \
+                         tpw);                                                                                                 \
+  }
+  AC_WAVE_CT_SIZES
+#undef AC_WAVE_CT
+  if (!done) return kTeamDeclined;
+  if (st) return st;
+  AC_HIP_CHECK(hipGetLastError());
+  return AC_OK;
+}
 #else
 int launch_fwd_wave_strided(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin, int F,
                             int C, hipStream_t s) {
@@ -2625,7 +3081,10 @@ static int launch_fwd_wave(const ac_mdct_plan* p, const TIO* x, TIO* X, const TI
       const int lay = wave_v_layout(C, {x, X, prev_block});
       if (lay >= 0) return lay == 0 ? launch_fwd_wave_v<0>(p, x, X, prev_block, B, Kin, F, 2, s)
              : lay == 1 ? launch_fwd_wave_mono(p, x, X, prev_block, B, Kin, F, s)
-                        : launch_fwd_wave_strided(p, x, X, prev_block, B, Kin, F, C, s);
+                        : [&] {   // whole cache lines where the shape has a team form, the strided channel pairs elsewhere
+                            const int st = launch_fwd_wave_team(p, x, X, prev_block, B, Kin, F, C, s);
+                            return st != kTeamDeclined ? st : launch_fwd_wave_strided(p, x, X, prev_block, B, Kin, F, C, s);
+                          }();
     }
   if (!wave_8_byte_range(p->N)) return kWaveDeclined;
   const WavePlan wp = lds_wave_plan(p->N, false);
@@ -2654,7 +3113,10 @@ static int launch_inv_wave(const ac_mdct_plan* p, const TIO* X, TIO* x, const fl
       const int lay = wave_v_layout(C, {X, x});
       if (lay >= 0) return lay == 0 ? launch_inv_wave_v<0>(p, X, x, tail_in, tail_out, B, Kp, nblk, 2, s)
              : lay == 1 ? launch_inv_wave_mono(p, X, x, tail_in, tail_out, B, Kp, nblk, s)
-                        : launch_inv_wave_strided(p, X, x, tail_in, tail_out, B, Kp, nblk, C, s);
+                        : [&] {
+                            const int st = launch_inv_wave_team(p, X, x, tail_in, tail_out, B, Kp, nblk, C, s);
+                            return st != kTeamDeclined ? st : launch_inv_wave_strided(p, X, x, tail_in, tail_out, B, Kp, nblk, C, s);
+                          }();
     }
   if (!wave_8_byte_range(p->N)) return kWaveDeclined;
   const WavePlan wp = lds_wave_plan(p->N, false);

@@ -200,6 +200,10 @@ bool wave_encode_fuses(const ac_mdct_plan* p, const ac_psy_plan* psy, int C, con
 int launch_enc_wave(const ac_mdct_plan* p, const ac_psy_plan* psy, const float* x, float* X, float* t, float* thr, float drown,
                     const float* prev_block, int B, int Kin, int F, int C, hipStream_t s);
 // ... and on channel pairs of any channel count / rows off the 16-byte grid (ac_wave_rows2.hip)
+int launch_fwd_wave_team(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin, int F, int C,
+                         hipStream_t s);
+int launch_inv_wave_team(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out, int B, int Kp,
+                         int nblk, int C, hipStream_t s);
 int launch_fwd_wave_strided(const ac_mdct_plan* p, const float* x, float* X, const float* prev_block, int B, int Kin, int F,
                             int C, hipStream_t s);
 int launch_inv_wave_strided(const ac_mdct_plan* p, const float* X, float* x, const float* tail_in, float* tail_out, int B,

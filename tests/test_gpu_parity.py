@@ -508,6 +508,44 @@ def test_fused_encode_of_the_lds_fft_tier_equals_the_unfused_calls(N, C, monkeyp
             assert tonality_err(host(t), t64) <= 1.0 and rel_elem(host(thr), o.global_masking_threshold(X64, t64)) <= TOL
 
 
+@pytest.mark.parametrize("N", [64, 120, 128, 480, 500, 960, 1024, 1536, 2048, 4096])
+@pytest.mark.parametrize("C", [3, 4, 5, 6, 7])
+def test_more_than_two_channels_through_whole_rows_equals_the_strided_pairs(N, C, monkeypatch):
+    """k_fwd_wave_c / k_inv_wave_c (ac_generic.hip): the channel pairs of one signal as a team that moves whole [filters_n, C]
+    rows between HBM and LDS in 16-byte pieces (mdctransformer.py:112, 289-297 takes any channels_n) -- forced on wherever the
+    shape fits (AC_LDS_WAVE_NOTEAM=2; the product takes it where it measured faster) against the strided channel pairs
+    (=1): bit for bit, one-shot and chunked (the stream state crosses the two forms), odd channel counts (a half-empty last
+    pair), several teams per workgroup and groups left over, short and ragged strips; and against the oracle at the bar."""
+    m = audiocodec_amd.MDCTransformer(N)
+    assert m.tier(C) == 2
+    for (B, K) in ((3, 7), (1, 1), (2, 41)):
+        x = (torch.rand((B, K * N, C), device="cuda") * 2 - 1) * torch.rand((B, 1, C), device="cuda")
+        monkeypatch.setenv("AC_LDS_WAVE_NOTEAM", "2")
+        X = m.transform(x)
+        y = m.inverse_transform(X)
+        monkeypatch.setenv("AC_LDS_WAVE_NOTEAM", "1")
+        X1 = m.transform(x)
+        y1 = m.inverse_transform(X1)
+        assert torch.equal(X, X1) and torch.equal(y, y1)
+        if (B, K) == (3, 7):
+            o = MDCTOracle(N, "vorbis", np.float64)
+            Xo = o.transform(host(x).astype(np.float64))
+            assert rel_peak(host(X), Xo) <= TOL and rel_l2(host(X), Xo) <= TOL
+            assert np.max(np.abs(host(y) - o.inverse_transform(Xo))) <= LSB
+            # chunked, the analysis in the team form and the synthesis in the strided one, then the other way round
+            for fwd_mode, inv_mode in (("2", "1"), ("1", "2")):
+                st = audiocodec_amd.StreamingMDCT(m, B, C)
+                parts = []
+                for a, b in ((0, 2), (2, 3), (3, 7)):
+                    monkeypatch.setenv("AC_LDS_WAVE_NOTEAM", fwd_mode)
+                    Xc = st.transform_chunk(x[:, a * N: b * N])
+                    assert torch.equal(Xc, X[:, a: b])
+                    monkeypatch.setenv("AC_LDS_WAVE_NOTEAM", inv_mode)
+                    parts.append(st.inverse_chunk(Xc))
+                assert torch.equal(torch.cat(parts, dim=1), y[:, : K * N])
+    monkeypatch.delenv("AC_LDS_WAVE_NOTEAM")
+
+
 @pytest.mark.parametrize("N,C,sr", [(512, 2, 48000), (512, 1, 48000), (256, 2, 48000), (256, 1, 44100), (128, 2, 48000), (128, 1, 48000),
                                     (64, 2, 48000), (64, 1, 32768), (64, 2, 64)])
 def test_fused_encode_below_1024_equals_the_unfused_calls(N, C, sr):
