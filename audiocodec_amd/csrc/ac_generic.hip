@@ -1060,6 +1060,7 @@ static __global__ __launch_bounds__(kThreads, 2) void k_inv_wave(const TIO* __re
 // per two samples); 1 two mono signals b, b + 1 (8 bytes each; the last pair of an odd batch is half empty); 2 the channels
 // c, c + 1 of three or more channels (8-byte accesses on the 4-byte grid; the last pair of an odd count is half empty).  bfloat16 tensors and filters_n % 4 == 2 run the 8-byte kernels above.
 typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float ola2(float a, float x, float b, float y) { return __builtin_fmaf(a, x, b * y); }   // a x + b y, one rounding order
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 typedef float v2u_t __attribute__((ext_vector_type(2), aligned(4)));   // two floats on the 4-byte grid
 constexpr int kWaveVSteps = 4;
@@ -1682,8 +1683,9 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
             const v4f_t A = *reinterpret_cast<const v4f_t*>(v + h - 2 - 2 * i) * scale;   // u_n[h-2-2i], u_n[h-1-2i]
             const v4f_t Bm = um[s];                                                         // u_{n-1}[h+2i], [h+2i+1]
             const v4f_t c0 = cv[2 * i], c1 = cv[2 * i + 1];   // (s1, s2)(2i), (s1, s2)(2i+1) | (s3, s4)(2i), (s3, s4)(2i+1)
-            const v4f_t o0 = {c0.x * A.z + c0.y * Bm.x, c0.x * A.w + c0.y * Bm.y, c0.z * A.x + c0.w * Bm.z, c0.z * A.y + c0.w * Bm.w};
-            const v4f_t o1 = {c1.z * A.x + c1.w * Bm.z, c1.z * A.y + c1.w * Bm.w, c1.x * A.z + c1.y * Bm.x, c1.x * A.w + c1.y * Bm.y};
+            // (one fixed rounding order, as the analysis kernels' fold2: the team form of this kernel returns the same bits)
+            const v4f_t o0 = {ola2(c0.x, A.z, c0.y, Bm.x), ola2(c0.x, A.w, c0.y, Bm.y), ola2(c0.z, A.x, c0.w, Bm.z), ola2(c0.z, A.y, c0.w, Bm.w)};
+            const v4f_t o1 = {ola2(c1.z, A.x, c1.w, Bm.z), ola2(c1.z, A.y, c1.w, Bm.w), ola2(c1.x, A.z, c1.y, Bm.x), ola2(c1.x, A.w, c1.y, Bm.y)};
             rp.store2(xa, xb, 2 * i, o0);
             rp.store2(xa, xb, N - 2 - 2 * i, o1);
           }
@@ -2009,8 +2011,8 @@ static __global__ __launch_bounds__(512, 2) void k_inv_wave_c(const float* __res
         const v4f_t A = *reinterpret_cast<const v4f_t*>(v + h - 2 - 2 * i) * scale;
         const v4f_t Bm = um[s];
         const v4f_t c0 = cv[2 * i], c1 = cv[2 * i + 1];
-        o0[s] = v4f_t{c0.x * A.z + c0.y * Bm.x, c0.x * A.w + c0.y * Bm.y, c0.z * A.x + c0.w * Bm.z, c0.z * A.y + c0.w * Bm.w};
-        o1[s] = v4f_t{c1.z * A.x + c1.w * Bm.z, c1.z * A.y + c1.w * Bm.w, c1.x * A.z + c1.y * Bm.x, c1.x * A.w + c1.y * Bm.y};
+        o0[s] = v4f_t{ola2(c0.x, A.z, c0.y, Bm.x), ola2(c0.x, A.w, c0.y, Bm.y), ola2(c0.z, A.x, c0.w, Bm.z), ola2(c0.z, A.y, c0.w, Bm.w)};
+        o1[s] = v4f_t{ola2(c1.z, A.x, c1.w, Bm.z), ola2(c1.z, A.y, c1.w, Bm.w), ola2(c1.x, A.z, c1.y, Bm.x), ola2(c1.x, A.w, c1.y, Bm.y)};
       }
     }
     if (act && t >= 0 && n >= nblk && tail_out) {
