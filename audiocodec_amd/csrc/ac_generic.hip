@@ -736,6 +736,15 @@ __device__ __forceinline__ void dct4_group_ct(float2* v, cpair* buf, const WaveT
 }
 
 // LDS floats per frame of the wave form: Bp (= v) and Ap, padded; of the in-place form above: one buffer
+// frames of at least AC_WAVE_INPLACE_LANES lanes (and two passes or more) are transformed in place in one buffer -- half the LDS
+// per frame, twice the frames resident; a frame on several waves always is.  For frames inside a wave it is OFF: built with
+// -DAC_WAVE_INPLACE_LANES=4 (tools/build_variant.sh) the tier ran within +-3 % of the two-buffer form at every size measured
+// (B = 256 stereo, 20 sizes 24 ... 1024: 960 0.467 / 0.479 -> 0.461 / 0.456 ms, 600 0.420 -> 0.462, 720 0.447 -> 0.428): with 9
+// or 18 frames resident the kernels run at the rate of a device copy of the same tensors (0.38 ms), so residency is not the limit.
+#ifndef AC_WAVE_INPLACE_LANES
+#define AC_WAVE_INPLACE_LANES 65
+#endif
+static inline __host__ __device__ constexpr bool wave_in_place(int ntc, int r1) { return ntc > 64 || (ntc >= AC_WAVE_INPLACE_LANES && r1 > 0); }
 static inline __host__ __device__ constexpr int wave_floats_per_group(int N, int ps = AC_PAD_SHIFT) { return 2 * 4 * padded_len(N / 2, ps); }
 static inline __host__ __device__ constexpr int group_floats_per_frame(int N, int ps = AC_PAD_SHIFT) { return 4 * padded_len(N / 2, ps); }
 
@@ -1170,7 +1179,7 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
                                                           int T, int nstrip, int B, int C, int adj, WavePlan wp) {
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int N = NC ? NC : N_rt, nt = NC ? NTC : wp.nt, gpw = (int)blockDim.x / nt, grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
-  constexpr bool GRP = NTC > 64;   // one frame per workgroup of NTC lanes, transformed in place
+  constexpr bool GRP = wave_in_place(NTC, R1);   // the frame transformed in place (a frame on several waves: one frame per workgroup of NTC lanes)
   const int ps = NC ? pad_shift_ct(NC) : AC_PAD_SHIFT;
   const int per = GRP ? group_floats_per_frame(N, ps) : wave_floats_per_group(N, ps), h = N >> 1, q = N >> 2;
   float2* tw = reinterpret_cast<float2*>(smem + (size_t)gpw * per);
@@ -1589,7 +1598,7 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
                                                           int C, int adj, WavePlan wp) {
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int N = NC ? NC : N_rt, nt = NC ? NTC : wp.nt, gpw = (int)blockDim.x / nt, grp = threadIdx.x / nt, tid = threadIdx.x - grp * nt;
-  constexpr bool GRP = NTC > 64;
+  constexpr bool GRP = wave_in_place(NTC, R1);
   const int ps = NC ? pad_shift_ct(NC) : AC_PAD_SHIFT;
   const int h = N >> 1, q = N >> 2, per = GRP ? group_floats_per_frame(N, ps) : wave_floats_per_group(N, ps);
   float2* tw = reinterpret_cast<float2*>(smem + (size_t)gpw * per);
@@ -2672,10 +2681,25 @@ static int wave_v_layout(int C, std::initializer_list<const void*> ptrs) {
 // says; a frame on more than one wave (in place) is a workgroup of its own with two tables behind its buffer
 static void wave_v_geometry(int N, const WavePlan& wp, int* w, int* gpw, size_t* lds) {
   const int ps = (lds_wave_ct_size(N) && !wave_ct_off()) ? pad_shift_ct(N) : AC_PAD_SHIFT;   // (as the kernel that will run pads)
+  const bool ct = lds_wave_ct_size(N) && !wave_ct_off();
   if (wp.nt > 64) {
     *w = wp.nt / 64;
     *gpw = 1;
     *lds = ((size_t)group_floats_per_frame(N, ps) + 2 * (size_t)N) * sizeof(float);
+  } else if (ct && wave_in_place(wp.nt, wp.r[1])) {   // (in place inside a wave: half the floats per frame, two tables)
+    int best_w = 1;
+    long best_res = 0;
+    for (int ww = 1; ww <= 4; ++ww) {
+      const size_t bytes = ((size_t)(64 / wp.nt) * ww * group_floats_per_frame(N, ps) + 2 * (size_t)N) * sizeof(float);
+      const long res = (long)std::min<size_t>(8, 160 * 1024 / std::max<size_t>(bytes, 1)) * ww;
+      if (bytes <= 160 * 1024 && res >= best_res) {
+        best_res = res;
+        best_w = ww;
+      }
+    }
+    *w = best_w;
+    *gpw = best_w * (64 / wp.nt);
+    *lds = ((size_t)*gpw * group_floats_per_frame(N, ps) + 2 * (size_t)N) * sizeof(float);
   } else {
     *w = lds_wave_block(N, wp, 0, lds, ps);
     *gpw = *w * (64 / wp.nt);
