@@ -132,8 +132,13 @@ echo "pmc n512 / n960 / n4096 done"
   SIZES=16,24,32,48,96,120,160,192,240,320,384,480,576,640,768,800,960,1000,1152,1280,1536,1920,2304,2880,3072,3840,4096,5120,6144,7680,8192 python tools/smooth_sizes_bench.py 2>&1 | grep "^N"
   echo "== the same, 128 mono clips"
   C=1 SIZES=32,120,240,480,960,1920,4096,8192 python tools/smooth_sizes_bench.py 2>&1 | grep "^N"
-  echo "== the same, 42 clips of 3 channels (channel pairs (0, 1), (2, -) through the instances with 4-byte accesses)"
+  echo "== the same, 42 clips of 3 channels (channel pairs (0, 1), (2, -): the team form -- whole rows through LDS -- where it pays)"
   C=3 B=42 SIZES=120,480,960,1920,4096 python tools/smooth_sizes_bench.py 2>&1 | grep "^N"
+  echo "== the same, the strided channel pairs everywhere (AC_LDS_WAVE_NOTEAM=1)"
+  AC_LDS_WAVE_NOTEAM=1 C=3 B=42 SIZES=120,480,960,1920,4096 python tools/smooth_sizes_bench.py 2>&1 | grep "^N"
+  echo "== 21 clips of 6 channels, team form where it pays / strided everywhere"
+  C=6 B=21 SIZES=120,480,960,1024,1920,2048 python tools/smooth_sizes_bench.py 2>&1 | grep "^N"
+  AC_LDS_WAVE_NOTEAM=1 C=6 B=21 SIZES=120,480,960,1024,1920,2048 python tools/smooth_sizes_bench.py 2>&1 | grep "^N"
   echo "== 64 stereo clips, the run-time form of the 16-byte kernels (AC_LDS_WAVE_NOCT=1) and the 8-byte kernels (AC_LDS_WAVE_NOVEC=1)"
   AC_LDS_WAVE_NOCT=1 SIZES=120,480,960 python tools/smooth_sizes_bench.py 2>&1 | grep "^N"
   AC_LDS_WAVE_NOVEC=1 SIZES=120,480,960,1920,4096 python tools/smooth_sizes_bench.py 2>&1 | grep "^N"
