@@ -2471,6 +2471,10 @@ static bool lds_wave_ok(int N, bool synthesis, int C, bool f32) {
 // rectangular window and, below 1024, more than two channels; the plan the search below would pick, with lanes >= N / 16).  Strides, round counts and buffer offsets fold into immediates: 960 runs 0.156 -> 0.103 ms against the run-time form of
 // the same kernel.  lds_wave_plan returns these plans, so the launch geometry and the instance agree by construction; any
 // other size runs the run-time form.
+// Plans re-measured against alternatives on the same tensors (tools/plan_ab.py, B = 256 stereo, transform / inverse ms): 576
+// (8,6,6) 0.393 / 0.446 -> (6,8,6) 0.389 / 0.398; 7680 (10,8,8,6) 0.574 / 0.589 -> (8,8,10,6) 0.472 / 0.603; at 800, 1152, 2304,
+// 2880 and 6144 four other orders and splits each ran within 2 % of (or behind) the plan listed: what keeps those sizes at
+// 3.7 - 4.0 TB/s where 960 runs at 4.4 is not the split (profiles/r4/lds_fft_plan_ab.txt).
 #ifndef AC_WAVE_CT_SIZES   // (a build for inspection may bring a shorter list)
 #define AC_WAVE_CT_SIZES \
   AC_WAVE_CT(16, 4, 8, 0, 0, 0) \
@@ -2505,7 +2509,7 @@ static bool lds_wave_ok(int N, bool synthesis, int C, bool f32) {
   AC_WAVE_CT(480, 32, 10, 8, 3, 0) \
   AC_WAVE_CT(500, 32, 10, 5, 5, 0) \
   AC_WAVE_CT(540, 64, 9, 6, 5, 0) \
-  AC_WAVE_CT(576, 64, 8, 6, 6, 0) \
+  AC_WAVE_CT(576, 64, 6, 8, 6, 0) \
   AC_WAVE_CT(600, 64, 10, 6, 5, 0) \
   AC_WAVE_CT(640, 64, 8, 8, 5, 0) \
   AC_WAVE_CT(648, 64, 9, 6, 6, 0) \
@@ -2568,7 +2572,7 @@ static bool lds_wave_ok(int N, bool synthesis, int C, bool f32) {
   AC_WAVE_CT(6480, 512, 9, 9, 8, 5) \
   AC_WAVE_CT(6912, 512, 9, 8, 8, 6) \
   AC_WAVE_CT(7200, 512, 10, 9, 8, 5) \
-  AC_WAVE_CT(7680, 512, 10, 8, 8, 6) \
+  AC_WAVE_CT(7680, 512, 8, 8, 10, 6) \
   AC_WAVE_CT(7776, 512, 9, 9, 8, 6) \
   AC_WAVE_CT(8000, 512, 10, 10, 8, 5) \
   AC_WAVE_CT(8100, 512, 10, 9, 9, 5) \
@@ -2735,7 +2739,7 @@ static int wave_strip(long long pairs, int per_sig, int gpw, int w, size_t lds, 
   AC_WAVE_CT(480, 32, 10, 8, 3, 0)   \
   AC_WAVE_CT(960, 64, 10, 8, 6, 0)   \
   AC_WAVE_CT(1920, 128, 8, 8, 5, 3)  \
-  AC_WAVE_CT(576, 64, 8, 6, 6, 0)    \
+  AC_WAVE_CT(576, 64, 6, 8, 6, 0)    \
   AC_WAVE_CT(1152, 128, 9, 8, 8, 0)
 template <int LAY, typename TX = float>
 static int launch_fwd_wave_v(const ac_mdct_plan* p, const TX* x, float* X, const float* prev_block, int B, int Kin, int F,
