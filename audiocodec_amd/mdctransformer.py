@@ -68,9 +68,14 @@ class MDCTransformer:
                                  ``:31-35``); streaming: float32, float64, bfloat16
         :param precompute_dtype: arithmetic type the window / fold constants are computed in on the host before they are
                                  cast to float32 tables (``:14,31-35,58-59``): float64 (default) or float32 -- the latter
-                                 reproduces the reference's float32 rounding, including the cancellation at ``:218-221``
-                                 (the reference's TensorFlow known-answer vector stems from such a revision); the fold
-                                 blocks are then no rotations and the kernels carry all four coefficients per block
+                                 rounds every constant and operation to float32 in the reference's order, the cancellation
+                                 at ``:218-221`` included.  How close that is to the reference: its dense ``H`` / ``H_inv``
+                                 from the reference's own source run with float32 precompute over numpy (a float32 LAPACK
+                                 LU inverse of the full ``F`` where this library inverts 2x2 blocks in closed form) are met
+                                 to 3e-7 / 5e-7 absolute, the reference's TensorFlow known-answer vector (which stems from
+                                 such a revision) to 5e-8; parity with a TensorFlow float32 run is not demonstrated beyond
+                                 that vector.  The fold blocks are then no rotations and the kernels carry all four
+                                 coefficients per block
         """
         assert (filters_n % 2) == 0, "number of filters used in mdct transformation needs to be even"
         self.filters_n = int(filters_n)
