@@ -21,9 +21,9 @@
 //   * the wave sums of the tonality (:102-120) of all the frames of a group are formed together: a reduction over lanes
 //     that halves the number of live registers with every exchange (4 FB values end as one register, lane & 15 = which
 //     value), one vector evaluation of the flatness formula for all of them.
-//   * the band x band product with the Toeplitz spreading matrix (:205-207, 223-228) runs as 16 v_mfma_f32_16x16x32_bf16 on
-//     split-bfloat16 operands for up to four frames at once (rows = frame x signal x {hi, lo}); the rest of the per-band
-//     arithmetic continues in the accumulator's layout.
+//   * the band x band product with the Toeplitz spreading matrix (:205-207, 223-228) runs on the matrix cores on
+//     split-bfloat16 operands (mid::spread_tiles: v_mfma_f32_4x4x4_16b_bf16, a step's B tiles read once for the frames of a
+//     group), lane = band before and after.
 // gfx950 only.
 #pragma once
 #include "ac_psy_mid_dev.h"
@@ -100,7 +100,7 @@ __device__ __forceinline__ RunsLane load_lane(const uint32_t* img, int lane) {
   return RunsLane{bc.x, __uint_as_float(bc.y), __uint_as_float(bc.z), bc.w};
 }
 
-// the zero word of each slot (threshold_frames writes them anew for every group: the A image of spread16 runs over them)
+// the zero word of each slot (threshold_frames writes them anew for every group: G and the entries of a group run over them in small slots)
 __device__ __forceinline__ void slot_init(const RunsParams& a, char* slot0, int nslots, int slot_bytes, int lane) {
   if (lane < nslots) *reinterpret_cast<v2f*>(slot0 + lane * slot_bytes + a.oz) = v2f{0.f, 0.f};
 }
@@ -275,74 +275,13 @@ struct RegIdx {
   __device__ __forceinline__ uint32_t operator()(int i) const { return w[i]; }
 };
 
-// ---- band x band product on the matrix cores, up to four frames at once -----------------------------------------------------
-//   acc_j = sum_i Q_i S[i, j],  S[i, j] = gp[64 + j - i]
-// as D = A B with v_mfma_f32_16x16x32_bf16: rows of A = (frame fb, part, signal) -- row 4 fb + 2 part + ch, part 0 = Q rounded to
-// bfloat16, part 1 = the remainder Q - hi -- K = band i (two steps of 32), columns = band j (four tiles of 16); S = hi + lo
-// likewise (two B tables), the four partial products meet in float32 accumulators: ~16 mantissa bits, thresholds within 1e-5 of
-// an all-float32 product.  A goes through LDS once (lane = band writes its rows' entries, 2 bytes each; lane l reads
-// A[row l & 15][k = 8 (l >> 4) .. + 7] as 16 bytes, rows of 160 bytes: conflict-free); with fewer than four frames the rows
-// repeat (row mod 4 FB), so every group of 16 lanes gets a copy of the result.  B[k][col] for lane (g = l >> 4, n = l & 15),
-// tile c, step s is rev[m0 .. m0 + 7], m0 = 64 - 16 c + 32 s - n + 8 g: eight consecutive entries of the reversed prototype,
-// 8-byte aligned in copy n & 3 of the table; tiles with equal 2 s - c are the same registers.
-// D of tile c: lane (g, n), register 2 part + ch = row 4 g + 2 part + ch, column 16 c + n.
-typedef __bf16 v8b __attribute__((ext_vector_type(8)));
-constexpr int A_ROW = 160;                 // bytes per row of the A image
-constexpr int A_BYTES = 16 * A_ROW;        // it takes the head of the group's slots once their intensities are done with
-template <int FB>
-__device__ __forceinline__ void spread16(const v2f (&Q)[FB], const uint32_t* img, char* abuf, int lane, v4f (&D)[4]) {
-#pragma unroll
-  for (int fb = 0; fb < FB; ++fb) {
-    const uint32_t whi = mid::pk_bf16(Q[fb].x, Q[fb].y);
-    const float hx = __uint_as_float(whi << 16), hy = __uint_as_float(whi & 0xffff0000u);
-    const uint32_t wlo = mid::pk_bf16(Q[fb].x - hx, Q[fb].y - hy);
-    char* w = abuf + (4 * fb) * A_ROW + 2 * lane;
-    *reinterpret_cast<uint16_t*>(w) = (uint16_t)whi;
-    *reinterpret_cast<uint16_t*>(w + A_ROW) = (uint16_t)(whi >> 16);
-    *reinterpret_cast<uint16_t*>(w + 2 * A_ROW) = (uint16_t)wlo;
-    *reinterpret_cast<uint16_t*>(w + 3 * A_ROW) = (uint16_t)(wlo >> 16);
-  }
-  wave_sync();
-  const int g = lane >> 4, n = lane & 15;
-  const char* ar = abuf + ((lane & 15) & (4 * FB - 1)) * A_ROW + 16 * g;
-  const v8b a0 = *reinterpret_cast<const v8b*>(ar), a1 = *reinterpret_cast<const v8b*>(ar + 64);
-  const char* bt = reinterpret_cast<const char*>(img + OFF_S) + (n & 3) * MF_COPY_STRIDE + 2 * (64 - (n & ~3) + 8 * g);
-  auto btile = [&](int d, int lo) {   // d = 2 s - c
-    const char* p = bt + lo * MF_TAB_BYTES + 32 * d;
-    typedef short s4v __attribute__((ext_vector_type(4)));
-    const s4v u0 = *reinterpret_cast<const s4v*>(p), u1 = *reinterpret_cast<const s4v*>(p + 8);
-    typedef short s8v __attribute__((ext_vector_type(8)));
-    const s8v u = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
-    return __builtin_bit_cast(v8b, u);
-  };
-#pragma unroll
-  for (int c = 0; c < 4; ++c) D[c] = v4f{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int d = -3; d <= 2; ++d) {   // tiles in the order of their B registers
-    const v8b bh = btile(d, 0), bl = btile(d, 1);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int c = 2 * s - d;
-      if (c < 0 || c > 3) continue;
-      D[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(s ? a1 : a0, bh, D[c], 0, 0, 0);
-      D[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(s ? a1 : a0, bl, D[c], 0, 0, 0);
-    }
-  }
-}
-
-// masking thresholds of FB frames whose intensities are in their slots (prep_frames, or the caller's own stores: bin f
-// at 8 f); emit(fb, i, th) receives the thresholds of granule 64 i + lane of frame fb (lanes with in_frame(i) only).
-// img: the LDS copy of the image.  NC: filter_bands_n where the kernel knows it at compile time (0: a.N).  The caller orders
-// its stores of the intensities before the call (wave_sync) and its next use of the slots after it.
-// The per-band part, in two steps (a kernel may keep the band intensities between them: the fused encode of the LDS-FFT tier
-// forms them frame by frame and finishes four frames at a time):
 // band_sums: P_j of FB frames whose intensities and partial sums are in their slots -- lane = band.  One wave.  The caller
 // orders the partial sums before the call (wave_sync, or a workgroup barrier where other waves formed them).
 template <int FB>
 __device__ __forceinline__ void band_sums(const RunsParams& a, const RunsLane& lc, const uint32_t* img, char* slot0, int slot_bytes, int lane,
                                           v2f (&P)[FB]) {
   static_assert(FB == 1 || FB == 2 || FB == 4, "frames side by side");
-  slot_init(a, slot0, FB, slot_bytes, lane);   // (the A image of the group before, or the caller's own use, ran over the zero words)
+  slot_init(a, slot0, FB, slot_bytes, lane);   // (the group before, or the caller's own use, ran over the zero words)
   wave_sync();
   // P_j = sum_f I_f W[f, j]  (:312-313): lane = band; two weighted edge bins, the interior through the list
   v2f P0[FB], P1[FB];
@@ -371,8 +310,7 @@ __device__ __forceinline__ void band_sums(const RunsParams& a, const RunsLane& l
 }
 
 // band_tail: from the band intensities to the threshold entries -- afterwards slot fb holds its frame's entries (the interior
-// entry of band j at 512 + 16 j, the entry of edge bin j at 512 + 16 j + 8); the slots need 1536 bytes each (FB = 1: 2560, the
-// A image of spread16), nothing in them is read.  One wave; the caller orders the look-ups after the call.
+// entry of band j at 512 + 16 j, the entry of edge bin j at 512 + 16 j + 8); the slots need 1536 bytes each, nothing in them is read.  One wave; the caller orders the look-ups after the call.
 template <int FB>
 __device__ __forceinline__ void band_tail(const v2f (&P)[FB], const v2f (&t)[FB], const RunsParams& a, const RunsLane& lc, const uint32_t* img,
                                           char* slot0, int slot_bytes, int lane) {
@@ -385,40 +323,28 @@ __device__ __forceinline__ void band_tail(const v2f (&P)[FB], const v2f (&t)[FB]
     q = v2f{P[fb].x == P[fb].x ? q.x : P[fb].x, P[fb].y == P[fb].y ? q.y : P[fb].y};
     Q[fb] = lane < a.M ? q : v2f{0.f, 0.f};
   }
-  wave_sync();   // every lane is done with the intensities and their sums: the head of the slots takes A, then G and the entries
-  v4f D[4];      // sum_i Q_i S[i, j] on the matrix cores, offset factor outside the sum  (:185-208)
-  spread16<FB>(Q, img, slot0, lane, D);
-  wave_sync();
-  // the rest of the per-band arithmetic in the accumulator's layout: lane (g, n) holds frame g % FB, bands 16 c + n of the FB
-  // tiles c = (g / FB) FB + ci
+  // sum_i Q_i S[i, j] on the matrix cores, lane = band in and out, offset factor outside the sum  (:185-208).  With the
+  // 4 x 4 x 4 tiles of ac_psy_mid_dev.h (the wave-level kernels' form): v_mfma_f32_16x16x32_bf16 took a quarter of the
+  // instructions, but with several waves per SIMD a wave issuing it made OTHER waves' vector arithmetic return wrong values
+  // (0.5 - 2 % of the frames of a bench-sized launch, none with one workgroup per CU or with the instruction replaced by
+  // s_sleep of the same length; DESIGN_LOG.md, round 4) -- not used anywhere in this library.
+  v2f acc[FB];
+  mid::spread_tiles<FB>(Q, reinterpret_cast<const char*>(img + OFF_S), lane, acc);
+  wave_sync();   // every lane is done with the intensities and their sums: the head of the slots takes G and the entries
   {
-    const int g = lane >> 4, n = lane & 15;
-    const int f = g & (FB - 1), cg = (g / FB) * FB;
-    // the frame's tonality (each candidate through an opaque copy: left alone the compiler turns the selection into an indexed
-    // load of t[] from scratch)
-    auto opaque = [](v2f x) { asm("" : "+v"(x)); return x; };
-    v2f tg = t[0];
-    if (FB >= 2) tg = (f & 1) ? opaque(t[1 % FB]) : tg;
-    if (FB == 4) tg = f == 2 ? opaque(t[2 % FB]) : f == 3 ? opaque(t[3 % FB]) : tg;
-    char* sf = slot0 + f * slot_bytes;
+    const v4f bd = reinterpret_cast<const v4f*>(img + OFF_BD)[lane];                              // {beta + 9, quiet, rho}
 #pragma unroll
-    for (int ci = 0; ci < FB; ++ci) {
-      v4f d;
-      if (FB == 4) d = D[ci];
-      else if (FB == 2) d = cg ? D[2 + ci] : D[ci];
-      else d = g == 0 ? D[0] : g == 1 ? D[1] : g == 2 ? D[2] : D[3];
-      const v2f acc = v2f{d.x + d.z, d.y + d.w};
-      const int b = 16 * (cg + ci) + n;
-      const v4f bd = reinterpret_cast<const v4f*>(img + OFF_BD)[b];                              // {beta + 9, quiet, rho}
-      const v2f offset = a.omd * (tg * bd.x + 5.5f);                                            // (1 - drown) (t beta + 9 t + 5.5)
-      const v2f y = maxv(log2v(acc) - (a.alpha * kLog2_10_10) * offset, kLog2Eps);              // log2 max(eps, fac acc)
+    for (int fb = 0; fb < FB; ++fb) {
+      char* sf = slot0 + fb * slot_bytes;
+      const v2f offset = a.omd * (t[fb] * bd.x + 5.5f);                                         // (1 - drown) (t beta + 9 t + 5.5)
+      const v2f y = maxv(log2v(acc[fb]) - (a.alpha * kLog2_10_10) * offset, kLog2Eps);          // log2 max(eps, fac acc)
       v2f G = maxv(exp2v(a.inv_alpha * y), bd.y);                                               // (:208, :144)
       // NaN where the reference has NaN: a poisoned product (above) or a NaN tonality (the clamps -- v_max -- would drop it)
-      const float poison_x = acc.x + tg.x, poison_y = acc.y + tg.y;
+      const float poison_x = acc[fb].x + t[fb].x, poison_y = acc[fb].y + t[fb].y;
       G = v2f{poison_x == poison_x ? G.x : poison_x, poison_y == poison_y ? G.y : poison_y};
-      const v2f A0 = maxv(G * bd.z, kEps);                                                      // interior bins of band b  (:330-331)
-      *reinterpret_cast<v2f*>(sf + 8 * b) = G;
-      *reinterpret_cast<v2f*>(sf + 512 + 16 * b) =
+      const v2f A0 = maxv(G * bd.z, kEps);                                                      // interior bins of band `lane`  (:330-331)
+      *reinterpret_cast<v2f*>(sf + 8 * lane) = G;
+      *reinterpret_cast<v2f*>(sf + 512 + 16 * lane) =
           v2f{G.x == G.x ? __builtin_amdgcn_sqrtf(A0.x) : G.x, G.y == G.y ? __builtin_amdgcn_sqrtf(A0.y) : G.y};
     }
   }

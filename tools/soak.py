@@ -11,7 +11,8 @@ lib = _lib.load()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 BIG = os.environ.get("BIG", "0") == "1"   # BIG=1: fewer, larger cases
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-SIZES = [64, 128, 256, 512, 1024, 2048, 960, 480, 240, 120, 576, 192, 96, 48, 32, 16, 1536, 3072, 4096, 24, 1000, 1920, 2880, 6144, 8192, 30, 90]
+SIZES = [64, 128, 256, 512, 1024, 2048, 960, 480, 240, 120, 576, 192, 96, 48, 32, 16, 1536, 3072, 4096, 24, 1000, 1920, 2880, 6144, 8192, 30, 90,
+         500, 600, 720, 800, 1080, 2160, 3000, 7680, 108]
 TOL, LSB = 1e-4, 1.0 / 32768
 t_end, cases = time.time() + budget, 0
 def fail(msg):
@@ -19,7 +20,10 @@ def fail(msg):
 while time.time() < t_end:
     N = int(rng.choice(SIZES)); wt = str(rng.choice(["vorbis", "sine", "vorbis", "sine", "rect"]))
     pre = "float32" if rng.integers(0, 5) == 0 else "float64"     # (one case in five: float32-precomputed constants)
-    B, C = int(rng.integers(1, 5)), int(rng.integers(1, 4))
+    B, C = int(rng.integers(1, 5)), int(rng.choice([1, 2, 3, 1, 2, 3, 4, 5, 6, 7]))
+    # the launch policies half of the time forced: every LDS-FFT instance with the fused encode, every shape with a team form
+    os.environ["AC_LDS_WAVE_NOFUSE"] = str(rng.choice(["0", "2"]))
+    os.environ["AC_LDS_WAVE_NOTEAM"] = str(rng.choice(["0", "2"]))
     K = int(rng.integers(0, max(2, min(60, 40000 // N))))
     if BIG:   # launches of many workgroups: frames per wave > 1, strips, persistent rounds (the O(N^2) check bounds the size)
         N = int(rng.choice([64, 128, 256, 512, 1024, 2048, 960, 480]))
@@ -27,7 +31,7 @@ while time.time() < t_end:
         K = int(rng.integers(1, max(2, (6000 if N >= 1024 else 20000) // (B * C))))
     M = int(rng.choice([64, 48, 20])) if N >= 128 else int(rng.choice([16, 8]))
     drown = float(rng.choice([0.0, 0.3, 1.0]))
-    tag = "N=%d %s pre=%s B=%d K=%d C=%d M=%d" % (N, wt, pre, B, K, C, M)
+    tag = "N=%d %s pre=%s B=%d K=%d C=%d M=%d fuse=%s team=%s" % (N, wt, pre, B, K, C, M, os.environ["AC_LDS_WAVE_NOFUSE"], os.environ["AC_LDS_WAVE_NOTEAM"])
     x = torch.from_numpy(rng.uniform(-1, 1, (B, K * N, C)).astype(np.float32)).cuda()
     codec = audiocodec_amd.AudioCodec(48000, N, bark_bands_n=M, window_type=wt, precompute_dtype=pre)
     lib.ac_set_force_generic(0)
