@@ -368,12 +368,130 @@ __device__ __forceinline__ void band_tail(const v2f (&P)[FB], const v2f (&t)[FB]
     }
   }
 }
+#ifdef AC_SPREAD_16X16X16
+// ---- the same product as 16 x 16 x 16 tiles (v_mfma_f32_16x16x16_bf16_1k) for up to four frames at once --------------------
+//   acc_j = sum_i Q_i S[i, j],  S[i, j] = gp[64 + j - i]
+// D = A B: rows of A = (frame fb, part, signal) -- row 4 fb + 2 part + ch, part 0 = Q rounded to bfloat16, part 1 = the
+// remainder -- K = band i (four steps of 16), columns = band j (four tiles of 16); S = hi + lo likewise (two B tables).  A goes
+// through LDS once (lane = band writes its rows' entries, 2 bytes each; lane (g, n) reads A[row n][16 s + 4 g .. + 3] as 8 bytes,
+// rows of 160 bytes); with fewer than four frames the rows repeat (row mod 4 FB).  B[k][col] for lane (g, n), tile c, step s is
+// rev[m0 .. m0 + 3], m0 = 64 - 16 (c - s) - n + 4 g: four consecutive entries of the reversed prototype, 8-byte aligned in
+// copy n & 3 of the table; tiles with equal s - c are the same registers.  D of tile c: lane (g, n), register 2 part + ch =
+// row 4 g + 2 part + ch, column 16 c + n.
+constexpr int A_ROW = 160;
+template <int FB>
+__device__ __forceinline__ void spread16k(const v2f (&Q)[FB], const uint32_t* img, char* abuf, int lane, v4f (&D)[4]) {
+  typedef short s4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int fb = 0; fb < FB; ++fb) {
+    const uint32_t whi = mid::pk_bf16(Q[fb].x, Q[fb].y);
+    const float hx = __uint_as_float(whi << 16), hy = __uint_as_float(whi & 0xffff0000u);
+    const uint32_t wlo = mid::pk_bf16(Q[fb].x - hx, Q[fb].y - hy);
+    char* w = abuf + (4 * fb) * A_ROW + 2 * lane;
+    *reinterpret_cast<uint16_t*>(w) = (uint16_t)whi;
+    *reinterpret_cast<uint16_t*>(w + A_ROW) = (uint16_t)(whi >> 16);
+    *reinterpret_cast<uint16_t*>(w + 2 * A_ROW) = (uint16_t)wlo;
+    *reinterpret_cast<uint16_t*>(w + 3 * A_ROW) = (uint16_t)(wlo >> 16);
+  }
+  wave_sync();
+  const int g = lane >> 4, n = lane & 15;
+  const char* ar = abuf + ((lane & 15) & (4 * FB - 1)) * A_ROW + 8 * g;
+  s4v av[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) av[s] = *reinterpret_cast<const s4v*>(ar + 32 * s);
+  const char* bt = reinterpret_cast<const char*>(img + OFF_S) + (n & 3) * mid::MF_COPY_STRIDE + 2 * (64 - (n & ~3) + 4 * g);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) D[c] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = -3; e <= 3; ++e) {   // e = s - c: tiles in the order of their B registers
+    const s4v bh = *reinterpret_cast<const s4v*>(bt + 32 * e), bl = *reinterpret_cast<const s4v*>(bt + mid::MF_TAB_BYTES + 32 * e);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int c = s - e;
+      if (c < 0 || c > 3) continue;
+      D[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av[s], bh, D[c], 0, 0, 0);
+      D[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av[s], bl, D[c], 0, 0, 0);
+    }
+  }
+}
+template <int FB>
+__device__ __forceinline__ void band_tail16(const v2f (&P)[FB], const v2f (&t)[FB], const RunsParams& a, const RunsLane& lc, const uint32_t* img,
+                                            char* slot0, int slot_bytes, int lane) {
+  v2f Q[FB];
+#pragma unroll
+  for (int fb = 0; fb < FB; ++fb) {
+    v2f q = exp2v(a.alpha * log2v(maxv(P[fb], kEps)));
+    q = v2f{P[fb].x == P[fb].x ? q.x : P[fb].x, P[fb].y == P[fb].y ? q.y : P[fb].y};
+    Q[fb] = lane < a.M ? q : v2f{0.f, 0.f};
+  }
+  wave_sync();   // every lane is done with the intensities and their sums: the head of the slots takes A, then G and the entries
+  v4f D[4];
+  spread16k<FB>(Q, img, slot0, lane, D);
+  wave_sync();
+  // the rest of the per-band arithmetic in the accumulator's layout: lane (g, n) holds frame g % FB, bands 16 c + n of the FB
+  // tiles c = (g / FB) FB + ci
+  {
+    const int g = lane >> 4, n = lane & 15;
+    const int f = g & (FB - 1), cg = (g / FB) * FB;
+    // the frame's tonality (each candidate through an opaque copy: left alone the compiler turns the selection into an indexed
+    // load of t[] from scratch)
+    auto opaque = [](v2f x) { asm("" : "+v"(x)); return x; };
+    v2f tg = t[0];
+    if (FB >= 2) tg = (f & 1) ? opaque(t[1 % FB]) : tg;
+    if (FB == 4) tg = f == 2 ? opaque(t[2 % FB]) : f == 3 ? opaque(t[3 % FB]) : tg;
+    char* sf = slot0 + f * slot_bytes;
+#pragma unroll
+    for (int ci = 0; ci < FB; ++ci) {
+      v4f d;
+      if (FB == 4) d = D[ci];
+      else if (FB == 2) d = cg ? D[2 + ci] : D[ci];
+      else d = g == 0 ? D[0] : g == 1 ? D[1] : g == 2 ? D[2] : D[3];
+      const v2f acc = v2f{d.x + d.z, d.y + d.w};
+      const int b = 16 * (cg + ci) + n;
+      const v4f bd = reinterpret_cast<const v4f*>(img + OFF_BD)[b];                              // {beta + 9, quiet, rho}
+      const v2f offset = a.omd * (tg * bd.x + 5.5f);                                            // (1 - drown) (t beta + 9 t + 5.5)
+      const v2f y = maxv(log2v(acc) - (a.alpha * kLog2_10_10) * offset, kLog2Eps);              // log2 max(eps, fac acc)
+      v2f G = maxv(exp2v(a.inv_alpha * y), bd.y);                                               // (:208, :144)
+      // NaN where the reference has NaN: a poisoned product (above) or a NaN tonality (the clamps -- v_max -- would drop it)
+      const float poison_x = acc.x + tg.x, poison_y = acc.y + tg.y;
+      G = v2f{poison_x == poison_x ? G.x : poison_x, poison_y == poison_y ? G.y : poison_y};
+      const v2f A0 = maxv(G * bd.z, kEps);                                                      // interior bins of band b  (:330-331)
+      *reinterpret_cast<v2f*>(sf + 8 * b) = G;
+      *reinterpret_cast<v2f*>(sf + 512 + 16 * b) =
+          v2f{G.x == G.x ? __builtin_amdgcn_sqrtf(A0.x) : G.x, G.y == G.y ? __builtin_amdgcn_sqrtf(A0.y) : G.y};
+    }
+  }
+  wave_sync();
+  // edge bin `lane`: sqrt(max(eps, sum_k G_{j0+k} u_k))  (:330-331)
+  {
+    v2f s[FB];
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb) s[fb] = v2f{0.f, 0.f};
+    const float* bw = reinterpret_cast<const float*>(img + off_bw(a.lw)) + lane;
+    for (int k = 0; k < a.kb; ++k) {
+      const float u = bw[64 * k];
+#pragma unroll
+      for (int fb = 0; fb < FB; ++fb) s[fb] += *reinterpret_cast<const v2f*>(slot0 + fb * slot_bytes + lc.goff + 8 * k) * u;
+    }
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb) {
+      const v2f A1 = maxv(s[fb], kEps);
+      *reinterpret_cast<v2f*>(slot0 + fb * slot_bytes + 512 + 16 * lane + 8) =
+          v2f{s[fb].x == s[fb].x ? __builtin_amdgcn_sqrtf(A1.x) : s[fb].x, s[fb].y == s[fb].y ? __builtin_amdgcn_sqrtf(A1.y) : s[fb].y};
+    }
+  }
+}
+#endif
 template <int FB>
 __device__ __forceinline__ void band_stage(const v2f (&t)[FB], const RunsParams& a, const RunsLane& lc, const uint32_t* img, char* slot0,
                                            int slot_bytes, int lane) {
   v2f P[FB];
   band_sums<FB>(a, lc, img, slot0, slot_bytes, lane, P);
+#ifdef AC_SPREAD_16X16X16
+  band_tail16<FB>(P, t, a, lc, img, slot0, slot_bytes, lane);
+#else
   band_tail<FB>(P, t, a, lc, img, slot0, slot_bytes, lane);
+#endif
 }
 
 // the threshold of granule q (bins 2 q, 2 q + 1) of the frame in `slot` from its entries; w = the granule's entry-offset word
