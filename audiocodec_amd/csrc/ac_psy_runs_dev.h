@@ -312,8 +312,8 @@ __device__ __forceinline__ void band_sums(const RunsParams& a, const RunsLane& l
 // band_tail: from the band intensities to the threshold entries -- afterwards slot fb holds its frame's entries (the interior
 // entry of band j at 512 + 16 j, the entry of edge bin j at 512 + 16 j + 8); the slots need 1536 bytes each, nothing in them is read.  One wave; the caller orders the look-ups after the call.
 template <int FB>
-__device__ __forceinline__ void band_tail(const v2f (&P)[FB], const v2f (&t)[FB], const RunsParams& a, const RunsLane& lc, const uint32_t* img,
-                                          char* slot0, int slot_bytes, int lane) {
+__device__ __forceinline__ void band_tail4(const v2f (&P)[FB], const v2f (&t)[FB], const RunsParams& a, const RunsLane& lc, const uint32_t* img,
+                                           char* slot0, int slot_bytes, int lane) {
   v2f Q[FB];   // max(eps, P)^alpha (:206); lanes beyond the M bands keep 0: the rows of S they would meet do not exist
 #pragma unroll
   for (int fb = 0; fb < FB; ++fb) {
@@ -323,11 +323,8 @@ __device__ __forceinline__ void band_tail(const v2f (&P)[FB], const v2f (&t)[FB]
     q = v2f{P[fb].x == P[fb].x ? q.x : P[fb].x, P[fb].y == P[fb].y ? q.y : P[fb].y};
     Q[fb] = lane < a.M ? q : v2f{0.f, 0.f};
   }
-  // sum_i Q_i S[i, j] on the matrix cores, lane = band in and out, offset factor outside the sum  (:185-208).  With the
-  // 4 x 4 x 4 tiles of ac_psy_mid_dev.h (the wave-level kernels' form): v_mfma_f32_16x16x32_bf16 took a quarter of the
-  // instructions, but with several waves per SIMD a wave issuing it made OTHER waves' vector arithmetic return wrong values
-  // (0.5 - 2 % of the frames of a bench-sized launch, none with one workgroup per CU or with the instruction replaced by
-  // s_sleep of the same length; DESIGN_LOG.md, round 4) -- not used anywhere in this library.
+  // sum_i Q_i S[i, j] on the matrix cores, lane = band in and out, offset factor outside the sum  (:185-208), with the
+  // 4 x 4 x 4 tiles of ac_psy_mid_dev.h (the wave-level kernels' form)
   v2f acc[FB];
   mid::spread_tiles<FB>(Q, reinterpret_cast<const char*>(img + OFF_S), lane, acc);
   wave_sync();   // every lane is done with the intensities and their sums: the head of the slots takes G and the entries
@@ -368,9 +365,11 @@ __device__ __forceinline__ void band_tail(const v2f (&P)[FB], const v2f (&t)[FB]
     }
   }
 }
-#ifdef AC_SPREAD_16X16X16
 // ---- the same product as 16 x 16 x 16 tiles (v_mfma_f32_16x16x16_bf16_1k) for up to four frames at once --------------------
 //   acc_j = sum_i Q_i S[i, j],  S[i, j] = gp[64 + j - i]
+// (NOT v_mfma_f32_16x16x32_bf16, which took half the instructions: with several waves per SIMD a wave issuing it made OTHER waves'
+// vector arithmetic return wrong values -- 0.5 - 2 % of the frames of a bench-sized launch, none with one workgroup per CU or
+// with the instruction replaced by s_sleep of the same length; DESIGN_LOG.md, round 4.  It is not used anywhere in this library.)
 // D = A B: rows of A = (frame fb, part, signal) -- row 4 fb + 2 part + ch, part 0 = Q rounded to bfloat16, part 1 = the
 // remainder -- K = band i (four steps of 16), columns = band j (four tiles of 16); S = hi + lo likewise (two B tables).  A goes
 // through LDS once (lane = band writes its rows' entries, 2 bytes each; lane (g, n) reads A[row n][16 s + 4 g .. + 3] as 8 bytes,
@@ -481,17 +480,23 @@ __device__ __forceinline__ void band_tail16(const v2f (&P)[FB], const v2f (&t)[F
     }
   }
 }
+// the form in use: 16 x 16 x 16 tiles (-DAC_SPREAD_4X4X4: the 4 x 4 x 4 tiles; both pass tools/scale_check.py at bench size; B =
+// 256 stereo, fused encode ms, 4x4x4 -> 16x16x16: 512 0.589 -> 0.573, 256 0.570 -> 0.549, 128 0.740 -> 0.682, 64 1.153 -> 1.048)
+template <int FB>
+__device__ __forceinline__ void band_tail(const v2f (&P)[FB], const v2f (&t)[FB], const RunsParams& a, const RunsLane& lc, const uint32_t* img,
+                                          char* slot0, int slot_bytes, int lane) {
+#ifdef AC_SPREAD_4X4X4
+  band_tail4<FB>(P, t, a, lc, img, slot0, slot_bytes, lane);
+#else
+  band_tail16<FB>(P, t, a, lc, img, slot0, slot_bytes, lane);
 #endif
+}
 template <int FB>
 __device__ __forceinline__ void band_stage(const v2f (&t)[FB], const RunsParams& a, const RunsLane& lc, const uint32_t* img, char* slot0,
                                            int slot_bytes, int lane) {
   v2f P[FB];
   band_sums<FB>(a, lc, img, slot0, slot_bytes, lane, P);
-#ifdef AC_SPREAD_16X16X16
-  band_tail16<FB>(P, t, a, lc, img, slot0, slot_bytes, lane);
-#else
   band_tail<FB>(P, t, a, lc, img, slot0, slot_bytes, lane);
-#endif
 }
 
 // the threshold of granule q (bins 2 q, 2 q + 1) of the frame in `slot` from its entries; w = the granule's entry-offset word
