@@ -2867,10 +2867,10 @@ static int launch_inv_wave_v(const ac_mdct_plan* p, const float* X, TX* x, const
 // 4096 (the masking model's range ends there; below 108 a frame's LDS is smaller than the model's smallest slot)
 static bool enc_size(int N) { return N >= 108 && N <= 4096 && lds_wave_ct_size(N); }
 // ... and where the one launch measured faster than transform + masking kernel on an MI355X (ratio <= 0.98 over B = 256 stereo
-// clips of 10 s, profiles/r4/lds_fft_fused_encode_sweep.txt: 0.74 - 0.98; the instances left out ran 1.0 - 1.33 x -- the ones
+// clips of 10 s, profiles/r4/lds_fft_fused_encode_sweep.txt: 0.73 - 0.98; the instances left out ran 0.99 - 1.31 x -- the ones
 // that spill registers, and the small sizes, where the per-frame part of the model outweighs the second read of X)
 static bool enc_pays(int N) {
-  static const int sizes[] = {500, 540, 600, 640, 648, 720, 768, 800, 864, 960, 1296, 1440, 1500, 1536, 1728, 2160, 2304, 2400, 2500,
+  static const int sizes[] = {640, 720, 768, 800, 864, 900, 960, 1000, 1152, 1200, 1296, 1440, 1500, 1536, 1728, 2160, 2304, 2400, 2500,
                               2560, 2592, 2700, 2880, 2916, 3000, 3072, 3200, 3456, 4096};
   for (int n : sizes)
     if (n == N) return true;
