@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, audiocodec_amd
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 bad = 0
-for N, C in ((64, 2), (128, 2), (256, 2), (512, 2), (512, 1), (1024, 2), (2048, 2), (960, 2), (960, 1), (600, 2), (2160, 2), (4096, 2), (1920, 2), (480, 2), (960, 6)):
+for N, C in ((64, 2), (128, 2), (256, 2), (512, 2), (512, 1), (1024, 2), (2048, 2), (960, 2), (960, 1), (600, 2), (2160, 2), (4096, 2), (1920, 2), (480, 2), (960, 6), (1024, 6), (2048, 3), (120, 4)):
     K = 480000 // N
     g = torch.Generator(device="cuda").manual_seed(N + C)
     x = torch.empty((B if C <= 2 else B // 3, K * N, C), device="cuda").uniform_(-1, 1, generator=g)
@@ -23,6 +23,18 @@ for N, C in ((64, 2), (128, 2), (256, 2), (512, 2), (512, 1), (1024, 2), (2048, 
     # (1024: the fused kernel and the transform-only kernel are two instances of k_fwd_fast: same values to rounding)
     r = dict(run_vs_run=rows(X, Xb) + rows(thr, thrb), X_vs_unfused=rows(X, X2) if exact else int(((X - X2).abs() > 2e-6 * X2.abs().amax(dim=2, keepdim=True)).any(dim=2).sum()), thr_vs_unfused=rows(thr, thr2) if exact else int((((thr - thr2).abs() / thr2) > 1e-4).any(dim=2).sum()),
              standalone_run_vs_run=rows(thr2, thr3))
+    # the synthesis: twice, and for more than two channels the team form against the strided channel pairs (both directions)
+    y = codec.decode(X2); yb = codec.decode(X2)
+    r["decode_run_vs_run"] = rows(y.reshape(y.shape[0], -1, N, C), yb.reshape(y.shape[0], -1, N, C))
+    if C > 2:
+        os.environ["AC_LDS_WAVE_NOTEAM"] = "2"
+        Xt = codec.mdct.transform(x); yt = codec.decode(Xt)
+        os.environ["AC_LDS_WAVE_NOTEAM"] = "1"
+        Xs = codec.mdct.transform(x); ys = codec.decode(Xs)
+        del os.environ["AC_LDS_WAVE_NOTEAM"]
+        r["team_vs_strided"] = rows(Xt, Xs) + rows(yt.reshape(y.shape[0], -1, N, C), ys.reshape(y.shape[0], -1, N, C))
+        del Xt, yt, Xs, ys
+    del y, yb
     ok = not any(r.values())
     bad += not ok
     print("N %5d C %d launches %d frames %8d: %s %s" % (N, C, codec.encode_launches(C) if C <= 2 else 2, X.shape[0] * X.shape[1] * C, "ok" if ok else "MISMATCH", r), flush=True)
