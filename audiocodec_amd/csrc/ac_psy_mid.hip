@@ -398,6 +398,135 @@ __global__ __launch_bounds__(256, (R >= 32 ? 1 : R >= 16 ? 2 : 3)) void k_psy_ru
   }
 }
 
+// ---- channel counts other than one and two with whole cache lines ("team" form, as k_fwd_wave_c of ac_generic.hip) ----------
+// A workgroup = the CP = ceil(C / 2) waves that take the channel pairs of ONE frame.  The row [N, C] comes in and the threshold
+// row goes out in 16-byte pieces, consecutive lanes on consecutive addresses: wave w moves piece w (8 N bytes) between HBM and
+// its own slot, and every wave picks its pair's bins out of (puts its thresholds into) the row image that the CP slots hold
+// together -- on the way in at the slots' heads (where the intensities go afterwards), on the way out behind the threshold
+// entries (bytes 1536 ...: intensities and partial sums are dead by then).  Four workgroup barriers per frame; the arithmetic is
+// k_psy_runs' (same device functions): equal results bit for bit.  filters_n 640 ... 2048 (a slot must hold 1536 + 8 N bytes).
+template <int R, bool WANT_T>
+__global__ __launch_bounds__(256, (R >= 16 ? 2 : 3)) void k_psy_runs_c(RunsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t* img = reinterpret_cast<uint32_t*>(smem);
+  const int slot = a.p.slot, N = a.p.N, C = a.C;
+  char* slots = smem + (size_t)a.p.lds_words * 4;
+  char* buf = slots + (size_t)wave * slot;
+  constexpr bool IDX_REGS = R <= 8;
+  for (int i = threadIdx.x; i < a.p.lds_words / 4; i += blockDim.x)
+    reinterpret_cast<uint4*>(img)[i] = reinterpret_cast<const uint4*>(a.img)[i];
+  __syncthreads();
+  const runs::RunsLane lc = runs::load_lane(img, lane);
+  runs::RegIdx<IDX_REGS ? R : 1> ridx = {};
+  if (IDX_REGS) ridx.load(a.img, a.p, lane);
+  const int c0 = 2 * wave;
+  const bool has1 = c0 + 1 < C, codd = (C & 1) != 0;
+  const int PN = 2 * N;                          // floats of the row per piece
+  const int adj = slot - 4 * PN;                 // bytes a piece's data sits further on than in the contiguous image
+  const int nch = N * C / 4, pch = N / 2;        // 16-byte pieces of a row / of a slot's share
+  // byte offset (from `slots`) of float v of the row image: piece v / PN at its slot
+  auto image_at = [&](int v) {
+    int pc = v >= PN ? 1 : 0;
+    pc = v >= 2 * PN ? 2 : pc;
+    pc = v >= 3 * PN ? 3 : pc;
+    return 4 * v + pc * adj;
+  };
+  const long long frame0 = (long long)blockIdx.x * a.T;
+  for (int tt = 0; tt < a.T && frame0 + tt < a.ntasks; ++tt) {   // (a.ntasks: frames B F; the loop is the workgroup's)
+    const long long fr = frame0 + tt;
+    const size_t ro = (size_t)fr * N * C;
+    // (a lane's image offsets are formed per frame: hoisted out of the loop -- they are invariant -- the 4 R of them spill)
+    int vb = 2 * lane * C + c0;
+    asm volatile("" : "+v"(vb));
+    // the row in: wave w's share, whole 16-byte pieces (no branch around a load; a piece past the row's end -- the half-empty
+    // last share of an odd channel count -- re-reads the row's last)
+    {
+      v4f raw[R];
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const int j = min(wave * pch + 64 * i + lane, nch - 1);
+        raw[i] = *reinterpret_cast<const v4f*>(a.X + ro + 4 * (size_t)j);
+      }
+#pragma unroll
+      for (int i = 0; i < R; ++i)
+        if (runs::in_frame<R>(a.p, i, lane)) *reinterpret_cast<v4f*>(buf + 16 * (64 * i + lane)) = raw[i];
+    }
+    __syncthreads();
+    v4f xq[1][R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int v0 = vb + 128 * i * C;
+      v2u u = {0.f, 0.f}, w = {0.f, 0.f};
+      if (runs::in_frame<R>(a.p, i, lane)) {
+        if (codd) {   // (an odd channel count: a pair's two floats may lie either side of a piece boundary)
+          u = v2u{*reinterpret_cast<const float*>(slots + image_at(v0)), *reinterpret_cast<const float*>(slots + image_at(v0 + 1))};
+          w = v2u{*reinterpret_cast<const float*>(slots + image_at(v0 + C)), *reinterpret_cast<const float*>(slots + image_at(v0 + C + 1))};
+        } else {
+          u = *reinterpret_cast<const v2u*>(slots + image_at(v0));
+          w = *reinterpret_cast<const v2u*>(slots + image_at(v0 + C));
+        }
+      }
+      xq[0][i] = has1 ? v4f{u.x, u.y, w.x, w.y} : v4f{u.x, u.x, w.x, w.x};
+    }
+    __syncthreads();   // every wave has its bins: the slots take the intensities
+    v2f t[1];
+    runs::prep_frames<R, 1, WANT_T, true>(xq, a.p, buf, slot, lane, t);
+    const size_t to = (size_t)fr * C + c0;
+    if (WANT_T) {
+      if (lane == 0) {
+        a.t_out[to] = t[0].x;
+        if (has1) a.t_out[to + 1] = t[0].y;
+      }
+    } else {
+      t[0] = v2f{a.t_in[to], has1 ? a.t_in[to + 1] : 0.f};
+    }
+    wave_sync();
+    {   // threshold_frames up to the entries (ac_psy_runs_dev.h)
+      const runs::RunsGeo geo = runs::runs_geo(N);
+      runs::level_sums<1>(buf, slot, 0, geo.o4, geo.n4, lane);
+      wave_sync();
+      runs::level_sums<1>(buf, slot, geo.o4, geo.o16, geo.n16, lane);
+      if (a.p.n64 > 0) {
+        wave_sync();
+        runs::level_sums<1>(buf, slot, geo.o16, geo.o64, a.p.n64, lane);
+      }
+      runs::band_stage<1>(t, a.p, lc, img, buf, slot, lane);
+    }
+    __syncthreads();   // every slot's intensities and sums are dead: bytes 1536 ... take the threshold row's image
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      if (runs::in_frame<R>(a.p, i, lane)) {
+        const uint32_t wd = IDX_REGS ? ridx(i) : img[runs::off_idx(a.p.lw, a.p.kb) + 64 * i + lane];
+        const v4f th = runs::entry_lookup(buf, wd);
+        const int v0 = vb + 128 * i * C;
+        char* o0 = slots + 1536 + image_at(v0);
+        char* o1 = slots + 1536 + image_at(v0 + C);
+        if (has1 && codd) {
+          *reinterpret_cast<float*>(o0) = th.x;
+          *reinterpret_cast<float*>(slots + 1536 + image_at(v0 + 1)) = th.y;
+          *reinterpret_cast<float*>(o1) = th.z;
+          *reinterpret_cast<float*>(slots + 1536 + image_at(v0 + C + 1)) = th.w;
+        } else if (has1) {
+          *reinterpret_cast<v2u*>(o0) = v2u{th.x, th.y};
+          *reinterpret_cast<v2u*>(o1) = v2u{th.z, th.w};
+        } else {
+          *reinterpret_cast<float*>(o0) = th.x;
+          *reinterpret_cast<float*>(o1) = th.z;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int jj = 64 * i + lane, j = wave * pch + jj;
+      if (runs::in_frame<R>(a.p, i, lane) && j < nch)
+        __builtin_nontemporal_store(*reinterpret_cast<const v4f*>(buf + 1536 + 16 * jj), reinterpret_cast<v4f*>(a.thr + ro) + j);
+    }
+    // (the next frame's share lands at the head of the wave's own slot, its image is read after the next barrier)
+  }
+}
+
 constexpr int runs_fb(int R) { return R >= 8 ? 1 : R == 4 ? 2 : 4; }
 
 template <int R, int CMODE>
@@ -429,6 +558,34 @@ int launch_psy_runs(const ac_psy_plan* p, const float* X, const float* t_in, flo
   a.nsig = (long long)B * C;
   a.ntasks = (C == 2 ? (long long)B : C == 1 ? (a.nsig + 1) / 2 : (long long)B * ((C + 1) / 2)) * F;
   const bool want_t = t_out != nullptr, want_thr = thr != nullptr;
+  // more than two channels with whole rows, where the shape has a team form (AC_PSY_NOTEAM=1: the strided channel pairs)
+  if (C > 2 && want_thr && (C + 1) / 2 <= 4 && (R == 8 || R == 16) && a.p.slot >= 1536 + 8 * p->N && !getenv("AC_PSY_NOTEAM") &&
+      !((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(thr)) & 15)) {
+    const int CP = (C + 1) / 2;
+    const size_t lds_c = (size_t)a.p.lds_words * 4 + (size_t)CP * a.p.slot;
+    if (lds_c <= 160 * 1024) {
+      RunsArgs c = a;
+      c.ntasks = (long long)B * F;   // frames: a workgroup takes all the channel pairs of a frame
+      const int cus_c = p->cus > 0 ? p->cus : 256;
+      int Tc = 8;
+      while (Tc > 1 && c.ntasks < (long long)Tc * cus_c * 6) Tc >>= 1;
+      c.T = Tc;
+      const long long g = (c.ntasks + Tc - 1) / Tc;
+      if (g > 2147483647ll) {
+        set_error("problem too large for one launch (%lld workgroups)", g);
+        return AC_EINVAL;
+      }
+      auto go = [&](auto kernel) -> int {
+        if (lds_c > 64 * 1024)
+          AC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+        hipLaunchKernelGGL(kernel, dim3((unsigned)g), dim3(64 * CP), lds_c, s, c);
+        AC_HIP_CHECK(hipGetLastError());
+        return AC_OK;
+      };
+      if (R == 8) return want_t ? go(k_psy_runs_c<8, true>) : go(k_psy_runs_c<8, false>);
+      return want_t ? go(k_psy_runs_c<16, true>) : go(k_psy_runs_c<16, false>);
+    }
+  }
   // waves per workgroup: the size that leaves the most waves resident (image + FB slots per wave; 160 KB of LDS per CU, the
   // kernels' register budget allows 12 / 8 / 4 waves per CU)
   const int wave_cap = R >= 32 ? 4 : R >= 16 ? 8 : 12;

@@ -508,6 +508,33 @@ def test_fused_encode_of_the_lds_fft_tier_equals_the_unfused_calls(N, C, monkeyp
             assert tonality_err(host(t), t64) <= 1.0 and rel_elem(host(thr), o.global_masking_threshold(X64, t64)) <= TOL
 
 
+@pytest.mark.parametrize("N", [640, 960, 1024, 1280, 1536, 2048])
+@pytest.mark.parametrize("C", [3, 4, 5, 6, 7, 8])
+def test_masking_model_of_more_than_two_channels_through_whole_rows(N, C, monkeypatch):
+    """k_psy_runs_c (ac_psy_mid.hip): the waves that take the channel pairs of one frame move the [filter_bands_n, C] row and
+    the threshold row in whole 16-byte pieces and pick their pairs out of a row image in LDS (psychoacoustic.py:102-148 takes
+    any channels_n) -- against the strided channel pairs (AC_PSY_NOTEAM=1): tonality and thresholds bit for bit, twice (no run
+    may differ from another), with a given tonality and with the kernel's own, odd channel counts (a pair either side of a
+    piece boundary, a half-empty last pair), ragged frame counts, a launch of thousands of workgroups; and against the oracle."""
+    psy = audiocodec_amd.PsychoacousticModel(48000, N)
+    for (B, F) in ((3, 5), (1, 1), (2, 37), (24, 96000 // N)):
+        X = (torch.rand((B, F, N, C), device="cuda") * 2 - 1) * torch.rand((B, F, 1, C), device="cuda")
+        monkeypatch.delenv("AC_PSY_NOTEAM", raising=False)
+        t = psy.tonality(X)
+        thr = psy.global_masking_threshold(X, t, 0.2)
+        thr_b = psy.global_masking_threshold(X, t, 0.2)
+        monkeypatch.setenv("AC_PSY_NOTEAM", "1")
+        t1 = psy.tonality(X)
+        thr1 = psy.global_masking_threshold(X, t1, 0.2)
+        assert torch.equal(t, t1) and torch.equal(thr, thr1) and torch.equal(thr, thr_b)
+        if (B, F) == (3, 5):
+            o = PsychoOracle(48000, N, 64, compute_dtype=np.float64)
+            X64 = host(X).astype(np.float64)
+            t64 = o.tonality(X64)
+            assert tonality_err(host(t), t64) <= 1.0 and rel_elem(host(thr), o.global_masking_threshold(X64, t64, 0.2)) <= TOL
+    monkeypatch.delenv("AC_PSY_NOTEAM", raising=False)
+
+
 @pytest.mark.parametrize("N,C", [(512, 2), (512, 1), (256, 2), (128, 2), (64, 2), (960, 2), (2160, 2), (4096, 1)])
 def test_fused_encode_at_launches_that_fill_the_chip(N, C, monkeypatch):
     """Several workgroups per CU, thousands of them: the launch shape the small parity cases never reach.  The fused encode

@@ -33,6 +33,11 @@ for N, C in ((64, 2), (128, 2), (256, 2), (512, 2), (512, 1), (1024, 2), (2048, 
         Xs = codec.mdct.transform(x); ys = codec.decode(Xs)
         del os.environ["AC_LDS_WAVE_NOTEAM"]
         r["team_vs_strided"] = rows(Xt, Xs) + rows(yt.reshape(y.shape[0], -1, N, C), ys.reshape(y.shape[0], -1, N, C))
+        os.environ["AC_PSY_NOTEAM"] = "1"      # the masking kernels: whole rows (k_psy_runs_c) against the strided channel pairs
+        ts_ = codec.psy.tonality(X2); thrs_ = codec.psy.global_masking_threshold(X2, ts_)
+        del os.environ["AC_PSY_NOTEAM"]
+        r["psy_team_vs_strided"] = int((ts_ != t2).sum()) + rows(thrs_, thr2)
+        del ts_, thrs_
         del Xt, yt, Xs, ys
     del y, yb
     ok = not any(r.values())
