@@ -404,7 +404,8 @@ __global__ __launch_bounds__(256, (R >= 32 ? 1 : R >= 16 ? 2 : 3)) void k_psy_ru
 // its own slot, and every wave picks its pair's bins out of (puts its thresholds into) the row image that the CP slots hold
 // together -- on the way in at the slots' heads (where the intensities go afterwards), on the way out behind the threshold
 // entries (bytes 1536 ...: intensities and partial sums are dead by then).  Four workgroup barriers per frame; the arithmetic is
-// k_psy_runs' (same device functions): equal results bit for bit.  filters_n 640 ... 2048 (a slot must hold 1536 + 8 N bytes).
+// k_psy_runs' (same device functions): equal results bit for bit.  filter_bands_n 258 ... 2048 (4, 8 or 16 granule registers per
+// lane; the slots are at least 1536 + 8 N bytes here).
 template <int R, bool WANT_T>
 __global__ __launch_bounds__(256, (R >= 16 ? 2 : 3)) void k_psy_runs_c(RunsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -559,12 +560,16 @@ int launch_psy_runs(const ac_psy_plan* p, const float* X, const float* t_in, flo
   a.ntasks = (C == 2 ? (long long)B : C == 1 ? (a.nsig + 1) / 2 : (long long)B * ((C + 1) / 2)) * F;
   const bool want_t = t_out != nullptr, want_thr = thr != nullptr;
   // more than two channels with whole rows, where the shape has a team form (AC_PSY_NOTEAM=1: the strided channel pairs)
-  if (C > 2 && want_thr && (C + 1) / 2 <= 4 && (R == 8 || R == 16) && a.p.slot >= 1536 + 8 * p->N && !getenv("AC_PSY_NOTEAM") &&
+  if (C > 2 && want_thr && (C + 1) / 2 <= 4 && (R == 4 || R == 8 || R == 16) && !getenv("AC_PSY_NOTEAM") &&
       !((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(thr)) & 15)) {
     const int CP = (C + 1) / 2;
-    const size_t lds_c = (size_t)a.p.lds_words * 4 + (size_t)CP * a.p.slot;
+    // (a slot also holds a share of the threshold row's image behind the entries: 1536 + 8 N bytes; the plan's slot is
+    // smaller below filters_n 640)
+    const int slot_c = std::max(a.p.slot, (1536 + 8 * p->N + 15) & ~15);
+    const size_t lds_c = (size_t)a.p.lds_words * 4 + (size_t)CP * slot_c;
     if (lds_c <= 160 * 1024) {
       RunsArgs c = a;
+      c.p.slot = slot_c;
       c.ntasks = (long long)B * F;   // frames: a workgroup takes all the channel pairs of a frame
       const int cus_c = p->cus > 0 ? p->cus : 256;
       int Tc = 8;
@@ -582,6 +587,7 @@ int launch_psy_runs(const ac_psy_plan* p, const float* X, const float* t_in, flo
         AC_HIP_CHECK(hipGetLastError());
         return AC_OK;
       };
+      if (R == 4) return want_t ? go(k_psy_runs_c<4, true>) : go(k_psy_runs_c<4, false>);
       if (R == 8) return want_t ? go(k_psy_runs_c<8, true>) : go(k_psy_runs_c<8, false>);
       return want_t ? go(k_psy_runs_c<16, true>) : go(k_psy_runs_c<16, false>);
     }

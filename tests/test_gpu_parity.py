@@ -508,7 +508,7 @@ def test_fused_encode_of_the_lds_fft_tier_equals_the_unfused_calls(N, C, monkeyp
             assert tonality_err(host(t), t64) <= 1.0 and rel_elem(host(thr), o.global_masking_threshold(X64, t64)) <= TOL
 
 
-@pytest.mark.parametrize("N", [640, 960, 1024, 1280, 1536, 2048])
+@pytest.mark.parametrize("N", [300, 480, 512, 600, 640, 960, 1024, 1280, 1536, 2048])
 @pytest.mark.parametrize("C", [3, 4, 5, 6, 7, 8])
 def test_masking_model_of_more_than_two_channels_through_whole_rows(N, C, monkeypatch):
     """k_psy_runs_c (ac_psy_mid.hip): the waves that take the channel pairs of one frame move the [filter_bands_n, C] row and

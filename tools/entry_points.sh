@@ -10,7 +10,7 @@ out=gpurun_out/entry_points.txt
   echo; echo "== N = 960 (LDS-FFT tier), B = 64 stereo, K = 499"; N=960 B=64 K=499 python tools/microbench.py 2>/dev/null | sed -n 1,5p
   echo; echo "== N = 960, B = 256 stereo, K = 499"; N=960 python tools/microbench.py 2>/dev/null | sed -n 1,6p
   echo; echo "== N = 960, B = 256 mono, K = 499"; N=960 C=1 python tools/microbench.py 2>/dev/null | sed -n 1,5p
-  echo; echo "== N = 960, B = 84 clips of six channels, K = 499 (team form of the LDS-FFT tier where it pays + the masking kernels on strided channel pairs)"; N=960 C=6 B=84 python tools/microbench.py 2>/dev/null | sed -n 1,5p
+  echo; echo "== N = 960, B = 84 clips of six channels, K = 499 (whole rows through LDS: team form of the LDS-FFT tier where it pays, k_psy_runs_c for the masking model)"; N=960 C=6 B=84 python tools/microbench.py 2>/dev/null | sed -n 1,5p
   echo; echo "== N = 1024, B = 84 clips of six channels, K = 468 (the same)"; N=1024 C=6 B=84 python tools/microbench.py 2>/dev/null | sed -n 1,5p
   echo; echo "== N = 960, B = 170 clips of three channels, K = 499"; N=960 C=3 B=170 python tools/microbench.py 2>/dev/null | sed -n 1,5p
   echo; echo "== N = 960 six channels, the strided channel pairs everywhere (AC_LDS_WAVE_NOTEAM=1)"; AC_LDS_WAVE_NOTEAM=1 N=960 C=6 B=84 python tools/microbench.py 2>/dev/null | sed -n 2,3p
