@@ -559,8 +559,14 @@ int launch_psy_runs(const ac_psy_plan* p, const float* X, const float* t_in, flo
   a.nsig = (long long)B * C;
   a.ntasks = (C == 2 ? (long long)B : C == 1 ? (a.nsig + 1) / 2 : (long long)B * ((C + 1) / 2)) * F;
   const bool want_t = t_out != nullptr, want_thr = thr != nullptr;
-  // more than two channels with whole rows, where the shape has a team form (AC_PSY_NOTEAM=1: the strided channel pairs)
-  if (C > 2 && want_thr && (C + 1) / 2 <= 4 && (R == 4 || R == 8 || R == 16) && !getenv("AC_PSY_NOTEAM") &&
+  // more than two channels with whole rows, where the shape has a team form and it measured faster (AC_PSY_NOTEAM=1: the
+  // strided channel pairs; AC_PSY_TEAM_ALWAYS=1: wherever the shape fits -- tests)
+  // (measured, B = 84 ... 170 clips of 10 s, team / strided ms: six channels 960 0.385 / 0.70, 1024 0.377 / 0.71, 512 0.41 / 0.65,
+  // 480 0.52 / 0.64, 600 0.44 / 0.66, eight channels 960 0.59 / 0.77, three channels 960 0.46 / 0.58, four channels 640 0.45 / 0.51;
+  // not at 4 granule registers with fewer than five channels: 512 x 3 0.50 / 0.47, 300 x 4 0.62 / 0.50)
+  const bool team_pays = R >= 8 || (R == 4 && C >= 5 && p->N >= 448);
+  if (C > 2 && want_thr && (C + 1) / 2 <= 4 && (R == 4 || R == 8 || R == 16) && (team_pays || getenv("AC_PSY_TEAM_ALWAYS")) &&
+      !getenv("AC_PSY_NOTEAM") &&
       !((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(thr)) & 15)) {
     const int CP = (C + 1) / 2;
     // (a slot also holds a share of the threshold row's image behind the entries: 1536 + 8 N bytes; the plan's slot is

@@ -520,6 +520,7 @@ def test_masking_model_of_more_than_two_channels_through_whole_rows(N, C, monkey
     for (B, F) in ((3, 5), (1, 1), (2, 37), (24, 96000 // N)):
         X = (torch.rand((B, F, N, C), device="cuda") * 2 - 1) * torch.rand((B, F, 1, C), device="cuda")
         monkeypatch.delenv("AC_PSY_NOTEAM", raising=False)
+        monkeypatch.setenv("AC_PSY_TEAM_ALWAYS", "1")     # (the product takes the form where it measured faster)
         t = psy.tonality(X)
         thr = psy.global_masking_threshold(X, t, 0.2)
         thr_b = psy.global_masking_threshold(X, t, 0.2)
@@ -533,6 +534,7 @@ def test_masking_model_of_more_than_two_channels_through_whole_rows(N, C, monkey
             t64 = o.tonality(X64)
             assert tonality_err(host(t), t64) <= 1.0 and rel_elem(host(thr), o.global_masking_threshold(X64, t64, 0.2)) <= TOL
     monkeypatch.delenv("AC_PSY_NOTEAM", raising=False)
+    monkeypatch.delenv("AC_PSY_TEAM_ALWAYS", raising=False)
 
 
 @pytest.mark.parametrize("N,C", [(512, 2), (512, 1), (256, 2), (128, 2), (64, 2), (960, 2), (2160, 2), (4096, 1)])
