@@ -15,6 +15,7 @@ SIZES = [64, 128, 256, 512, 1024, 2048, 960, 480, 240, 120, 576, 192, 96, 48, 32
          500, 600, 720, 800, 1080, 2160, 3000, 7680, 108]
 TOL, LSB = 1e-4, 1.0 / 32768
 t_end, cases = time.time() + budget, 0
+t_tick = time.time() + 60.0
 def fail(msg):
     print("MISMATCH:", msg); sys.exit(1)
 while time.time() < t_end:
@@ -89,4 +90,7 @@ while time.time() < t_end:
         if not (torch.equal(Xp, Xq) if C <= 2 else float((Xp - Xq).abs().max()) <= 2e-6 * float(Xq.abs().max())): fail(tag + " pcm16 encode")
         if not torch.equal(codec.decode(Xp, pcm16=True)[:, N:-N], pcm): fail(tag + " pcm16 round trip")
     cases += 1
+    if time.time() > t_tick:      # (a run that says nothing for minutes is taken to be hung)
+        print("... %d cases" % cases, flush=True)
+        t_tick = time.time() + 60.0
 print("soak: %d random cases in %.0f s, no mismatch" % (cases, budget))
