@@ -1302,6 +1302,9 @@ struct WaveEncArgs {
   float* t;              // [B, F, 1, C]
   float* thr;            // as X
 };
+static inline __host__ __device__ constexpr bool enc_rebase(int N) {
+  return N == 540 || N == 576 || N == 2160 || N == 2304 || N == 3200 || N == 3240 || N == 3600;
+}
 static inline __host__ __device__ constexpr int enc_r(int N) { return N <= 128 ? 1 : N <= 256 ? 2 : N <= 512 ? 4 : N <= 1024 ? 8 : N <= 2048 ? 16 : 32; }
 constexpr int kEncSlot2 = 1536;   // bytes per frame in phase 2: G (512) + the threshold entries (1024)
 // floats of LDS per frame: what the transform needs, or the model's largest slot; a frame on several waves: and room for every
@@ -1395,7 +1398,25 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
   constexpr int SLOT = per * 4;
   const runs::RunsGeo geo = runs::runs_geo(NC);
   // ---- phase 1
+  // The lane's LDS offsets are invariant and get hoisted out of the frame loop -- dozens of registers (the instances stand at
+  // 204 ... 256, two waves per SIMD).  Formed per frame from opaque copies of the lane's index and buffer offset the kernels take
+  // 130 ... 170 registers, but most of them run SLOWER (B = 256 stereo, fused encode, 52 sizes: +3 ... +20 %); the sizes where it
+  // measured faster (-5 ... -24 %) take that form: enc_rebase().
+#ifdef AC_ENC_REBASE_ALL
+  constexpr bool REBASE = true;
+#else
+  constexpr bool REBASE = enc_rebase(NC);
+#endif
+  const int tid_outer = tid;
   for (int it = 0; it < T; ++it) {   // (every group of a wave walks T steps: the model needs all 64 lanes on each)
+    int boff = grp * per, tid_l = tid_outer;   // (opaque OFFSETS: an opaque pointer would lose its address space)
+    if constexpr (REBASE) asm volatile("" : "+v"(boff), "+v"(tid_l));
+    const int tid = tid_l;
+    float* base = smem + boff;
+    float2* v = reinterpret_cast<float2*>(base);
+    cpair* Bp = reinterpret_cast<cpair*>(base);
+    cpair* Ap = reinterpret_cast<cpair*>(base + 4 * padded_len(h, ps));
+    char* myslot = reinterpret_cast<char*>(base);
     const int n = n0 + it;
     const bool fr = n < n1;          // this group has a frame in this step
     if (GRP && !fr) break;
@@ -2870,8 +2891,8 @@ static bool enc_size(int N) { return N >= 108 && N <= 4096 && lds_wave_ct_size(N
 // clips of 10 s, profiles/r4/lds_fft_fused_encode_sweep.txt: 0.73 - 0.98; the instances left out ran 0.99 - 1.31 x -- the ones
 // that spill registers, and the small sizes, where the per-frame part of the model outweighs the second read of X)
 static bool enc_pays(int N) {
-  static const int sizes[] = {640, 720, 768, 800, 864, 900, 960, 1000, 1152, 1200, 1296, 1440, 1500, 1536, 1728, 2160, 2304, 2400, 2500,
-                              2560, 2592, 2700, 2880, 2916, 3000, 3072, 3200, 3456, 4096};
+  static const int sizes[] = {540, 576, 640, 720, 768, 800, 864, 900, 960, 1000, 1152, 1200, 1296, 1440, 1500, 1536, 1728, 2160, 2304,
+                              2400, 2500, 2560, 2592, 2700, 2880, 2916, 3000, 3072, 3200, 3240, 3456, 3600, 4096};
   for (int n : sizes)
     if (n == N) return true;
   return false;

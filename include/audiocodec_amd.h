@@ -205,8 +205,8 @@ AC_API int ac_encode_fused(const ac_mdct_plan* mdct, const ac_psy_plan* psy, con
 
 /* How ac_encode_fused serves (mdct, psy) on tensors of C channels: 1 = ONE launch (filters_n 1024 / 2048 with the fused
  * wave-level epilogue; filters_n 64 ... 512, mono / stereo, with the masking model for general band layouts in the
- * several-frames-per-wave kernels; the LDS-FFT sizes where one launch measured faster than two on an MI355X -- 29 sizes
- * 640 ... 4096, 960 among them -- mono / stereo float32), 2 = the transform, then tonality + threshold in one pass over X,
+ * several-frames-per-wave kernels; the LDS-FFT sizes where one launch measured faster than two on an MI355X -- 33 sizes
+ * 540 ... 4096, 960 among them -- mono / stereo float32), 2 = the transform, then tonality + threshold in one pass over X,
  * 3 = three launches (generic kernels).  0 for inconsistent plans.  The results do not depend on it: the fused launches
  * return what the separate calls return, bit for bit (filters_n 1024 / 2048: within 1e-5). */
 AC_API int ac_encode_launches(const ac_mdct_plan* mdct, const ac_psy_plan* psy, int C);
