@@ -1069,6 +1069,13 @@ static __global__ __launch_bounds__(kThreads, 2) void k_inv_wave(const TIO* __re
 // per two samples); 1 two mono signals b, b + 1 (8 bytes each; the last pair of an odd batch is half empty); 2 the channels
 // c, c + 1 of three or more channels (8-byte accesses on the 4-byte grid; the last pair of an odd count is half empty).  bfloat16 tensors and filters_n % 4 == 2 run the 8-byte kernels above.
 typedef float v4f_t __attribute__((ext_vector_type(4)));
+// instances of the 16-byte kernels that form the lane's LDS offsets per frame from opaque copies instead of holding them, hoisted,
+// across the frame loop (-DAC_WAVE_REBASE: all of them): ~130 instead of ~200 registers, slower at most sizes (+2 ... +13 %, 18
+// sizes on the same tensors), faster at these: transform 1152 0.490 -> 0.434 ms, 2160 0.508 -> 0.457, 2304 0.537 -> 0.502;
+// inverse 2304 0.501 -> 0.479, 7680 0.603 -> 0.545 (B = 256 stereo)
+static inline __host__ __device__ constexpr bool wave_rebase(int N, bool inverse) {
+  return inverse ? (N == 2304 || N == 7680) : (N == 1152 || N == 2160 || N == 2304);
+}
 __device__ __forceinline__ float ola2(float a, float x, float b, float y) { return __builtin_fmaf(a, x, b * y); }   // a x + b y, one rounding order
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 typedef float v2u_t __attribute__((ext_vector_type(2), aligned(4)));   // two floats on the 4-byte grid
@@ -1247,7 +1254,20 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
     }
   }
   if (n0 < Kin) load_block(x + gx.off_a + (size_t)n0 * gx.block_stride, x + gx.off_b + (size_t)n0 * gx.block_stride);
+#ifdef AC_WAVE_REBASE
+  constexpr bool REBASE_W = NC != 0;
+#else
+  constexpr bool REBASE_W = wave_rebase(NC, false);
+#endif
+  const int tid_outer = tid;
   for (int n = n0; n < n1; ++n) {
+    int boff = grp * per, tid_l = tid_outer;   // (see k_enc_wave_v: per-frame offsets from opaque copies)
+    if constexpr (REBASE_W) asm volatile("" : "+v"(boff), "+v"(tid_l));
+    const int tid = tid_l;
+    float* base = smem + boff;
+    float2* v = reinterpret_cast<float2*>(base);
+    cpair* Bp = reinterpret_cast<cpair*>(base);
+    cpair* Ap = reinterpret_cast<cpair*>(base + 4 * padded_len(h, ps));
     const bool has_cur = n < Kin;
 #pragma unroll
     for (int s = 0; s < kWaveVSteps; ++s) {
@@ -1683,7 +1703,20 @@ static __global__ __launch_bounds__((NTC > kThreads ? NTC : kThreads), 2) void k
   };
   const int t0 = n0 >= 1 ? -1 : 0;
   if (frame_ok(t0)) load_frame(t0);
+#ifdef AC_WAVE_REBASE
+  constexpr bool REBASE_W = NC != 0;
+#else
+  constexpr bool REBASE_W = wave_rebase(NC, true);
+#endif
+  const int tid_outer = tid;
   for (int t = t0; t < seg; ++t) {
+    int boff = grp * per, tid_l = tid_outer;
+    if constexpr (REBASE_W) asm volatile("" : "+v"(boff), "+v"(tid_l));
+    const int tid = tid_l;
+    float* base = smem + boff;
+    float2* v = reinterpret_cast<float2*>(base);
+    cpair* Bp = reinterpret_cast<cpair*>(base);
+    cpair* Ap = reinterpret_cast<cpair*>(base + 4 * padded_len(h, ps));
     const int n = n0 + t;
     if (t >= 0 && n >= nlast) break;
     const bool has_n = frame_ok(t);
