@@ -193,13 +193,16 @@ int ac_workspace_create(const ac_mdct_plan* mdct, const ac_psy_plan* psy, int B,
   w->chosen = (int)(std::min_element(w->ms, w->ms + w->tries) - w->ms);
   // no candidate pairs well with region A where it is (one process in eight on the bench box: A itself sits across two
   // classes): another region A -- first from further along (the spacers are still held), then, if that one pairs no better,
-  // from the hole a spacer in the middle of the row leaves -- each tried against the candidates at hand
-  for (int attempt = 0; attempt < 2 && cands.size() >= 2 && enc_bytes / (w->ms[w->chosen] * 1e-3) < good_rate; ++attempt) {
-    if (attempt == 1) {
+  // from the hole a spacer in the middle of the row leaves, then the first's, then the last's -- each tried against the
+  // candidates at hand
+  // (round 4: two more holes -- the first and the last spacer's -- before giving up: one driver-style process in ~40 still ended
+  // without a two-class pair, 0.513 ms where the others reach 0.497 - 0.505; an attempt costs ~30 ms of timing)
+  for (int attempt = 0; attempt < 4 && cands.size() >= 2 && enc_bytes / (w->ms[w->chosen] * 1e-3) < good_rate; ++attempt) {
+    if (attempt >= 1) {
       if (spacers.size() < 2) break;
-      const size_t mid = spacers.size() / 2;
-      (void)hipFree(spacers[mid]);
-      spacers.erase(spacers.begin() + (long)mid);
+      const size_t hole = attempt == 1 ? spacers.size() / 2 : attempt == 2 ? 0 : spacers.size() - 1;
+      (void)hipFree(spacers[hole]);
+      spacers.erase(spacers.begin() + (long)hole);
     }
     void* a2 = nullptr;
     if (hipMalloc(&a2, w->bytes_a) != hipSuccess) {
