@@ -12,7 +12,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 BIG = os.environ.get("BIG", "0") == "1"   # BIG=1: fewer, larger cases
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 SIZES = [64, 128, 256, 512, 1024, 2048, 960, 480, 240, 120, 576, 192, 96, 48, 32, 16, 1536, 3072, 4096, 24, 1000, 1920, 2880, 6144, 8192, 30, 90,
-         500, 600, 720, 800, 1080, 2160, 3000, 7680, 108]
+         500, 600, 720, 800, 1080, 2160, 3000, 7680, 108, 1152, 2304, 540, 576, 3240, 3600]
 TOL, LSB = 1e-4, 1.0 / 32768
 t_end, cases = time.time() + budget, 0
 t_tick = time.time() + 60.0
